@@ -1,0 +1,165 @@
+// ============================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY (see bamio.hpp header).
+// Plain C entry points so tests/ (ctypes) can drive the CPU restatement. Nothing in the product links this.
+// Counter vector layout (int64[ORC_NCOUNTERS]) is the same order as include/ngsqc.h NGSQC_C_* so that tests
+// can compare the two arrays element by element.
+// ============================================================================
+#include "stats.hpp"
+#include <chrono>
+
+using namespace orc;
+
+namespace {
+struct Result
+{
+	MappingResult m;
+	std::string text;       // accession \t name \t value \t is_plot per line
+	std::string bed_text;   // coverage tools: output BED as written by BedFile::store (without tool headers)
+	std::vector<int64_t> cov;
+	std::vector<int32_t> depth;
+	double seconds_load = 0, seconds_compute = 0;
+};
+void seterr(char* err, int n, const std::string& s) { if (err && n>0) { snprintf(err, (size_t)n, "%s", s.c_str()); } }
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+extern "C" {
+
+enum { ORC_NCOUNTERS = 1032 };
+
+void* orc_bam_load(const char* path, char* err, int errlen)
+{
+	try { auto* b = new BamFile(); b->load(path); return b; }
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
+void orc_bam_free(void* b) { delete (BamFile*)b; }
+int64_t orc_bam_count(void* b) { return (int64_t)((BamFile*)b)->count(); }
+int64_t orc_bam_inflated_size(void* b) { return (int64_t)((BamFile*)b)->data.size(); }
+int64_t orc_bam_first_record_offset(void* b) { return (int64_t)((BamFile*)b)->first_rec; }
+int64_t orc_bam_n_blocks(void* b) { return (int64_t)((BamFile*)b)->n_blocks; }
+int orc_bam_sorted(void* b) { return ((BamFile*)b)->sorted ? 1 : 0; }
+int orc_bam_n_ref(void* b) { return (int)((BamFile*)b)->ref_names.size(); }
+const char* orc_bam_ref_name(void* b, int i) { return ((BamFile*)b)->ref_names[i].c_str(); }
+int64_t orc_bam_ref_len(void* b, int i) { return ((BamFile*)b)->ref_lens[i]; }
+// copies the inflated stream (for checking the GPU inflate kernel)
+int64_t orc_bam_inflated(void* b, uint8_t* out, int64_t cap)
+{
+	auto* f = (BamFile*)b; int64_t n = std::min<int64_t>(cap, (int64_t)f->data.size());
+	memcpy(out, f->data.data(), (size_t)n); return n;
+}
+int64_t orc_bam_record_offsets(void* b, int64_t* out, int64_t cap)
+{
+	auto* f = (BamFile*)b; int64_t n = std::min<int64_t>(cap, (int64_t)f->rec_off.size());
+	for (int64_t i=0;i<n;++i) out[i] = (int64_t)f->rec_off[i];
+	return n;
+}
+
+// mode: 0 = Statistics::mapping(bed,...) [ROI], 1 = Statistics::mapping(bam,...) [no ROI], 2 = Statistics::mapping_wgs
+// bed: path or NULL ; merge_bed: apply BedFile::merge() after load (MappingQC main.cpp:130-132) ; fasta: path or NULL
+void* orc_mapping(void* bam, int mode, const char* bed, int merge_bed, const char* fasta, int min_mapq, int is_cfdna, char* err, int errlen)
+{
+	try
+	{
+		auto* r = new Result();
+		std::unique_ptr<Fasta> fa; if (fasta && *fasta) fa.reset(new Fasta(fasta));
+		BedFile roi; bool have = bed && *bed;
+		if (have) { roi.load(bed); if (merge_bed) roi.merge(); }
+		double t0 = now();
+		if (mode==0) r->m = mapping_roi(roi, *(BamFile*)bam, fa.get(), min_mapq, is_cfdna!=0);
+		else if (mode==1) r->m = mapping_noroi(*(BamFile*)bam, fa.get(), min_mapq);
+		else r->m = mapping_wgs(*(BamFile*)bam, have ? &roi : nullptr, fa.get(), min_mapq);
+		r->seconds_compute = now() - t0;
+		for (auto& l : r->m.lines) r->text += l.accession + "\t" + l.name + "\t" + l.value + "\t" + (l.is_plot ? "1" : "0") + "\n";
+		return r;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
+
+void orc_result_counters(void* res, int64_t* out)
+{
+	const MappingResult& m = ((Result*)res)->m;
+	int64_t v[32] = { m.al_total, m.al_mapped, m.al_ontarget, m.al_neartarget, m.al_dup, m.al_proper_paired, m.insert_size_read_count,
+		m.bases_trimmed, m.bases_mapped, m.bases_clipped, m.insert_size_sum, m.bases_usable, m.bases_usable_no_overlap, m.bases_usable_raw, m.bases_usable_roi,
+		m.bases_usable_dp[0], m.bases_usable_dp[1], m.bases_usable_dp[2], m.bases_usable_dp[3], m.bases_usable_dp[4],
+		m.dp_dist[0], m.dp_dist[1], m.dp_dist[2], m.dp_dist[3], m.max_length, m.paired_end, m.roi_bases, m.half_depth, m.bases_covered_half,
+		m.reads_x, m.reads_y, m.yx_valid };
+	memcpy(out, v, sizeof(v));
+	memcpy(out+32, m.insert_hist, sizeof(m.insert_hist));
+}
+const char* orc_result_text(void* res) { return ((Result*)res)->text.c_str(); }
+int64_t orc_result_depth(void* res, int32_t* out, int64_t cap)
+{
+	auto* r = (Result*)res; const std::vector<int32_t>& d = r->depth.empty() ? r->m.depth : r->depth;
+	int64_t n = std::min<int64_t>(cap, (int64_t)d.size());
+	if (out) memcpy(out, d.data(), (size_t)n*4);
+	return (int64_t)d.size();
+}
+int orc_result_gc(void* res, double* gc_roi100, double* gc_reads100)
+{
+	const MappingResult& m = ((Result*)res)->m;
+	for (int i=0;i<100;++i) { gc_roi100[i] = (size_t)i<m.gc_roi.size() ? m.gc_roi[i] : 0; gc_reads100[i] = (size_t)i<m.gc_reads.size() ? m.gc_reads[i] : 0; }
+	return m.have_gc ? 1 : 0;
+}
+double orc_result_seconds(void* res) { return ((Result*)res)->seconds_compute; }
+void orc_result_free(void* res) { delete (Result*)res; }
+
+// BedCoverage core: Statistics::avgCoverage. merge_bed: 0 none (tool behaviour), 1 = merge() first (as the unit tests do).
+// Result: bed_text = lines with the appended coverage column; cov = raw per-line sums.
+void* orc_avg_coverage(void* bam, const char* bed, int merge_bed, int min_mapq, int decimals, int random_access, int skip_mismapped, int clear, char* err, int errlen)
+{
+	try
+	{
+		auto* r = new Result();
+		BedFile f; f.load(bed);
+		if (clear) { f.headers.clear(); for (auto& l : f.lines) l.annos.clear(); }
+		if (merge_bed) f.merge();
+		double t0 = now();
+		r->cov = avg_coverage(f, *(BamFile*)bam, min_mapq, decimals, random_access!=0, skip_mismapped!=0);
+		r->seconds_compute = now() - t0;
+		r->bed_text = f.toText(true);
+		return r;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
+int64_t orc_result_cov(void* res, int64_t* out, int64_t cap)
+{
+	auto* r = (Result*)res; int64_t n = std::min<int64_t>(cap, (int64_t)r->cov.size());
+	if (out) memcpy(out, r->cov.data(), (size_t)n*8);
+	return (int64_t)r->cov.size();
+}
+const char* orc_result_bed(void* res) { return ((Result*)res)->bed_text.c_str(); }
+
+// BedLowCoverage / BedHighCoverage core. The tools load the BED and call merge(true,true) (src/BedLowCoverage/main.cpp:47-49).
+void* orc_low_high_coverage(void* bam, const char* bed, int tool_merge, int cutoff, int min_mapq, int min_baseq, int is_high, int random_access, char* err, int errlen)
+{
+	try
+	{
+		auto* r = new Result();
+		BedFile f; f.load(bed);
+		if (tool_merge==1) f.merge(true, true); else if (tool_merge==2) f.merge();
+		double t0 = now();
+		BedFile out = low_high_coverage(f, *(BamFile*)bam, cutoff, min_mapq, min_baseq, is_high!=0, random_access!=0, &r->depth);
+		r->seconds_compute = now() - t0;
+		r->bed_text = out.toText(false);
+		r->m.roi_bases = f.baseCount();
+		r->cov.push_back((int64_t)f.count()); r->cov.push_back(f.baseCount()); r->cov.push_back((int64_t)out.count()); r->cov.push_back(out.baseCount());
+		return r;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
+
+// BED helpers for host-logic tests: load -> (merge) -> text
+int64_t orc_bed_roundtrip(const char* bed, int merge_mode, char* out, int64_t cap, char* err, int errlen)
+{
+	try
+	{
+		BedFile f; f.load(bed);
+		if (merge_mode==1) f.merge(); else if (merge_mode==2) f.merge(true, true); else if (merge_mode==3) { f.sort(); f.merge(); } else if (merge_mode==4) { f.merge(); f.chunk(100); }
+		std::string t = f.toText(false);
+		if (out && cap>0) { size_t n = std::min<size_t>((size_t)cap-1, t.size()); memcpy(out, t.data(), n); out[n] = 0; }
+		return (int64_t)t.size();
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
+}
+
+} // extern "C"

@@ -1,0 +1,192 @@
+"""ctypes binding of oracle/liboracle.so (CPU restatement — the parity checker, never the product)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+NCOUNTERS = 1032
+
+COUNTER_NAMES = [
+    "al_total", "al_mapped", "al_ontarget", "al_neartarget", "al_dup", "al_proper_paired", "insert_size_read_count",
+    "bases_trimmed", "bases_mapped", "bases_clipped", "insert_size_sum", "bases_usable", "bases_usable_no_overlap",
+    "bases_usable_raw", "bases_usable_roi", "bases_usable_dp0", "bases_usable_dp1", "bases_usable_dp2", "bases_usable_dp3",
+    "bases_usable_dp4", "dp_dist0", "dp_dist1", "dp_dist2", "dp_dist3", "max_length", "paired_end", "roi_bases",
+    "half_depth", "bases_covered_half", "reads_x", "reads_y", "yx_valid",
+]
+
+_lib = None
+
+
+def build():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("capi.cpp", "stats.hpp", "bed.hpp", "bamio.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        vp, cp, i64, i32 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int
+        L.orc_bam_load.restype = vp; L.orc_bam_load.argtypes = [cp, cp, i32]
+        L.orc_bam_free.argtypes = [vp]
+        for f in ("orc_bam_count", "orc_bam_inflated_size", "orc_bam_first_record_offset", "orc_bam_n_blocks"):
+            getattr(L, f).restype = i64; getattr(L, f).argtypes = [vp]
+        L.orc_bam_sorted.restype = i32; L.orc_bam_sorted.argtypes = [vp]
+        L.orc_bam_n_ref.restype = i32; L.orc_bam_n_ref.argtypes = [vp]
+        L.orc_bam_ref_name.restype = cp; L.orc_bam_ref_name.argtypes = [vp, i32]
+        L.orc_bam_ref_len.restype = i64; L.orc_bam_ref_len.argtypes = [vp, i32]
+        L.orc_bam_inflated.restype = i64; L.orc_bam_inflated.argtypes = [vp, vp, i64]
+        L.orc_bam_record_offsets.restype = i64; L.orc_bam_record_offsets.argtypes = [vp, vp, i64]
+        L.orc_mapping.restype = vp; L.orc_mapping.argtypes = [vp, i32, cp, i32, cp, i32, i32, cp, i32]
+        L.orc_result_counters.argtypes = [vp, vp]
+        L.orc_result_text.restype = cp; L.orc_result_text.argtypes = [vp]
+        L.orc_result_depth.restype = i64; L.orc_result_depth.argtypes = [vp, vp, i64]
+        L.orc_result_gc.restype = i32; L.orc_result_gc.argtypes = [vp, vp, vp]
+        L.orc_result_seconds.restype = C.c_double; L.orc_result_seconds.argtypes = [vp]
+        L.orc_result_free.argtypes = [vp]
+        L.orc_avg_coverage.restype = vp; L.orc_avg_coverage.argtypes = [vp, cp, i32, i32, i32, i32, i32, i32, cp, i32]
+        L.orc_result_cov.restype = i64; L.orc_result_cov.argtypes = [vp, vp, i64]
+        L.orc_result_bed.restype = cp; L.orc_result_bed.argtypes = [vp]
+        L.orc_low_high_coverage.restype = vp; L.orc_low_high_coverage.argtypes = [vp, cp, i32, i32, i32, i32, i32, i32, cp, i32]
+        L.orc_bed_roundtrip.restype = i64; L.orc_bed_roundtrip.argtypes = [cp, i32, cp, i64, cp, i32]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _b(s):
+    return None if s is None else os.fsencode(s)
+
+
+class Bam:
+    def __init__(self, path):
+        err = C.create_string_buffer(1024)
+        self.h = lib().orc_bam_load(_b(path), err, 1024)
+        if not self.h:
+            raise OracleError(err.value.decode())
+        self.path = path
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_bam_free(self.h); self.h = None
+
+    @property
+    def count(self): return lib().orc_bam_count(self.h)
+    @property
+    def inflated_size(self): return lib().orc_bam_inflated_size(self.h)
+    @property
+    def first_record_offset(self): return lib().orc_bam_first_record_offset(self.h)
+    @property
+    def n_blocks(self): return lib().orc_bam_n_blocks(self.h)
+    @property
+    def refs(self):
+        L = lib()
+        return [(L.orc_bam_ref_name(self.h, i).decode(), L.orc_bam_ref_len(self.h, i)) for i in range(L.orc_bam_n_ref(self.h))]
+
+    def inflated(self):
+        a = np.empty(self.inflated_size, dtype=np.uint8)
+        lib().orc_bam_inflated(self.h, a.ctypes.data, a.size)
+        return a
+
+    def record_offsets(self):
+        a = np.empty(self.count, dtype=np.int64)
+        lib().orc_bam_record_offsets(self.h, a.ctypes.data, a.size)
+        return a
+
+
+class MappingResult:
+    def __init__(self, h):
+        L = lib()
+        self.counters = np.zeros(NCOUNTERS, dtype=np.int64)
+        L.orc_result_counters(h, self.counters.ctypes.data)
+        self.lines = []
+        for ln in L.orc_result_text(h).decode().splitlines():
+            acc, name, value, plot = ln.split("\t")
+            self.lines.append((acc, name, value, plot == "1"))
+        n = L.orc_result_depth(h, None, 0)
+        self.depth = np.zeros(n, dtype=np.int32)
+        if n:
+            L.orc_result_depth(h, self.depth.ctypes.data, n)
+        self.gc_roi = np.zeros(100); self.gc_reads = np.zeros(100)
+        self.have_gc = bool(L.orc_result_gc(h, self.gc_roi.ctypes.data, self.gc_reads.ctypes.data))
+        self.seconds = L.orc_result_seconds(h)
+        L.orc_result_free(h)
+
+    def __getitem__(self, name):
+        return int(self.counters[COUNTER_NAMES.index(name)])
+
+    @property
+    def insert_hist(self):
+        return self.counters[32:]
+
+    def values(self):
+        """name -> value string for non-plot lines (what MappingQC -txt prints)."""
+        return {n: v for (_, n, v, p) in self.lines if not p}
+
+    def txt(self):
+        return [f"{n}: {v}" for (_, n, v, p) in self.lines if not p]
+
+
+MODE_ROI, MODE_NOROI, MODE_WGS = 0, 1, 2
+
+
+def mapping(bam, mode, bed=None, merge_bed=True, fasta=None, min_mapq=1, cfdna=False):
+    err = C.create_string_buffer(1024)
+    h = lib().orc_mapping(bam.h, mode, _b(bed), int(merge_bed), _b(fasta), min_mapq, int(cfdna), err, 1024)
+    if not h:
+        raise OracleError(err.value.decode())
+    return MappingResult(h)
+
+
+def avg_coverage(bam, bed, merge_bed=False, min_mapq=1, decimals=2, random_access=False, skip_mismapped=False, clear=False):
+    err = C.create_string_buffer(1024)
+    L = lib()
+    h = L.orc_avg_coverage(bam.h, _b(bed), int(merge_bed), min_mapq, decimals, int(random_access), int(skip_mismapped), int(clear), err, 1024)
+    if not h:
+        raise OracleError(err.value.decode())
+    n = L.orc_result_cov(h, None, 0)
+    cov = np.zeros(n, dtype=np.int64)
+    if n:
+        L.orc_result_cov(h, cov.ctypes.data, n)
+    text = L.orc_result_bed(h).decode()
+    secs = L.orc_result_seconds(h)
+    L.orc_result_free(h)
+    return cov, text, secs
+
+
+def low_high_coverage(bam, bed, cutoff, min_mapq=1, min_baseq=0, is_high=False, random_access=False, tool_merge=1):
+    """tool_merge: 1 = merge(true,true) like the tools, 2 = plain merge() like the unit tests, 0 = none."""
+    err = C.create_string_buffer(1024)
+    L = lib()
+    h = L.orc_low_high_coverage(bam.h, _b(bed), tool_merge, cutoff, min_mapq, min_baseq, int(is_high), int(random_access), err, 1024)
+    if not h:
+        raise OracleError(err.value.decode())
+    st = np.zeros(4, dtype=np.int64)
+    L.orc_result_cov(h, st.ctypes.data, 4)
+    n = L.orc_result_depth(h, None, 0)
+    depth = np.zeros(n, dtype=np.int32)
+    if n:
+        L.orc_result_depth(h, depth.ctypes.data, n)
+    text = L.orc_result_bed(h).decode()
+    secs = L.orc_result_seconds(h)
+    L.orc_result_free(h)
+    return {"roi_regions": int(st[0]), "roi_bases": int(st[1]), "out_regions": int(st[2]), "out_bases": int(st[3]),
+            "bed": text, "depth": depth, "seconds": secs}
+
+
+def bed_roundtrip(bed, merge_mode=0):
+    err = C.create_string_buffer(1024)
+    n = lib().orc_bed_roundtrip(_b(bed), merge_mode, None, 0, err, 1024)
+    if n < 0:
+        raise OracleError(err.value.decode())
+    buf = C.create_string_buffer(n + 1)
+    lib().orc_bed_roundtrip(_b(bed), merge_mode, buf, n + 1, err, 1024)
+    return buf.value.decode()
