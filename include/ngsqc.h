@@ -1,0 +1,146 @@
+/*
+ * ngsqc.h — C ABI of the MI355X-native BAM mapping-QC / coverage engine (libngsqc_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of imgag/ngs-bits: the per-read loop behind
+ *   Statistics::mapping(bed,...)      src/cppNGS/Statistics.h:40   (Statistics.cpp:343-803)
+ *   Statistics::mapping(bam,...)      src/cppNGS/Statistics.h:42   (Statistics.cpp:805-988)
+ *   Statistics::mapping_wgs           src/cppNGS/Statistics.h:44   (Statistics.cpp:990-1359)
+ *   Statistics::avgCoverage           src/cppNGS/Statistics.h:70   (Statistics.cpp:2698-2804)
+ *   Statistics::lowCoverage/highCoverage  Statistics.h:66,68       (Statistics.cpp:2534-2657,2693-2696,2806-2809)
+ *   Statistics::yxRatio               Statistics.cpp:2659-2691
+ * and the reader underneath them, BamReader::getNextAlignment / setRegion (src/cppNGS/BamReader.h:386-398,
+ * BamReader.cpp:734-768), i.e. what the reference gets from htslib's sam_read1 / sam_itr_next / bam_endpos.
+ *
+ * The reference has no FFI for this path; the seam is the static C++ API above. The host layer
+ * (ngs-bits_amd/host, plain C++17) keeps those function names/arguments/errors and calls into this ABI.
+ * Everything here is plain C: pointers + sizes, caller-owned output buffers, int return codes
+ * (0 = ok, <0 = error; message via ngsqc_last_error). No torch / HIP types cross the boundary.
+ *
+ * Coordinates: regions are 1-based, closed [start,end] (the in-memory convention of BedLine, BedFile.cpp:157-159).
+ * Chromosomes are addressed by BAM reference id (tid); name -> tid mapping is host logic.
+ */
+#ifndef NGSQC_H
+#define NGSQC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngsqc_handle ngsqc_handle;
+
+/* ---- error codes ---- */
+#define NGSQC_OK            0
+#define NGSQC_E_IO         -1   /* "Could not open BAM/CRAM file ..."            BamReader.cpp:465-468 */
+#define NGSQC_E_FORMAT     -2   /* not BGZF / not BAM / corrupt record           BamReader.h:389-392  */
+#define NGSQC_E_ARG        -3   /* invalid argument (ArgumentException cases)    */
+#define NGSQC_E_DEVICE     -4   /* HIP runtime error / no device / out of memory */
+#define NGSQC_E_UNSUPPORTED -5  /* CRAM input (not implemented), etc.            */
+
+/* ---- lifecycle (replaces BamReader ctor/dtor, BamReader.cpp:462-523) ---- */
+int  ngsqc_open(const char* bam_path, int device, ngsqc_handle** out);
+/* Same, from a BAM image already in host memory (bytes are copied to HBM; caller keeps ownership). */
+int  ngsqc_open_memory(const void* bam_bytes, size_t n_bytes, int device, ngsqc_handle** out);
+void ngsqc_close(ngsqc_handle* h);
+/* Message of the last failing call on h (or of the last failing ngsqc_open* when h is NULL). */
+const char* ngsqc_last_error(const ngsqc_handle* h);
+
+/* ---- header access (BamReader::chromosomes/chromosomeSize, BamReader.cpp:770-800) ---- */
+int         ngsqc_n_ref(const ngsqc_handle* h);
+const char* ngsqc_ref_name(const ngsqc_handle* h, int tid);
+int64_t     ngsqc_ref_len(const ngsqc_handle* h, int tid);
+int64_t     ngsqc_n_records(ngsqc_handle* h);     /* forces inflate + record indexing */
+int64_t     ngsqc_inflated_size(ngsqc_handle* h); /* bytes of the inflated BGZF stream */
+int64_t     ngsqc_n_bgzf_blocks(const ngsqc_handle* h);
+int64_t     ngsqc_compressed_size(const ngsqc_handle* h);
+
+/* ---- stage control ----
+ * Inflate (K1) and record indexing (K2) run lazily and their result stays in HBM for subsequent scans on the
+ * same handle (the reference re-reads the file for every pass). ngsqc_drop_decoded() frees/invalidates that
+ * state so that the next scan redoes the whole job from the compressed bytes (what bench.py times). */
+int ngsqc_decode(ngsqc_handle* h);
+int ngsqc_drop_decoded(ngsqc_handle* h);
+/* test hooks: copy device results back (caller buffers) */
+int ngsqc_copy_inflated(ngsqc_handle* h, uint8_t* out, int64_t cap);
+int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap);
+
+/* ---- regions ---- */
+typedef struct ngsqc_region { int32_t tid; int32_t start; int32_t end; } ngsqc_region; /* 1-based closed */
+
+/* ---- mapping QC scan (Statistics::mapping x2, mapping_wgs) ---- */
+#define NGSQC_MODE_ROI    0   /* Statistics.cpp:343  target-region mode                 */
+#define NGSQC_MODE_NOROI  1   /* Statistics.cpp:805  -rna / -wgs -build non_human       */
+#define NGSQC_MODE_WGS    2   /* Statistics.cpp:990  -wgs, optional OMIM ROI second pass */
+
+/* counter vector indices (int64). Doubles of the reference that only ever hold integers are kept as int64. */
+enum {
+	NGSQC_C_AL_TOTAL = 0, NGSQC_C_AL_MAPPED, NGSQC_C_AL_ONTARGET, NGSQC_C_AL_NEARTARGET, NGSQC_C_AL_DUP,
+	NGSQC_C_AL_PROPER_PAIRED, NGSQC_C_INSERT_SIZE_READ_COUNT, NGSQC_C_BASES_TRIMMED, NGSQC_C_BASES_MAPPED,
+	NGSQC_C_BASES_CLIPPED, NGSQC_C_INSERT_SIZE_SUM, NGSQC_C_BASES_USABLE, NGSQC_C_BASES_USABLE_NO_OVERLAP,
+	NGSQC_C_BASES_USABLE_RAW, NGSQC_C_BASES_USABLE_ROI, NGSQC_C_BASES_USABLE_DP0, /* ..DP4 = +4 */
+	NGSQC_C_DP_DIST0 = 20, /* ..3 */
+	NGSQC_C_MAX_LENGTH = 24, NGSQC_C_PAIRED_END, NGSQC_C_ROI_BASES, NGSQC_C_HALF_DEPTH, NGSQC_C_BASES_COVERED_HALF,
+	NGSQC_C_READS_X, NGSQC_C_READS_Y, NGSQC_C_YX_VALID,
+	NGSQC_C_INSERT_HIST0 = 32, /* 1000 bins: reads per integer insert size 0..999 (binned on host, Statistics.cpp:401) */
+	NGSQC_NCOUNTERS = 1032
+};
+
+typedef struct ngsqc_mapping_params {
+	int32_t mode;                 /* NGSQC_MODE_*                                                        */
+	int32_t min_mapq;             /* Statistics.cpp:343 min_mapq                                          */
+	int32_t tid_x, tid_y;         /* tids of chrX / chrY or -1 (yxRatio, Statistics.cpp:2662-2666)        */
+	const uint8_t* tid_nonspecial;/* [n_ref] 1 if Chromosome::isNonSpecial (Chromosome.h:78-81)           */
+	const ngsqc_region* regions;  /* merged + sorted target regions (NULL for NOROI / WGS without ROI)     */
+	int64_t n_regions;
+	const ngsqc_region* gc_chunks;/* roi.chunk(100) lines, same order (Statistics.cpp:366) or NULL        */
+	const int32_t* gc_bin;        /* per chunk: GC bin 0..100 or -1                                       */
+	int64_t n_gc_chunks;
+} ngsqc_mapping_params;
+
+/* Runs the scan. counters: int64[NGSQC_NCOUNTERS]. gc_reads: double[101] (may be NULL).
+ * HALF_DEPTH / BASES_COVERED_HALF are left 0 here (they need avg depth): use ngsqc_depth_stats. */
+int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* counters, double* gc_reads);
+
+/* ---- plain depth scan (avgCoverage / lowOrHighCoverage filters) ---- */
+typedef struct ngsqc_depth_params {
+	int32_t min_mapq;
+	int32_t min_baseq;        /* >0: per-base quality mask of BamAlignment::qualities (BamReader.cpp:210-255) */
+	int32_t skip_mismapped;   /* WorkerAverageCoverage.cpp:44                                                 */
+	int32_t reserved;
+	const ngsqc_region* regions; /* merged + sorted */
+	int64_t n_regions;
+} ngsqc_depth_params;
+int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p);
+
+/* ---- consumers of the per-base depth left in HBM by the last ngsqc_scan_mapping / ngsqc_scan_depth ---- */
+/* hist[d] for d in 0..hist_cap (depths > cap are clamped into hist[cap]); covered = #bases with depth >= half_depth */
+int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int64_t* hist, int64_t* covered);
+/* per-base depth, regions concatenated in order (roi_bases int32) */
+int ngsqc_depth_copy(ngsqc_handle* h, int32_t* out, int64_t cap);
+/* BedCoverage: sum of depth over each (possibly overlapping, unmerged) line; every line must lie inside the scanned regions */
+int ngsqc_region_sums(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int64_t* sums);
+/* BedLow/HighCoverage: maximal runs inside each line with depth<cutoff (is_high=0) or depth>=cutoff (is_high=1).
+ * saturate254 reproduces the sweep mode's uchar array (WorkerLowOrHighCoverage.cpp:199-203). Output runs are
+ * (line index, start, end) triples in line order; returns number of runs via n_runs (call with cap=0 to size). */
+typedef struct ngsqc_run { int64_t line; int32_t start; int32_t end; } ngsqc_run;
+int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int32_t cutoff, int32_t is_high,
+                       int32_t saturate254, ngsqc_run* runs, int64_t cap, int64_t* n_runs);
+
+/* ---- measurement: HIP-event timings (ms) of the stages of the last job on this handle ---- */
+typedef struct ngsqc_timings {
+	double h2d_ms, inflate_ms, index_ms, scan_ms, finalize_ms, total_ms;
+	int64_t inflate_launches, scan_launches;
+	int64_t scan_algorithmic_bytes;   /* sum over records of (4 + block_size)  — SURVEY.md §8(d) */
+	int64_t compressed_bytes, inflated_bytes, n_records;
+} ngsqc_timings;
+int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
+
+/* library / device info string (static storage) */
+const char* ngsqc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGSQC_H */

@@ -1,0 +1,10 @@
+"""ngs-bits_amd — MI355X-native BAM mapping-QC / coverage hot path (drop-in for one path of imgag/ngs-bits).
+
+The product is the C-ABI library libngsqc_hip.so (include/ngsqc.h) built from csrc/*.hip plus the C++ host tools under
+host/. This Python package is only a thin ctypes binding used by tests/ and bench.py; it fails loudly if the HIP
+library has not been built (there is no CPU fallback).
+"""
+from .capi import (  # noqa: F401
+    NgsqcError, Handle, Region, MappingParams, lib, lib_path, build_library,
+    MODE_ROI, MODE_NOROI, MODE_WGS, NCOUNTERS, COUNTER_NAMES,
+)

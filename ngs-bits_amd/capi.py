@@ -1,0 +1,233 @@
+"""ctypes binding of include/ngsqc.h (libngsqc_hip.so). Plumbing only — all compute is in the HIP library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+MODE_ROI, MODE_NOROI, MODE_WGS = 0, 1, 2
+NCOUNTERS = 1032
+COUNTER_NAMES = [
+    "al_total", "al_mapped", "al_ontarget", "al_neartarget", "al_dup", "al_proper_paired", "insert_size_read_count",
+    "bases_trimmed", "bases_mapped", "bases_clipped", "insert_size_sum", "bases_usable", "bases_usable_no_overlap",
+    "bases_usable_raw", "bases_usable_roi", "bases_usable_dp0", "bases_usable_dp1", "bases_usable_dp2", "bases_usable_dp3",
+    "bases_usable_dp4", "dp_dist0", "dp_dist1", "dp_dist2", "dp_dist3", "max_length", "paired_end", "roi_bases",
+    "half_depth", "bases_covered_half", "reads_x", "reads_y", "yx_valid",
+]
+
+
+class NgsqcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ngsqc error {code}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+class Region(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
+
+
+class Run(C.Structure):
+    _fields_ = [("line", C.c_int64), ("start", C.c_int32), ("end", C.c_int32)]
+
+
+class MappingParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("min_mapq", C.c_int32), ("tid_x", C.c_int32), ("tid_y", C.c_int32),
+                ("tid_nonspecial", C.c_void_p), ("regions", C.c_void_p), ("n_regions", C.c_int64),
+                ("gc_chunks", C.c_void_p), ("gc_bin", C.c_void_p), ("n_gc_chunks", C.c_int64)]
+
+
+class DepthParams(C.Structure):
+    _fields_ = [("min_mapq", C.c_int32), ("min_baseq", C.c_int32), ("skip_mismapped", C.c_int32), ("reserved", C.c_int32),
+                ("regions", C.c_void_p), ("n_regions", C.c_int64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("inflate_ms", C.c_double), ("index_ms", C.c_double), ("scan_ms", C.c_double),
+                ("finalize_ms", C.c_double), ("total_ms", C.c_double), ("inflate_launches", C.c_int64),
+                ("scan_launches", C.c_int64), ("scan_algorithmic_bytes", C.c_int64), ("compressed_bytes", C.c_int64),
+                ("inflated_bytes", C.c_int64), ("n_records", C.c_int64)]
+
+
+def lib_path():
+    return os.path.join(PKG_DIR, "libngsqc_hip.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(PKG_DIR, "csrc"), "-s", "-j8"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return lib_path()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise NgsqcError(-4, f"{p} is missing: build it with __graft_entry__.build() (there is no CPU fallback)")
+        L = C.CDLL(p)
+        vp, cp, i64, i32 = C.c_void_p, C.c_char_p, C.c_int64, C.c_int
+        L.ngsqc_open.restype = i32; L.ngsqc_open.argtypes = [cp, i32, C.POINTER(vp)]
+        L.ngsqc_open_memory.restype = i32; L.ngsqc_open_memory.argtypes = [vp, C.c_size_t, i32, C.POINTER(vp)]
+        L.ngsqc_close.argtypes = [vp]
+        L.ngsqc_last_error.restype = cp; L.ngsqc_last_error.argtypes = [vp]
+        L.ngsqc_n_ref.restype = i32; L.ngsqc_n_ref.argtypes = [vp]
+        L.ngsqc_ref_name.restype = cp; L.ngsqc_ref_name.argtypes = [vp, i32]
+        L.ngsqc_ref_len.restype = i64; L.ngsqc_ref_len.argtypes = [vp, i32]
+        for f in ("ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size"):
+            getattr(L, f).restype = i64; getattr(L, f).argtypes = [vp]
+        for f in ("ngsqc_decode", "ngsqc_drop_decoded"):
+            getattr(L, f).restype = i32; getattr(L, f).argtypes = [vp]
+        L.ngsqc_copy_inflated.restype = i32; L.ngsqc_copy_inflated.argtypes = [vp, vp, i64]
+        L.ngsqc_copy_record_offsets.restype = i32; L.ngsqc_copy_record_offsets.argtypes = [vp, vp, i64]
+        L.ngsqc_scan_mapping.restype = i32; L.ngsqc_scan_mapping.argtypes = [vp, C.POINTER(MappingParams), vp, vp]
+        L.ngsqc_scan_depth.restype = i32; L.ngsqc_scan_depth.argtypes = [vp, C.POINTER(DepthParams)]
+        L.ngsqc_depth_stats.restype = i32; L.ngsqc_depth_stats.argtypes = [vp, C.c_int32, i64, vp, vp]
+        L.ngsqc_depth_copy.restype = i32; L.ngsqc_depth_copy.argtypes = [vp, vp, i64]
+        L.ngsqc_region_sums.restype = i32; L.ngsqc_region_sums.argtypes = [vp, vp, i64, vp]
+        L.ngsqc_lowhigh_runs.restype = i32
+        L.ngsqc_lowhigh_runs.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, i64, C.POINTER(i64)]
+        L.ngsqc_get_timings.restype = i32; L.ngsqc_get_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.ngsqc_version.restype = cp
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "ngsqc_open", "ngsqc_open_memory", "ngsqc_close", "ngsqc_last_error", "ngsqc_n_ref", "ngsqc_ref_name", "ngsqc_ref_len",
+    "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
+    "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
+    "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
+]
+
+
+def _regions_array(regions):
+    arr = (Region * max(len(regions), 1))()
+    for i, (tid, s, e) in enumerate(regions):
+        arr[i].tid, arr[i].start, arr[i].end = int(tid), int(s), int(e)
+    return arr
+
+
+class Handle:
+    """One open BAM on one GPU (ngsqc_handle)."""
+
+    def __init__(self, path=None, data=None, device=0):
+        L = lib()
+        h = C.c_void_p()
+        if path is not None:
+            rc = L.ngsqc_open(os.fsencode(path), device, C.byref(h))
+        else:
+            buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
+            rc = L.ngsqc_open_memory(buf.ctypes.data, buf.size, device, C.byref(h))
+        if rc != 0:
+            raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ngsqc_close(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NgsqcError(rc, lib().ngsqc_last_error(self.h).decode())
+
+    @property
+    def refs(self):
+        L = lib()
+        return [(L.ngsqc_ref_name(self.h, i).decode(), L.ngsqc_ref_len(self.h, i)) for i in range(L.ngsqc_n_ref(self.h))]
+
+    @property
+    def n_records(self):
+        n = lib().ngsqc_n_records(self.h)
+        if n < 0:
+            self._chk(int(n))
+        return n
+
+    @property
+    def inflated_size(self): return lib().ngsqc_inflated_size(self.h)
+    @property
+    def n_blocks(self): return lib().ngsqc_n_bgzf_blocks(self.h)
+    @property
+    def compressed_size(self): return lib().ngsqc_compressed_size(self.h)
+
+    def decode(self): self._chk(lib().ngsqc_decode(self.h))
+    def drop_decoded(self): self._chk(lib().ngsqc_drop_decoded(self.h))
+
+    def inflated(self):
+        a = np.empty(self.inflated_size, dtype=np.uint8)
+        self._chk(lib().ngsqc_copy_inflated(self.h, a.ctypes.data, a.size))
+        return a
+
+    def record_offsets(self):
+        a = np.empty(self.n_records, dtype=np.int64)
+        self._chk(lib().ngsqc_copy_record_offsets(self.h, a.ctypes.data, a.size))
+        return a
+
+    def scan_mapping(self, mode, regions=None, min_mapq=1, tid_x=-1, tid_y=-1, nonspecial=None, gc_chunks=None, gc_bin=None):
+        """regions / gc_chunks: lists of (tid, start, end), 1-based closed, merged+sorted. Returns (counters, gc_reads)."""
+        p = MappingParams()
+        p.mode, p.min_mapq, p.tid_x, p.tid_y = mode, min_mapq, tid_x, tid_y
+        n_ref = len(self.refs)
+        ns = np.ascontiguousarray(nonspecial if nonspecial is not None else np.zeros(n_ref, np.uint8), dtype=np.uint8)
+        p.tid_nonspecial = ns.ctypes.data
+        keep = [ns]
+        if regions:
+            ra = _regions_array(regions); keep.append(ra)
+            p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions)
+        if gc_chunks:
+            ga = _regions_array(gc_chunks); gb = np.ascontiguousarray(gc_bin, dtype=np.int32); keep += [ga, gb]
+            p.gc_chunks = C.cast(ga, C.c_void_p).value; p.gc_bin = gb.ctypes.data; p.n_gc_chunks = len(gc_chunks)
+        counters = np.zeros(NCOUNTERS, dtype=np.int64)
+        gc = np.zeros(101, dtype=np.float64)
+        self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
+        return counters, gc
+
+    def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False):
+        p = DepthParams()
+        ra = _regions_array(regions)
+        p.min_mapq, p.min_baseq, p.skip_mismapped = min_mapq, min_baseq, int(skip_mismapped)
+        p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions)
+        self._chk(lib().ngsqc_scan_depth(self.h, C.byref(p)))
+
+    def depth_stats(self, hist_cap, half_depth):
+        hist = np.zeros(hist_cap + 1, dtype=np.int64)
+        cov = C.c_int64(0)
+        self._chk(lib().ngsqc_depth_stats(self.h, hist_cap, int(half_depth), hist.ctypes.data, C.addressof(cov)))
+        return hist, cov.value
+
+    def depth(self, roi_bases):
+        out = np.zeros(max(roi_bases, 1), dtype=np.int32)
+        self._chk(lib().ngsqc_depth_copy(self.h, out.ctypes.data, roi_bases))
+        return out[:roi_bases]
+
+    def region_sums(self, lines):
+        la = _regions_array(lines)
+        sums = np.zeros(max(len(lines), 1), dtype=np.int64)
+        self._chk(lib().ngsqc_region_sums(self.h, C.cast(la, C.c_void_p), len(lines), sums.ctypes.data))
+        return sums[:len(lines)]
+
+    def lowhigh_runs(self, lines, cutoff, is_high=False, saturate254=False):
+        la = _regions_array(lines)
+        n = C.c_int64(0)
+        self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), len(lines), cutoff, int(is_high), int(saturate254), None, 0, C.byref(n)))
+        runs = (Run * max(n.value, 1))()
+        if n.value:
+            self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), len(lines), cutoff, int(is_high), int(saturate254),
+                                               C.cast(runs, C.c_void_p), n.value, C.byref(n)))
+        return [(runs[i].line, runs[i].start, runs[i].end) for i in range(n.value)]
+
+    def timings(self):
+        t = Timings()
+        self._chk(lib().ngsqc_get_timings(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timings._fields_}

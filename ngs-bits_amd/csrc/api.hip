@@ -1,0 +1,617 @@
+// Host side of libngsqc_hip.so: the C ABI of include/ngsqc.h on top of the HIP kernels (K1 inflate.hip, K2 index.hip,
+// K3-K5 scan.hip, K6 depth.hip). Owns the compressed image, the inflated stream, the record index and the depth array
+// in HBM; one HIP stream per handle; stage times are taken with HIP events on that stream.
+// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails with
+// NGSQC_E_DEVICE.
+#include "common.h"
+#include <algorithm>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+using namespace ngsqc;
+
+namespace {
+thread_local std::string g_open_error;
+
+struct FormatError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+template <typename T> struct DevBuf
+{
+	T* p = nullptr; size_t n = 0;
+	void alloc(size_t count) { release(); if (count) { HIPCHK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
+	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+	void upload(const std::vector<T>& v, hipStream_t s) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
+	~DevBuf() { release(); }
+	DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Timer
+{
+	hipEvent_t a = nullptr, b = nullptr; hipStream_t s;
+	explicit Timer(hipStream_t st) : s(st) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); }
+	~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+	void start() { HIPCHK(hipEventRecord(a, s)); }
+	double stop() { HIPCHK(hipEventRecord(b, s)); HIPCHK(hipEventSynchronize(b)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); return ms; }
+};
+
+uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+} // namespace
+
+struct ngsqc_handle
+{
+	std::string err, path;
+	int device = 0; hipStream_t stream = nullptr;
+	size_t csize = 0;
+	std::vector<BlockDesc> blocks; int64_t total = 0;
+	DevBuf<uint8_t> d_comp; DevBuf<BlockDesc> d_blocks;
+	// decoded state
+	bool decoded = false;
+	DevBuf<uint8_t> d_infl; DevBuf<BlockStatus> d_status; DevBuf<int64_t> d_recoff; int64_t n_rec = 0; int64_t first_rec = 0;
+	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
+	// region / depth state of the last scan
+	std::vector<ngsqc_region> regions; std::vector<int64_t> doff; std::vector<int32_t> rlen; int64_t n_slots = 0; int64_t roi_bases = 0;
+	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth;
+	bool depth_ready = false;
+	ngsqc_timings tm{};
+};
+
+namespace {
+
+// ---- BGZF member table (host): SAM spec §4.1 ----
+void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, int64_t& total)
+{
+	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+	size_t off = 0; uint64_t upos = 0;
+	while (off < n)
+	{
+		if (off + 18 > n) throw FormatError("truncated BGZF header");
+		const uint8_t* p = file + off;
+		if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) throw FormatError("not a BGZF block (gzip member without BC extra field)");
+		uint32_t xlen = rd16(p + 10), bsize = 0; bool found = false;
+		size_t x = 12, xend = 12 + (size_t)xlen;
+		if (off + xend > n) throw FormatError("truncated BGZF extra field");
+		while (x + 4 <= xend) { uint16_t slen = rd16(p + x + 2); if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) { bsize = rd16(p + x + 4) + 1u; found = true; } x += 4 + slen; }
+		if (!found || bsize < xend + 8 || off + bsize > n) throw FormatError("invalid BGZF block size");
+		uint32_t isize = rd32(p + bsize - 4);
+		if (isize > 65536) throw FormatError("BGZF block inflates to more than 64 KiB");
+		if (isize) blocks.push_back(BlockDesc{(uint64_t)(off + xend), upos, (uint32_t)(bsize - xend - 8), isize});
+		upos += isize; off += bsize;
+	}
+	total = (int64_t)upos;
+}
+
+void init_device(ngsqc_handle* h, int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw std::runtime_error("no HIP device available (libngsqc_hip has no CPU fallback)");
+	if (device < 0 || device >= n) throw ArgError("invalid HIP device ordinal");
+	h->device = device;
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+}
+
+void check_inflate(ngsqc_handle* h, int64_t n_blocks)
+{
+	std::vector<BlockStatus> st((size_t)n_blocks);
+	HIPCHK(hipMemcpyAsync(st.data(), h->d_status.p, st.size() * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	for (int64_t i = 0; i < n_blocks; ++i)
+		if (st[i].error) throw FormatError("BGZF inflate failed in block " + std::to_string(i) + " (code " + std::to_string(st[i].error) + ")");
+}
+
+// inflate the first members until the BAM header (magic, text, reference table) is complete; parse it
+void read_header(ngsqc_handle* h)
+{
+	int64_t k = std::min<int64_t>(8, (int64_t)h->blocks.size());
+	while (true)
+	{
+		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
+		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
+		h->d_status.alloc((size_t)std::max<int64_t>(k, 1));
+		launch_inflate(h->d_comp.p, h->d_blocks.p, k, tmp.p, h->d_status.p, h->stream);
+		check_inflate(h, k);
+		std::vector<uint8_t> hb((size_t)bytes);
+		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
+		bool complete = false;
+		do
+		{
+			if (bytes < 12) break;
+			if (memcmp(hb.data(), "BAM\1", 4) != 0) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
+			size_t o = 4; uint32_t l_text = rd32(&hb[o]); o += 4 + (size_t)l_text;
+			if (o + 4 > (size_t)bytes) break;
+			uint32_t n_ref = rd32(&hb[o]); o += 4;
+			std::vector<std::string> names; std::vector<int64_t> lens; bool ok = true;
+			for (uint32_t i = 0; i < n_ref; ++i)
+			{
+				if (o + 4 > (size_t)bytes) { ok = false; break; }
+				uint32_t l_name = rd32(&hb[o]); o += 4;
+				if (o + l_name + 4 > (size_t)bytes) { ok = false; break; }
+				names.emplace_back((const char*)&hb[o], l_name ? l_name - 1 : 0); o += l_name;
+				lens.push_back(rd32(&hb[o])); o += 4;
+			}
+			if (!ok) break;
+			h->ref_names.swap(names); h->ref_lens.swap(lens); h->first_rec = (int64_t)o; complete = true;
+		} while (false);
+		if (complete) return;
+		if (k >= (int64_t)h->blocks.size()) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
+		k = std::min<int64_t>(k * 4, (int64_t)h->blocks.size());
+	}
+}
+
+void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device)
+{
+	h->csize = n;
+	scan_bgzf(bytes, n, h->blocks, h->total);
+	init_device(h, device);
+	Timer t(h->stream); t.start();
+	h->d_comp.alloc(n + 64);
+	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 64, h->stream));
+	if (n) HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes, n, hipMemcpyHostToDevice, h->stream));
+	h->d_blocks.upload(h->blocks, h->stream);
+	h->tm.h2d_ms = t.stop();
+	h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
+	read_header(h);
+}
+
+void do_decode(ngsqc_handle* h)
+{
+	if (h->decoded) return;
+	HIPCHK(hipSetDevice(h->device));
+	const int64_t nb = (int64_t)h->blocks.size();
+	Timer t(h->stream);
+	// ---- K1 ----
+	h->d_infl.alloc((size_t)h->total + 64);
+	h->d_status.alloc((size_t)std::max<int64_t>(nb, 1));
+	t.start();
+	launch_inflate(h->d_comp.p, h->d_blocks.p, nb, h->d_infl.p, h->d_status.p, h->stream);
+	h->tm.inflate_ms = t.stop(); h->tm.inflate_launches = 1;
+	check_inflate(h, nb);
+	// ---- K2 ----
+	t.start();
+	std::vector<int32_t> start((size_t)nb);
+	for (int64_t b = 0; b < nb; ++b)
+	{
+		int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
+		start[b] = hi <= h->first_rec ? -1 : (lo <= h->first_rec ? (int32_t)(h->first_rec - lo) : -2);
+	}
+	DevBuf<int32_t> d_start; d_start.upload(start, h->stream);
+	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)nb + 1);
+	DevBuf<int64_t> d_next; d_next.alloc((size_t)nb + 1);
+	DevBuf<uint32_t> d_bad; d_bad.alloc(1);
+	std::vector<int64_t> next((size_t)nb);
+	int64_t from = 0; int rounds = 0;
+	while (nb > 0)
+	{
+		HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), h->stream));
+		launch_index_count(h->d_infl.p, h->total, h->d_blocks.p + from, nb - from, d_start.p + from, d_cnt.p + from, d_next.p + from, d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+		HIPCHK(hipMemcpyAsync(start.data() + from, d_start.p + from, (size_t)(nb - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(nb - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		// exact verification of the chain: every member's exit must land on the next member's start
+		int64_t expected = h->first_rec; int64_t mismatch = -1;
+		for (int64_t b = 0; b < nb; ++b)
+		{
+			int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
+			int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
+			if (start[b] != want) { mismatch = b; start[b] = want; break; }
+			if (want >= 0)
+			{
+				if (next[b] == -2) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
+				expected = next[b];
+			}
+		}
+		if (mismatch < 0)
+		{
+			if (expected != h->total) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
+			break;
+		}
+		if (++rounds > 100000) throw FormatError("could not resolve the BAM record chain");
+		HIPCHK(hipMemcpyAsync(d_start.p + mismatch, &start[mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		from = mismatch;
+	}
+	DevBuf<int64_t> d_base; d_base.alloc((size_t)nb + 1);
+	DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(nb) + 64);
+	launch_scan_counts(d_cnt.p, nb, d_base.p, d_tmp.p, h->stream);
+	int64_t n_rec = 0;
+	HIPCHK(hipMemcpyAsync(&n_rec, d_base.p + nb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	h->n_rec = n_rec;
+	h->d_recoff.alloc((size_t)std::max<int64_t>(n_rec, 1));
+	launch_index_write(h->d_infl.p, h->d_blocks.p, nb, d_start.p, d_base.p, h->d_recoff.p, h->stream);
+	h->tm.index_ms = t.stop();
+	h->tm.n_records = n_rec;
+	h->decoded = true;
+}
+
+// regions -> device tables. Regions must be sorted by start within a tid, non-overlapping, and each tid contiguous.
+void setup_regions(ngsqc_handle* h, const ngsqc_region* regions, int64_t n)
+{
+	const int n_ref = (int)h->ref_names.size();
+	h->regions.assign(regions, regions + (n > 0 ? n : 0));
+	h->doff.assign((size_t)n + 1, 0); h->rlen.assign((size_t)n, 0);
+	std::vector<int32_t> rs((size_t)n), re((size_t)n), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
+	std::vector<uint8_t> seen((size_t)std::max(n_ref, 1), 0);
+	int64_t slots = 0, bases = 0;
+	for (int64_t i = 0; i < n; ++i)
+	{
+		const ngsqc_region& r = regions[i];
+		if (r.tid < 0 || r.tid >= n_ref) throw ArgError("region with invalid reference id");
+		if (r.start < 1 || r.end < r.start) throw ArgError("invalid region range");
+		if (i > 0 && regions[i - 1].tid == r.tid) { if (regions[i - 1].end >= r.start) throw ArgError("Merged and sorted BED file required for coverage details statistics!"); }
+		else { if (seen[r.tid]) throw ArgError("Merged and sorted BED file required for coverage details statistics!"); seen[r.tid] = 1; tf[r.tid] = (int32_t)i; }
+		tl[r.tid] = (int32_t)i + 1;
+		rs[i] = r.start; re[i] = r.end; h->rlen[i] = r.end - r.start + 1; h->doff[i] = slots;
+		slots += (int64_t)h->rlen[i] + 1; bases += h->rlen[i];
+	}
+	h->doff[n] = slots; h->n_slots = slots; h->roi_bases = bases;
+	h->d_reg_start.upload(rs, h->stream); h->d_reg_end.upload(re, h->stream); h->d_reg_len.upload(h->rlen, h->stream);
+	h->d_tid_first.upload(tf, h->stream); h->d_tid_last.upload(tl, h->stream);
+	std::vector<int64_t> doff(h->doff.begin(), h->doff.begin() + n);
+	h->d_doff.upload(doff, h->stream);
+	h->d_depth.alloc((size_t)slots + 1);
+	HIPCHK(hipMemsetAsync(h->d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
+	h->depth_ready = false;
+}
+
+void finalize_depth(ngsqc_handle* h)
+{
+	if (h->n_slots > 0)
+	{
+		DevBuf<uint8_t> tmp; tmp.alloc(scan_tmp_bytes(h->n_slots) + 64);
+		launch_depth_prefix(h->d_depth.p, h->n_slots, tmp.p, h->stream);
+		launch_depth_mark_spare(h->d_depth.p, h->d_doff.p, h->d_reg_len.p, (int64_t)h->regions.size(), h->stream);
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	h->depth_ready = true;
+}
+
+struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
+
+void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev)
+{
+	DevBuf<unsigned long long> d_counters; d_counters.alloc(A_DEV_TOTAL);
+	std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
+	HIPCHK(hipMemcpyAsync(d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	DevBuf<int64_t> d_long; d_long.alloc((size_t)std::max<int64_t>(h->n_rec, 1));
+	sp.infl = h->d_infl.p; sp.total = h->total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec;
+	sp.counters = d_counters.p; sp.diff = h->d_depth.p; sp.long_list = d_long.p; sp.long_cap = h->n_rec;
+	sp.n_ref = (int32_t)h->ref_names.size();
+	Timer t(h->stream); t.start();
+	launch_scan(sp, h->stream);
+	unsigned long long n_long = 0;
+	HIPCHK(hipMemcpyAsync(&n_long, d_counters.p + A_LONG_COUNT, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	h->tm.scan_launches = 1;
+	if (n_long) { launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_launches++; }
+	dev.assign(A_DEV_TOTAL, 0ull);
+	HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	if (sp.mode != MODE_DEPTH)
+	{
+		// order-dependent carries: running maximum of the read length and "a paired read has been seen"
+		const unsigned long long key = dev[A_FIRST_MAX_KEY];
+		const int gmax = (int)(key >> 40);
+		const int64_t f = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : 0;
+		const int64_t pidx = (sp.mode != NGSQC_MODE_ROI && dev[A_FIRST_PAIRED] != ~0ull) ? (int64_t)dev[A_FIRST_PAIRED] : 0;
+		if (f > 0 || pidx > 0)
+		{
+			launch_prefix_fix(sp, f, pidx, gmax, h->stream);
+			HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+		}
+	}
+	h->tm.scan_ms = t.stop();
+	h->tm.scan_algorithmic_bytes = (int64_t)dev[A_ALG_BYTES];
+}
+
+template <typename F> int guarded(ngsqc_handle* h, F f)
+{
+	if (!h) return NGSQC_E_ARG;
+	try { HIPCHK(hipSetDevice(h->device)); f(); return NGSQC_OK; }
+	catch (FormatError& e) { h->err = e.what(); return NGSQC_E_FORMAT; }
+	catch (ArgError& e) { h->err = e.what(); return NGSQC_E_ARG; }
+	catch (IoError& e) { h->err = e.what(); return NGSQC_E_IO; }
+	catch (std::domain_error& e) { h->err = e.what(); return NGSQC_E_UNSUPPORTED; }
+	catch (std::exception& e) { h->err = e.what(); return NGSQC_E_DEVICE; }
+}
+
+int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n, int device)
+{
+	if (!out) return NGSQC_E_ARG;
+	*out = nullptr;
+	ngsqc_handle* h = new ngsqc_handle();
+	int rc = NGSQC_OK;
+	void* map = nullptr; size_t map_n = 0; int fd = -1;
+	try
+	{
+		if (path)
+		{
+			h->path = path;
+			fd = ::open(path, O_RDONLY);
+			if (fd < 0) throw IoError(std::string("Could not open BAM/CRAM file ") + path);
+			struct stat st; if (fstat(fd, &st) != 0) throw IoError(std::string("Could not open BAM/CRAM file ") + path);
+			map_n = (size_t)st.st_size;
+			if (map_n)
+			{
+				map = mmap(nullptr, map_n, PROT_READ, MAP_PRIVATE, fd, 0);
+				if (map == MAP_FAILED) { map = nullptr; throw IoError(std::string("Could not open BAM/CRAM file ") + path); }
+			}
+			bytes = map; n = map_n;
+		}
+		else h->path = "<memory>";
+		if (!bytes && n) throw ArgError("null BAM buffer");
+		open_common(h, (const uint8_t*)bytes, n, device);
+	}
+	catch (FormatError& e) { g_open_error = e.what(); rc = NGSQC_E_FORMAT; }
+	catch (ArgError& e) { g_open_error = e.what(); rc = NGSQC_E_ARG; }
+	catch (IoError& e) { g_open_error = e.what(); rc = NGSQC_E_IO; }
+	catch (std::domain_error& e) { g_open_error = e.what(); rc = NGSQC_E_UNSUPPORTED; }
+	catch (std::exception& e) { g_open_error = e.what(); rc = NGSQC_E_DEVICE; }
+	if (map) munmap(map, map_n);
+	if (fd >= 0) ::close(fd);
+	if (rc != NGSQC_OK) { ngsqc_close(h); return rc; }
+	*out = h;
+	return NGSQC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ngsqc_open(const char* bam_path, int device, ngsqc_handle** out) { if (!bam_path) return NGSQC_E_ARG; return open_impl(out, bam_path, nullptr, 0, device); }
+int ngsqc_open_memory(const void* bam_bytes, size_t n_bytes, int device, ngsqc_handle** out) { return open_impl(out, nullptr, bam_bytes, n_bytes, device); }
+
+void ngsqc_close(ngsqc_handle* h)
+{
+	if (!h) return;
+	if (h->stream) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+	delete h;
+}
+
+const char* ngsqc_last_error(const ngsqc_handle* h) { return h ? h->err.c_str() : g_open_error.c_str(); }
+int ngsqc_n_ref(const ngsqc_handle* h) { return h ? (int)h->ref_names.size() : 0; }
+const char* ngsqc_ref_name(const ngsqc_handle* h, int tid) { return (h && tid >= 0 && tid < (int)h->ref_names.size()) ? h->ref_names[tid].c_str() : nullptr; }
+int64_t ngsqc_ref_len(const ngsqc_handle* h, int tid) { return (h && tid >= 0 && tid < (int)h->ref_lens.size()) ? h->ref_lens[tid] : -1; }
+int64_t ngsqc_n_bgzf_blocks(const ngsqc_handle* h) { return h ? (int64_t)h->blocks.size() : 0; }
+int64_t ngsqc_compressed_size(const ngsqc_handle* h) { return h ? (int64_t)h->csize : 0; }
+int64_t ngsqc_inflated_size(ngsqc_handle* h) { return h ? h->total : 0; }
+int64_t ngsqc_n_records(ngsqc_handle* h) { int rc = guarded(h, [&] { do_decode(h); }); return rc == NGSQC_OK ? h->n_rec : (int64_t)rc; }
+
+int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { do_decode(h); }); }
+int ngsqc_drop_decoded(ngsqc_handle* h)
+{
+	return guarded(h, [&] { h->d_infl.release(); h->d_recoff.release(); h->d_status.release(); h->decoded = false; h->depth_ready = false; h->n_rec = 0; });
+}
+
+int ngsqc_copy_inflated(ngsqc_handle* h, uint8_t* out, int64_t cap)
+{
+	return guarded(h, [&] { do_decode(h); int64_t n = std::min(cap, h->total); if (n > 0) HIPCHK(hipMemcpy(out, h->d_infl.p, (size_t)n, hipMemcpyDeviceToHost)); });
+}
+int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap)
+{
+	return guarded(h, [&] { do_decode(h); int64_t n = std::min(cap, h->n_rec); if (n > 0) HIPCHK(hipMemcpy(out, h->d_recoff.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost)); });
+}
+
+int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* counters, double* gc_reads)
+{
+	return guarded(h, [&] {
+		if (!p || !counters) throw ArgError("null argument");
+		if (p->mode < NGSQC_MODE_ROI || p->mode > NGSQC_MODE_WGS) throw ArgError("invalid mode");
+		if (p->mode == NGSQC_MODE_ROI && (!p->regions || p->n_regions <= 0)) throw ArgError("target-region mode needs regions");
+		Timer total(h->stream); total.start();
+		do_decode(h);
+		const int n_ref = (int)h->ref_names.size();
+		const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
+		setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
+		ScanParams sp{};
+		sp.mode = p->mode; sp.min_mapq = p->min_mapq; sp.min_baseq = 0; sp.skip_mismapped = 0;
+		sp.tid_x = p->tid_x; sp.tid_y = p->tid_y;
+		const bool yx = p->tid_x >= 0 && p->tid_x < n_ref && p->tid_y >= 0 && p->tid_y < n_ref;
+		if (!yx) { sp.tid_x = -2; sp.tid_y = -2; }
+		sp.len_x = yx ? h->ref_lens[p->tid_x] : 0; sp.len_y = yx ? h->ref_lens[p->tid_y] : 0;
+		std::vector<uint8_t> ns((size_t)std::max(n_ref, 1), 0);
+		if (p->tid_nonspecial) for (int i = 0; i < n_ref; ++i) ns[i] = p->tid_nonspecial[i];
+		DevBuf<uint8_t> d_ns; d_ns.upload(ns, h->stream); sp.tid_nonspecial = d_ns.p;
+		sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
+		sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
+		// GC chunks
+		GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
+		const bool use_gc = use_regions && p->gc_chunks && p->gc_bin && p->n_gc_chunks > 0;
+		d_gctab.alloc(101 * GC_NMAX); d_gcover.alloc(101);
+		HIPCHK(hipMemsetAsync(d_gctab.p, 0, 101 * GC_NMAX * sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_gcover.p, 0, 101 * sizeof(double), h->stream));
+		if (use_gc)
+		{
+			const int64_t n = p->n_gc_chunks;
+			std::vector<int32_t> s((size_t)n), e((size_t)n), b((size_t)n), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
+			for (int64_t i = 0; i < n; ++i)
+			{
+				const ngsqc_region& r = p->gc_chunks[i];
+				if (r.tid < 0 || r.tid >= n_ref) throw ArgError("GC chunk with invalid reference id");
+				if (i == 0 || p->gc_chunks[i - 1].tid != r.tid) tf[r.tid] = (int32_t)i;
+				tl[r.tid] = (int32_t)i + 1;
+				s[i] = r.start; e[i] = r.end; b[i] = p->gc_bin[i] > 100 ? -1 : p->gc_bin[i];
+			}
+			gc.start.upload(s, h->stream); gc.end.upload(e, h->stream); gc.bin.upload(b, h->stream); gc.tf.upload(tf, h->stream); gc.tl.upload(tl, h->stream);
+			sp.gc_start = gc.start.p; sp.gc_end = gc.end.p; sp.gc_bin = gc.bin.p; sp.tid_gc_first = gc.tf.p; sp.tid_gc_last = gc.tl.p; sp.n_gc = n;
+		}
+		sp.gc_tab = d_gctab.p; sp.gc_over = d_gcover.p;
+		std::vector<unsigned long long> dev;
+		run_scan(h, sp, dev);
+		Timer fin(h->stream); fin.start();
+		finalize_depth(h);
+		h->tm.finalize_ms = fin.stop();
+
+		// ---- device accumulators -> the reference's counters ----
+		auto S = [&](int i) { return (int64_t)dev[i]; };
+		for (int i = 0; i < NGSQC_NCOUNTERS; ++i) counters[i] = 0;
+		const int gmax = (int)(dev[A_FIRST_MAX_KEY] >> 40);
+		const bool paired_end = dev[A_FIRST_PAIRED] != ~0ull;
+		counters[NGSQC_C_AL_TOTAL] = S(A_TOTAL); counters[NGSQC_C_AL_MAPPED] = S(A_MAPPED); counters[NGSQC_C_AL_ONTARGET] = S(A_ONTARGET);
+		counters[NGSQC_C_AL_NEARTARGET] = S(A_NEAR); counters[NGSQC_C_AL_DUP] = S(A_DUP); counters[NGSQC_C_AL_PROPER_PAIRED] = S(A_PP);
+		counters[NGSQC_C_INSERT_SIZE_READ_COUNT] = S(A_INS_CNT);
+		counters[NGSQC_C_BASES_TRIMMED] = S(A_TOTAL) * gmax - S(A_SUM_LEN) - S(A_FIX_TRIM);
+		counters[NGSQC_C_BASES_MAPPED] = S(A_BASES_MAPPED); counters[NGSQC_C_BASES_CLIPPED] = S(A_CLIPPED); counters[NGSQC_C_INSERT_SIZE_SUM] = S(A_INS_SUM);
+		if (p->mode == NGSQC_MODE_ROI)
+		{
+			counters[NGSQC_C_BASES_USABLE] = S(A_USABLE);
+			counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = S(A_NO_OVERLAP);
+		}
+		else
+		{
+			counters[NGSQC_C_BASES_USABLE] = S(A_USABLE) - S(A_CLIPPED);                        // Statistics.cpp:917 / :1183
+			counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = (paired_end ? S(A_USABLE) - S(A_FIX_LEN) : 0) + S(A_NO_OVERLAP); // :879,:898-901
+		}
+		counters[NGSQC_C_BASES_USABLE_RAW] = S(A_USABLE_RAW); counters[NGSQC_C_BASES_USABLE_ROI] = S(A_USABLE_ROI);
+		for (int i = 0; i < 5; ++i) counters[NGSQC_C_BASES_USABLE_DP0 + i] = S(A_DP0 + i);
+		for (int i = 0; i < 4; ++i) counters[NGSQC_C_DP_DIST0 + i] = S(A_DD0 + i);
+		counters[NGSQC_C_MAX_LENGTH] = gmax; counters[NGSQC_C_PAIRED_END] = paired_end ? 1 : 0;
+		counters[NGSQC_C_ROI_BASES] = h->roi_bases;
+		counters[NGSQC_C_READS_X] = yx ? S(A_READS_X) : 0; counters[NGSQC_C_READS_Y] = yx ? S(A_READS_Y) : 0;
+		counters[NGSQC_C_YX_VALID] = (yx && S(A_READS_X) != 0) ? 1 : 0;
+		for (int i = 0; i < 1000; ++i) counters[NGSQC_C_INSERT_HIST0 + i] = S(A_HIST0 + i);
+		if (gc_reads)
+		{
+			std::vector<unsigned long long> tab(101 * GC_NMAX); std::vector<double> over(101);
+			HIPCHK(hipMemcpy(tab.data(), d_gctab.p, tab.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(over.data(), d_gcover.p, over.size() * sizeof(double), hipMemcpyDeviceToHost));
+			for (int b = 0; b <= 100; ++b)
+			{
+				double v = over[b];
+				for (int n = 1; n < GC_NMAX; ++n) if (tab[(size_t)b * GC_NMAX + n]) v += (double)tab[(size_t)b * GC_NMAX + n] * (1.0 / (double)n);
+				gc_reads[b] = v;
+			}
+		}
+		h->tm.total_ms = total.stop();
+	});
+}
+
+int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p)
+{
+	return guarded(h, [&] {
+		if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
+		Timer total(h->stream); total.start();
+		do_decode(h);
+		setup_regions(h, p->regions, p->n_regions);
+		ScanParams sp{};
+		sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;
+		sp.tid_x = -2; sp.tid_y = -2;
+		sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
+		sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
+		std::vector<unsigned long long> dev;
+		run_scan(h, sp, dev);
+		Timer fin(h->stream); fin.start();
+		finalize_depth(h);
+		h->tm.finalize_ms = fin.stop();
+		h->tm.total_ms = total.stop();
+	});
+}
+
+int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int64_t* hist, int64_t* covered)
+{
+	return guarded(h, [&] {
+		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
+		if (hist_cap < 0 || hist_cap > 30000 || !hist || !covered) throw ArgError("invalid histogram request");
+		DevBuf<unsigned long long> d_hist; d_hist.alloc((size_t)hist_cap + 2);
+		HIPCHK(hipMemsetAsync(d_hist.p, 0, ((size_t)hist_cap + 2) * sizeof(unsigned long long), h->stream));
+		launch_depth_hist(h->d_depth.p, h->n_slots, hist_cap, half_depth, d_hist.p, d_hist.p + hist_cap + 1, h->stream);
+		std::vector<unsigned long long> out((size_t)hist_cap + 2);
+		HIPCHK(hipMemcpyAsync(out.data(), d_hist.p, out.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		for (int i = 0; i <= hist_cap; ++i) hist[i] = (int64_t)out[i];
+		*covered = (int64_t)out[(size_t)hist_cap + 1];
+	});
+}
+
+int ngsqc_depth_copy(ngsqc_handle* h, int32_t* out, int64_t cap)
+{
+	return guarded(h, [&] {
+		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
+		if (cap < h->roi_bases) throw ArgError("depth buffer too small");
+		if (h->roi_bases == 0) return;
+		DevBuf<int32_t> d_out; d_out.alloc((size_t)h->roi_bases);
+		launch_depth_compact(h->d_depth.p, h->d_doff.p, h->d_reg_len.p, (int64_t)h->regions.size(), d_out.p, h->stream);
+		HIPCHK(hipMemcpyAsync(out, d_out.p, (size_t)h->roi_bases * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+
+namespace {
+// locate each line inside the scanned (merged) regions: slot offset of its first base
+void locate_lines(ngsqc_handle* h, const ngsqc_region* lines, int64_t n, std::vector<int64_t>& slot, std::vector<int32_t>& len, std::vector<int32_t>& lstart)
+{
+	slot.resize((size_t)n); len.resize((size_t)n); lstart.resize((size_t)n);
+	const auto& R = h->regions;
+	std::vector<std::pair<int32_t, int32_t>> group(h->ref_names.size(), {0, 0}); // per tid: [first,last) in R
+	for (size_t k = 0; k < R.size();) { size_t e = k; while (e < R.size() && R[e].tid == R[k].tid) ++e; group[R[k].tid] = {(int32_t)k, (int32_t)e}; k = e; }
+	for (int64_t i = 0; i < n; ++i)
+	{
+		const ngsqc_region& l = lines[i];
+		if (l.start < 1 || l.end < l.start) throw ArgError("invalid line range");
+		if (l.tid < 0 || l.tid >= (int32_t)group.size()) throw ArgError("line with invalid reference id");
+		int lo = group[l.tid].first, last = group[l.tid].second, hi = last;
+		while (lo < hi) { int m = (lo + hi) / 2; if (R[m].end < l.start) lo = m + 1; else hi = m; }
+		if (!(lo < last && R[lo].start <= l.start && R[lo].end >= l.end)) throw ArgError("line is not covered by the scanned regions");
+		slot[i] = h->doff[lo] + (l.start - R[lo].start); len[i] = l.end - l.start + 1; lstart[i] = l.start;
+	}
+}
+}
+
+int ngsqc_region_sums(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int64_t* sums)
+{
+	return guarded(h, [&] {
+		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
+		if (n_lines <= 0) return;
+		if (!lines || !sums) throw ArgError("null argument");
+		std::vector<int64_t> slot; std::vector<int32_t> len, ls;
+		locate_lines(h, lines, n_lines, slot, len, ls);
+		DevBuf<int64_t> d_slot; d_slot.upload(slot, h->stream);
+		DevBuf<int32_t> d_len; d_len.upload(len, h->stream);
+		DevBuf<long long> d_sums; d_sums.alloc((size_t)n_lines);
+		launch_line_sums(h->d_depth.p, d_slot.p, d_len.p, n_lines, d_sums.p, h->stream);
+		HIPCHK(hipMemcpyAsync(sums, d_sums.p, (size_t)n_lines * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+
+int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int32_t cutoff, int32_t is_high, int32_t saturate254,
+                       ngsqc_run* runs, int64_t cap, int64_t* n_runs)
+{
+	return guarded(h, [&] {
+		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
+		if (!n_runs) throw ArgError("null argument");
+		*n_runs = 0;
+		if (n_lines <= 0) return;
+		std::vector<int64_t> slot; std::vector<int32_t> len, ls;
+		locate_lines(h, lines, n_lines, slot, len, ls);
+		DevBuf<int64_t> d_slot; d_slot.upload(slot, h->stream);
+		DevBuf<int32_t> d_len; d_len.upload(len, h->stream);
+		DevBuf<int32_t> d_ls; d_ls.upload(ls, h->stream);
+		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_lines + 1);
+		DevBuf<int64_t> d_base; d_base.alloc((size_t)n_lines + 1);
+		DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(n_lines) + 64);
+		launch_line_runs(false, h->d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, nullptr, nullptr, h->stream);
+		launch_scan_counts(d_cnt.p, n_lines, d_base.p, d_tmp.p, h->stream);
+		int64_t total = 0;
+		HIPCHK(hipMemcpyAsync(&total, d_base.p + n_lines, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		*n_runs = total;
+		if (!runs || cap < total || total == 0) return;
+		DevBuf<ngsqc_run> d_runs; d_runs.alloc((size_t)total);
+		launch_line_runs(true, h->d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, d_base.p, d_runs.p, h->stream);
+		HIPCHK(hipMemcpyAsync(runs, d_runs.p, (size_t)total * sizeof(ngsqc_run), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+
+int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t) { if (!h || !t) return NGSQC_E_ARG; *t = h->tm; return NGSQC_OK; }
+
+const char* ngsqc_version(void) { return "ngsqc-hip 0.1 (gfx950; K1 bgzf_inflate, K2 bam_record_index, K3-K5 scan, K6 depth)"; }
+
+} // extern "C"

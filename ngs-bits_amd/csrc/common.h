@@ -1,0 +1,81 @@
+// Shared declarations of the HIP hot path (libngsqc_hip.so). gfx950 only — no CUDA paths, no compat shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/ngsqc.h"
+
+namespace ngsqc {
+
+// One BGZF member as the device sees it (SAM spec §4.1). cpos = byte offset of the raw DEFLATE payload inside the
+// compressed image in HBM, clen = payload bytes, upos/usize = where its output goes in the inflated stream.
+struct BlockDesc { uint64_t cpos; uint64_t upos; uint32_t clen; uint32_t usize; };
+
+// Per-member result of K1: bytes produced (must equal usize) and an error code (0 = ok).
+struct BlockStatus { uint32_t produced; uint32_t error; };
+
+// ---- K1 ----
+void launch_inflate(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status, hipStream_t s);
+
+// ---- K2 ----
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s);
+void launch_index_write(const uint8_t* d_infl, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+                        const int64_t* d_base, int64_t* d_recoff, hipStream_t s);
+void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
+void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
+size_t scan_tmp_bytes(int64_t n);
+
+// ---- K3-K5 ----
+constexpr int GC_NMAX = 64;      // (bin, n) integer hit table for reads overlapping n < GC_NMAX GC chunks
+constexpr int LONG_CIGAR = 64;   // records with more CIGAR ops go to the wave-per-record kernel
+constexpr int MODE_DEPTH = 3;
+
+// device accumulator slots (scan.hip); the host side of the library maps them onto NGSQC_C_*
+enum { A_TOTAL, A_MAPPED, A_ONTARGET, A_NEAR, A_DUP, A_PP, A_INS_CNT, A_SUM_LEN, A_BASES_MAPPED, A_CLIPPED, A_INS_SUM,
+       A_USABLE, A_NO_OVERLAP, A_USABLE_RAW, A_USABLE_ROI, A_DP0, A_DP1, A_DP2, A_DP3, A_DP4, A_DD0, A_DD1, A_DD2, A_DD3,
+       A_READS_X, A_READS_Y, A_ALG_BYTES, A_COUNT,
+       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
+
+struct ScanParams
+{
+	int32_t mode;            // NGSQC_MODE_* or MODE_DEPTH
+	int32_t min_mapq, min_baseq, skip_mismapped;
+	int32_t tid_x, tid_y, n_ref;
+	int64_t len_x, len_y;
+	const uint8_t* tid_nonspecial;     // [n_ref]
+	// target regions (merged, sorted by tid then start) + per-tid index ranges [first,last)
+	const int32_t* reg_start; const int32_t* reg_end; const int64_t* reg_doff; // doff: first slot of the region in the diff array (len+1 slots each)
+	const int32_t* tid_reg_first; const int32_t* tid_reg_last;
+	int64_t n_regions;
+	// GC chunks (roi.chunk(100))
+	const int32_t* gc_start; const int32_t* gc_end; const int32_t* gc_bin;
+	const int32_t* tid_gc_first; const int32_t* tid_gc_last; int64_t n_gc;
+	// data
+	const uint8_t* infl; int64_t total; const int64_t* recoff; int64_t n_rec;
+	// outputs
+	unsigned long long* counters;  // [A_DEV_TOTAL]
+	int32_t* diff;                 // difference array -> depth
+	unsigned long long* gc_tab;    // [101][GC_NMAX]
+	double* gc_over;               // [101]
+	int64_t* long_list; int64_t long_cap;
+};
+
+void launch_scan(const ScanParams& p, hipStream_t s);
+void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, int32_t gmax, hipStream_t s);
+
+// ---- K6 ----
+void launch_depth_mark_spare(int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, hipStream_t s);
+void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int64_t half, unsigned long long* d_hist, unsigned long long* d_cov, hipStream_t s);
+void launch_depth_compact(const int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, int32_t* d_out, hipStream_t s);
+void launch_line_sums(const int32_t* d_depth, const int64_t* d_slot, const int32_t* d_n, int64_t n_lines, long long* d_sums, hipStream_t s);
+void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot, const int32_t* d_n, const int32_t* d_line_start, int64_t n_lines,
+                      int32_t cutoff, int32_t is_high, int32_t sat, uint32_t* d_cnt, const int64_t* d_base, ngsqc_run* d_runs, hipStream_t s);
+
+} // namespace ngsqc
+
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); } } while (0)

@@ -1,0 +1,183 @@
+// K2 — BAM record index: find the start of every record in the inflated stream.
+//
+// A BAM record is {u32 block_size; block_size bytes} (SAM spec §4.2); the stream is a chain of them that ignores BGZF
+// member boundaries. htslib-written files start a record at the beginning of (almost) every member, other writers do
+// not. The chain is therefore resolved as: GUESS a first-record offset per member (offset 0 first, then a plausibility
+// scan like a BAM split guesser) -> walk every member's sub-chain in parallel -> VERIFY on the host side of the library
+// that every member's chain exit lands exactly on the next member's guessed start. Verification makes the result exact
+// (no heuristic can mis-sync silently); a wrong guess only costs a repair round.
+//
+// Replaces the sequential record pull of BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-398).
+#include "common.h"
+
+namespace ngsqc {
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
+__device__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
+{
+	if (o + 36 > total) return false;
+	const uint8_t* r = infl + o;
+	uint32_t bs = ld32u(r);
+	if (bs < 32 || bs > (1u << 28) || o + 4 + (int64_t)bs > total) return false;
+	int32_t tid = (int32_t)ld32u(r + 4), pos = (int32_t)ld32u(r + 8);
+	uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16);
+	int32_t l_seq = (int32_t)ld32u(r + 20), mtid = (int32_t)ld32u(r + 24), mpos = (int32_t)ld32u(r + 28);
+	uint32_t l_name = w & 0xff, n_cigar = w2 & 0xffff;
+	if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_seq < 0 || l_name == 0) return false;
+	uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+	if (need > bs) return false;
+	if (r[36 + l_name - 1] != 0) return false; // qname is NUL-terminated
+	return true;
+}
+
+// start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
+__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+                                   int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
+                                   uint32_t* __restrict__ bad, int32_t n_ref)
+{
+	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	const BlockDesc bd = blocks[b];
+	const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+	int32_t s = start[b];
+	if (s == -2)
+	{
+		s = -1;
+		for (int64_t o = lo; o < hi; ++o)
+		{
+			if (!plausible(infl, total, o, n_ref)) continue;
+			int64_t o2 = o + 4 + ld32u(infl + o);
+			if (o2 < total && !plausible(infl, total, o2, n_ref)) continue; // chain one more record
+			s = (int32_t)(o - lo); break;
+		}
+		start[b] = s;
+	}
+	if (s < 0) { cnt[b] = 0; next_abs[b] = -1; return; }
+	int64_t o = lo + s; uint32_t n = 0; bool ok = true;
+	while (o < hi)
+	{
+		if (o + 4 > total) { ok = false; break; }
+		uint32_t bs = ld32u(infl + o);
+		if (bs < 32 || o + 4 + (int64_t)bs > total) { ok = false; break; }
+		++n; o += 4 + (int64_t)bs;
+	}
+	cnt[b] = n; next_abs[b] = ok ? o : -2;
+	if (!ok) atomicAdd(bad, 1u);
+}
+
+__global__ void index_write_kernel(const uint8_t* __restrict__ infl, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+                                   const int32_t* __restrict__ start, const int64_t* __restrict__ base, int64_t* __restrict__ recoff)
+{
+	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	int32_t s = start[b];
+	if (s < 0) return;
+	const BlockDesc bd = blocks[b];
+	const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+	int64_t o = lo + s; int64_t k = base[b];
+	while (o < hi) { recoff[k++] = o; o += 4 + (int64_t)ld32u(infl + o); }
+}
+
+// ---- generic 3-kernel exclusive scans (u32 -> i64) and in-place inclusive (i32) ----
+constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+template <typename TIn>
+__global__ void scan_tile_sums(const TIn* __restrict__ in, int64_t n, int64_t* __restrict__ tile_sums)
+{
+	__shared__ int64_t sh[SCAN_T];
+	int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+	int64_t acc = 0;
+	for (int i = threadIdx.x; i < SCAN_TILE; i += SCAN_T) { int64_t j = base + i; if (j < n) acc += (int64_t)in[j]; }
+	sh[threadIdx.x] = acc; __syncthreads();
+	for (int s = SCAN_T / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+	if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh[0];
+}
+
+__global__ void scan_tile_prefix(int64_t* tile_sums, int64_t n_tiles) // single workgroup, exclusive in place; total -> tile_sums[n_tiles]
+{
+	__shared__ int64_t sh[SCAN_T]; __shared__ int64_t carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int64_t base = 0; base < n_tiles; base += SCAN_T)
+	{
+		int64_t j = base + threadIdx.x;
+		int64_t v = j < n_tiles ? tile_sums[j] : 0;
+		sh[threadIdx.x] = v; __syncthreads();
+		for (int d = 1; d < SCAN_T; d <<= 1) { int64_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+		int64_t incl = sh[threadIdx.x]; int64_t c = carry;
+		if (j < n_tiles) tile_sums[j] = c + incl - v;
+		__syncthreads();
+		if (threadIdx.x == SCAN_T - 1) carry = c + incl;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+
+// each thread owns SCAN_ITEMS consecutive items of its tile
+template <typename TIn, typename TOut, bool INCLUSIVE>
+__global__ void scan_tile_apply(const TIn* __restrict__ in, int64_t n, const int64_t* __restrict__ tile_prefix, TOut* __restrict__ out)
+{
+	__shared__ int64_t sh[SCAN_T];
+	int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+	int64_t v[SCAN_ITEMS]; int64_t acc = 0;
+	#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; ++i) { int64_t j = base + i; v[i] = j < n ? (int64_t)in[j] : 0; acc += v[i]; }
+	sh[threadIdx.x] = acc; __syncthreads();
+	for (int d = 1; d < SCAN_T; d <<= 1) { int64_t t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+	int64_t run = tile_prefix[blockIdx.x] + sh[threadIdx.x] - acc;
+	#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; ++i)
+	{
+		int64_t j = base + i;
+		if (INCLUSIVE) { run += v[i]; if (j < n) out[j] = (TOut)run; }
+		else { if (j < n) out[j] = (TOut)run; run += v[i]; }
+	}
+}
+
+size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE; return (size_t)(tiles + 2) * sizeof(int64_t); }
+
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s)
+{
+	if (n_blocks <= 0) return;
+	int grid = (int)((n_blocks + 63) / 64);
+	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_cnt, d_next_abs, d_bad, n_ref);
+}
+
+void launch_index_write(const uint8_t* d_infl, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+                        const int64_t* d_base, int64_t* d_recoff, hipStream_t s)
+{
+	if (n_blocks <= 0) return;
+	int grid = (int)((n_blocks + 63) / 64);
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, d_blocks, n_blocks, d_start, d_base, d_recoff);
+}
+
+// exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).
+void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s)
+{
+	int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+	int64_t* ts = (int64_t*)d_tmp;
+	if (tiles > 0)
+	{
+		hipLaunchKernelGGL(scan_tile_sums<uint32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts);
+		hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles);
+		hipLaunchKernelGGL((scan_tile_apply<uint32_t, int64_t, false>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts, d_base);
+		hipMemcpyAsync(d_base + n, ts + tiles, sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+	}
+	else hipMemsetAsync(d_base, 0, sizeof(int64_t), s);
+}
+
+// in-place inclusive prefix sum of the int32 difference array -> per-base depth
+void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s)
+{
+	int64_t tiles = (n_slots + SCAN_TILE - 1) / SCAN_TILE;
+	if (tiles <= 0) return;
+	int64_t* ts = (int64_t*)d_tmp;
+	hipLaunchKernelGGL(scan_tile_sums<int32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts);
+	hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles);
+	hipLaunchKernelGGL((scan_tile_apply<int32_t, int32_t, true>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts, d_diff);
+}
+
+} // namespace ngsqc

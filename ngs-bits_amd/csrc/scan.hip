@@ -1,0 +1,517 @@
+// K3/K4/K5 — per-record decode + classify, target-region depth scatter, counter reduction.
+//
+// One lane per BAM record (short reads); records with long CIGARs (or a possible CG:B,I long-CIGAR tag) are deferred to
+// a wave-per-record kernel that strides the CIGAR across the 64 lanes and combines with wave reductions / prefix sums.
+// Loop bodies restated from (not translated line by line):
+//   Statistics::mapping(bed..)  src/cppNGS/Statistics.cpp:416-574      (MODE_ROI)
+//   Statistics::mapping(bam..)  src/cppNGS/Statistics.cpp:830-916      (MODE_NOROI)
+//   Statistics::mapping_wgs     src/cppNGS/Statistics.cpp:1068-1182    (MODE_WGS: pass 1 + the indexed ROI pass fused)
+//   Statistics::yxRatio         src/cppNGS/Statistics.cpp:2659-2691    (two counters instead of two indexed re-reads)
+//   WorkerAverageCoverage*/WorkerLowOrHighCoverage* filters and depth loops (MODE_DEPTH)
+//   BamAlignment::qualities     src/cppNGS/BamReader.cpp:210-255       (min_baseq mask as sparse decrements)
+// Depth is accumulated as a DIFFERENCE array (+1 at overlap start, -1 behind overlap end; one spare slot per region):
+// the reference increments the whole reference span [start,end] of a read (RegionDepth::incrementRegion,
+// Statistics.cpp:45-53), which is exactly a prefix sum over these differences. All arithmetic is integer.
+#include "common.h"
+
+namespace ngsqc {
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// per-lane partial sums (A_* in common.h), reduced per wave at the end of the kernel: one atomic per wave and counter
+struct Acc { long long v[A_COUNT]; int max_len; unsigned long long best_key; unsigned long long first_paired; };
+
+struct RecView
+{
+	const uint8_t* core;   // points at refID (record + 4)
+	uint32_t bs; int32_t tid, pos; uint32_t l_name, mapq, n_cigar_raw, flag; int32_t l_seq, isize;
+	const uint8_t* cigar; uint32_t n_cigar;  // effective CIGAR (may be the CG tag payload)
+};
+
+__device__ __forceinline__ RecView load_rec(const uint8_t* infl, int64_t off)
+{
+	RecView r; const uint8_t* p = infl + off;
+	r.bs = ld32(p); r.core = p + 4;
+	r.tid = (int32_t)ld32(p + 4); r.pos = (int32_t)ld32(p + 8);
+	uint32_t w = ld32(p + 12), w2 = ld32(p + 16);
+	r.l_name = w & 0xff; r.mapq = (w >> 8) & 0xff; r.n_cigar_raw = w2 & 0xffff; r.flag = w2 >> 16;
+	r.l_seq = (int32_t)ld32(p + 20); r.isize = (int32_t)ld32(p + 32);
+	r.cigar = p + 36 + r.l_name; r.n_cigar = r.n_cigar_raw;
+	return r;
+}
+__device__ __forceinline__ const uint8_t* rec_qual(const RecView& r) { return r.core + 32 + r.l_name + 4ull * r.n_cigar_raw + ((uint32_t)r.l_seq + 1) / 2; }
+__device__ __forceinline__ const uint8_t* rec_aux(const RecView& r) { return rec_qual(r) + (uint32_t)r.l_seq; }
+__device__ __forceinline__ const uint8_t* rec_end(const RecView& r) { return r.core + r.bs; }
+
+// linear aux scan (what htslib's bam_aux_get does); returns pointer to the type byte or nullptr
+__device__ static const uint8_t* aux_find(const uint8_t* p, const uint8_t* end, uint8_t t0, uint8_t t1)
+{
+	while (p + 3 <= end)
+	{
+		const uint8_t* t = p + 2;
+		if (p[0] == t0 && p[1] == t1) return t;
+		uint8_t type = *t; const uint8_t* v = t + 1; size_t sz;
+		switch (type)
+		{
+			case 'A': case 'c': case 'C': sz = 1; break;
+			case 's': case 'S': sz = 2; break;
+			case 'i': case 'I': case 'f': sz = 4; break;
+			case 'd': sz = 8; break;
+			case 'Z': case 'H': { const uint8_t* q = v; while (q < end && *q) ++q; sz = (size_t)(q - v) + 1; break; }
+			case 'B': { if (v + 5 > end) return nullptr; uint8_t st = v[0]; uint32_t n = ld32(v + 1); size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; sz = 5 + es * (size_t)n; break; }
+			default: return nullptr;
+		}
+		p = v + sz;
+	}
+	return nullptr;
+}
+// BamAlignment::tagi (BamReader.cpp:286-297)
+__device__ static int aux_tagi(const RecView& r, uint8_t t0, uint8_t t1)
+{
+	const uint8_t* t = aux_find(rec_aux(r), rec_end(r), t0, t1);
+	if (!t) return 0;
+	switch (*t)
+	{
+		case 'c': return (int8_t)t[1];
+		case 'C': return t[1];
+		case 's': return (int16_t)ld16(t + 1);
+		case 'S': return ld16(t + 1);
+		case 'i': return (int32_t)ld32(t + 1);
+		case 'I': return (int)ld32(t + 1);
+		default: return 0;
+	}
+}
+
+// first region index in [first,last) with reg_end >= s  (merged regions: ends are sorted too)
+__device__ __forceinline__ int lower_region(const int32_t* __restrict__ reg_end, int first, int last, int s)
+{
+	int a = first, b = last;
+	while (a < b) { int m = (a + b) >> 1; if (reg_end[m] < s) a = m + 1; else b = m; }
+	return a;
+}
+
+__device__ __forceinline__ void diff_add(const ScanParams& p, int reg, int a, int b) // +1 on [a,b] of region reg
+{
+	int32_t* d = p.diff + p.reg_doff[reg] - p.reg_start[reg];
+	atomicAdd(d + a, 1); atomicAdd(d + b + 1, -1);
+}
+
+__device__ static void gc_hit(const ScanParams& p, int tid, int s, int e)
+{
+	if (!p.n_gc) return;
+	int first = p.tid_gc_first[tid], last = p.tid_gc_last[tid];
+	if (first >= last) return;
+	int i0 = lower_region(p.gc_end, first, last, s);
+	int i1 = i0; while (i1 < last && p.gc_start[i1] <= e) ++i1;
+	int n = i1 - i0;
+	if (n <= 0) return;
+	for (int i = i0; i < i1; ++i)
+	{
+		int bin = p.gc_bin[i];
+		if (bin < 0) continue;
+		if (n < GC_NMAX) atomicAdd(&p.gc_tab[(size_t)bin * GC_NMAX + n], 1ull);
+		else atomicAdd(&p.gc_over[bin], 1.0 / (double)n);
+	}
+}
+
+// min_baseq mask (BamAlignment::qualities): M-op bases with qual < min_baseq are NOT counted -> point decrement.
+// Quirk kept: '=' / 'X' / 'H' / 'P' advance neither index.
+__device__ static void baseq_decrements(const ScanParams& p, const RecView& r, int start1, int i0, int i1)
+{
+	const uint8_t* q = rec_qual(r);
+	uint32_t ai = 0; int gi = 0;
+	for (uint32_t k = 0; k < r.n_cigar; ++k)
+	{
+		uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
+		if (op == 0)
+		{
+			for (uint32_t j = 0; j < len; ++j)
+			{
+				if (q[ai + j] < p.min_baseq)
+				{
+					int pos1 = start1 + gi + (int)j;
+					for (int i = i0; i < i1; ++i) if (pos1 >= p.reg_start[i] && pos1 <= p.reg_end[i]) { int32_t* d = p.diff + p.reg_doff[i] - p.reg_start[i]; atomicAdd(d + pos1, -1); atomicAdd(d + pos1 + 1, 1); }
+				}
+			}
+			ai += len; gi += (int)len;
+		}
+		else if (op == 2 || op == 3) gi += (int)len;
+		else if (op == 1 || op == 4) ai += len;
+	}
+}
+
+// Everything after the CIGAR sums are known. ord = ordinal of the record in the file.
+template <int MODE>
+__device__ static void classify(const ScanParams& p, const RecView& r, long long ord, long long ref_len, long long clip, bool spliced, Acc& a, uint32_t* lds_hist)
+{
+	const uint32_t flag = r.flag;
+	const bool unmapped = flag & 0x4, secondary = flag & 0x100, supp = flag & 0x800, dup = flag & 0x400;
+	const bool paired = flag & 0x1, proper = flag & 0x2, read1 = flag & 0x40;
+	long long rlen = unmapped ? 0 : ref_len; if (rlen == 0) rlen = 1;
+	const int start1 = r.pos + 1, end1 = (int)(r.pos + rlen);   // 1-based closed (BamReader.h:80-94)
+	const int length = r.l_seq;
+	const bool tid_ok = r.tid >= 0 && r.tid < p.n_ref;
+	a.v[A_ALG_BYTES] += 4 + (long long)r.bs;
+
+	if (MODE == 3)
+	{
+		// coverage-tool filter: WorkerAverageCoverage.cpp:41-45 / WorkerLowOrHighCoverage.cpp:47-49
+		if (dup || secondary || supp || unmapped || (int)r.mapq < p.min_mapq) return;
+		if (p.skip_mismapped && !proper && r.mapq < 20) return;
+		if (!tid_ok) return;
+		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+		if (first >= last) return;
+		int i0 = lower_region(p.reg_end, first, last, start1), i1 = i0;
+		for (; i1 < last && p.reg_start[i1] <= end1; ++i1) diff_add(p, i1, max(start1, p.reg_start[i1]), min(end1, p.reg_end[i1]));
+		if (p.min_baseq > 0 && i1 > i0) baseq_decrements(p, r, start1, i0, i1);
+		return;
+	}
+
+	// chrY/chrX read counts: index query chr:[1,len] returns tid==t && pos < len && endpos > 0, minus secondary/supplementary
+	if (!secondary && !supp)
+	{
+		if (r.tid == p.tid_x && r.pos < p.len_x && r.pos + rlen > 0) a.v[A_READS_X]++;
+		if (r.tid == p.tid_y && r.pos < p.len_y && r.pos + rlen > 0) a.v[A_READS_Y]++;
+	}
+
+	// indexed ROI pass of mapping_wgs (Statistics.cpp:1154-1182), fused: per (read, overlapped region) pair
+	if (MODE == NGSQC_MODE_WGS && p.n_regions && !secondary && !supp && !unmapped && tid_ok)
+	{
+		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+		if (first < last)
+		{
+			int i0 = lower_region(p.reg_end, first, last, start1);
+			for (int i = i0; i < last && p.reg_start[i] <= end1; ++i)
+			{
+				gc_hit(p, r.tid, start1, end1);
+				if (!dup && (int)r.mapq >= p.min_mapq)
+				{
+					a.v[A_USABLE_ROI] += length;
+					diff_add(p, i, max(start1, p.reg_start[i]), min(end1, p.reg_end[i]));
+				}
+			}
+		}
+	}
+
+	if (secondary || supp) return;
+	a.v[A_TOTAL]++;
+	if (paired && (unsigned long long)ord < a.first_paired) a.first_paired = (unsigned long long)ord;
+	a.v[A_SUM_LEN] += length;
+	if (length > a.max_len) a.max_len = length;
+	{
+		// (max length, first ordinal reaching it) for the running-max "trimmed bases" rule (Statistics.cpp:428-429,565-568)
+		unsigned long long key = ((unsigned long long)(uint32_t)length << 40) | (0xFFFFFFFFFFull - (unsigned long long)ord);
+		if (key > a.best_key) a.best_key = key;
+	}
+
+	if (!unmapped)
+	{
+		a.v[A_MAPPED]++;
+		a.v[A_BASES_MAPPED] += length;
+		a.v[A_CLIPPED] += clip;
+		if (MODE == NGSQC_MODE_ROI)
+		{
+			if (tid_ok)
+			{
+				int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+				if (first < last)
+				{
+					int n0 = lower_region(p.reg_end, first, last, start1 - 250);
+					if (n0 < last && p.reg_start[n0] <= end1 + 250)
+					{
+						a.v[A_NEAR]++;
+						int i0 = lower_region(p.reg_end, n0, last, start1);
+						if (i0 < last && p.reg_start[i0] <= end1)
+						{
+							a.v[A_ONTARGET]++;
+							int dp = aux_tagi(r, 'D', 'P');
+							if (dp != 0) { int bin = min(dp, 4); bin = bin < 1 ? 0 : bin - 1; a.v[A_DD0 + bin]++; }
+							if (!dup && (int)r.mapq >= p.min_mapq)
+							{
+								int dpi = min(max(dp, 0), 4);
+								for (int i = i0; i < last && p.reg_start[i] <= end1; ++i)
+								{
+									int s = max(p.reg_start[i], start1), e = min(p.reg_end[i], end1);
+									long long n = e - s + 1;
+									a.v[A_USABLE] += n; a.v[A_DP0 + dpi] += n; a.v[A_USABLE_RAW] += n * ((long long)dp + 1);
+									a.v[A_NO_OVERLAP] += n;
+									diff_add(p, i, s, e);
+								}
+								int insert_size = abs(r.isize);
+								if (read1 && paired && proper && !spliced && 2 * length > insert_size)
+								{
+									int ovl = 2 * length - insert_size;
+									int os = r.isize > 0 ? start1 + length - ovl : start1;
+									int oe = os + ovl - 1;
+									for (int i = lower_region(p.reg_end, first, last, os); i < last && p.reg_start[i] <= oe; ++i)
+										a.v[A_NO_OVERLAP] -= (min(p.reg_end[i], oe) - max(p.reg_start[i], os) + 1);
+								}
+							}
+							gc_hit(p, r.tid, start1, end1);
+						}
+					}
+				}
+			}
+		}
+		else
+		{
+			if (tid_ok && p.tid_nonspecial[r.tid])
+			{
+				a.v[A_ONTARGET]++;
+				if (!dup && (int)r.mapq >= p.min_mapq) a.v[A_USABLE] += length; // "no overlap" share is resolved with first_paired_idx afterwards
+			}
+		}
+	}
+
+	if (paired && proper)
+	{
+		a.v[A_PP]++;
+		if (!spliced)
+		{
+			int insert_size = abs(r.isize);
+			if (insert_size < 1000)
+			{
+				a.v[A_INS_CNT]++; a.v[A_INS_SUM] += insert_size;
+				atomicAdd(&lds_hist[insert_size], 1u);
+				if (MODE != NGSQC_MODE_ROI && read1 && !dup && (int)r.mapq >= p.min_mapq && 2 * length > insert_size) a.v[A_NO_OVERLAP] -= (2 * length) - insert_size;
+			}
+		}
+	}
+	if (dup) a.v[A_DUP]++;
+}
+
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+__device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
+{
+	const int lane = threadIdx.x & 63;
+	for (int i = 0; i < A_COUNT; ++i) { long long s = wave_sum(a.v[i]); if (lane == 0 && s) atomicAdd(&p.counters[i], (unsigned long long)s); }
+	int m = a.max_len; unsigned long long bk = a.best_key, fp = a.first_paired;
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		m = max(m, __shfl_xor(m, o));
+		unsigned long long t = __shfl_xor(bk, o); if (t > bk) bk = t;
+		t = __shfl_xor(fp, o); if (t < fp) fp = t;
+	}
+	if (lane == 0)
+	{
+		if (m > 0) atomicMax(&p.counters[A_MAX_LEN], (unsigned long long)m);
+		if (bk) atomicMax(&p.counters[A_FIRST_MAX_KEY], bk);
+		if (fp != ~0ull) atomicMin(&p.counters[A_FIRST_PAIRED], fp);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < 1000; i += blockDim.x) if (lds_hist[i]) atomicAdd(&p.counters[A_HIST0 + i], (unsigned long long)lds_hist[i]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
+{
+	__shared__ uint32_t lds_hist[1000];
+	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
+	__syncthreads();
+	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	const long long stride = (long long)gridDim.x * blockDim.x;
+	for (long long ord = (long long)blockIdx.x * blockDim.x + threadIdx.x; ord < p.n_rec; ord += stride)
+	{
+		RecView r = load_rec(p.infl, p.recoff[ord]);
+		bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
+		if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
+		{
+			uint32_t c0 = ld32(r.cigar);
+			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq) defer = true; // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
+		}
+		if (defer)
+		{
+			unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
+			if ((long long)k < p.long_cap) p.long_list[k] = ord;
+			continue;
+		}
+		long long ref_len = 0, clip = 0; bool spliced = false;
+		for (uint32_t k = 0; k < r.n_cigar; ++k)
+		{
+			uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
+			if ((0x18Du >> op) & 1u) ref_len += len;            // M,D,N,=,X  (bits 0,2,3,7,8)
+			else if (op == 4 || op == 5) clip += len;
+			if (op == 3) spliced = true;
+		}
+		classify<MODE>(p, r, ord, ref_len, clip, spliced, a, lds_hist);
+	}
+	flush(p, a, lds_hist);
+}
+
+// wave-per-record path: long CIGARs (ONT) and CG-tag records
+template <int MODE>
+__global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long long n_long)
+{
+	__shared__ uint32_t lds_hist[1000];
+	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
+	__syncthreads();
+	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	const int lane = threadIdx.x & 63;
+	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+	for (long long w = wave; w < n_long; w += n_waves)
+	{
+		long long ord = p.long_list[w];
+		RecView r = load_rec(p.infl, p.recoff[ord]);
+		// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries
+		if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
+		{
+			uint32_t c0 = ld32(r.cigar);
+			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq)
+			{
+				unsigned long long cg = 0; uint32_t n = 0;
+				if (lane == 0)
+				{
+					const uint8_t* t = aux_find(rec_aux(r), rec_end(r), 'C', 'G');
+					if (t && t[0] == 'B' && t[1] == 'I') { n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) cg = (unsigned long long)(uintptr_t)(t + 6); }
+				}
+				cg = __shfl(cg, 0); n = __shfl(n, 0);
+				if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; }
+			}
+		}
+		long long ref_len = 0, clip = 0; int spl = 0;
+		for (uint32_t k = lane; k < r.n_cigar; k += 64)
+		{
+			uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
+			if ((0x18Du >> op) & 1u) ref_len += len;
+			else if (op == 4 || op == 5) clip += len;
+			if (op == 3) spl = 1;
+		}
+		ref_len = wave_sum(ref_len); clip = wave_sum(clip); spl = __any(spl);
+		if (MODE == 3 && p.min_baseq > 0)
+		{
+			// coverage filter first (same as classify), then the per-base mask with a wave prefix sum over CIGAR ops
+			const uint32_t flag = r.flag;
+			bool pass = !(flag & 0x400) && !(flag & 0x100) && !(flag & 0x800) && !(flag & 0x4) && (int)r.mapq >= p.min_mapq
+			            && !(p.skip_mismapped && !(flag & 0x2) && r.mapq < 20) && r.tid >= 0 && r.tid < p.n_ref;
+			if (pass)
+			{
+				long long rlen = ref_len ? ref_len : 1;
+				const int start1 = r.pos + 1, end1 = (int)(r.pos + rlen);
+				int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+				int i0 = first < last ? lower_region(p.reg_end, first, last, start1) : last, i1 = i0;
+				while (i1 < last && p.reg_start[i1] <= end1) ++i1;
+				if (lane == 0) for (int i = i0; i < i1; ++i) diff_add(p, i, max(start1, p.reg_start[i]), min(end1, p.reg_end[i]));
+				if (i1 > i0)
+				{
+					const uint8_t* q = rec_qual(r);
+					long long ai_base = 0, gi_base = 0;
+					for (uint32_t k0 = 0; k0 < r.n_cigar; k0 += 64)
+					{
+						uint32_t k = k0 + lane; uint32_t op = 15, len = 0;
+						if (k < r.n_cigar) { uint32_t c = ld32(r.cigar + 4ull * k); op = c & 15u; len = c >> 4; }
+						long long da = (op == 0 || op == 1 || op == 4) ? len : 0, dg = (op == 0 || op == 2 || op == 3) ? len : 0;
+						long long sa = da, sg = dg; // inclusive wave scan
+						for (int o = 1; o < 64; o <<= 1) { long long ta = __shfl_up(sa, o), tg = __shfl_up(sg, o); if (lane >= o) { sa += ta; sg += tg; } }
+						long long ai = ai_base + sa - da, gi = gi_base + sg - dg;
+						if (op == 0)
+						{
+							for (uint32_t j = 0; j < len; ++j)
+							{
+								if (q[ai + j] < p.min_baseq)
+								{
+									int pos1 = start1 + (int)gi + (int)j;
+									for (int i = i0; i < i1; ++i) if (pos1 >= p.reg_start[i] && pos1 <= p.reg_end[i]) { int32_t* d = p.diff + p.reg_doff[i] - p.reg_start[i]; atomicAdd(d + pos1, -1); atomicAdd(d + pos1 + 1, 1); }
+								}
+							}
+						}
+						ai_base += __shfl(sa, 63); gi_base += __shfl(sg, 63);
+					}
+				}
+			}
+			if (lane == 0) a.v[A_ALG_BYTES] += 4 + (long long)r.bs;
+			continue;
+		}
+		if (lane == 0)
+		{
+			classify<MODE>(p, r, ord, ref_len, clip, spl != 0, a, lds_hist);
+		}
+	}
+	flush(p, a, lds_hist);
+}
+
+// ---- order-dependent fix-ups on a record prefix ----
+// out2[0] += sum over counted records with ordinal < upto_max of (gmax - running_max_i)     [single workgroup, sequential chunks]
+// out2[1] += sum over "passing" records with ordinal < upto_paired of length                [same loop]
+__global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired, int gmax)
+{
+	__shared__ int sh[256]; __shared__ int carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	long long upto = upto_max > upto_paired ? upto_max : upto_paired;
+	long long s_trim = 0, s_len = 0;
+	for (long long base = 0; base < upto; base += 256)
+	{
+		long long ord = base + threadIdx.x;
+		int len = 0; bool counted = false, passing = false;
+		if (ord < upto)
+		{
+			RecView r = load_rec(p.infl, p.recoff[ord]);
+			const uint32_t flag = r.flag;
+			counted = !(flag & 0x100) && !(flag & 0x800);
+			if (counted)
+			{
+				len = r.l_seq;
+				bool tid_ok = r.tid >= 0 && r.tid < p.n_ref;
+				passing = !(flag & 0x4) && tid_ok && p.tid_nonspecial[r.tid] && !(flag & 0x400) && (int)r.mapq >= p.min_mapq;
+			}
+		}
+		sh[threadIdx.x] = counted ? len : 0; __syncthreads();
+		for (int d = 1; d < 256; d <<= 1) { int t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] = max(sh[threadIdx.x], t); __syncthreads(); }
+		int run = max(carry, sh[threadIdx.x]);
+		if (counted && ord < upto_max) s_trim += gmax - run;
+		if (passing && ord < upto_paired) s_len += len;
+		__syncthreads();
+		if (threadIdx.x == 255) carry = run;
+		__syncthreads();
+	}
+	s_trim = wave_sum(s_trim); s_len = wave_sum(s_len);
+	if ((threadIdx.x & 63) == 0) { if (s_trim) atomicAdd(&p.counters[A_FIX_TRIM], (unsigned long long)s_trim); if (s_len) atomicAdd(&p.counters[A_FIX_LEN], (unsigned long long)s_len); }
+}
+
+static int scan_grid(long long n, int per_wg)
+{
+	long long wgs = (n + per_wg - 1) / per_wg;
+	long long cap = 256 * 8;
+	return (int)(wgs < 1 ? 1 : (wgs < cap ? wgs : cap));
+}
+
+void launch_scan(const ScanParams& p, hipStream_t s)
+{
+	if (p.n_rec <= 0) return;
+	int grid = scan_grid(p.n_rec, 256);
+	switch (p.mode)
+	{
+		case NGSQC_MODE_ROI: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(256), 0, s, p); break;
+		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(256), 0, s, p); break;
+		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p); break;
+		default: hipLaunchKernelGGL(scan_kernel<3>, dim3(grid), dim3(256), 0, s, p); break;
+	}
+}
+
+void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
+{
+	if (n_long <= 0) return;
+	int grid = scan_grid(n_long, 4);
+	switch (p.mode)
+	{
+		case NGSQC_MODE_ROI: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
+		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
+		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
+		default: hipLaunchKernelGGL(scan_long_kernel<3>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
+	}
+}
+
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, int32_t gmax, hipStream_t s)
+{
+	if (upto_max <= 0 && upto_paired <= 0) return;
+	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, gmax);
+}
+
+} // namespace ngsqc
