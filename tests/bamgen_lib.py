@@ -1,0 +1,41 @@
+"""ctypes binding of tools/libbamgen.so — synthetic BAM images (SURVEY.md §8(d) shapes) for tests and bench.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(ROOT, "tools")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(TOOLS, "libbamgen.so")
+        src = os.path.join(TOOLS, "bamgen.cpp")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+            subprocess.check_call(["make", "-C", TOOLS, "-s"])
+        L = C.CDLL(so)
+        L.bamgen_generate.restype = C.c_void_p
+        L.bamgen_generate.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.bamgen_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def generate(n_reads, seed=20260821, mode=0, depth=30.0, first_contig=0, start_pos=0, level=6, aligned=True, threads=0):
+    """Returns the BAM file image as a numpy uint8 array. mode 0 = short-read WGS, 1 = ONT-like long reads."""
+    n = C.c_size_t(0)
+    p = lib().bamgen_generate(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, C.byref(n))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+    finally:
+        lib().bamgen_free(p)
+
+
+def write(path, **kw):
+    a = generate(**kw)
+    a.tofile(path)
+    return a.size

@@ -122,7 +122,7 @@ def test_depth_tools(bam, bed, mapq, baseq):
             ed = exp["depth"] if ra else np.minimum(exp["depth"], 254)
             assert np.array_equal(np.minimum(d, 254) if not ra else d, ed)
     if baseq == 0:
-        cov, _, _ = O.avg_coverage(ob, p(bed), merge_bed=False, min_mapq=mapq)
+        cov, _, _ = O.avg_coverage(ob, p(bed), merge_bed=False, min_mapq=mapq, random_access=True)
         lines, _ = H.bed_regions(p(bed), h.refs, 0)
         assert np.array_equal(h.region_sums(lines), cov)
     h.close()

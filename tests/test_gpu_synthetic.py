@@ -1,0 +1,79 @@
+"""GPU parity on synthetic BAMs (sizes the oracle finishes in seconds): short-read WGS shape, unaligned BGZF members
+(records straddling members), ONT-like long reads with CG-tag CIGARs, coverage tools with min_baseq."""
+import os
+
+import numpy as np
+import pytest
+
+import bamgen_lib as G
+import hostprep as H
+import oracle_lib as O
+from conftest import RESOURCES
+
+pytestmark = pytest.mark.gpu
+ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+OMIM = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
+SKIP = {O.COUNTER_NAMES.index("half_depth"), O.COUNTER_NAMES.index("bases_covered_half")}
+
+
+def _check(tmp_path, name, bed, qc_mode, merge_mode, **gen):
+    path = str(tmp_path / name)
+    G.write(path, **gen)
+    ob = O.Bam(path)
+    h = ngsqc.Handle(path=path)
+    assert h.n_records == ob.count
+    assert np.array_equal(h.record_offsets(), ob.record_offsets())
+    regs = None
+    if bed:
+        regs, _ = H.bed_regions(bed, h.refs, merge_mode)
+    tx, ty = H.xy_tids(h.refs)
+    counters, _ = h.scan_mapping(qc_mode, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs))
+    exp = O.mapping(ob, qc_mode, bed, merge_bed=(merge_mode == 1))
+    for i in range(len(counters)):
+        if i not in SKIP:
+            assert int(counters[i]) == int(exp.counters[i]), (i, int(counters[i]), int(exp.counters[i]))
+    if regs:
+        assert np.array_equal(h.depth(int(counters[26])), exp.depth)
+    t = h.timings()
+    assert t["scan_algorithmic_bytes"] == ob.inflated_size - ob.first_record_offset
+    h.close()
+    return ob
+
+
+def test_wgs_short_reads(tmp_path):
+    _check(tmp_path, "wgs.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=300_000, seed=1, start_pos=15_900_000)
+
+
+def test_wgs_unaligned_members(tmp_path):
+    """htsjdk-style BGZF: records straddle members -> exercises the guess + verify + repair path of K2."""
+    _check(tmp_path, "unaligned.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=120_000, seed=2, aligned=False, start_pos=15_900_000)
+
+
+def test_chrX_chrY_counts(tmp_path):
+    _check(tmp_path, "xy.bam", None, ngsqc.MODE_NOROI, 0, n_reads=100_000, seed=3, first_contig=22, start_pos=156_000_000, depth=2.0)
+
+
+def test_long_reads_cg_tag(tmp_path):
+    _check(tmp_path, "ont.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=1500, seed=4, mode=1, depth=40.0, start_pos=15_900_000)
+
+
+def test_roi_mode_exome_like(tmp_path):
+    bed = tmp_path / "exome.bed"
+    rng = np.random.default_rng(5)
+    starts = np.sort(rng.integers(16_000_000, 17_400_000, 700))
+    with open(bed, "w") as f:
+        for s in starts:
+            f.write(f"chr1\t{s}\t{s + int(rng.integers(60, 900))}\tex{s}\n")
+    ob = _check(tmp_path, "roi.bam", str(bed), ngsqc.MODE_ROI, 1, n_reads=250_000, seed=6, start_pos=15_900_000)
+    # coverage tools on the same pair, with and without base-quality mask
+    h = ngsqc.Handle(path=str(tmp_path / "roi.bam"))
+    regs, _ = H.bed_regions(str(bed), h.refs, 2)
+    for baseq in (0, 20):
+        h.scan_depth(regs, min_mapq=1, min_baseq=baseq)
+        exp = O.low_high_coverage(ob, str(bed), 20, 1, baseq, is_high=False, random_access=True, tool_merge=1)
+        assert np.array_equal(h.depth(exp["roi_bases"]), exp["depth"]), baseq
+    lines, _ = H.bed_regions(str(bed), h.refs, 0)
+    h.scan_depth(regs, min_mapq=1)
+    cov, _, _ = O.avg_coverage(ob, str(bed), min_mapq=1, random_access=False)
+    assert np.array_equal(h.region_sums(lines), cov)
+    h.close()
