@@ -134,6 +134,8 @@ typedef struct ngsqc_timings {
 	int64_t inflate_launches, scan_launches;
 	int64_t scan_algorithmic_bytes;   /* sum over records of (4 + block_size)  — SURVEY.md §8(d) */
 	int64_t compressed_bytes, inflated_bytes, n_records;
+	double scan_kernel_ms;            /* K3-K5 kernels only (HIP events around the scan launches on the handle's stream) */
+	double depth_kernel_ms;           /* K6 prefix sum + histogram kernels */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

@@ -6,6 +6,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -180,6 +181,9 @@ void do_decode(ngsqc_handle* h)
 		int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
 		start[b] = hi <= h->first_rec ? -1 : (lo <= h->first_rec ? (int32_t)(h->first_rec - lo) : -2);
 	}
+	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
+	auto lap = [&](const char* what) { if (dbg) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
+	lap("k2 begin");
 	DevBuf<int32_t> d_start; d_start.upload(start, h->stream);
 	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)nb + 1);
 	DevBuf<int64_t> d_next; d_next.alloc((size_t)nb + 1);
@@ -193,13 +197,18 @@ void do_decode(ngsqc_handle* h)
 		HIPCHK(hipMemcpyAsync(start.data() + from, d_start.p + from, (size_t)(nb - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(nb - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
+		lap("k2 count+d2h");
 		// exact verification of the chain: every member's exit must land on the next member's start
 		int64_t expected = h->first_rec; int64_t mismatch = -1;
 		for (int64_t b = 0; b < nb; ++b)
 		{
 			int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
 			int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
-			if (start[b] != want) { mismatch = b; start[b] = want; break; }
+			if (start[b] != want)
+			{
+				if (dbg && rounds < 3) fprintf(stderr, "[ngsqc] member %lld: start=%d want=%d expected=%lld lo=%lld hi=%lld prev_next=%lld prev_start=%d\n", (long long)b, start[b], want, (long long)expected, (long long)lo, (long long)hi, b ? (long long)next[b - 1] : -9LL, b ? start[b - 1] : -9);
+				mismatch = b; start[b] = want; break;
+			}
 			if (want >= 0)
 			{
 				if (next[b] == -2) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
@@ -211,10 +220,12 @@ void do_decode(ngsqc_handle* h)
 			if (expected != h->total) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 			break;
 		}
+		if (dbg) fprintf(stderr, "[ngsqc] chain mismatch at member %lld (round %d)\n", (long long)mismatch, rounds);
 		if (++rounds > 100000) throw FormatError("could not resolve the BAM record chain");
 		HIPCHK(hipMemcpyAsync(d_start.p + mismatch, &start[mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 		from = mismatch;
 	}
+	lap("k2 verify");
 	DevBuf<int64_t> d_base; d_base.alloc((size_t)nb + 1);
 	DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(nb) + 64);
 	launch_scan_counts(d_cnt.p, nb, d_base.p, d_tmp.p, h->stream);
@@ -222,9 +233,12 @@ void do_decode(ngsqc_handle* h)
 	HIPCHK(hipMemcpyAsync(&n_rec, d_base.p + nb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	h->n_rec = n_rec;
+	lap("k2 scan");
 	h->d_recoff.alloc((size_t)std::max<int64_t>(n_rec, 1));
+	lap("k2 alloc recoff");
 	launch_index_write(h->d_infl.p, h->d_blocks.p, nb, d_start.p, d_base.p, h->d_recoff.p, h->stream);
 	h->tm.index_ms = t.stop();
+	lap("k2 write");
 	h->tm.n_records = n_rec;
 	h->decoded = true;
 }
@@ -283,12 +297,14 @@ void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& 
 	sp.counters = d_counters.p; sp.diff = h->d_depth.p; sp.long_list = d_long.p; sp.long_cap = h->n_rec;
 	sp.n_ref = (int32_t)h->ref_names.size();
 	Timer t(h->stream); t.start();
+	Timer tk(h->stream); tk.start();
 	launch_scan(sp, h->stream);
+	h->tm.scan_kernel_ms = tk.stop();
 	unsigned long long n_long = 0;
 	HIPCHK(hipMemcpyAsync(&n_long, d_counters.p + A_LONG_COUNT, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	h->tm.scan_launches = 1;
-	if (n_long) { launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_launches++; }
+	if (n_long) { tk.start(); launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_kernel_ms += tk.stop(); h->tm.scan_launches++; }
 	dev.assign(A_DEV_TOTAL, 0ull);
 	HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));

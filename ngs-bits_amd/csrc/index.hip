@@ -15,7 +15,7 @@ namespace ngsqc {
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 // cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
-__device__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
+__device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
 {
 	if (o + 36 > total) return false;
 	const uint8_t* r = infl + o;
@@ -34,7 +34,7 @@ __device__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, 
 
 // start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
 __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
-                                   int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
+                                   int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                    uint32_t* __restrict__ bad, int32_t n_ref)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

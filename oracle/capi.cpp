@@ -5,6 +5,7 @@
 // can compare the two arrays element by element.
 // ============================================================================
 #include "stats.hpp"
+#include "stream.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -146,6 +147,23 @@ void* orc_low_high_coverage(void* bam, const char* bed, int tool_merge, int cuto
 		return r;
 	}
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
+
+// bench.py cpu_baseline: streaming MappingQC -wgs loop over a BAM image in memory (see stream.hpp). Returns seconds.
+// out_counters: int64[ORC_NCOUNTERS] ; out_stats: {n_records, inflated bytes, compressed bytes consumed}
+double orc_baseline_wgs_stream(const uint8_t* image, int64_t n, const char* bed, int min_mapq, int64_t max_records, int64_t* out_counters, int64_t* out_stats, char* err, int errlen)
+{
+	try
+	{
+		BedFile roi; bool have = bed && *bed; if (have) roi.load(bed);
+		StreamStats st; double t0 = now();
+		Result r; r.m = mapping_wgs_stream(image, (size_t)n, have ? &roi : nullptr, min_mapq, max_records, st);
+		double secs = now() - t0;
+		if (out_counters) orc_result_counters(&r, out_counters);
+		if (out_stats) { out_stats[0] = st.n_records; out_stats[1] = st.inflated; out_stats[2] = st.compressed; }
+		return secs;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }
 }
 
 // BED helpers for host-logic tests: load -> (merge) -> text

@@ -1,0 +1,158 @@
+// ============================================================================
+// ORACLE — TEST INFRASTRUCTURE ONLY (see bamio.hpp header).
+// Streaming form of the MappingQC -wgs loop used as bench.py's cpu_baseline ("port"): one thread pulls records
+// sequentially out of the BGZF stream through a reused 64 KiB buffer, exactly the execution shape of
+// BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-398; the reference adds one htslib inflate helper thread,
+// BamReader.cpp:472). The per-record body is the same restatement as stats.hpp (Statistics.cpp:1068-1182), with the
+// indexed ROI pass and the chrX/chrY queries evaluated on the fly for every record — i.e. the CPU does LESS work than
+// the reference (no second, index-driven re-read), which only makes the reported baseline faster.
+// tests/test_oracle_stream.py checks that its counters equal mapping_wgs() of stats.hpp.
+// ============================================================================
+#pragma once
+#include "stats.hpp"
+
+namespace orc {
+
+struct StreamStats { int64_t n_records = 0, inflated = 0, compressed = 0; double seconds = 0; };
+
+inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int64_t max_records, StreamStats& st)
+{
+	MappingResult r;
+	std::vector<uint8_t> fv; // bgzf_scan works on a vector; avoid the copy by scanning headers inline
+	// --- sequential BGZF member walk with a carry buffer for records that straddle members ---
+	std::vector<uint8_t> buf; buf.reserve(1 << 20);
+	size_t off = 0; bool header_done = false; std::vector<std::string> names; std::vector<int64_t> lens;
+	std::vector<int> num; int tid_x = -1, tid_y = -1;
+	BedFile roi; bool roi_available = roi_in != nullptr; if (roi_in) roi = *roi_in;
+	if (roi_available && !roi.isMergedAndSorted()) { roi.sort(); roi.merge(); }
+	std::vector<size_t> doff(roi.count() + 1, 0);
+	for (size_t i = 0; i < roi.count(); ++i) doff[i + 1] = doff[i] + roi.lines[i].length();
+	r.depth.assign(doff.back(), 0); r.roi_bases = (int64_t)doff.back();
+	std::unique_ptr<ChrIndex> roi_index; if (roi_available) roi_index.reset(new ChrIndex(roi));
+	uint8_t out[65536 + 8]; size_t consumed = 0; // bytes of buf already parsed
+	auto process = [&](const Rec& al)
+	{
+		const int nm = (al.tid >= 0 && (size_t)al.tid < num.size()) ? num[al.tid] : 0;
+		// yxRatio: index query chr:[1,len]
+		if (!al.isSecondary() && !al.isSupplementary())
+		{
+			if (al.tid == tid_x && tid_x >= 0 && tid_y >= 0 && al.pos < lens[tid_x] && al.end() > 0) ++r.reads_x;
+			if (al.tid == tid_y && tid_x >= 0 && tid_y >= 0 && al.pos < lens[tid_y] && al.end() > 0) ++r.reads_y;
+		}
+		// indexed ROI pass (Statistics.cpp:1154-1182)
+		if (roi_available && !al.isSecondary() && !al.isSupplementary() && !al.isUnmapped() && nm > 0)
+		{
+			roi_index->forMatches(nm, al.start(), al.end(), [&](int i){
+				if (!al.isDuplicate() && al.mapq >= min_mapq)
+				{
+					r.bases_usable_roi += al.length();
+					const BedLine& reg = roi.lines[i];
+					int a = std::max(al.start(), reg.start), b = std::min(al.end(), reg.end);
+					int* d = r.depth.data() + doff[i] - reg.start;
+					for (int p = a; p <= b; ++p) d[p] += 1;
+				}
+			});
+		}
+		if (al.isSecondary() || al.isSupplementary()) return;
+		++r.al_total;
+		if (al.isPaired()) r.paired_end = 1;
+		const int length = al.length();
+		r.max_length = std::max(r.max_length, length);
+		bool spliced = false;
+		if (!al.isUnmapped())
+		{
+			++r.al_mapped; r.bases_mapped += length;
+			for (uint32_t i = 0; i < al.n_cigar; ++i) { uint32_t op = al.cigarOp(i); if (op == 4 || op == 5) r.bases_clipped += al.cigarLen(i); else if (op == 3) spliced = true; }
+			if (chr_non_special(nm))
+			{
+				++r.al_ontarget;
+				if (!al.isDuplicate() && al.mapq >= min_mapq) { r.bases_usable += length; if (r.paired_end) r.bases_usable_no_overlap += length; }
+			}
+		}
+		if (al.isPaired() && al.isProperPair())
+		{
+			++r.al_proper_paired;
+			if (!spliced)
+			{
+				const int insert_size = std::abs(al.isize);
+				if (insert_size < 1000)
+				{
+					++r.insert_size_read_count; r.insert_size_sum += insert_size; r.insert_hist[insert_size]++;
+					if (al.isRead1() && !al.isDuplicate() && al.mapq >= min_mapq && 2 * length > insert_size) r.bases_usable_no_overlap -= (2 * length) - insert_size;
+				}
+			}
+		}
+		if (length < r.max_length && length != -1) r.bases_trimmed += (r.max_length - length);
+		if (al.isDuplicate()) ++r.al_dup;
+	};
+	bool stop = false;
+	while (off < n && !stop)
+	{
+		if (off + 18 > n) throw Error("Truncated BGZF header");
+		const uint8_t* p = file + off;
+		if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) throw Error("Not a BGZF block");
+		uint16_t xlen = rd16(p + 10); uint32_t bsize = 0; size_t x = 12, xend = 12 + xlen;
+		while (x + 4 <= xend) { uint16_t slen = rd16(p + x + 2); if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = rd16(p + x + 4) + 1u; x += 4 + slen; }
+		if (!bsize || off + bsize > n) throw Error("Invalid BGZF block");
+		uint32_t isize = rd32(p + bsize - 4);
+		if (isize)
+		{
+			z_stream zs; memset(&zs, 0, sizeof(zs));
+			if (inflateInit2(&zs, -15) != Z_OK) throw Error("inflateInit2 failed");
+			zs.next_in = const_cast<uint8_t*>(p + xend); zs.avail_in = (uInt)(bsize - xend - 8); zs.next_out = out; zs.avail_out = isize;
+			int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+			if (rc != Z_STREAM_END || zs.total_out != isize) throw Error("BGZF inflate failed");
+			if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out, isize) != rd32(p + bsize - 8)) throw Error("BGZF CRC mismatch");
+			// compact the carry buffer, append
+			if (consumed) { buf.erase(buf.begin(), buf.begin() + (long)consumed); consumed = 0; }
+			buf.insert(buf.end(), out, out + isize);
+			st.inflated += isize;
+			if (!header_done)
+			{
+				do
+				{
+					if (buf.size() < 12) break;
+					if (memcmp(buf.data(), "BAM\1", 4) != 0) throw Error("Could not read header from BAM file");
+					size_t o = 4; uint32_t l_text = rd32(&buf[o]); o += 4 + (size_t)l_text;
+					if (o + 4 > buf.size()) break;
+					uint32_t n_ref = rd32(&buf[o]); o += 4; bool ok = true; names.clear(); lens.clear();
+					for (uint32_t i = 0; i < n_ref; ++i)
+					{
+						if (o + 4 > buf.size()) { ok = false; break; }
+						uint32_t l_name = rd32(&buf[o]); o += 4;
+						if (o + l_name + 4 > buf.size()) { ok = false; break; }
+						names.emplace_back((const char*)&buf[o], l_name ? l_name - 1 : 0); o += l_name; lens.push_back(rd32(&buf[o])); o += 4;
+					}
+					if (!ok) break;
+					header_done = true; consumed = o;
+					for (auto& nme : names) num.push_back(chr_num(nme));
+					for (size_t i = 0; i < num.size(); ++i) { if (num[i] == 1001 && tid_x < 0) tid_x = (int)i; if (num[i] == 1002 && tid_y < 0) tid_y = (int)i; }
+				} while (false);
+			}
+			if (header_done)
+			{
+				while (consumed + 4 <= buf.size())
+				{
+					uint32_t bs = rd32(&buf[consumed]);
+					if (consumed + 4 + bs > buf.size()) break;
+					process(parse_rec(&buf[consumed]));
+					consumed += 4 + (size_t)bs;
+					if (++st.n_records == max_records) { stop = true; break; }
+				}
+			}
+		}
+		off += bsize;
+	}
+	st.compressed = (int64_t)off;
+	r.bases_usable -= r.bases_clipped;
+	r.yx_valid = (tid_x >= 0 && tid_y >= 0 && r.reads_x != 0) ? 1 : 0;
+	if (r.roi_bases > 0)
+	{
+		double avg_depth = (double)r.bases_usable_roi / (double)r.roi_bases;
+		int half = (int)std::round(0.5 * avg_depth); r.half_depth = half;
+		for (int32_t d : r.depth) if (d >= half) ++r.bases_covered_half;
+	}
+	return r;
+}
+
+} // namespace orc

@@ -21,7 +21,7 @@ _lib = None
 
 def build():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("capi.cpp", "stats.hpp", "bed.hpp", "bamio.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("capi.cpp", "stats.hpp", "stream.hpp", "bed.hpp", "bamio.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
@@ -53,6 +53,8 @@ def lib():
         L.orc_result_cov.restype = i64; L.orc_result_cov.argtypes = [vp, vp, i64]
         L.orc_result_bed.restype = cp; L.orc_result_bed.argtypes = [vp]
         L.orc_low_high_coverage.restype = vp; L.orc_low_high_coverage.argtypes = [vp, cp, i32, i32, i32, i32, i32, i32, cp, i32]
+        L.orc_baseline_wgs_stream.restype = C.c_double
+        L.orc_baseline_wgs_stream.argtypes = [vp, i64, cp, i32, i64, vp, vp, cp, i32]
         L.orc_bed_roundtrip.restype = i64; L.orc_bed_roundtrip.argtypes = [cp, i32, cp, i64, cp, i32]
         _lib = L
     return _lib
@@ -190,3 +192,15 @@ def bed_roundtrip(bed, merge_mode=0):
     buf = C.create_string_buffer(n + 1)
     lib().orc_bed_roundtrip(_b(bed), merge_mode, buf, n + 1, err, 1024)
     return buf.value.decode()
+
+
+def baseline_wgs_stream(image, bed=None, min_mapq=1, max_records=-1):
+    """Streaming single-thread MappingQC -wgs loop on a BAM image (numpy uint8). Returns (counters, stats dict, seconds)."""
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    counters = np.zeros(NCOUNTERS, dtype=np.int64)
+    st = np.zeros(3, dtype=np.int64)
+    err = C.create_string_buffer(1024)
+    secs = lib().orc_baseline_wgs_stream(img.ctypes.data, img.size, _b(bed), min_mapq, max_records, counters.ctypes.data, st.ctypes.data, err, 1024)
+    if secs < 0:
+        raise OracleError(err.value.decode())
+    return counters, {"n_records": int(st[0]), "inflated": int(st[1]), "compressed": int(st[2])}, secs
