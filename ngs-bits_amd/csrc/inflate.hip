@@ -1,62 +1,50 @@
 // K1 — BGZF block inflate (RFC 1951 DEFLATE) for gfx950.
 //
 // Replaces what the reference gets from htslib inside sam_read1() (src/cppNGS/BamReader.h:388): every BGZF member is an
-// independent raw-DEFLATE stream of <= 64 KiB output, so the parallelism is ACROSS members. One decoder group of G lanes
-// per member: the group's leader lane runs the bit-serial Huffman decode out of LDS tables; literals are stored by the
-// leader, every LZ77 match is copied cooperatively by all G lanes (periodic-source form, so overlapping matches need no
-// intra-copy ordering). The bit reader keeps a 128-bit window in registers (w0..w3) that is refilled with aligned dword
-// loads two words ahead of use, so the HBM/L2 latency of the compressed stream is off the decode dependency chain.
+// independent raw-DEFLATE stream of <= 64 KiB output, so the parallelism is ACROSS members.
 //
-// This kernel is integer / bit-serial work: no MFMA. It is bounded by per-wave issue rate and LDS latency, not HBM.
+// Mapping to the wave: a 64-lane wave hosts 64/G independent decoder GROUPS of G lanes, one BGZF member per group.
+//   * GROUP-REDUNDANT DECODE: every lane of a group carries the same bit-reader / Huffman state and executes the decode
+//     redundantly (SIMT executes the lanes together anyway). There is no leader lane, so no exec-mask juggling and no
+//     broadcast of decoded symbols; table look-ups are same-address LDS broadcasts.
+//   * LOCKSTEP: the wave runs ONE flat loop; each trip decodes one symbol for every group (state machine per group), so
+//     the instruction stream is shared by all groups instead of being issued once per member.
+//   * the compressed stream lives in REGISTERS: lane j of a group holds word base+j (coalesced dword loads by the whole
+//     group, the following G words prefetched one batch ahead); the decoder pulls a word with a cross-lane read
+//     (ds_bpermute) — no LDS ring, and HBM/L2 latency never sits on the decode dependency chain;
+//   * literals are stored by lane 0 of the group, every LZ77 match is copied cooperatively by the G lanes
+//     (periodic-source form, so overlapping matches need no intra-copy ordering);
+//   * per-group LDS is only the two 16-bit Huffman look-up tables + the canonical arrays for long codes (~2.4 KiB), which
+//     is what bounds the number of members in flight per CU (LDS 160 KiB).
+// Integer / bit-serial work: no MFMA; bounded by issue rate and LDS/L2 latency, not by HBM bandwidth.
 #include "common.h"
+#include <cstdlib>
 
 namespace ngsqc {
 
-constexpr int LIT_BITS = 10;
-constexpr int DIST_BITS = 8;
-constexpr int MAX_LIT_RUN = 16;   // leader re-syncs with its group at least every MAX_LIT_RUN literals
-
+template <int LIT_BITS, int DIST_BITS>
 struct GroupTables
 {
-	uint16_t lit_lut[1 << LIT_BITS];   // (sym << 4) | len, 0 = not in fast table
+	uint16_t lit_lut[1 << LIT_BITS];   // (sym << 4) | code length ; 0 = not in the fast table
 	uint16_t dist_lut[1 << DIST_BITS];
-	uint16_t lit_sym[288];             // symbols sorted by (len, sym) for the canonical slow path
+	uint16_t lit_sym[288];             // symbols sorted by (len, sym): canonical decode of codes longer than the LUT
 	uint16_t dist_sym[32];
 	uint16_t lit_cnt[16];
 	uint16_t dist_cnt[16];
 	uint16_t offs[16];
 	uint16_t next_code[16];
-	uint8_t  lens[344];                // [0..20) code-length code lengths, [20..20+316) litlen+dist code lengths
+	uint8_t  lens[340];                // [0..20) code-length code lengths, [20..20+316) litlen+dist code lengths
 };
 
-__constant__ uint16_t c_lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
-__constant__ uint8_t  c_lext[29]  = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
-__constant__ uint16_t c_dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
-__constant__ uint8_t  c_dext[30]  = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
-__constant__ uint8_t  c_clorder[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
-
-struct BitReader
+// RFC 1951 code-length alphabet order {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15} packed 5 bits each
+__device__ __forceinline__ uint32_t clorder(int k)
 {
-	const uint32_t* base; uint32_t idx; uint32_t limit; // idx = next word to load; limit = last word index that may be loaded
-	uint32_t w0, w1, w2, w3; uint32_t shift;
-	__device__ __forceinline__ uint32_t ld(uint32_t i) const { return i <= limit ? base[i] : 0u; }
-	__device__ void init(const uint8_t* p, uint32_t nbytes)
-	{
-		uintptr_t a = (uintptr_t)p;
-		base = (const uint32_t*)(a & ~(uintptr_t)3);
-		shift = (uint32_t)(a & 3) * 8;
-		limit = (uint32_t)(((a & 3) + nbytes + 3) / 4); // one word of slack; the compressed image is padded
-		w0 = ld(0); w1 = ld(1); w2 = ld(2); w3 = ld(3); idx = 4;
-	}
-	__device__ __forceinline__ void norm() { if (shift >= 32) { shift -= 32; w0 = w1; w1 = w2; w2 = w3; w3 = ld(idx); ++idx; } }
-	__device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w1, w0, shift); } // 32 valid bits, shift < 32
-	__device__ __forceinline__ void consume(uint32_t n) { shift += n; }
-	__device__ __forceinline__ uint32_t get(uint32_t n) { norm(); uint32_t v = peek() & ((1u << n) - 1u); consume(n); return v; } // n <= 16
-	__device__ __forceinline__ uint64_t bytepos() const { return (uint64_t)(idx - 4) * 4 + (shift >> 3); } // relative to base
-	__device__ __forceinline__ bool overrun() const { return idx > limit + 6; }
-};
+	const uint64_t lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) | (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+	const uint64_t hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+	return (uint32_t)((k < 12 ? lo >> (5 * k) : hi >> (5 * (k - 12))) & 31u);
+}
 
-// canonical decode for codes longer than the fast table (and as the general fallback): puff-style, LSB-first bits
+// canonical decode for codes longer than the fast table: puff-style, LSB-first bits. returns (sym << 4) | len, 0 = invalid
 __device__ static uint32_t slow_decode(uint32_t bits, const uint16_t* cnt, const uint16_t* sym)
 {
 	int code = 0, first = 0, index = 0;
@@ -70,20 +58,35 @@ __device__ static uint32_t slow_decode(uint32_t bits, const uint16_t* cnt, const
 	return 0;
 }
 
-// Build canonical tables from code lengths (leader lane only; LUT must be zeroed by the group beforehand).
+// Build canonical tables from code lengths. Executed redundantly by every lane of the group (same values, same
+// addresses); the LUT must have been zeroed beforehand.
 __device__ static void build_tables(const uint8_t* lens, int n, uint16_t* cnt, uint16_t* sym, uint16_t* lut, int bits, uint16_t* offs, uint16_t* next_code)
 {
 	for (int i = 0; i < 16; ++i) cnt[i] = 0;
-	for (int s = 0; s < n; ++s) cnt[lens[s]]++;
-	cnt[0] = 0;
-	uint32_t o = 0, code = 0;
-	for (int l = 1; l <= 15; ++l) { offs[l] = (uint16_t)o; o += cnt[l]; next_code[l] = (uint16_t)code; code = (code + cnt[l]) << 1; }
+	__builtin_amdgcn_wave_barrier();
+	{
+		// histogram of code lengths in registers (4 bits per... up to 288 -> 16 counters of 9+ bits): avoid LDS read-modify-write chains
+		uint32_t c[16];
+		#pragma unroll
+		for (int i = 0; i < 16; ++i) c[i] = 0;
+		for (int s = 0; s < n; ++s)
+		{
+			uint32_t l = lens[s];
+			#pragma unroll
+			for (int i = 1; i < 16; ++i) c[i] += (l == (uint32_t)i);
+		}
+		uint32_t o = 0, code = 0;
+		#pragma unroll
+		for (int l = 1; l <= 15; ++l) { cnt[l] = (uint16_t)c[l]; offs[l] = (uint16_t)o; o += c[l]; next_code[l] = (uint16_t)code; code = (code + c[l]) << 1; }
+	}
+	__builtin_amdgcn_wave_barrier();
 	for (int s = 0; s < n; ++s)
 	{
 		int l = lens[s];
 		if (!l) continue;
-		sym[offs[l]++] = (uint16_t)s;
-		uint32_t c = next_code[l]++;
+		uint32_t k = offs[l]; offs[l] = (uint16_t)(k + 1);
+		sym[k] = (uint16_t)s;
+		uint32_t c = next_code[l]; next_code[l] = (uint16_t)(c + 1);
 		if (l <= bits)
 		{
 			uint32_t rev = __brev(c) >> (32 - l);
@@ -91,211 +94,256 @@ __device__ static void build_tables(const uint8_t* lens, int n, uint16_t* cnt, u
 			for (uint32_t i = rev; i < (1u << bits); i += (1u << l)) lut[i] = e;
 		}
 	}
+	__builtin_amdgcn_wave_barrier();
 }
 
-template <int G>
+enum { ST_NEXT_MEMBER = 0, ST_BLOCK_HEADER = 1, ST_SYMBOLS = 2, ST_DONE = 3 };
+
+template <int G, int LIT_BITS, int DIST_BITS, int DBG = 0>
 __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                                             uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
 {
 	constexpr int GROUPS = 256 / G;
-	__shared__ GroupTables tabs[GROUPS];
+	__shared__ GroupTables<LIT_BITS, DIST_BITS> tabs[GROUPS];
 	const int tid = threadIdx.x;
-	const int g = tid / G;          // group within workgroup
-	const int gl = tid % G;         // lane within group
+	const int g = tid / G;            // group within workgroup
+	const int gl = tid % G;           // lane within group
 	const int lane = tid & 63;
-	const int leader_lane = lane - gl; // wave-relative lane index of this group's leader
-	const bool leader = gl == 0;
-	GroupTables& T = tabs[g];
+	const int gbase = lane - gl;      // wave-relative lane index of this group's lane 0
+	GroupTables<LIT_BITS, DIST_BITS>& T = tabs[g];
 
-	for (int64_t b = (int64_t)blockIdx.x * GROUPS + g; b < n_blocks; b += (int64_t)gridDim.x * GROUPS)
+	// ---- per-group state (identical in all lanes of the group unless noted) ----
+	int state = ST_NEXT_MEMBER;
+	int64_t b = (int64_t)blockIdx.x * GROUPS + g - (int64_t)gridDim.x * GROUPS;   // advanced before first use
+	const uint32_t* in_words = nullptr; uint32_t n_words = 0, misalign = 0, clen = 0, usize = 0;
+	uint8_t* out = nullptr; const uint8_t* pay = nullptr;
+	uint32_t myword = 0, nextword = 0;   // per lane: words batch_base+gl and batch_base+G+gl
+	uint32_t batch_base = 0, w = 0, w0 = 0, w1 = 0, shift = 0;
+	uint32_t out_pos = 0, err = 0; int bfinal = 0;
+
+	auto ldw = [&](uint32_t wi) -> uint32_t { return wi < n_words ? in_words[wi] : 0u; };
+	auto fetch = [&](uint32_t k) -> uint32_t {   // word k of the compressed stream, k in [batch_base, batch_base + 2G)
+		uint32_t idx = k - batch_base;
+		if (idx >= (uint32_t)G) { myword = nextword; batch_base += G; nextword = ldw(batch_base + G + gl); idx -= G; }
+		return (uint32_t)__shfl((int)myword, gbase + (int)idx);
+	};
+	auto norm = [&]() { if (shift >= 32) { shift -= 32; ++w; w0 = w1; w1 = fetch(w + 1); } };
+	auto peek = [&]() -> uint32_t { return __builtin_amdgcn_alignbit(w1, w0, shift); };  // 32 valid bits when shift < 32
+	auto get = [&](uint32_t n) -> uint32_t { norm(); uint32_t v = peek() & ((1u << n) - 1u); shift += n; return v; };   // n <= 16
+	auto reader_init = [&](uint32_t byte_rel) {   // restart the bit reader at a payload-relative byte position
+		uint32_t abs_byte = misalign + byte_rel;
+		batch_base = abs_byte / 4; w = batch_base; shift = (abs_byte & 3) * 8;
+		myword = ldw(batch_base + gl); nextword = ldw(batch_base + G + gl);
+		w0 = fetch(w); w1 = fetch(w + 1);
+	};
+
+	while (true)
 	{
-		const BlockDesc bd = blocks[b];
-		uint8_t* out = out_base + bd.upos;
-		const uint32_t usize = bd.usize;
-		BitReader br;
-		uint32_t out_pos = 0;
-		uint32_t err = 0;
-		if (leader) br.init(comp + bd.cpos, bd.clen);
-		int bfinal = 0;
-		while (!bfinal && !err)
+		if (state == ST_NEXT_MEMBER)
 		{
-			// ---- block header (leader) ----
-			int btype = 0;
-			if (leader) { bfinal = (int)br.get(1); btype = (int)br.get(2); if (br.overrun()) err = 1; }
-			bfinal = __shfl(bfinal, leader_lane); btype = __shfl(btype, leader_lane); err = __shfl(err, leader_lane);
-			if (err) break;
-			if (btype == 0)
+			b += (int64_t)gridDim.x * GROUPS;
+			if (b >= n_blocks) state = ST_DONE;
+			else
 			{
-				// stored block: skip to byte boundary, LEN, NLEN, then LEN raw bytes
-				uint32_t len = 0, rel = 0;
-				if (leader)
-				{
-					br.norm(); br.shift = (br.shift + 7u) & ~7u; br.norm();
-					uint32_t v = br.peek(); br.consume(32); br.norm();
-					len = v & 0xffffu;
-					if ((len ^ (v >> 16)) != 0xffffu) err = 2;
-					rel = (uint32_t)(((const uint8_t*)br.base + br.bytepos()) - (comp + bd.cpos)); // payload-relative byte position
-					if (out_pos + len > usize || rel + len > bd.clen) err = 3;
-				}
-				len = __shfl(len, leader_lane); err = __shfl(err, leader_lane); rel = __shfl(rel, leader_lane);
-				uint32_t opos = __shfl(out_pos, leader_lane);
-				if (err) break;
-				const uint8_t* src = comp + bd.cpos + rel;
-				for (uint32_t i = gl; i < len; i += G) out[opos + i] = src[i];
-				if (leader)
-				{
-					out_pos += len;
-					br.init(src + len, bd.clen - (rel + len));
-				}
-				continue;
+				const BlockDesc bd = blocks[b];
+				out = out_base + bd.upos; usize = bd.usize; clen = bd.clen;
+				pay = comp + bd.cpos;
+				in_words = (const uint32_t*)((uintptr_t)pay & ~(uintptr_t)3);
+				misalign = (uint32_t)((uintptr_t)pay & 3);
+				n_words = (misalign + clen + 3) / 4 + 1;   // one word of slack (the compressed image is padded)
+				reader_init(0);
+				out_pos = 0; err = 0; bfinal = 0;
+				state = ST_BLOCK_HEADER;
 			}
-			if (btype == 3) { err = 4; break; }
-
-			// ---- Huffman tables ----
-			for (int i = gl; i < (1 << LIT_BITS); i += G) T.lit_lut[i] = 0;
-			for (int i = gl; i < (1 << DIST_BITS); i += G) T.dist_lut[i] = 0;
-			__builtin_amdgcn_wave_barrier();
-			if (leader)
+		}
+		else if (state == ST_BLOCK_HEADER)
+		{
+			if (bfinal || err)
 			{
-				int nlit, ndist;
-				uint8_t* L = T.lens + 20; // litlen code lengths, then dist code lengths
-				if (btype == 1)
+				if (!err && out_pos != usize) err = 14;
+				if (gl == 0) { status[b].produced = out_pos; status[b].error = err; }
+				state = ST_NEXT_MEMBER;
+			}
+			else
+			{
+				bfinal = (int)get(1);
+				int btype = (int)get(2);
+				if (w > n_words + 2) err = 1;
+				else if (btype == 0)
 				{
-					for (int i = 0; i < 144; ++i) L[i] = 8;
-					for (int i = 144; i < 256; ++i) L[i] = 9;
-					for (int i = 256; i < 280; ++i) L[i] = 7;
-					for (int i = 280; i < 288; ++i) L[i] = 8;
-					for (int i = 0; i < 30; ++i) L[288 + i] = 5;
-					nlit = 288; ndist = 30;
+					// stored block: skip to byte boundary, LEN, NLEN, then LEN raw bytes
+					norm(); shift = (shift + 7u) & ~7u; norm();
+					uint32_t v = peek(); shift += 32; norm();
+					uint32_t len = v & 0xffffu;
+					uint32_t rel = w * 4 + (shift >> 3) - misalign;   // payload-relative byte position
+					if ((len ^ (v >> 16)) != 0xffffu) err = 2;
+					else if (out_pos + len > usize || rel + len > clen) err = 3;
+					else
+					{
+						const uint8_t* src = pay + rel;
+						for (uint32_t i = gl; i < len; i += G) out[out_pos + i] = src[i];
+						out_pos += len;
+						reader_init(rel + len);
+					}
 				}
+				else if (btype == 3) err = 4;
 				else
 				{
-					nlit = (int)br.get(5) + 257; ndist = (int)br.get(5) + 1; int ncl = (int)br.get(4) + 4;
-					if (nlit > 286 || ndist > 30) err = 5;
-					uint8_t* cl = T.lens; // 19 code-length code lengths, built into dist_lut (7-bit table) temporarily
-					for (int i = 0; i < 19; ++i) cl[i] = 0;
-					for (int i = 0; i < ncl; ++i) cl[c_clorder[i]] = (uint8_t)br.get(3);
-					build_tables(cl, 19, T.dist_cnt, T.dist_sym, T.dist_lut, 7, T.offs, T.next_code);
-					int i = 0, n = nlit + ndist; uint32_t prev = 0;
-					while (i < n && !err)
+					// ---- Huffman tables ----
+					for (int i = gl; i < (1 << LIT_BITS); i += G) T.lit_lut[i] = 0;
+					for (int i = gl; i < (1 << DIST_BITS); i += G) T.dist_lut[i] = 0;
+					__builtin_amdgcn_wave_barrier();
+					int nlit, ndist;
+					uint8_t* L = T.lens + 20; // litlen code lengths, then dist code lengths
+					if (btype == 1)
 					{
-						br.norm();
-						uint32_t e = T.dist_lut[br.peek() & 127u];
-						if (!(e & 15u)) { err = 6; break; }
-						br.consume(e & 15u);
-						uint32_t s = e >> 4;
-						if (s < 16) { L[i++] = (uint8_t)s; prev = s; }
-						else
-						{
-							uint32_t rep, val = 0;
-							if (s == 16) { if (i == 0) { err = 7; break; } rep = 3 + br.get(2); val = prev; }
-							else if (s == 17) { rep = 3 + br.get(3); prev = 0; }
-							else { rep = 11 + br.get(7); prev = 0; }
-							if (i + (int)rep > n) { err = 8; break; }
-							for (uint32_t k = 0; k < rep; ++k) L[i++] = (uint8_t)val;
-						}
-						if (br.overrun()) err = 1;
-					}
-					if (!err && L[256] == 0) err = 15; // no end-of-block code
-					for (int k = 0; k < (1 << DIST_BITS); ++k) T.dist_lut[k] = 0;
-				}
-				if (!err)
-				{
-					build_tables(L, nlit, T.lit_cnt, T.lit_sym, T.lit_lut, LIT_BITS, T.offs, T.next_code);
-					build_tables(L + nlit, ndist, T.dist_cnt, T.dist_sym, T.dist_lut, DIST_BITS, T.offs, T.next_code);
-				}
-			}
-			err = __shfl(err, leader_lane);
-			if (err) break;
-			__builtin_amdgcn_wave_barrier();
-
-			// ---- symbols ----
-			while (true)
-			{
-				int kind = 0; uint32_t mlen = 0, mdist = 0;
-				if (leader)
-				{
-					int nlit = 0;
-					while (true)
-					{
-						br.norm();
-						uint32_t bits = br.peek();
-						uint32_t e = T.lit_lut[bits & ((1u << LIT_BITS) - 1u)];
-						if (!(e & 15u)) { e = slow_decode(bits, T.lit_cnt, T.lit_sym); if (!e) { err = 9; kind = 3; break; } }
-						uint32_t l = e & 15u, s = e >> 4;
-						if (s < 256)
-						{
-							br.consume(l);
-							if (out_pos >= usize) { err = 3; kind = 3; break; }
-							out[out_pos++] = (uint8_t)s;
-							if (++nlit >= MAX_LIT_RUN) { kind = 0; break; }
-							continue;
-						}
-						if (s == 256) { br.consume(l); kind = 2; break; }
-						s -= 257;
-						if (s >= 29) { err = 10; kind = 3; break; }
-						uint32_t eb = c_lext[s];
-						mlen = c_lbase[s] + ((bits >> l) & ((1u << eb) - 1u));
-						br.consume(l + eb);
-						br.norm();
-						bits = br.peek();
-						e = T.dist_lut[bits & ((1u << DIST_BITS) - 1u)];
-						if (!(e & 15u)) { e = slow_decode(bits, T.dist_cnt, T.dist_sym); if (!e) { err = 11; kind = 3; break; } }
-						l = e & 15u; s = e >> 4;
-						if (s >= 30) { err = 12; kind = 3; break; }
-						eb = c_dext[s];
-						mdist = c_dbase[s] + ((bits >> l) & ((1u << eb) - 1u));
-						br.consume(l + eb);
-						if (mdist > out_pos || out_pos + mlen > usize) { err = 13; kind = 3; break; }
-						if (br.overrun()) { err = 1; kind = 3; break; }
-						kind = 1; break;
-					}
-				}
-				kind = __shfl(kind, leader_lane);
-				if (kind == 1)
-				{
-					mlen = __shfl(mlen, leader_lane); mdist = __shfl(mdist, leader_lane);
-					uint32_t opos = __shfl(out_pos, leader_lane);
-					uint8_t* dst = out + opos; const uint8_t* src = dst - mdist;
-					if (mdist >= mlen)
-					{
-						for (uint32_t i = gl; i < mlen; i += G) dst[i] = src[i];
+						for (int i = gl; i < 288; i += G) L[i] = (uint8_t)(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+						for (int i = gl; i < 30; i += G) L[288 + i] = 5;
+						nlit = 288; ndist = 30;
+						__builtin_amdgcn_wave_barrier();
 					}
 					else
 					{
-						// overlapping match: out[i] = window[i mod dist]; every source byte precedes the match
-						float rcp = __frcp_rn((float)mdist);
-						for (uint32_t i = gl; i < mlen; i += G)
+						nlit = (int)get(5) + 257; ndist = (int)get(5) + 1; int ncl = (int)get(4) + 4;
+						if (nlit > 286 || ndist > 30) err = 5;
+						uint8_t* cl = T.lens; // 19 code-length code lengths, built into dist_lut (7-bit table) temporarily
+						for (int i = gl; i < 19; i += G) cl[i] = 0;
+						__builtin_amdgcn_wave_barrier();
+						for (int i = 0; i < ncl; ++i) { uint32_t v = get(3); cl[clorder(i)] = (uint8_t)v; }
+						__builtin_amdgcn_wave_barrier();
+						build_tables(cl, 19, T.dist_cnt, T.dist_sym, T.dist_lut, 7, T.offs, T.next_code);
+						int i = 0, n = nlit + ndist; uint32_t prev = 0;
+						while (i < n && !err)
 						{
-							uint32_t q = (uint32_t)((float)i * rcp);
-							int r = (int)i - (int)(q * mdist);
-							if (r < 0) r += (int)mdist; else if (r >= (int)mdist) r -= (int)mdist;
-							dst[i] = src[r];
+							norm();
+							uint32_t e = T.dist_lut[peek() & 127u];
+							if (!(e & 15u)) { err = 6; break; }
+							shift += (e & 15u);
+							uint32_t s = e >> 4;
+							if (s < 16) { L[i++] = (uint8_t)s; prev = s; }
+							else
+							{
+								uint32_t rep, val = 0;
+								if (s == 16) { if (i == 0) { err = 7; break; } rep = 3 + get(2); val = prev; }
+								else if (s == 17) { rep = 3 + get(3); prev = 0; }
+								else { rep = 11 + get(7); prev = 0; }
+								if (i + (int)rep > n) { err = 8; break; }
+								for (uint32_t k = 0; k < rep; ++k) L[i++] = (uint8_t)val;
+							}
+						}
+						__builtin_amdgcn_wave_barrier();
+						if (!err && L[256] == 0) err = 15; // no end-of-block code
+						for (int k = gl; k < (1 << DIST_BITS); k += G) T.dist_lut[k] = 0;
+						__builtin_amdgcn_wave_barrier();
+					}
+					if (!err)
+					{
+						build_tables(L, nlit, T.lit_cnt, T.lit_sym, T.lit_lut, LIT_BITS, T.offs, T.next_code);
+						build_tables(L + nlit, ndist, T.dist_cnt, T.dist_sym, T.dist_lut, DIST_BITS, T.offs, T.next_code);
+						state = ST_SYMBOLS;
+					}
+				}
+			}
+		}
+		else if (state == ST_SYMBOLS)
+		{
+			// ---- one Huffman symbol per trip ----
+			norm();
+			uint32_t bits = peek();
+			uint32_t e = T.lit_lut[bits & ((1u << LIT_BITS) - 1u)];
+			if (!(e & 15u)) e = slow_decode(bits, T.lit_cnt, T.lit_sym);
+			uint32_t l = e & 15u, s = e >> 4;
+			if (!e) { err = 9; state = ST_BLOCK_HEADER; }
+			else if (s < 256)
+			{
+				shift += l;
+				if (out_pos >= usize) { err = 3; state = ST_BLOCK_HEADER; }
+				else { if (DBG < 2 && gl == 0) out[out_pos] = (uint8_t)s; ++out_pos; }
+			}
+			else if (s == 256) { shift += l; state = ST_BLOCK_HEADER; }
+			else
+			{
+				s -= 257;
+				if (s >= 29) { err = 10; state = ST_BLOCK_HEADER; }
+				else
+				{
+					// length base / extra bits computed arithmetically (RFC 1951 §3.2.5)
+					uint32_t eb = s < 8 ? 0u : (s == 28 ? 0u : (s - 4) >> 2);
+					uint32_t base = s < 8 ? s + 3 : (s == 28 ? 258u : ((4u + ((s - 4) & 3u)) << eb) + 3u);
+					uint32_t mlen = base + ((bits >> l) & ((1u << eb) - 1u));
+					shift += l + eb;
+					norm();
+					bits = peek();
+					e = T.dist_lut[bits & ((1u << DIST_BITS) - 1u)];
+					if (!(e & 15u)) e = slow_decode(bits, T.dist_cnt, T.dist_sym);
+					l = e & 15u; s = e >> 4;
+					if (!e || s >= 30) { err = 11; state = ST_BLOCK_HEADER; }
+					else
+					{
+						eb = s < 4 ? 0u : (s >> 1) - 1u;
+						base = s < 4 ? s + 1 : ((2u + (s & 1u)) << eb) + 1u;
+						uint32_t mdist = base + ((bits >> l) & ((1u << eb) - 1u));
+						shift += l + eb;
+						if (mdist > out_pos || out_pos + mlen > usize || w > n_words + 2) { err = 13; state = ST_BLOCK_HEADER; }
+						else
+						{
+							if (DBG < 1)
+							{
+								uint8_t* dst = out + out_pos; const uint8_t* src = dst - mdist;
+								if (mdist >= mlen)
+								{
+									for (uint32_t i = gl; i < mlen; i += G) dst[i] = src[i];
+								}
+								else
+								{
+									// overlapping match: out[i] = window[i mod dist]; every source byte precedes the match
+									float rcp = __frcp_rn((float)mdist);
+									for (uint32_t i = gl; i < mlen; i += G)
+									{
+										uint32_t q = (uint32_t)((float)i * rcp);
+										int r = (int)i - (int)(q * mdist);
+										if (r < 0) r += (int)mdist; else if (r >= (int)mdist) r -= (int)mdist;
+										dst[i] = src[r];
+									}
+								}
+							}
+							out_pos += mlen;
 						}
 					}
-					if (leader) out_pos += mlen;
 				}
-				else if (kind >= 2) break;
 			}
-			err = __shfl(err, leader_lane);
 		}
-		if (leader)
-		{
-			if (!err && out_pos != usize) err = 14;
-			status[b].produced = out_pos; status[b].error = err;
-		}
+		else break;   // ST_DONE (a wave leaves the loop when all its groups are done)
 	}
+}
+
+template <int G, int LB, int DB, int DBG = 0>
+static void launch_inflate_t(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status, hipStream_t s)
+{
+	constexpr int GROUPS = 256 / G;
+	int64_t wgs = (n_blocks + GROUPS - 1) / GROUPS;
+	int64_t cap = 256 * 8; // persistent-style grid: the flat loop walks members grid-stride
+	int grid = (int)(wgs < cap ? wgs : cap);
+	hipLaunchKernelGGL((bgzf_inflate_kernel<G, LB, DB, DBG>), dim3(grid), dim3(256), 0, s, d_comp, d_blocks, n_blocks, d_out, d_status);
 }
 
 void launch_inflate(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	constexpr int G = 64;
-	constexpr int GROUPS = 256 / G;
-	int64_t wgs = (n_blocks + GROUPS - 1) / GROUPS;
-	int64_t cap = 256 * 8 * 4; // enough workgroups to fill the chip several times over; grid-stride beyond
-	int grid = (int)(wgs < cap ? wgs : cap);
-	hipLaunchKernelGGL(bgzf_inflate_kernel<G>, dim3(grid), dim3(256), 0, s, d_comp, d_blocks, n_blocks, d_out, d_status);
+	const char* ev = getenv("NGSQC_INFLATE_VARIANT"); const int variant = ev ? atoi(ev) : 0;
+	switch (variant)
+	{
+		case 1: launch_inflate_t<32, 10, 8>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 2: launch_inflate_t<16, 10, 8>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 3: launch_inflate_t<16, 9, 7>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 4: launch_inflate_t<8, 9, 7>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 5: launch_inflate_t<32, 9, 7>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 6: launch_inflate_t<64, 10, 8>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 7: launch_inflate_t<8, 10, 8>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 12: launch_inflate_t<16, 9, 7, 1>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		case 13: launch_inflate_t<16, 9, 7, 2>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+		default: launch_inflate_t<16, 9, 7>(d_comp, d_blocks, n_blocks, d_out, d_status, s); break;
+	}
 }
 
 } // namespace ngsqc
