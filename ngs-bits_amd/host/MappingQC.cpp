@@ -1,0 +1,81 @@
+// MappingQC — drop-in for src/MappingQC/main.cpp:21-188 on the MI355X path: same flags, defaults, checks and output
+// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): the contamination check (-no_cont is implied),
+// -somatic_custom_bed and -read_qc; they are accepted and reported as not implemented instead of silently ignored.
+#include "Statistics.hpp"
+using namespace ngsbits;
+
+class ConcreteTool : public ToolBase
+{
+public:
+	ConcreteTool(int argc, char** argv) : ToolBase(argc, argv) {}
+	void setup() override
+	{
+		setDescription("Calculates QC metrics based on mapped NGS reads.");
+		addInfile("in", "Input BAM/CRAM file.", false, true);
+		addOutfile("out", "Output qcML file. If unset, writes to STDOUT.", true);
+		addInfile("roi", "Input target region BED file (for panel, WES, etc.).", true, true);
+		addFlag("wgs", "WGS mode without target region. Genome information is taken from the BAM/CRAM file.");
+		addFlag("rna", "RNA mode without target region. Genome information is taken from the BAM/CRAM file.");
+		addFlag("txt", "Writes TXT format instead of qcML.");
+		addInt("min_mapq", "Minmum mapping quality to consider a read mapped.", true, 1);
+		addFlag("no_cont", "Disables sample contamination calculation, e.g. for tumor or non-human samples.");
+		addFlag("debug", "Enables verbose debug outout.");
+		addEnum("build", "Genome build used to generate the input (needed for WGS and contamination only).", true, {"hg19", "hg38", "non_human"}, "hg38");
+		addInfile("ref", "Reference genome FASTA file. If unset 'reference_genome' from the 'settings.ini' file is used.", true, false);
+		addFlag("cfdna", "Add additional QC parameters for cfDNA samples. Only supported mit '-roi'.");
+		addInfile("somatic_custom_bed", "Somatic custom region of interest (subpanel of actual roi). If specified, additional depth metrics will be calculated.", true, true);
+		addOutfile("read_qc", "If set, a read QC file in qcML format is created (just like ReadQC/SeqPurge).", true);
+		addFlag("single_end", "Enable single-end mode. Use for ONT, PacBio and Roche. Illumina single-end data is auto-detected based on paired reads.");
+		addFlag("no_ref", "[ngsqc extension] Run without a reference genome: GC/AT dropout become n/a, no N-base correction in WGS mode.");
+	}
+	void main() override
+	{
+		std::string roi_file = getInfile("roi");
+		bool wgs = getFlag("wgs"), rna = getFlag("rna");
+		std::string in = getInfile("in");
+		std::string ref_file = getInfile("ref");
+		if (getFlag("no_ref")) ref_file = NO_REF;
+		if (ref_file == "") ref_file = settingsString("reference_genome");
+		if (ref_file == "") NB_THROW(CommandLineParsingException, "Reference genome FASTA unset in both command-line and settings.ini file!");
+		bool cfdna = getFlag("cfdna"); int min_mapq = getInt("min_mapq");
+		int parameters_set = (roi_file != "" ? 1 : 0) + wgs + rna;
+		if (parameters_set != 1) NB_THROW(CommandLineParsingException, "You have to use exactly one of the parameters 'roi', 'wgs', or 'rna' !");
+		if (cfdna && roi_file == "") NB_THROW(CommandLineParsingException, "The flag 'cfdna' can only be used with parameter 'roi'!");
+		if (getOutfile("read_qc") != "") NB_THROW(NotImplementedException, "'-read_qc' is not available in the MI355X build yet (StatisticsReads is a 'next' row of the hot-path scope).");
+		if (getInfile("somatic_custom_bed") != "") NB_THROW(NotImplementedException, "'-somatic_custom_bed' is not available in the MI355X build yet (somaticCustomDepth is a 'next' row of the hot-path scope).");
+
+		std::vector<std::string> parameters; QCCollection metrics;
+		if (wgs)
+		{
+			std::string build = getEnum("build");
+			if (build == "non_human") metrics = Statistics::mapping(in, ref_file, min_mapq);
+			else metrics = Statistics::mapping_wgs(in, resourceDir() + "/" + (build == "hg19" ? "hg19_439_omim_genes.bed" : "hg38_440_omim_genes.bed"), min_mapq, ref_file);
+			parameters.push_back("-wgs");
+		}
+		else if (rna) { metrics = Statistics::mapping(in, ref_file, min_mapq); parameters.push_back("-rna"); }
+		else
+		{
+			BedFile roi; roi.load(roi_file); roi.merge();
+			metrics = Statistics::mapping(roi, in, ref_file, min_mapq, cfdna);
+			parameters.push_back("-roi"); parameters.push_back(fileName(roi_file));
+			if (cfdna) parameters.push_back("-cfdna");
+		}
+		// sample contamination (Statistics::contamination, main.cpp:146-151): not on the GPU path yet -> behaves like -no_cont
+		QCCollection metrics_cont;
+		if (getFlag("single_end")) parameters.push_back("-single_end");
+		std::string out = getOutfile("out");
+		if (getFlag("txt"))
+		{
+			std::vector<std::string> output; metrics.appendToStringList(output); output.push_back(""); metrics_cont.appendToStringList(output);
+			std::string text; for (auto& l : output) text += l + "\n";
+			if (out.empty()) fwrite(text.data(), 1, text.size(), stdout);
+			else { FILE* f = fopen(out.c_str(), "wb"); if (!f) NB_THROW(FileAccessException, "Could not open file for writing: '" + out + "'!"); fwrite(text.data(), 1, text.size(), f); fclose(f); }
+		}
+		else
+		{
+			metrics.insert(metrics_cont);
+			metrics.storeToQCML(out, {in}, join(parameters, " "), "MappingQC", version());
+		}
+	}
+};
+int main(int argc, char** argv) { ConcreteTool tool(argc, argv); return tool.execute(); }

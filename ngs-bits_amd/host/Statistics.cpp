@@ -1,0 +1,446 @@
+#include "Statistics.hpp"
+#include <zlib.h>
+
+namespace ngsbits {
+
+const char* const NO_REF = "<none>";
+
+// ---------------------------------------------------------------- BamReader
+BamReader::BamReader(const std::string& bam_file, const std::string&) : bam_file_(bam_file)
+{
+	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
+	int rc = ngsqc_open(bam_file.c_str(), dev, &h_);
+	if (rc != NGSQC_OK)
+	{
+		std::string msg = ngsqc_last_error(nullptr);
+		if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file);   // BamReader.cpp:467
+		if (rc == NGSQC_E_DEVICE) NB_THROW(Exception, "GPU backend unavailable: " + msg);
+		NB_THROW(FileAccessException, msg);
+	}
+	for (int i = 0; i < ngsqc_n_ref(h_); ++i) { chrs_.emplace_back(ngsqc_ref_name(h_, i)); sizes_.push_back(ngsqc_ref_len(h_, i)); }
+}
+BamReader::~BamReader() { if (h_) ngsqc_close(h_); }
+int BamReader::chromosomeID(const Chromosome& chr) const { for (size_t i = 0; i < chrs_.size(); ++i) if (chrs_[i] == chr) return (int)i; return -1; }
+int BamReader::chromosomeSize(const Chromosome& chr) const
+{
+	int id = chromosomeID(chr);
+	if (id < 0) NB_THROW(ArgumentException, "Chromosome '" + chr.str() + "' not known in BAM/CRAM file " + bam_file_);
+	return (int)sizes_[(size_t)id];
+}
+double BamReader::genomeSize(bool include_special) const { double s = 0; for (size_t i = 0; i < chrs_.size(); ++i) if (chrs_[i].isNonSpecial() || include_special) s += (double)sizes_[i]; return s; }
+void BamReader::requireIndex() const
+{
+	// the reference needs a .bai/.csi for every region query; the GPU path does not, but the error is part of the contract
+	std::string base = bam_file_; size_t dot = base.rfind('.'); std::string noext = dot == std::string::npos ? base : base.substr(0, dot);
+	if (fileExists(bam_file_ + ".bai") || fileExists(noext + ".bai") || fileExists(bam_file_ + ".csi")) return;
+	NB_THROW(FileAccessException, "Could not load index of BAM/CRAM file " + bam_file_);
+}
+void BamReader::check(int rc) const
+{
+	if (rc == NGSQC_OK) return;
+	std::string msg = ngsqc_last_error(h_);
+	if (rc == NGSQC_E_ARG) NB_THROW(ArgumentException, msg);
+	if (rc == NGSQC_E_FORMAT) NB_THROW(FileAccessException, msg);
+	NB_THROW(Exception, msg);
+}
+
+// ---------------------------------------------------------------- QC value helpers
+void Statistics::addQcValue(QCCollection& output, const std::string& accession, const std::string& name, double value)
+{
+	auto it = qcmlTerms().find(accession);
+	if (it == qcmlTerms().end()) NB_THROW(ProgrammingException, "qcML does not contain term with accession '" + accession + "'!");
+	if (it->second.name != name) NB_THROW(ProgrammingException, "qcML term with accession '" + accession + "' does not have name '" + name + "'!");
+	QCValue v; v.name = name; v.accession = accession; v.description = it->second.definition; v.type = QCValueType::DOUBLE; v.d = value; output.insert(v);
+}
+void Statistics::addQcValue(QCCollection& output, const std::string& accession, const std::string& name, const std::string& value)
+{
+	auto it = qcmlTerms().find(accession);
+	if (it == qcmlTerms().end()) NB_THROW(ProgrammingException, "qcML does not contain term with accession '" + accession + "'!");
+	if (it->second.name != name) NB_THROW(ProgrammingException, "qcML term with accession '" + accession + "' does not have name '" + name + "'!");
+	QCValue v; v.name = name; v.accession = accession; v.description = it->second.definition; v.type = QCValueType::STRING; v.s = value; output.insert(v);
+}
+
+// Minimal line plot -> PNG -> base64 (the reference renders with QtCharts; payloads are not compared by its tests,
+// MappingQC_Test.cpp:15-16). Axes + polylines, no text.
+static std::string base64(const std::vector<uint8_t>& d)
+{
+	static const char* T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"; std::string o;
+	for (size_t i = 0; i < d.size(); i += 3)
+	{
+		uint32_t v = d[i] << 16 | (i + 1 < d.size() ? d[i + 1] << 8 : 0) | (i + 2 < d.size() ? d[i + 2] : 0);
+		o += T[(v >> 18) & 63]; o += T[(v >> 12) & 63]; o += i + 1 < d.size() ? T[(v >> 6) & 63] : '='; o += i + 2 < d.size() ? T[v & 63] : '=';
+	}
+	return o;
+}
+static std::string plotPng(const std::vector<double>& x, const std::vector<std::vector<double>>& lines)
+{
+	const int W = 640, H = 480, L = 40, B = 30; std::vector<uint8_t> img((size_t)W * H * 3, 255);
+	auto px = [&](int xx, int yy, uint8_t r, uint8_t g, uint8_t b) { if (xx < 0 || yy < 0 || xx >= W || yy >= H) return; size_t o = ((size_t)yy * W + xx) * 3; img[o] = r; img[o + 1] = g; img[o + 2] = b; };
+	for (int i = L; i < W - 10; ++i) px(i, H - B, 0, 0, 0);
+	for (int j = 10; j <= H - B; ++j) px(L, j, 0, 0, 0);
+	double xmin = 1e300, xmax = -1e300, ymin = 0, ymax = -1e300;
+	for (double v : x) { xmin = std::min(xmin, v); xmax = std::max(xmax, v); }
+	for (auto& l : lines) for (double v : l) if (std::isfinite(v)) ymax = std::max(ymax, v);
+	if (!(xmax > xmin)) xmax = xmin + 1; if (!(ymax > ymin)) ymax = ymin + 1;
+	const uint8_t cols[3][3] = {{31, 119, 180}, {255, 127, 14}, {44, 160, 44}}; int li = 0;
+	for (auto& l : lines)
+	{
+		int lx = -1, ly = -1;
+		for (size_t i = 0; i < l.size() && i < x.size(); ++i)
+		{
+			if (!std::isfinite(l[i])) continue;
+			int cx = L + (int)((x[i] - xmin) / (xmax - xmin) * (W - L - 11)), cy = H - B - (int)((l[i] - ymin) / (ymax - ymin) * (H - B - 11));
+			if (lx >= 0) { int n = std::max(abs(cx - lx), abs(cy - ly)) + 1; for (int k = 0; k <= n; ++k) px(lx + (cx - lx) * k / n, ly + (cy - ly) * k / n, cols[li % 3][0], cols[li % 3][1], cols[li % 3][2]); }
+			lx = cx; ly = cy;
+		}
+		++li;
+	}
+	std::vector<uint8_t> raw; raw.reserve((size_t)(W * 3 + 1) * H);
+	for (int j = 0; j < H; ++j) { raw.push_back(0); raw.insert(raw.end(), img.begin() + (size_t)j * W * 3, img.begin() + (size_t)(j + 1) * W * 3); }
+	uLongf clen = compressBound((uLong)raw.size()); std::vector<uint8_t> comp(clen); compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6); comp.resize(clen);
+	std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back((x >> 16) & 255); v.push_back((x >> 8) & 255); v.push_back(x & 255); };
+	auto chunk = [&](const char* type, const std::vector<uint8_t>& data) { be32(png, (uint32_t)data.size()); std::vector<uint8_t> td(type, type + 4); td.insert(td.end(), data.begin(), data.end()); png.insert(png.end(), td.begin(), td.end()); be32(png, (uint32_t)crc32(0, td.data(), (uInt)td.size())); };
+	std::vector<uint8_t> ihdr; be32(ihdr, W); be32(ihdr, H); ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+	chunk("IHDR", ihdr); chunk("IDAT", comp); chunk("IEND", {});
+	return base64(png);
+}
+void Statistics::addQcPlot(QCCollection& output, const std::string& accession, const std::string& name, const std::vector<double>& x, const std::vector<std::vector<double>>& lines)
+{
+	auto it = qcmlTerms().find(accession);
+	if (it == qcmlTerms().end()) NB_THROW(ProgrammingException, "qcML does not contain term with accession '" + accession + "'!");
+	if (it->second.name != name) NB_THROW(ProgrammingException, "qcML term with accession '" + accession + "' does not have name '" + name + "'!");
+	QCValue v; v.name = name; v.accession = accession; v.description = it->second.definition; v.type = QCValueType::IMAGE; v.s = plotPng(x, lines); output.insert(v);
+}
+
+// ---------------------------------------------------------------- shared pieces of the three mapping variants
+namespace {
+
+struct GcPrep
+{
+	BedFile dropout; std::vector<int32_t> bin; std::vector<double> gc_roi = std::vector<double>(101, 0.0); bool enabled = false;
+	// Statistics.cpp:363-387 / 1022-1045
+	GcPrep(const BedFile& roi, FastaFileIndex* fa)
+	{
+		if (!fa) return;
+		enabled = true; dropout.add(roi); dropout.chunk(100); bin.assign((size_t)dropout.count(), -1);
+		for (long long i = 0; i < dropout.count(); ++i)
+		{
+			const BedLine& l = dropout[i];
+			double gc = gcContent(fa->seq(l.chr(), l.start(), l.length()));
+			if (!std::isfinite(gc)) continue;
+			int b = (int)std::floor(100.0 * gc); bin[(size_t)i] = b; gc_roi[(size_t)std::min(b, 100)] += 1.0;
+		}
+	}
+};
+
+std::vector<ngsqc_region> toRegions(const BedFile& bed, const BamReader& reader, bool need_all)
+{
+	std::vector<ngsqc_region> r;
+	for (long long i = 0; i < bed.count(); ++i)
+	{
+		int tid = reader.chromosomeID(bed[i].chr());
+		if (tid < 0) { if (need_all) NB_THROW(FileAccessException, "Could not find chromosome '" + bed[i].chr().str() + "' in BAM/CRAM file " + reader.fileName()); continue; } // BamReader.cpp:751-754
+		r.push_back(ngsqc_region{tid, bed[i].start(), bed[i].end()});
+	}
+	return r;
+}
+
+struct Scan
+{
+	std::vector<int64_t> c = std::vector<int64_t>(NGSQC_NCOUNTERS, 0); std::vector<double> gc_reads = std::vector<double>(101, 0.0);
+	int64_t operator[](int i) const { return c[(size_t)i]; }
+};
+
+Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_region>& regions, const GcPrep* gc, const BedFile* gc_bed)
+{
+	Scan s; ngsqc_mapping_params p{}; p.mode = mode; p.min_mapq = min_mapq;
+	p.tid_x = reader.chromosomeID(Chromosome("chrX")); p.tid_y = reader.chromosomeID(Chromosome("chrY"));
+	std::vector<uint8_t> ns; for (auto& c : reader.chromosomes()) ns.push_back(c.isNonSpecial() ? 1 : 0);
+	p.tid_nonspecial = ns.data();
+	p.regions = regions.empty() ? nullptr : regions.data(); p.n_regions = (int64_t)regions.size();
+	std::vector<ngsqc_region> chunks; std::vector<int32_t> bins;
+	if (gc && gc->enabled && gc_bed)
+	{
+		for (long long i = 0; i < gc->dropout.count(); ++i) { int tid = reader.chromosomeID(gc->dropout[i].chr()); if (tid < 0) continue; chunks.push_back(ngsqc_region{tid, gc->dropout[i].start(), gc->dropout[i].end()}); bins.push_back(gc->bin[(size_t)i]); }
+		p.gc_chunks = chunks.data(); p.gc_bin = bins.data(); p.n_gc_chunks = (int64_t)chunks.size();
+	}
+	reader.check(ngsqc_scan_mapping(reader.handle(), &p, s.c.data(), s.gc_reads.data()));
+	return s;
+}
+
+// Statistics.cpp:576-604
+void dropoutValues(const std::vector<double>& gc_roi, const std::vector<double>& gc_reads, double& at, double& gc, std::vector<double>& roi_perc, std::vector<double>& read_perc)
+{
+	double gc_sum = 0, roi_sum = 0; for (double v : gc_roi) gc_sum += v; for (double v : gc_reads) roi_sum += v;
+	at = 0; gc = 0;
+	for (int i = 0; i < 100; ++i)
+	{
+		double rp = 100.0 * gc_roi[(size_t)i] / gc_sum, dp = 100.0 * gc_reads[(size_t)i] / roi_sum; roi_perc.push_back(rp); read_perc.push_back(dp);
+		double diff = rp - dp; if (diff > 0) { if (i <= 50) at += diff; if (i >= 50) gc += diff; }
+	}
+}
+
+Histogram insertHistogram(const Scan& s) { Histogram h(0, 999, 5); for (int v = 0; v < 1000; ++v) if (s[NGSQC_C_INSERT_HIST0 + v]) h.inc(v, true, (double)s[NGSQC_C_INSERT_HIST0 + v]); return h; }
+
+// depth histogram from the exact per-depth counts of K6 (Statistics.cpp:631-645 / 1192-1204)
+Histogram depthHistogram(BamReader& reader, int hist_max, int hist_step, long long half_depth, long long& covered)
+{
+	std::vector<int64_t> hist((size_t)hist_max + 1, 0); int64_t cov = 0;
+	reader.check(ngsqc_depth_stats(reader.handle(), hist_max, half_depth, hist.data(), &cov));
+	covered = cov;
+	Histogram h(0, hist_max, hist_step);
+	for (int d = 0; d <= hist_max; ++d) if (hist[(size_t)d]) h.inc(d, true, (double)hist[(size_t)d]);
+	return h;
+}
+
+void addYx(QCCollection& output, const Scan& s)
+{
+	if (s[NGSQC_C_YX_VALID]) Statistics::addQcValue(output, "QC:2000139", "chrY/chrX read ratio", number((double)s[NGSQC_C_READS_Y] / (double)s[NGSQC_C_READS_X], 4)); // Statistics.cpp:796-800
+}
+
+std::vector<double> range100() { std::vector<double> x; for (int i = 0; i < 100; ++i) x.push_back(i); return x; }
+
+} // namespace
+
+// ---------------------------------------------------------------- Statistics::mapping (ROI)   Statistics.cpp:343-803
+QCCollection Statistics::mapping(const BedFile& bed_file, const std::string& bam_file, const std::string& ref_file, int min_mapq, bool is_cfdna)
+{
+	if (!bed_file.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for coverage details statistics!");
+	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
+	long long roi_bases = bed_file.baseCount();
+	GcPrep gc(bed_file, fa.get());
+	BamReader reader(bam_file, ref_file);
+	// ROI lines on chromosomes the BAM does not know never match a read in the reference (ChromosomalIndex lookup by name)
+	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
+	Scan s = runScan(reader, NGSQC_MODE_ROI, min_mapq, regions, &gc, &bed_file);
+	const double al_total = (double)s[NGSQC_C_AL_TOTAL]; const int max_length = (int)s[NGSQC_C_MAX_LENGTH]; const bool paired_end = s[NGSQC_C_PAIRED_END] != 0;
+	const long long bases_usable = s[NGSQC_C_BASES_USABLE];
+
+	double at_dropout = 0, gc_dropout = 0; std::vector<double> roi_perc, read_perc;
+	dropoutValues(gc.gc_roi, s.gc_reads, at_dropout, gc_dropout, roi_perc, read_perc);
+
+	double avg_depth = (double)bases_usable / roi_bases;
+	int half_depth = (int)std::round(0.5 * avg_depth);
+	int hist_max = 599, hist_step = 5;
+	if (avg_depth > 200) { hist_max += 400; hist_step += 5; }
+	if (avg_depth > 500) hist_max += 500;
+	if (avg_depth > 1000) hist_max += 1000;
+	if (is_cfdna) { hist_max = 20000; hist_step = 500; }
+	long long covered_half = 0;
+	// regions missing from the BAM have depth 0 everywhere: they fall into bin 0 and count for half_depth only if it is 0
+	long long missing_bases = roi_bases; for (auto& r : regions) missing_bases -= (r.end - r.start + 1);
+	Histogram depth_dist = depthHistogram(reader, hist_max, hist_step, half_depth, covered_half);
+	if (missing_bases > 0) { depth_dist.inc(0, true, (double)missing_bases); if (0 >= half_depth) covered_half += missing_bases; }
+
+	QCCollection output;
+	addQcValue(output, "QC:2000019", "trimmed base percentage", 100.0 * (double)s[NGSQC_C_BASES_TRIMMED] / al_total / max_length);
+	addQcValue(output, "QC:2000052", "clipped base percentage", 100.0 * (double)s[NGSQC_C_BASES_CLIPPED] / (double)s[NGSQC_C_BASES_MAPPED]);
+	addQcValue(output, "QC:2000020", "mapped read percentage", 100.0 * s[NGSQC_C_AL_MAPPED] / al_total);
+	addQcValue(output, "QC:2000021", "on-target read percentage", 100.0 * s[NGSQC_C_AL_ONTARGET] / al_total);
+	addQcValue(output, "QC:2000057", "near-target read percentage", 100.0 * s[NGSQC_C_AL_NEARTARGET] / al_total);
+	if (paired_end)
+	{
+		addQcValue(output, "QC:2000022", "properly-paired read percentage", 100.0 * s[NGSQC_C_AL_PROPER_PAIRED] / al_total);
+		addQcValue(output, "QC:2000023", "insert size", (double)s[NGSQC_C_INSERT_SIZE_SUM] / (double)s[NGSQC_C_INSERT_SIZE_READ_COUNT]);
+		addQcValue(output, "QC:2000150", "target region read depth (no ol)", (double)s[NGSQC_C_BASES_USABLE_NO_OVERLAP] / roi_bases);
+	}
+	else
+	{
+		addQcValue(output, "QC:2000022", "properly-paired read percentage", std::string("n/a (single end)"));
+		addQcValue(output, "QC:2000023", "insert size", std::string("n/a (single end)"));
+	}
+	if (s[NGSQC_C_AL_DUP] == 0) addQcValue(output, "QC:2000024", "duplicate read percentage", std::string("n/a (no duplicates marked or duplicates removed during data analysis)"));
+	else addQcValue(output, "QC:2000024", "duplicate read percentage", 100.0 * s[NGSQC_C_AL_DUP] / al_total);
+	addQcValue(output, "QC:2000050", "bases usable (MB)", (double)bases_usable / 1000000.0);
+	addQcValue(output, "QC:2000025", "target region read depth", avg_depth);
+
+	std::vector<double> cumsum_depth(5, 0.0);
+	if (is_cfdna)
+	{
+		double run = 0;
+		for (int i = 4; i >= 0; --i) { run += (double)s[NGSQC_C_BASES_USABLE_DP0 + i] / roi_bases; cumsum_depth[(size_t)i] = run; }
+		for (int i = 2; i <= 4; ++i) addQcValue(output, "QC:200007" + std::to_string(i - 1), "target region read depth " + std::to_string(i) + "-fold duplication", cumsum_depth[(size_t)i]);
+		addQcValue(output, "QC:2000074", "raw target region read depth", (double)s[NGSQC_C_BASES_USABLE_RAW] / roi_bases);
+	}
+	std::vector<int> depths = {10, 20, 30, 50, 60, 100, 200, 500};
+	std::vector<std::string> accessions = {"QC:2000026", "QC:2000027", "QC:2000028", "QC:2000029", "QC:2000099", "QC:2000030", "QC:2000031", "QC:2000032"};
+	if (is_cfdna) { for (int d : {1000, 2500, 5000, 7500, 10000, 15000}) depths.push_back(d); for (const char* a : {"QC:2000065", "QC:2000066", "QC:2000067", "QC:2000068", "QC:2000069", "QC:2000070"}) accessions.push_back(a); }
+	for (size_t i = 0; i < depths.size(); ++i)
+	{
+		double cov_bases = 0.0;
+		for (int bin = depth_dist.binIndex(depths[i]); bin < depth_dist.binCount(); ++bin) cov_bases += depth_dist.binValue(bin);
+		addQcValue(output, accessions[i], "target region " + std::to_string(depths[i]) + "x percentage", 100.0 * cov_bases / roi_bases);
+	}
+	addQcValue(output, "QC:2000058", "target region half depth percentage", 100.0 * covered_half / roi_bases);
+	if (fa) { addQcValue(output, "QC:2000059", "AT dropout", at_dropout); addQcValue(output, "QC:2000060", "GC dropout", gc_dropout); }
+	else { addQcValue(output, "QC:2000059", "AT dropout", std::string("n/a (no reference genome)")); addQcValue(output, "QC:2000060", "GC dropout", std::string("n/a (no reference genome)")); }
+
+	addQcPlot(output, "QC:2000037", "depth distribution plot", depth_dist.xCoords(), {depth_dist.yCoords(true)});
+	Histogram insert_dist = insertHistogram(s);
+	if (paired_end) addQcPlot(output, "QC:2000038", "insert size distribution plot", insert_dist.xCoords(), {insert_dist.yCoords(true)});
+	double dp_sum = 0; for (int i = 0; i < 4; ++i) dp_sum += (double)s[NGSQC_C_DP_DIST0 + i];
+	if (is_cfdna && dp_sum != 0)
+	{
+		std::vector<double> y; for (int i = 0; i < 4; ++i) y.push_back(100.0 * (double)s[NGSQC_C_DP_DIST0 + i] / dp_sum);
+		addQcPlot(output, "QC:2000075", "fragment duplication distribution plot", {1, 2, 3, 4}, {y});
+		addQcPlot(output, "QC:2000076", "duplication-coverage plot", {1, 2, 3, 4}, {std::vector<double>(cumsum_depth.begin() + 1, cumsum_depth.end())});
+	}
+	addQcPlot(output, "QC:2000061", "GC bias plot", range100(), {roi_perc, read_perc});
+	addYx(output, s);
+	return output;
+}
+
+namespace {
+// shared output block of the two ROI-less variants (Statistics.cpp:930-960 / 1247-1279)
+void noRoiOutput(QCCollection& output, const Scan& s, bool wgs_style, double genome_size, double no_base)
+{
+	const double al_total = (double)s[NGSQC_C_AL_TOTAL]; const int max_length = (int)s[NGSQC_C_MAX_LENGTH]; const bool paired_end = s[NGSQC_C_PAIRED_END] != 0;
+	if (!wgs_style || paired_end) Statistics::addQcValue(output, "QC:2000019", "trimmed base percentage", 100.0 * (double)s[NGSQC_C_BASES_TRIMMED] / al_total / max_length);
+	else Statistics::addQcValue(output, "QC:2000019", "trimmed base percentage", std::string("n/a (single end)"));
+	Statistics::addQcValue(output, "QC:2000052", "clipped base percentage", 100.0 * (double)s[NGSQC_C_BASES_CLIPPED] / (double)s[NGSQC_C_BASES_MAPPED]);
+	Statistics::addQcValue(output, "QC:2000020", "mapped read percentage", 100.0 * s[NGSQC_C_AL_MAPPED] / al_total);
+	Statistics::addQcValue(output, "QC:2000021", "on-target read percentage", 100.0 * s[NGSQC_C_AL_ONTARGET] / al_total);
+	if (paired_end)
+	{
+		Statistics::addQcValue(output, "QC:2000022", "properly-paired read percentage", 100.0 * s[NGSQC_C_AL_PROPER_PAIRED] / al_total);
+		Statistics::addQcValue(output, "QC:2000023", "insert size", (double)s[NGSQC_C_INSERT_SIZE_SUM] / (double)s[NGSQC_C_INSERT_SIZE_READ_COUNT]);
+		Statistics::addQcValue(output, "QC:2000150", "target region read depth (no ol)", (double)s[NGSQC_C_BASES_USABLE_NO_OVERLAP] / (genome_size - no_base));
+	}
+	else
+	{
+		Statistics::addQcValue(output, "QC:2000022", "properly-paired read percentage", std::string("n/a (single end)"));
+		Statistics::addQcValue(output, "QC:2000023", "insert size", std::string("n/a (single end)"));
+	}
+	if (s[NGSQC_C_AL_DUP] == 0) Statistics::addQcValue(output, "QC:2000024", "duplicate read percentage", std::string("n/a (duplicates not marked or removed during data analysis)"));
+	else Statistics::addQcValue(output, "QC:2000024", "duplicate read percentage", 100.0 * s[NGSQC_C_AL_DUP] / al_total);
+	Statistics::addQcValue(output, "QC:2000050", "bases usable (MB)", (double)s[NGSQC_C_BASES_USABLE] / 1000000.0);
+	Statistics::addQcValue(output, "QC:2000025", "target region read depth", (double)s[NGSQC_C_BASES_USABLE] / (genome_size - no_base));
+}
+double nBases(const BamReader& reader, FastaFileIndex* fa) { double n = 0; if (fa) for (auto& c : reader.chromosomes()) if (c.isNonSpecial()) n += fa->n(c); return n; } // Statistics.cpp:920-928
+}
+
+// ---------------------------------------------------------------- Statistics::mapping(bam, ref, min_mapq)   Statistics.cpp:805-988
+QCCollection Statistics::mapping(const std::string& bam_file, const std::string& ref_file, int min_mapq)
+{
+	BamReader reader(bam_file, ref_file);
+	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
+	Scan s = runScan(reader, NGSQC_MODE_NOROI, min_mapq, {}, nullptr, nullptr);
+	QCCollection output;
+	noRoiOutput(output, s, false, reader.genomeSize(false), nBases(reader, fa.get()));
+	if (s[NGSQC_C_PAIRED_END])
+	{
+		Histogram insert_dist = insertHistogram(s);
+		if (insert_dist.binSum() > 0) addQcPlot(output, "QC:2000038", "insert size distribution plot", insert_dist.xCoords(), {insert_dist.yCoords(true)});
+		else fprintf(stderr, "Skipping insert size histogram - no read pairs found!\n");
+	}
+	addYx(output, s);
+	return output;
+}
+
+// ---------------------------------------------------------------- Statistics::mapping_wgs   Statistics.cpp:990-1359
+QCCollection Statistics::mapping_wgs(const std::string& bam_file, const std::string& bedpath, int min_mapq, const std::string& ref_file)
+{
+	BamReader reader(bam_file, ref_file);
+	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
+	bool roi_available = false; BedFile roi;
+	if (!bedpath.empty())
+	{
+		roi_available = true; roi.load(bedpath, false);
+		if (!roi.isMergedAndSorted()) { roi.sort(); roi.merge(); }
+	}
+	GcPrep gc(roi, fa.get());
+	std::vector<ngsqc_region> regions;
+	if (roi_available) { reader.requireIndex(); regions = toRegions(roi, reader, true); }
+	Scan s = runScan(reader, NGSQC_MODE_WGS, min_mapq, regions, &gc, &roi);
+
+	QCCollection output;
+	noRoiOutput(output, s, true, reader.genomeSize(false), nBases(reader, fa.get()));
+	Histogram insert_dist = insertHistogram(s);
+	if (roi_available)
+	{
+		const double roi_bases = (double)roi.baseCount();
+		double avg_depth = (double)s[NGSQC_C_BASES_USABLE_ROI] / roi_bases;
+		int half_depth = (int)std::round(0.5 * avg_depth);
+		long long covered_half = 0;
+		Histogram depth_dist = depthHistogram(reader, 599, 5, half_depth, covered_half);
+		double at_dropout = 0, gc_dropout = 0; std::vector<double> roi_perc, read_perc;
+		dropoutValues(gc.gc_roi, s.gc_reads, at_dropout, gc_dropout, roi_perc, read_perc);
+		const int depth_values[8] = {10, 20, 30, 50, 60, 100, 200, 500};
+		const char* accessions[8] = {"QC:2000026", "QC:2000027", "QC:2000028", "QC:2000029", "QC:2000099", "QC:2000030", "QC:2000031", "QC:2000032"};
+		for (int i = 0; i < 8; ++i)
+		{
+			double cov_bases = 0.0;
+			for (int bin = depth_dist.binIndex(depth_values[i]); bin < depth_dist.binCount(); ++bin) cov_bases += depth_dist.binValue(bin);
+			addQcValue(output, accessions[i], "target region " + std::to_string(depth_values[i]) + "x percentage", 100.0 * cov_bases / roi_bases);
+		}
+		addQcValue(output, "QC:2000058", "target region half depth percentage", 100.0 * covered_half / roi_bases);
+		if (fa) { addQcValue(output, "QC:2000059", "AT dropout", at_dropout); addQcValue(output, "QC:2000060", "GC dropout", gc_dropout); }
+		else { addQcValue(output, "QC:2000059", "AT dropout", std::string("n/a (no reference genome)")); addQcValue(output, "QC:2000060", "GC dropout", std::string("n/a (no reference genome)")); }
+		addQcPlot(output, "QC:2000037", "depth distribution plot", depth_dist.xCoords(), {depth_dist.yCoords(true)});
+		if (s[NGSQC_C_PAIRED_END])
+		{
+			if (insert_dist.binSum() > 0) addQcPlot(output, "QC:2000038", "insert size distribution plot", insert_dist.xCoords(), {insert_dist.yCoords(true)});
+			else fprintf(stderr, "Skipping insert size histogram - no read pairs found!\n");
+		}
+		addQcPlot(output, "QC:2000061", "GC bias plot", range100(), {roi_perc, read_perc});
+	}
+	else if (s[NGSQC_C_PAIRED_END])
+	{
+		if (insert_dist.binSum() > 0) addQcPlot(output, "QC:2000038", "insert size distribution plot", insert_dist.xCoords(), {insert_dist.yCoords(true)});
+		else fprintf(stderr, "Skipping insert size histogram - no read pairs found!\n");
+	}
+	addYx(output, s);
+	return output;
+}
+
+// ---------------------------------------------------------------- coverage tools
+namespace {
+// merged + sorted union of the BED lines (the scan's depth array), restricted to chromosomes known to the BAM
+std::vector<ngsqc_region> unionRegions(const BedFile& bed, const BamReader& reader, bool back_to_back)
+{
+	BedFile u; u.add(bed); u.clearAnnotations(); u.merge(back_to_back);
+	return toRegions(u, reader, true);
+}
+}
+
+void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
+{
+	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
+	if (bed_file.count() == 0) return;
+	BamReader reader(bam_file, ref_file);
+	reader.requireIndex();
+	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
+	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = skip_mismapped ? 1 : 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
+	reader.check(ngsqc_scan_depth(reader.handle(), &p));
+	std::vector<ngsqc_region> lines = toRegions(bed_file, reader, true);
+	std::vector<int64_t> sums(lines.size(), 0);
+	reader.check(ngsqc_region_sums(reader.handle(), lines.data(), (int64_t)lines.size(), sums.data()));
+	// sum of read/line overlaps == sum of per-base depth over the line (WorkerAverageCoverage.cpp:47-55,135-155)
+	for (long long i = 0; i < bed_file.count(); ++i) bed_file[i].annotations().push_back(number((double)sums[(size_t)i] / bed_file[i].length(), decimals));
+}
+
+BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access)
+{
+	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
+	if (!random_access && cutoff > 255) NB_THROW(ArgumentException, "Cutoff cannot be bigger than 255!");   // WorkerLowOrHighCoverage.cpp:149
+	BedFile output;
+	if (bed_file.count() == 0) return output;
+	BamReader reader(bam_file, "");
+	reader.requireIndex();
+	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
+	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = min_baseq; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
+	reader.check(ngsqc_scan_depth(reader.handle(), &p));
+	std::vector<ngsqc_region> lines = toRegions(bed_file, reader, true);
+	int64_t n_runs = 0;
+	reader.check(ngsqc_lowhigh_runs(reader.handle(), lines.data(), (int64_t)lines.size(), cutoff, is_high ? 1 : 0, random_access ? 0 : 1, nullptr, 0, &n_runs));
+	std::vector<ngsqc_run> runs((size_t)std::max<int64_t>(n_runs, 1));
+	if (n_runs) reader.check(ngsqc_lowhigh_runs(reader.handle(), lines.data(), (int64_t)lines.size(), cutoff, is_high ? 1 : 0, random_access ? 0 : 1, runs.data(), n_runs, &n_runs));
+	for (int64_t i = 0; i < n_runs; ++i) { const BedLine& src = bed_file[runs[(size_t)i].line]; output.append(BedLine(src.chr(), runs[(size_t)i].start, runs[(size_t)i].end, src.annotations())); }
+	output.merge(true, true, true);   // Statistics.cpp:2655
+	return output;
+}
+BedFile Statistics::lowCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string&, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, false, random_access); }
+BedFile Statistics::highCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string&, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, true, random_access); }
+
+} // namespace ngsbits

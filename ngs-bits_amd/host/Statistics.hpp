@@ -1,0 +1,54 @@
+// Host mirror of the hot-path part of the reference's Statistics class (src/cppNGS/Statistics.h:40-46,53,66-70):
+// same static entry points, argument meaning and error messages; the per-read work is delegated to libngsqc_hip.so.
+#pragma once
+#include <memory>
+#include "core.hpp"
+#include "../../include/ngsqc.h"
+
+namespace ngsbits {
+
+// RAII wrapper of one open BAM on the GPU (role of BamReader for this path: BamReader.h:350-455)
+class BamReader
+{
+public:
+	BamReader(const std::string& bam_file, const std::string& ref_genome = "");
+	~BamReader();
+	BamReader(const BamReader&) = delete; BamReader& operator=(const BamReader&) = delete;
+	const std::vector<Chromosome>& chromosomes() const { return chrs_; }
+	int chromosomeID(const Chromosome& chr) const;              // tid or -1
+	int chromosomeSize(const Chromosome& chr) const;
+	double genomeSize(bool include_special_chromosomes) const; // BamReader.cpp:789-800
+	ngsqc_handle* handle() const { return h_; }
+	const std::string& fileName() const { return bam_file_; }
+	void requireIndex() const;                                  // setRegion's "Could not load index" (BamReader.cpp:742-746)
+	void check(int rc) const;
+private:
+	std::string bam_file_; ngsqc_handle* h_ = nullptr; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
+};
+
+class Statistics
+{
+public:
+	// Statistics.cpp:343  — target-region mode (MappingQC -roi)
+	static QCCollection mapping(const BedFile& bed_file, const std::string& bam_file, const std::string& ref_file, int min_mapq = 1, bool is_cfdna = false);
+	// Statistics.cpp:805  — -rna / -wgs -build non_human
+	static QCCollection mapping(const std::string& bam_file, const std::string& ref_file, int min_mapq = 1);
+	// Statistics.cpp:990  — -wgs with the embedded OMIM ROI
+	static QCCollection mapping_wgs(const std::string& bam_file, const std::string& bedpath, int min_mapq, const std::string& ref_file);
+	// Statistics.cpp:2698 / 2693 / 2806
+	static void avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq = 1, int threads = 1, int decimals = 2, const std::string& ref_file = "", bool random_access = false, bool skip_mismapped = false, bool debug = false);
+	static BedFile lowCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq = 1, int min_baseq = 0, int threads = 1, const std::string& ref_file = "", bool random_access = true, bool debug = false);
+	static BedFile highCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq = 1, int min_baseq = 0, int threads = 1, const std::string& ref_file = "", bool random_access = true, bool debug = false);
+	// Statistics.cpp:2904-2922
+	static void addQcValue(QCCollection& output, const std::string& accession, const std::string& name, double value);
+	static void addQcValue(QCCollection& output, const std::string& accession, const std::string& name, const std::string& value);
+	static void addQcPlot(QCCollection& output, const std::string& accession, const std::string& name, const std::vector<double>& x, const std::vector<std::vector<double>>& lines);
+private:
+	static BedFile lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access);
+};
+
+// ref_file == NO_REF: run without a reference genome (an extension for genome-less test boxes; GC/AT dropout become
+// "n/a" and the N-base correction of the WGS depth denominators is skipped). The reference always needs a FASTA.
+extern const char* const NO_REF;
+
+} // namespace ngsbits

@@ -1,0 +1,161 @@
+// Implementation of the host-layer helpers declared in core.hpp (resource lookup, qcML writer, CLI conventions).
+#include "core.hpp"
+#include <ctime>
+#include <unistd.h>
+
+namespace ngsbits {
+
+static std::string exeDir()
+{
+	char buf[4096]; ssize_t n = readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+	if (n <= 0) return ".";
+	buf[n] = 0; std::string p(buf); size_t i = p.find_last_of('/');
+	return i == std::string::npos ? "." : p.substr(0, i);
+}
+
+std::string resourceDir()
+{
+	const char* e = getenv("NGSQC_RESOURCES");
+	if (e && *e) return e;
+	std::string d = exeDir();   // <repo>/ngs-bits_amd/bin -> <repo>/ngs-bits_amd/resources
+	for (const char* rel : {"/../resources", "/resources", "/../../ngs-bits_amd/resources"}) if (fileExists(d + rel + "/qcml_terms.tsv")) return d + rel;
+	return d + "/../resources";
+}
+
+const std::map<std::string, OntologyTerm>& qcmlTerms()
+{
+	static std::map<std::string, OntologyTerm> terms;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		std::ifstream f(resourceDir() + "/qcml_terms.tsv");
+		if (!f) NB_THROW(FileAccessException, "Could not open qcML term table '" + resourceDir() + "/qcml_terms.tsv'!");
+		std::string line;
+		while (std::getline(f, line)) { auto p = split(line, '\t'); if (p.size() >= 3) terms[p[0]] = OntologyTerm{p[1], p[2]}; }
+	});
+	return terms;
+}
+
+static std::string pad4(int i) { char b[16]; snprintf(b, sizeof(b), "%04d", i); return b; }
+
+// QCCollection::storeToQCML (QCCollection.cpp:200-339). Layout facts: SURVEY.md §8 a16b.
+void QCCollection::storeToQCML(const std::string& filename, const std::vector<std::string>& source_files, const std::string& parameters, const std::string& app_name, const std::string& app_version) const
+{
+	std::string o;
+	o += "<?xml version=\"1.0\" encoding=\"ISO-8859-1\"?>\n";
+	o += "<?xml-stylesheet type=\"text/xml\" href=\"#stylesheet\"?>\n";
+	o += "<!DOCTYPE catelog [\n  <!ATTLIST xsl:stylesheet\n  id  ID  #REQUIRED>\n  ]>\n";
+	o += "<qcML version=\"0.0.8\" xmlns=\"http://www.prime-xs.eu/ms/qcml\" >\n";
+	o += "  <runQuality ID=\"rq0001\">\n";
+	char date[64]; time_t t = time(nullptr); struct tm tmv; localtime_r(&t, &tmv); strftime(date, sizeof(date), "%Y-%m-%dT%H:%M:%S", &tmv);
+	o += "    <metaDataParameter ID=\"md0001\" name=\"creation software\" value=\"" + app_name + " " + app_version + "\" cvRef=\"QC\" accession=\"QC:1000002\"/>\n";
+	o += "    <metaDataParameter ID=\"md0002\" name=\"creation software parameters\" value=\"" + htmlEscaped(parameters) + "\" cvRef=\"QC\" accession=\"QC:1000003\"/>\n";
+	o += std::string("    <metaDataParameter ID=\"md0003\" name=\"creation date\" value=\"") + date + "\" cvRef=\"QC\" accession=\"QC:1000004\"/>\n";
+	int idx = 4;
+	for (auto& sf : source_files) { o += "    <metaDataParameter ID=\"md" + pad4(idx) + "\" name=\"source file\" value=\"" + fileName(sf) + "\" cvRef=\"QC\" accession=\"QC:1000005\"/>\n"; ++idx; }
+	for (int i = 0; i < count(); ++i)
+	{
+		const QCValue& v = values_[(size_t)i];
+		if (v.type == QCValueType::IMAGE) continue;
+		o += "    <qualityParameter ID=\"qp" + pad4(i + 1) + "\" name=\"" + v.name + "\" description=\"" + htmlEscaped(v.description) + "\" value=\"" + v.toString() + "\" cvRef=\"QC\" accession=\"" + v.accession + "\"/>\n";
+	}
+	for (int i = 0; i < count(); ++i)
+	{
+		const QCValue& v = values_[(size_t)i];
+		if (v.type != QCValueType::IMAGE) continue;
+		o += "    <attachment ID=\"qp" + pad4(i + 1) + "\" name=\"" + v.name + "\" description=\"" + htmlEscaped(v.description) + "\" cvRef=\"QC\" accession=\"" + v.accession + "\">\n";
+		o += "      <binary>" + v.s + "</binary>\n";
+		o += "    </attachment>\n";
+	}
+	o += "  </runQuality>\n";
+	{
+		std::ifstream f(resourceDir() + "/qcml_tail.txt", std::ios::binary);
+		if (!f) NB_THROW(FileAccessException, "Could not open qcML stylesheet block '" + resourceDir() + "/qcml_tail.txt'!");
+		std::stringstream ss; ss << f.rdbuf(); o += ss.str();
+	}
+	if (filename.empty()) { fwrite(o.data(), 1, o.size(), stdout); return; }
+	FILE* f = fopen(filename.c_str(), "wb");
+	if (!f) NB_THROW(FileAccessException, "Could not open file for writing: '" + filename + "'!");
+	fwrite(o.data(), 1, o.size(), f); fclose(f);
+}
+
+std::string ToolBase::settingsString(const std::string& key) const
+{
+	for (const std::string& p : {exeDir() + "/settings.ini", exeDir() + "/../settings.ini"})
+	{
+		std::ifstream f(p); if (!f) continue;
+		std::string line;
+		while (std::getline(f, line))
+		{
+			size_t eq = line.find('='); if (eq == std::string::npos) continue;
+			if (trimmed(line.substr(0, eq)) == key) return trimmed(line.substr(eq + 1));
+		}
+	}
+	return "";
+}
+
+void ToolBase::printHelp() const
+{
+	printf("%s (%s)\n\n%s\n", appName().c_str(), version().c_str(), description_.c_str());
+	for (auto& e : ext_) printf("%s\n", e.c_str());
+	printf("\nMandatory parameters:\n");
+	for (auto& p : params_) if (!p.optional) printf("  -%s <%s>\t%s\n", p.name.c_str(), p.type.c_str(), p.desc.c_str());
+	printf("\nOptional parameters:\n");
+	for (auto& p : params_) if (p.optional)
+	{
+		if (p.type == "flag") printf("  -%s\t%s\n\t\tDefault value: 'false'\n", p.name.c_str(), p.desc.c_str());
+		else printf("  -%s <%s>\t%s\n\t\tDefault value: '%s'\n", p.name.c_str(), p.type.c_str(), p.desc.c_str(), p.value.c_str());
+	}
+	printf("\nSpecial parameters:\n  --help\tShows this help and exits.\n  --version\tPrints version and exits.\n");
+}
+
+void ToolBase::parse()
+{
+	std::vector<bool> given(params_.size(), false);
+	for (size_t i = 1; i < args_.size(); ++i)
+	{
+		const std::string& a = args_[i];
+		if (a.size() < 2 || a[0] != '-') NB_THROW(CommandLineParsingException, "Trailing parameter '" + a + "' given.");
+		std::string name = a.substr(1);
+		size_t k = params_.size();
+		for (size_t j = 0; j < params_.size(); ++j) if (params_[j].name == name) k = j;
+		if (k == params_.size()) NB_THROW(CommandLineParsingException, "Unknown parameter '" + name + "' given.");
+		if (given[k]) NB_THROW(CommandLineParsingException, "Parameter '" + name + "' given more than once.");
+		given[k] = true;
+		Param& p = params_[k];
+		if (p.type == "flag") { p.set = true; continue; }
+		std::vector<std::string> vals;
+		while (i + 1 < args_.size() && !(args_[i + 1].size() >= 2 && args_[i + 1][0] == '-' && !isdigit((unsigned char)args_[i + 1][1]))) vals.push_back(args_[++i]);
+		if (p.type == "infilelist") { if (vals.empty()) NB_THROW(CommandLineParsingException, "Parameter '" + name + "' given without value."); p.list = vals; p.set = true; continue; }
+		if (vals.size() != 1) NB_THROW(CommandLineParsingException, vals.empty() ? "Parameter '" + name + "' given without value." : "Parameter '" + name + "' given with more than one value.");
+		if (p.type == "int") { char* e; strtol(vals[0].c_str(), &e, 10); if (vals[0].empty() || *e) NB_THROW(CommandLineParsingException, "Value '" + vals[0] + "' given for parameter '" + name + "' cannot be converted to integer."); }
+		if (p.type == "enum" && std::find(p.values.begin(), p.values.end(), vals[0]) == p.values.end()) NB_THROW(CommandLineParsingException, "Value '" + vals[0] + "' given for parameter '" + name + "' is not valid. Valid are: '" + join(p.values, ",") + "'.");
+		if ((p.type == "infile" || p.type == "infilelist") && !vals[0].empty() && !fileExists(vals[0])) NB_THROW(CommandLineParsingException, "Input file '" + vals[0] + "' given for parameter '" + name + "' does not exist.");
+		p.value = vals[0]; p.set = true;
+	}
+	for (size_t j = 0; j < params_.size(); ++j) if (!params_[j].optional && !given[j]) NB_THROW(CommandLineParsingException, "Mandatory parameter '" + params_[j].name + "' not given.");
+}
+
+int ToolBase::execute()
+{
+	try
+	{
+		setup();
+		for (size_t i = 1; i < args_.size(); ++i)
+		{
+			if (args_[i] == "--help") { printHelp(); return 0; }
+			if (args_[i] == "--version") { printf("%s %s\n", appName().c_str(), version().c_str()); return 0; }
+		}
+		parse();
+		main();
+		return 0;
+	}
+	catch (Exception& e)
+	{
+		if (e.type == "CommandLineParsingException") fprintf(stderr, "%s %s\nCommand line parsing exception: %s\nCall this tool with the argument '--help' for help.\n", appName().c_str(), version().c_str(), e.what());
+		else fprintf(stderr, "%s %s\n%s: %s\n", appName().c_str(), version().c_str(), e.type.c_str(), e.what());
+		return 1;
+	}
+	catch (std::exception& e) { fprintf(stderr, "%s %s\nException: %s\n", appName().c_str(), version().c_str(), e.what()); return 1; }
+}
+
+} // namespace ngsbits

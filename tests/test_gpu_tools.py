@@ -1,0 +1,72 @@
+"""Drop-in check of the four host tools (C++ above the C ABI) on the GPU: output files vs the reference's own expected
+outputs (src/tools-TEST/data_out, copied to tests/golden/ref_out) and vs the oracle for the coverage tools."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN_IN as GI, GOLDEN_OUT as GO, ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "ngs-bits_amd", "bin")
+# lines the reference's own test strips (MappingQC_Test.cpp:15-16) + lines that need a genome FASTA / the contamination pass
+STRIP = re.compile(r"creation |<binary>|AT dropout|GC dropout|SNV allele frequency deviation")
+
+
+def run(tool, *args):
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return p
+
+
+def _lines(path):
+    return [ln for ln in open(path).read().splitlines() if not STRIP.search(ln)]
+
+
+@pytest.mark.parametrize("args,expected", [
+    (["-in", "MappingQC_in2.bam", "-roi", "MappingQC_in2.bed", "-build", "hg19", "-txt"], "MappingQC_test02_out.txt"),
+    (["-in", "MappingQC_in1.bam", "-roi", "MappingQC_in2.bed", "-build", "hg19"], "MappingQC_test03_out.qcML"),
+    (["-in", "MappingQC_in2.bam", "-wgs", "-build", "hg19"], "MappingQC_test04_out.qcML"),
+    (["-in", "MappingQC_in1.bam", "-wgs", "-build", "hg19"], "MappingQC_test05_out.qcML"),
+    (["-in", "MappingQC_in3.bam", "-rna", "-build", "hg19"], "MappingQC_test07_out.qcML"),
+    (["-in", "MappingQC_in4.bam", "-roi", "MappingQC_in3.bed", "-cfdna", "-build", "hg19"], "MappingQC_test08_out.qcML"),
+    (["-in", "MappingQC_in5.bam", "-wgs", "-build", "hg38"], "MappingQC_test10_out.qcML"),
+])
+def test_mappingqc_matches_reference_expected_output(tmp_path, args, expected):
+    """src/tools-TEST/MappingQC_Test.cpp test02/03/04/05/07/08/10, byte-compared after the reference's own REMOVE_LINES."""
+    a = [os.path.join(GI, x) if x.endswith((".bam", ".bed")) else x for x in args]
+    out = str(tmp_path / expected)
+    run("MappingQC", *a, "-out", out, "-no_ref")
+    got, exp = _lines(out), _lines(os.path.join(GO, expected))
+    if expected.endswith(".txt"):
+        exp = [ln for ln in exp if ln]  # the TXT file ends with the (empty) contamination block
+        got = [ln for ln in got if ln]
+    assert got == exp
+
+
+def test_coverage_tools_match_oracle(tmp_path):
+    bam, bed = os.path.join(GI, "close_exons.bam"), os.path.join(GI, "close_exons.bed")
+    ob = O.Bam(bam)
+    out = str(tmp_path / "cov.tsv")
+    run("BedCoverage", "-bam", bam, "-in", bed, "-out", out, "-min_mapq", "20", "-decimals", "1")
+    _, text, _ = O.avg_coverage(ob, bed, merge_bed=False, min_mapq=20, decimals=1)
+    assert open(out).read() == "#chr\tstart\tend\tclose_exons\n" + text
+    for tool, high in (("BedLowCoverage", False), ("BedHighCoverage", True)):
+        for ra, cutoff in ((False, 200), (True, 200), (True, 400)):
+            out = str(tmp_path / f"{tool}_{ra}_{cutoff}.bed")
+            run(tool, "-bam", bam, "-in", bed, "-cutoff", str(cutoff), "-out", out, *(["-random_access"] if ra else []))
+            exp = O.low_high_coverage(ob, bed, cutoff, 1, 0, is_high=high, random_access=ra, tool_merge=1)
+            lines = open(out).read().splitlines()
+            assert [ln for ln in lines if not ln.startswith("#")] == exp["bed"].splitlines(), (tool, ra, cutoff)
+            hdr = [ln for ln in lines if ln.startswith("#")]
+            assert hdr == ([] if high else ["#BAM: close_exons.bam", "#ROI: close_exons.bed", "#ROI regions: 2", "#ROI bases: 154"])
+
+
+def test_tool_errors():
+    p = subprocess.run([os.path.join(BIN, "MappingQC"), "-in", os.path.join(GI, "close_exons.bam"), "-wgs", "-rna", "-no_ref"], capture_output=True, text=True)
+    assert p.returncode != 0 and "exactly one of the parameters 'roi', 'wgs', or 'rna'" in p.stderr
+    p = subprocess.run([os.path.join(BIN, "BedLowCoverage"), "-bam", os.path.join(GI, "close_exons.bam"), "-in", os.path.join(GI, "close_exons.bed"), "-cutoff", "300"], capture_output=True, text=True)
+    assert p.returncode != 0 and "Cutoff cannot be bigger than 255!" in p.stderr

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Regenerates the DATA resources the host tools need for byte-compatible output, from the reference checkout.
+Runs only where /root/reference exists (this container); the generated files are committed.
+  ngs-bits_amd/resources/qcml_terms.tsv : accession<TAB>name<TAB>definition for the qcML terms the hot path emits
+                                          (from src/cppNGS/Resources/qcML.obo; looked up by Statistics::addQcValue,
+                                          Statistics.cpp:2904-2922)
+  ngs-bits_amd/resources/qcml_tail.txt  : the fixed cvList + XSL stylesheet block every qcML file ends with
+                                          (QCCollection.cpp:260-336), cut from the reference's own expected output
+                                          src/tools-TEST/data_out/MappingQC_test10_out.qcML
+"""
+import os
+import re
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RES = os.path.join(ROOT, "ngs-bits_amd", "resources")
+WANTED = set(["QC:1000002", "QC:1000003", "QC:1000004", "QC:1000005", "QC:1000006"] +
+             ["QC:20000%02d" % i for i in list(range(19, 33)) + [37, 38, 50, 51, 52, 57, 58, 59, 60, 61] + list(range(65, 77)) + [99]] +
+             ["QC:2000139", "QC:2000150"] + ["QC:20001%02d" % i for i in range(0, 10)])
+
+
+def main():
+    obo = open(os.path.join(REF, "src/cppNGS/Resources/qcML.obo"), encoding="utf-8").read()
+    rows = []
+    for term in obo.split("[Term]")[1:]:
+        tid = re.search(r"^id: (\S+)", term, re.M)
+        name = re.search(r"^name: (.*)$", term, re.M)
+        d = re.search(r'^def: "(.*?)(?<!\\)"', term, re.M)
+        if tid and tid.group(1) in WANTED:
+            rows.append((tid.group(1), name.group(1).strip(), d.group(1) if d else ""))
+    rows.sort()
+    with open(os.path.join(RES, "qcml_terms.tsv"), "w", encoding="utf-8") as f:
+        for r in rows:
+            f.write("\t".join(r) + "\n")
+    exp = open(os.path.join(REF, "src/tools-TEST/data_out/MappingQC_test10_out.qcML"), encoding="utf-8").read()
+    tail = exp[exp.index("  <cvList>"):]
+    with open(os.path.join(RES, "qcml_tail.txt"), "w", encoding="utf-8") as f:
+        f.write(tail)
+    print(len(rows), "terms;", len(tail), "bytes of tail")
+
+
+if __name__ == "__main__":
+    main()
