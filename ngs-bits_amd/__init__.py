@@ -8,3 +8,4 @@ from .capi import (  # noqa: F401
     NgsqcError, Handle, Region, MappingParams, lib, lib_path, build_library,
     MODE_ROI, MODE_NOROI, MODE_WGS, NCOUNTERS, COUNTER_NAMES,
 )
+from .dist import allreduce_counters, combine_counters_local, shard_blocks  # noqa: F401,E402

@@ -1,0 +1,105 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/ngsqc.h, fails loudly without a
+device, the host tools parse their CLI like the reference, and the multi-process counter reduction works on gloo."""
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_IN as GI, ROOT
+
+ngsqc = importlib.import_module("ngs-bits_amd")
+BIN = os.path.join(ROOT, "ngs-bits_amd", "bin")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ngsqc.h")).read()
+    declared = sorted(set(re.findall(r"\b(ngsqc_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = ngsqc.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert b"gfx950" in L.ngsqc_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.Handle(path=os.path.join(GI, "close_exons.bam"))
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def _tool(name, *args):
+    exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ngs-bits_amd", "host"), "-s"])
+    return subprocess.run([exe] + list(args), capture_output=True, text=True)
+
+
+def test_tool_cli_contract():
+    bam = os.path.join(GI, "close_exons.bam")
+    p = _tool("MappingQC", "--help")
+    assert p.returncode == 0
+    for flag in ("-in", "-out", "-roi", "-wgs", "-rna", "-txt", "-min_mapq", "-no_cont", "-debug", "-build", "-ref", "-cfdna",
+                 "-somatic_custom_bed", "-read_qc", "-single_end"):  # src/MappingQC/main.cpp:23-39
+        assert f"  {flag}" in p.stdout, flag
+    p = _tool("MappingQC", "-in", bam, "-wgs", "-rna", "-no_ref")
+    assert p.returncode != 0 and "You have to use exactly one of the parameters 'roi', 'wgs', or 'rna' !" in p.stderr
+    p = _tool("MappingQC", "-in", bam, "-wgs", "-cfdna", "-no_ref")
+    assert p.returncode != 0 and "The flag 'cfdna' can only be used with parameter 'roi'!" in p.stderr
+    p = _tool("MappingQC", "-wgs")
+    assert p.returncode != 0 and "Mandatory parameter 'in' not given." in p.stderr
+    p = _tool("MappingQC", "-in", bam, "-wgs", "-build", "hg20")
+    assert p.returncode != 0 and "is not valid" in p.stderr
+    p = _tool("BedCoverage", "--help")
+    for flag in ("-bam", "-min_mapq", "-in", "-decimals", "-out", "-ref", "-clear", "-threads", "-random_access", "-debug", "-skip_mismapped"):
+        assert f"  {flag}" in p.stdout, flag   # src/BedCoverage/main.cpp:19-31
+    for tool in ("BedLowCoverage", "BedHighCoverage"):
+        p = _tool(tool, "--help")
+        for flag in ("-bam", "-cutoff", "-in", "-random_access", "-out", "-min_mapq", "-min_baseq", "-ref", "-threads", "-debug"):
+            assert f"  {flag}" in p.stdout, (tool, flag)
+        p = _tool(tool, "-bam", bam)
+        assert p.returncode != 0 and "Mandatory parameter 'cutoff' not given." in p.stderr
+
+
+def test_combine_counters_semantics():
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 1000, ngsqc.NCOUNTERS), rng.integers(0, 1000, ngsqc.NCOUNTERS)
+    c = ngsqc.combine_counters_local([a, b])
+    assert c[0] == a[0] + b[0] and c[24] == max(a[24], b[24]) and c[25] == max(a[25], b[25]) and c[1000] == a[1000] + b[1000]
+    assert [ngsqc.shard_blocks(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+_WORKER = r"""
+import importlib, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+ngsqc = importlib.import_module("ngs-bits_amd")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+vecs = [np.random.default_rng(100 + r).integers(0, 10**9, ngsqc.NCOUNTERS) for r in range(world)]
+got = ngsqc.allreduce_counters(vecs[rank])
+exp = ngsqc.combine_counters_local(vecs)
+assert np.array_equal(got, exp), "rank %d mismatch" % rank
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_counter_allreduce_gloo_world2(tmp_path):
+    """The N>1 path of bench.py: one process per rank, one collective over the counter vectors (gloo here, RCCL on GPUs)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        assert "ok" in out
