@@ -151,8 +151,8 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device)
 	scan_bgzf(bytes, n, h->blocks, h->total);
 	init_device(h, device);
 	Timer t(h->stream); t.start();
-	h->d_comp.alloc(n + 64);
-	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 64, h->stream));
+	h->d_comp.alloc(n + 1024);
+	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
 	if (n) HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes, n, hipMemcpyHostToDevice, h->stream));
 	h->d_blocks.upload(h->blocks, h->stream);
 	h->tm.h2d_ms = t.stop();

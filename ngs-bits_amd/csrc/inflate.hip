@@ -115,25 +115,37 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
 	// ---- per-group state (identical in all lanes of the group unless noted) ----
 	int state = ST_NEXT_MEMBER;
 	int64_t b = (int64_t)blockIdx.x * GROUPS + g - (int64_t)gridDim.x * GROUPS;   // advanced before first use
-	const uint32_t* in_words = nullptr; uint32_t n_words = 0, misalign = 0, clen = 0, usize = 0;
-	uint8_t* out = nullptr; const uint8_t* pay = nullptr;
-	uint32_t myword = 0, nextword = 0;   // per lane: words batch_base+gl and batch_base+G+gl
-	uint32_t batch_base = 0, w = 0, w0 = 0, w1 = 0, shift = 0;
+	const uint32_t* const comp_words = (const uint32_t*)comp;   // hipMalloc'ed: 256-byte aligned
+	uint64_t word0 = 0; uint32_t n_words = 0, misalign = 0, clen = 0, usize = 0;
+	uint8_t* out = nullptr; uint8_t* out_lane = nullptr; const uint8_t* pay = nullptr;   // out_lane = out + gl
+	uint4 myw = make_uint4(0, 0, 0, 0);  // per lane: absolute words abase + 4*gl .. +3 of the compressed image (16-byte load)
+	uint64_t abase = 0;                  // absolute word index of the group's resident batch (4*G words)
+	uint32_t w = 0, w0 = 0, w1 = 0, shift = 0;   // w = payload-relative word index of w0
 	uint32_t out_pos = 0, err = 0; int bfinal = 0;
+	// Memory ordering: a load that may read bytes stored earlier by this wave is only issued after an explicit
+	// s_waitcnt vmcnt(0) (the match path below); literals never read memory.
+	constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt/lgkmcnt untouched), gfx9 encoding
 
-	auto ldw = [&](uint32_t wi) -> uint32_t { return wi < n_words ? in_words[wi] : 0u; };
-	auto fetch = [&](uint32_t k) -> uint32_t {   // word k of the compressed stream, k in [batch_base, batch_base + 2G)
-		uint32_t idx = k - batch_base;
-		if (idx >= (uint32_t)G) { myword = nextword; batch_base += G; nextword = ldw(batch_base + G + gl); idx -= G; }
-		return (uint32_t)__shfl((int)myword, gbase + (int)idx);
+	const uint4* const comp_q = (const uint4*)comp;
+	auto load_batch = [&]() {   // synchronous: nothing stays in flight across the loop back-edge (keeps s_waitcnt out of the hot trips)
+		myw = comp_q[(abase >> 2) + gl];
+		__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+	};
+	uint32_t kbase = 0;   // payload-relative word index of the batch's first word (may be "negative": wraps, only differences are used)
+	auto fetch = [&](uint32_t k) -> uint32_t {   // payload-relative word k of the compressed stream
+		uint32_t idx = k - kbase;
+		if (idx >= (uint32_t)(4 * G)) { uint64_t a = word0 + k; abase = a & ~(uint64_t)(4 * G - 1); kbase = k - (uint32_t)(a - abase); load_batch(); idx = k - kbase; }
+		uint32_t sel = idx & 3u;
+		uint32_t mine = sel == 0 ? myw.x : (sel == 1 ? myw.y : (sel == 2 ? myw.z : myw.w));
+		return (uint32_t)__shfl((int)mine, gbase + (int)(idx >> 2));
 	};
 	auto norm = [&]() { if (shift >= 32) { shift -= 32; ++w; w0 = w1; w1 = fetch(w + 1); } };
 	auto peek = [&]() -> uint32_t { return __builtin_amdgcn_alignbit(w1, w0, shift); };  // 32 valid bits when shift < 32
 	auto get = [&](uint32_t n) -> uint32_t { norm(); uint32_t v = peek() & ((1u << n) - 1u); shift += n; return v; };   // n <= 16
 	auto reader_init = [&](uint32_t byte_rel) {   // restart the bit reader at a payload-relative byte position
 		uint32_t abs_byte = misalign + byte_rel;
-		batch_base = abs_byte / 4; w = batch_base; shift = (abs_byte & 3) * 8;
-		myword = ldw(batch_base + gl); nextword = ldw(batch_base + G + gl);
+		w = abs_byte / 4; shift = (abs_byte & 3) * 8;
+		abase = (word0 + w) & ~(uint64_t)(4 * G - 1); kbase = w - (uint32_t)(word0 + w - abase); load_batch();
 		w0 = fetch(w); w1 = fetch(w + 1);
 	};
 
@@ -146,10 +158,11 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
 			else
 			{
 				const BlockDesc bd = blocks[b];
-				out = out_base + bd.upos; usize = bd.usize; clen = bd.clen;
+				__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+				out = out_base + bd.upos; out_lane = out + gl; usize = bd.usize; clen = bd.clen;
 				pay = comp + bd.cpos;
-				in_words = (const uint32_t*)((uintptr_t)pay & ~(uintptr_t)3);
-				misalign = (uint32_t)((uintptr_t)pay & 3);
+				word0 = bd.cpos >> 2;
+				misalign = (uint32_t)(bd.cpos & 3);
 				n_words = (misalign + clen + 3) / 4 + 1;   // one word of slack (the compressed image is padded)
 				reader_init(0);
 				out_pos = 0; err = 0; bfinal = 0;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
 			{
 				shift += l;
 				if (out_pos >= usize) { err = 3; state = ST_BLOCK_HEADER; }
-				else { if (DBG < 2 && gl == 0) out[out_pos] = (uint8_t)s; ++out_pos; }
+				else { if (DBG < 2 && gl == 0) out_lane[out_pos] = (uint8_t)s; ++out_pos; }
 			}
 			else if (s == 256) { shift += l; state = ST_BLOCK_HEADER; }
 			else
@@ -289,22 +302,28 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
 						{
 							if (DBG < 1)
 							{
-								uint8_t* dst = out + out_pos; const uint8_t* src = dst - mdist;
-								if (mdist >= mlen)
+								// a load may read bytes this wave stored in earlier trips: make those stores complete first
+								__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+								uint8_t* dstl = out_lane + out_pos;            // this lane's first destination byte
+								// source index of byte i is i mod dist (periodic form: every source byte precedes the match)
+								uint32_t r = (uint32_t)gl, step = (uint32_t)G;
+								if (mdist < (uint32_t)G)
 								{
-									for (uint32_t i = gl; i < mlen; i += G) dst[i] = src[i];
+									// floor(x / d) for x <= 16, d < 16 via the 8.8 reciprocal ceil(256/d) (exact in this range)
+									const uint64_t RLO = 0ull | (0ull << 8) | (128ull << 16) | (86ull << 24) | (64ull << 32) | (52ull << 40) | (43ull << 48) | (37ull << 56);   // d = 0..7 (d=1 handled below)
+									const uint64_t RHI = 32ull | (29ull << 8) | (26ull << 16) | (24ull << 24) | (22ull << 32) | (20ull << 40) | (19ull << 48) | (18ull << 56);   // d = 8..15
+									uint32_t m = (uint32_t)((mdist < 8 ? RLO >> (8 * mdist) : RHI >> (8 * (mdist - 8))) & 255u);
+									uint32_t q = mdist == 1 ? (uint32_t)gl : ((uint32_t)gl * m) >> 8;
+									r = (uint32_t)gl - q * mdist;
+									q = mdist == 1 ? (uint32_t)G : ((uint32_t)G * m) >> 8;
+									step = (uint32_t)G - q * mdist;
 								}
-								else
+								const uint8_t* srcl = dstl - mdist - gl;       // window start (byte 0 of the period)
+								if ((uint32_t)gl < mlen) dstl[0] = srcl[r];
+								for (uint32_t i = gl + G; i < mlen; i += G)
 								{
-									// overlapping match: out[i] = window[i mod dist]; every source byte precedes the match
-									float rcp = __frcp_rn((float)mdist);
-									for (uint32_t i = gl; i < mlen; i += G)
-									{
-										uint32_t q = (uint32_t)((float)i * rcp);
-										int r = (int)i - (int)(q * mdist);
-										if (r < 0) r += (int)mdist; else if (r >= (int)mdist) r -= (int)mdist;
-										dst[i] = src[r];
-									}
+									r += step; if (r >= mdist) r -= mdist;
+									dstl[i - gl] = srcl[r];
 								}
 							}
 							out_pos += mlen;
