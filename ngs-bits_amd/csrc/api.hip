@@ -59,6 +59,8 @@ struct ngsqc_handle
 	std::vector<ngsqc_region> regions; std::vector<int64_t> doff; std::vector<int32_t> rlen; int64_t n_slots = 0; int64_t roi_bases = 0;
 	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth;
 	bool depth_ready = false;
+	std::vector<BlockStatus> h_status; std::vector<int32_t> h_start; std::vector<int64_t> h_next;   // host scratch reused across decodes (no per-step page faults)
+	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
 	ngsqc_timings tm{};
 };
 
@@ -97,13 +99,42 @@ void init_device(ngsqc_handle* h, int device)
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 }
 
-void check_inflate(ngsqc_handle* h, int64_t n_blocks)
+void check_status(ngsqc_handle* h, int64_t n_blocks)
 {
-	std::vector<BlockStatus> st((size_t)n_blocks);
-	HIPCHK(hipMemcpyAsync(st.data(), h->d_status.p, st.size() * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
 	for (int64_t i = 0; i < n_blocks; ++i)
-		if (st[i].error) throw FormatError("BGZF inflate failed in block " + std::to_string(i) + " (code " + std::to_string(st[i].error) + ")");
+		if (h->h_status[(size_t)i].error) throw FormatError("BGZF inflate failed in block " + std::to_string(i) + " (code " + std::to_string(h->h_status[(size_t)i].error) + ")");
+}
+
+// K1 dispatcher. Default: two-phase (lane-per-member Huffman -> tokens, wave-per-member LZ77 resolve). A member whose
+// token stream overflows its budget (clen + 64 tokens) makes the whole range fall back to the group kernel.
+bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, uint8_t* d_out_base)
+{
+	const char* ev = getenv("NGSQC_INFLATE_VARIANT"); const int variant = ev ? atoi(ev) : 20;
+	if (n <= 0) return true;
+	if (variant >= 20)
+	{
+		if (h->tok_first != first || h->tok_n != n)
+		{
+			std::vector<uint64_t> off((size_t)n + 1, 0);
+			for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] = off[(size_t)i] + (((uint64_t)h->blocks[(size_t)(first + i)].clen + 64 + 3) & ~3ull);
+			h->d_tok_off.upload(off, h->stream);
+			if (h->d_tok.n < (size_t)off[(size_t)n] + 16) h->d_tok.alloc((size_t)off[(size_t)n] + 16);
+			if (h->d_tok_cnt.n < (size_t)n + 8) h->d_tok_cnt.alloc((size_t)n + 8);
+			h->tok_first = first; h->tok_n = n;
+		}
+		launch_inflate_two_phase(h->d_comp.p, h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
+		HIPCHK(hipMemcpyAsync(h->h_status.data(), h->d_status.p + first, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		bool overflow = false; for (int64_t i = 0; i < n; ++i) if (h->h_status[(size_t)i].error == 100) overflow = true;
+		if (!overflow) { check_status(h, n); return true; }
+	}
+	launch_inflate(h->d_comp.p, h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->stream);
+	if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
+	HIPCHK(hipMemcpyAsync(h->h_status.data(), h->d_status.p + first, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	check_status(h, n);
+	return true;
 }
 
 // inflate the first members until the BAM header (magic, text, reference table) is complete; parse it
@@ -115,8 +146,7 @@ void read_header(ngsqc_handle* h)
 		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
 		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
 		h->d_status.alloc((size_t)std::max<int64_t>(k, 1));
-		launch_inflate(h->d_comp.p, h->d_blocks.p, k, tmp.p, h->d_status.p, h->stream);
-		check_inflate(h, k);
+		inflate_members(h, 0, k, tmp.p);
 		std::vector<uint8_t> hb((size_t)bytes);
 		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
 		bool complete = false;
@@ -166,16 +196,20 @@ void do_decode(ngsqc_handle* h)
 	HIPCHK(hipSetDevice(h->device));
 	const int64_t nb = (int64_t)h->blocks.size();
 	Timer t(h->stream);
+	const bool dbg0 = getenv("NGSQC_DEBUG") != nullptr;
+	auto lap0 = [&](const char* what) { if (dbg0) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
+	lap0("decode begin");
 	// ---- K1 ----
 	h->d_infl.alloc((size_t)h->total + 64);
+	lap0("alloc infl");
 	h->d_status.alloc((size_t)std::max<int64_t>(nb, 1));
 	t.start();
-	launch_inflate(h->d_comp.p, h->d_blocks.p, nb, h->d_infl.p, h->d_status.p, h->stream);
+	inflate_members(h, 0, nb, h->d_infl.p);
 	h->tm.inflate_ms = t.stop(); h->tm.inflate_launches = 1;
-	check_inflate(h, nb);
+	lap0("inflate");
 	// ---- K2 ----
 	t.start();
-	std::vector<int32_t> start((size_t)nb);
+	std::vector<int32_t>& start = h->h_start; if (start.size() < (size_t)nb) start.resize((size_t)nb);
 	for (int64_t b = 0; b < nb; ++b)
 	{
 		int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
@@ -184,11 +218,11 @@ void do_decode(ngsqc_handle* h)
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
 	auto lap = [&](const char* what) { if (dbg) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
 	lap("k2 begin");
-	DevBuf<int32_t> d_start; d_start.upload(start, h->stream);
+	DevBuf<int32_t> d_start; d_start.alloc((size_t)nb); HIPCHK(hipMemcpyAsync(d_start.p, start.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)nb + 1);
 	DevBuf<int64_t> d_next; d_next.alloc((size_t)nb + 1);
 	DevBuf<uint32_t> d_bad; d_bad.alloc(1);
-	std::vector<int64_t> next((size_t)nb);
+	std::vector<int64_t>& next = h->h_next; if (next.size() < (size_t)nb) next.resize((size_t)nb);
 	int64_t from = 0; int rounds = 0;
 	while (nb > 0)
 	{
@@ -421,7 +455,11 @@ int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* 
 		if (p->mode < NGSQC_MODE_ROI || p->mode > NGSQC_MODE_WGS) throw ArgError("invalid mode");
 		if (p->mode == NGSQC_MODE_ROI && (!p->regions || p->n_regions <= 0)) throw ArgError("target-region mode needs regions");
 		Timer total(h->stream); total.start();
+		const bool dbgs = getenv("NGSQC_DEBUG") != nullptr;
+		auto laps = [&](const char* what) { if (dbgs) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc:scan] %-20s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
+		laps("begin");
 		do_decode(h);
+		laps("decode");
 		const int n_ref = (int)h->ref_names.size();
 		const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
 		setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
@@ -459,10 +497,13 @@ int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* 
 		}
 		sp.gc_tab = d_gctab.p; sp.gc_over = d_gcover.p;
 		std::vector<unsigned long long> dev;
+		laps("setup");
 		run_scan(h, sp, dev);
+		laps("run_scan");
 		Timer fin(h->stream); fin.start();
 		finalize_depth(h);
 		h->tm.finalize_ms = fin.stop();
+		laps("finalize");
 
 		// ---- device accumulators -> the reference's counters ----
 		auto S = [&](int i) { return (int64_t)dev[i]; };

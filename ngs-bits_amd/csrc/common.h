@@ -20,6 +20,9 @@ struct BlockStatus { uint32_t produced; uint32_t error; };
 // ---- K1 ----
 void launch_inflate(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status, hipStream_t s);
 
+void launch_inflate_two_phase(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
+                              const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, hipStream_t s);
+
 // ---- K2 ----
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s);
