@@ -19,12 +19,10 @@
 namespace ngsqc {
 
 // ---------------------------------------------------------------------------------------------------------------- phase 1
-constexpr int P1_SYM_W = 144;    // lit_sym : 288 x u16
-constexpr int P1_DSYM_W = 8;     // dist_sym: 32 x u8
-constexpr int P1_RING_W = 16;    // compressed input ring (64 B)
+constexpr int P1_SYM_W = 81;     // lit_sym : 288 x 9 bit as a byte plane (72 words) + a bit plane (9 words)
+constexpr int P1_RING_W = 8;     // compressed input ring (32 B)
 constexpr int P1_TOK_W = 8;      // token ring
-constexpr int P1_LIM_W = 15;     // per alphabet: (limit | delta << 16) per code length, see lim_decode
-constexpr int P1_LANE_W = P1_SYM_W + P1_DSYM_W + P1_RING_W + P1_TOK_W + 2 * P1_LIM_W;   // 206 words per lane
+constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W + P1_TOK_W;   // 97 words per lane (24.8 KB per wave -> 6 waves per CU)
 constexpr int P1_SERVICE = 4;    // symbols between service blocks
 
 enum { S_NEXT = 0, S_HDR = 1, S_P1 = 2, S_P2 = 3, S_SYM = 4, S_STORED = 5, S_FINISH = 6, S_DONE = 7 };
@@ -34,13 +32,18 @@ struct P1Lds
 {
 	uint32_t* base; int lane;
 	__device__ __forceinline__ uint32_t& at(int k) const { return base[k * 64 + lane]; }
-	__device__ __forceinline__ uint32_t litsym(uint32_t i) const { uint32_t w = at((int)(i >> 1)); return (i & 1) ? (w >> 16) : (w & 0xffffu); }
-	__device__ __forceinline__ void set_litsym(uint32_t i, uint32_t s) const { uint32_t& w = at((int)(i >> 1)); w = (i & 1) ? ((w & 0x0000ffffu) | (s << 16)) : ((w & 0xffff0000u) | s); }
-	__device__ __forceinline__ uint32_t distsym(uint32_t i) const { return (at(P1_SYM_W + (int)(i >> 2)) >> (8 * (i & 3))) & 255u; }
-	__device__ __forceinline__ void set_distsym(uint32_t i, uint32_t s) const { uint32_t& w = at(P1_SYM_W + (int)(i >> 2)); uint32_t sh = 8 * (i & 3); w = (w & ~(255u << sh)) | (s << sh); }
-	__device__ __forceinline__ uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + P1_DSYM_W + (int)(i & (P1_RING_W - 1))); }
-	__device__ __forceinline__ uint32_t& tok(uint32_t i) const { return at(P1_SYM_W + P1_DSYM_W + P1_RING_W + (int)(i & (P1_TOK_W - 1))); }
-	__device__ __forceinline__ uint32_t& lim(int alphabet, int l) const { return at(P1_SYM_W + P1_DSYM_W + P1_RING_W + P1_TOK_W + alphabet * P1_LIM_W + l); }
+	__device__ __forceinline__ uint32_t litsym(uint32_t i) const
+	{
+		uint32_t lo = at((int)(i >> 2)), hi = at(72 + (int)(i >> 5));
+		return ((lo >> (8 * (i & 3))) & 255u) | (((hi >> (i & 31)) & 1u) << 8);
+	}
+	__device__ __forceinline__ void set_litsym(uint32_t i, uint32_t s) const
+	{
+		uint32_t& lo = at((int)(i >> 2)); uint32_t sh = 8 * (i & 3); lo = (lo & ~(255u << sh)) | ((s & 255u) << sh);
+		uint32_t& hi = at(72 + (int)(i >> 5)); hi = (hi & ~(1u << (i & 31))) | ((s >> 8) << (i & 31));
+	}
+	__device__ __forceinline__ uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
+	__device__ __forceinline__ uint32_t& tok(uint32_t i) const { return at(P1_SYM_W + P1_RING_W + (int)(i & (P1_TOK_W - 1))); }
 };
 
 // packed per-length counters: FW bits per field, 32/FW fields per register (FW = 10 for lit/len, 5+1 for dist/CL -> use 6)
@@ -51,9 +54,10 @@ template <int FW, int NREG> struct Packed
 	__device__ __forceinline__ uint32_t get_const(int idx) const { constexpr int PER = 32 / FW; return (r[idx / PER] >> (FW * (idx % PER))) & ((1u << FW) - 1u); }   // idx compile-time after unrolling
 	__device__ __forceinline__ uint32_t get(uint32_t idx) const
 	{
-		constexpr int PER = 32 / FW; uint32_t reg = idx / PER, sh = FW * (idx % PER); uint32_t v = r[0];
+		// mask-select (not an indexed read: keeps the counters in VGPRs instead of scratch memory)
+		constexpr int PER = 32 / FW; uint32_t reg = idx / PER, sh = FW * (idx % PER); uint32_t v = 0;
 		#pragma unroll
-		for (int i = 1; i < NREG; ++i) v = reg == (uint32_t)i ? r[i] : v;
+		for (int i = 0; i < NREG; ++i) v |= r[i] & (0u - (uint32_t)(reg == (uint32_t)i));
 		return (v >> sh) & ((1u << FW) - 1u);
 	}
 	__device__ __forceinline__ void add(uint32_t idx, uint32_t delta)
@@ -88,35 +92,55 @@ __device__ __forceinline__ int canon_decode(uint32_t bits, const CNT& c, uint32_
 	len_out = 15; return -1;
 }
 
-// Branch-free canonical decode. For code length l (1..15) the LDS word holds
+// Branch-free canonical decode out of REGISTERS (occupancy is LDS-bound at < 1 wave per SIMD, so VGPRs are free).
+// For code length l (1..15) the word holds
 //   limit_l = (first_code_l + count_l) << (15 - l)   (upper bound, left-aligned to 15 bits; non-decreasing in l)
 //   delta_l = offset_l - first_code_l                (index of the length's first symbol in the sorted array minus its first code)
 // With v = the next 15 stream bits MSB-first: length = 1 + #{l : v >= limit_l}, index = (v >> (15 - length)) + delta.
-__device__ __forceinline__ int lim_decode(const P1Lds& L, int alphabet, uint32_t bits, uint32_t& len_out)
+struct DistSyms
 {
-	const uint32_t v = __brev(bits) >> 17;
-	uint32_t n = 0;
-	#pragma unroll
-	for (int l = 0; l < 15; ++l) n += (v >= (L.lim(alphabet, l) & 0xffffu)) ? 1u : 0u;
-	len_out = n + 1;
-	if (n >= 15) return -1;
-	const uint32_t w = L.lim(alphabet, (int)n);
-	return (int)(v >> (14 - n)) + (int)(int16_t)(w >> 16);
-}
-
-template <class CNT>
-__device__ __forceinline__ void build_limits(const P1Lds& L, int alphabet, const CNT& c)
-{
-	uint32_t code = 0, o = 0;
-	#pragma unroll
-	for (int l = 1; l <= 15; ++l)
+	uint64_t q[3];
+	__device__ __forceinline__ void clear() { q[0] = q[1] = q[2] = 0; }
+	__device__ __forceinline__ uint32_t get(uint32_t i) const
 	{
-		const uint32_t cnt = c.get_const(l - 1);
-		uint32_t lim = (code + cnt) << (15 - l); if (lim > 0x8000u) lim = 0x8000u;   // over-subscribed codes are rejected by the index checks
-		L.lim(alphabet, l - 1) = lim | (((o - code) & 0xffffu) << 16);
-		o += cnt; code = (code + cnt) << 1;
+		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u);   // i / 12 for i < 36
+		uint64_t v = (q[0] & (0ull - (uint64_t)(reg == 0))) | (q[1] & (0ull - (uint64_t)(reg == 1))) | (q[2] & (0ull - (uint64_t)(reg == 2)));
+		return (uint32_t)(v >> sh) & 31u;
 	}
-}
+	__device__ __forceinline__ void set(uint32_t i, uint32_t s)
+	{
+		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u); uint64_t m = 31ull << sh, val = (uint64_t)s << sh;
+		#pragma unroll
+		for (int k = 0; k < 3; ++k) q[k] = reg == (uint32_t)k ? ((q[k] & ~m) | val) : q[k];
+	}
+};
+
+struct LimTab
+{
+	uint32_t w[15];
+	__device__ __forceinline__ int decode(uint32_t bits, uint32_t& len_out) const
+	{
+		const uint32_t v = __brev(bits) >> 17;
+		uint32_t n = 0, sel = 0;
+		#pragma unroll
+		for (int l = 14; l >= 0; --l) { const bool ge = v >= (w[l] & 0xffffu); n += ge ? 1u : 0u; sel = ge ? sel : w[l]; }   // sel ends as the word of the smallest l with v < limit_l
+		len_out = n + 1;
+		if (n >= 15) return -1;
+		return (int)(v >> (14 - n)) + (int)(int16_t)(sel >> 16);
+	}
+	template <class CNT> __device__ __forceinline__ void build(const CNT& c)
+	{
+		uint32_t code = 0, o = 0;
+		#pragma unroll
+		for (int l = 1; l <= 15; ++l)
+		{
+			const uint32_t cnt = c.get_const(l - 1);
+			uint32_t lim = (code + cnt) << (15 - l); if (lim > 0x8000u) lim = 0x8000u;   // over-subscribed codes are rejected by the index checks
+			w[l - 1] = lim | (((o - code) & 0xffffu) << 16);
+			o += cnt; code = (code + cnt) << 1;
+		}
+	}
+};
 
 __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
@@ -139,9 +163,15 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	uint4 pf = make_uint4(0, 0, 0, 0); bool pf_valid = false;
 	uint32_t* tok_ptr = nullptr; uint32_t tok_cap = 0, tok_n = 0, tok_flushed = 0;
 	uint32_t out_n = 0, err = 0; int bfinal = 0;
+	LimTab limL, limD;                                       // decode tables of the current deflate block (registers)
+	DistSyms dsym; dsym.clear();                             // distance symbols sorted by (len, sym)
+	#pragma unroll
+	for (int i = 0; i < 15; ++i) { limL.w[i] = 0; limD.w[i] = 0; }
 	LitCnt cl; DistCnt cd; cl.clear(); cd.clear();          // code-length counts
 	LitCnt ol; DistCnt od; ol.clear(); od.clear();          // placement cursors of pass 2
-	uint64_t ccl_cnt = 0; uint64_t ccl_lo = 0, ccl_hi = 0;  // code-length alphabet: counts (7 x 6 bit), sorted symbols (19 x 5 bit)
+	uint64_t ccl_lo = 0, ccl_hi = 0; uint32_t limC[7];       // code-length alphabet: sorted symbols (19 x 5 bit), limit/delta words per length 1..7
+	#pragma unroll
+	for (int i = 0; i < 7; ++i) limC[i] = 0;
 	uint32_t h_i = 0, h_n = 0, h_nlit = 0, h_prev = 0, hdr_bits = 0; uint32_t stored_left = 0;
 
 	auto exhausted = [&]() -> bool { return rd == wr && next_q >= n_q && !pf_valid; };
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 			{
 				refill();
 				uint32_t len;
-				int idx = lim_decode(L, 0, (uint32_t)bitbuf, len);
+				int idx = limL.decode((uint32_t)bitbuf, len);
 				if (idx < 0 || idx >= 288) { err = 9; state = S_FINISH; }
 				else
 				{
@@ -214,11 +244,11 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 							uint32_t mlen = base + take(eb);
 							refill();
 							uint32_t dl;
-							int di = lim_decode(L, 1, (uint32_t)bitbuf, dl);
+							int di = limD.decode((uint32_t)bitbuf, dl);
 							if (di < 0 || di >= 30) { err = 11; state = S_FINISH; }
 							else
 							{
-								uint32_t ds = L.distsym((uint32_t)di);
+								uint32_t ds = dsym.get((uint32_t)di);
 								bitbuf >>= dl; bitcnt -= dl; bits_used += dl;
 								if (ds >= 30) { err = 12; state = S_FINISH; }
 								else
@@ -243,14 +273,17 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 			{
 				refill();
 				// canonical decode of the 19-symbol alphabet (lengths 1..7) from registers
-				uint32_t bits = (uint32_t)bitbuf; int code = 0, first = 0, index = 0; int sym = -1; uint32_t len = 0;
-				#pragma unroll
-				for (int l = 1; l <= 7; ++l)
+				int sym = -1; uint32_t len = 0;
 				{
-					code |= (int)(bits & 1u); bits >>= 1;
-					int count = (int)((ccl_cnt >> (6 * (l - 1))) & 63u);
-					if (sym < 0 && code - count < first) { int k = index + (code - first); sym = (int)(k < 12 ? (ccl_lo >> (5 * k)) & 31u : (ccl_hi >> (5 * (k - 12))) & 31u); len = (uint32_t)l; }
-					index += count; first += count; first <<= 1; code <<= 1;
+					const uint32_t v = __brev((uint32_t)bitbuf) >> 25;   // next 7 bits, MSB-first
+					uint32_t n = 0, sel = 0;
+					#pragma unroll
+					for (int l = 6; l >= 0; --l) { const bool ge = v >= (limC[l] & 0xffffu); n += ge ? 1u : 0u; sel = ge ? sel : limC[l]; }
+					if (n < 7)
+					{
+						const uint32_t k = (v >> (6 - n)) + (uint32_t)(int)(int16_t)(sel >> 16);
+						if (k < 19) { sym = (int)(k < 12 ? (ccl_lo >> (5 * k)) & 31u : (ccl_hi >> (5 * (k - 12))) & 31u); len = n + 1; }
+					}
 				}
 				if (sym < 0) { err = 6; state = S_FINISH; }
 				else
@@ -265,12 +298,16 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 					{
 						if (val != 0)
 						{
-							for (uint32_t k = 0; k < rep; ++k)
+							if (state == S_P1)
+							{
+								const uint32_t n_lit = h_i >= h_nlit ? 0u : (h_nlit - h_i < rep ? h_nlit - h_i : rep);
+								cl.add(val - 1, n_lit); cd.add(val - 1, rep - n_lit);
+							}
+							else for (uint32_t k = 0; k < rep; ++k)
 							{
 								uint32_t i = h_i + k;
-								if (state == S_P1) { if (i < h_nlit) cl.add(val - 1, 1); else cd.add(val - 1, 1); }
-								else if (i < h_nlit) { uint32_t o = ol.get(val - 1); ol.add(val - 1, 1); L.set_litsym(o, i); }
-								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); L.set_distsym(o, i - h_nlit); }
+								if (i < h_nlit) { uint32_t o = ol.get(val - 1); ol.add(val - 1, 1); L.set_litsym(o, i); }
+								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); dsym.set(o, i - h_nlit); }
 							}
 						}
 						h_i += rep; if (sym < 16) h_prev = (uint32_t)sym; else if (sym != 16) h_prev = 0;
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 								#pragma unroll
 								for (int l = 0; l < 15; ++l) { od.set(l, o); o += cd.get_const(l); }
 								if (o > 32) { err = 5; state = S_FINISH; }
-								if (err == 0) { build_limits(L, 0, cl); build_limits(L, 1, cd); seek(hdr_bits); h_i = 0; h_prev = 0; state = S_P2; }
+								if (err == 0) { limL.build(cl); limD.build(cd); seek(hdr_bits); h_i = 0; h_prev = 0; state = S_P2; }
 							}
 							else state = S_SYM;
 						}
@@ -319,8 +356,8 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 					for (uint32_t s = 0; s < 144; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 280; s < 288; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 144; s < 256; ++s) L.set_litsym(k++, s);
-					for (uint32_t s = 0; s < 30; ++s) L.set_distsym(s, s);
-					build_limits(L, 0, cl); build_limits(L, 1, cd);
+					for (uint32_t s = 0; s < 30; ++s) dsym.set(s, s);
+					limL.build(cl); limD.build(cd);
 					state = S_SYM;
 				}
 				else if (btype == 2)
@@ -341,15 +378,21 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 							uint32_t s = (uint32_t)((i < 12 ? ORD_LO >> (5 * i) : ORD_HI >> (5 * (i - 12))) & 31u);
 							cll |= (uint64_t)v << (3 * s);
 						}
-						ccl_cnt = 0; ccl_lo = 0; ccl_hi = 0; uint32_t k = 0;
-						for (uint32_t l = 1; l <= 7; ++l)
+						ccl_lo = 0; ccl_hi = 0; uint32_t k = 0, ccode = 0;
+						#pragma unroll
+						for (int l = 1; l <= 7; ++l)
+						{
+							uint32_t cnt = 0; const uint32_t o = k;
 							for (uint32_t s = 0; s < 19; ++s)
-								if (((cll >> (3 * s)) & 7u) == l)
+								if (((cll >> (3 * s)) & 7u) == (uint32_t)l)
 								{
-									ccl_cnt += 1ull << (6 * (l - 1));
 									if (k < 12) ccl_lo |= (uint64_t)s << (5 * k); else ccl_hi |= (uint64_t)s << (5 * (k - 12));
-									++k;
+									++k; ++cnt;
 								}
+							uint32_t lim = (ccode + cnt) << (7 - l); if (lim > 0x80u) lim = 0x80u;
+							limC[l - 1] = lim | (((o - ccode) & 0xffffu) << 16);
+							ccode = (ccode + cnt) << 1;
+						}
 						hdr_bits = bits_used;
 						state = S_P1;
 					}
@@ -503,7 +546,7 @@ void launch_inflate_two_phase(const uint8_t* d_comp, const BlockDesc* d_blocks, 
 	hipMemsetAsync(d_work, 0, sizeof(unsigned long long), s);
 	if (n_blocks <= 0) return;
 	int64_t wgs = (n_blocks + 63) / 64;
-	int grid1 = (int)(wgs < 256 * 3 ? wgs : 256 * 3);
+	int grid1 = (int)(wgs < 256 * 6 ? wgs : 256 * 6);   // 6 one-wave workgroups fit a CU (24.8 KB LDS each)
 	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work);
 	int64_t wg2 = (n_blocks + 3) / 4;
 	int grid2 = (int)(wg2 < 256 * 8 ? wg2 : 256 * 8);
