@@ -26,6 +26,7 @@ template <typename T> struct DevBuf
 	T* p = nullptr; size_t n = 0;
 	void alloc(size_t count) { release(); if (count) { HIPCHK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
 	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+	void ensure(size_t count) { if (n < count) alloc(count); }   // keep a big-enough allocation (hipMalloc/hipFree of multi-GB buffers can stall for a second)
 	void upload(const std::vector<T>& v, hipStream_t s) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
 	~DevBuf() { release(); }
 	DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
@@ -60,6 +61,7 @@ struct ngsqc_handle
 	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth;
 	bool depth_ready = false;
 	std::vector<BlockStatus> h_status; std::vector<int32_t> h_start; std::vector<int64_t> h_next;   // host scratch reused across decodes (no per-step page faults)
+	DevBuf<int64_t> d_long;
 	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
 	ngsqc_timings tm{};
 };
@@ -145,7 +147,7 @@ void read_header(ngsqc_handle* h)
 	{
 		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
 		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
-		h->d_status.alloc((size_t)std::max<int64_t>(k, 1));
+		h->d_status.ensure((size_t)std::max<int64_t>(k, 1));
 		inflate_members(h, 0, k, tmp.p);
 		std::vector<uint8_t> hb((size_t)bytes);
 		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
@@ -200,9 +202,9 @@ void do_decode(ngsqc_handle* h)
 	auto lap0 = [&](const char* what) { if (dbg0) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
 	lap0("decode begin");
 	// ---- K1 ----
-	h->d_infl.alloc((size_t)h->total + 64);
+	h->d_infl.ensure((size_t)h->total + 64);
 	lap0("alloc infl");
-	h->d_status.alloc((size_t)std::max<int64_t>(nb, 1));
+	h->d_status.ensure((size_t)std::max<int64_t>(nb, 1));
 	t.start();
 	inflate_members(h, 0, nb, h->d_infl.p);
 	h->tm.inflate_ms = t.stop(); h->tm.inflate_launches = 1;
@@ -268,7 +270,7 @@ void do_decode(ngsqc_handle* h)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	h->n_rec = n_rec;
 	lap("k2 scan");
-	h->d_recoff.alloc((size_t)std::max<int64_t>(n_rec, 1));
+	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec, 1));
 	lap("k2 alloc recoff");
 	launch_index_write(h->d_infl.p, h->d_blocks.p, nb, d_start.p, d_base.p, h->d_recoff.p, h->stream);
 	h->tm.index_ms = t.stop();
@@ -302,7 +304,7 @@ void setup_regions(ngsqc_handle* h, const ngsqc_region* regions, int64_t n)
 	h->d_tid_first.upload(tf, h->stream); h->d_tid_last.upload(tl, h->stream);
 	std::vector<int64_t> doff(h->doff.begin(), h->doff.begin() + n);
 	h->d_doff.upload(doff, h->stream);
-	h->d_depth.alloc((size_t)slots + 1);
+	h->d_depth.ensure((size_t)slots + 1);
 	HIPCHK(hipMemsetAsync(h->d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
 	h->depth_ready = false;
 }
@@ -326,7 +328,7 @@ void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& 
 	DevBuf<unsigned long long> d_counters; d_counters.alloc(A_DEV_TOTAL);
 	std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
 	HIPCHK(hipMemcpyAsync(d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	DevBuf<int64_t> d_long; d_long.alloc((size_t)std::max<int64_t>(h->n_rec, 1));
+	h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1)); DevBuf<int64_t>& d_long = h->d_long;
 	sp.infl = h->d_infl.p; sp.total = h->total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec;
 	sp.counters = d_counters.p; sp.diff = h->d_depth.p; sp.long_list = d_long.p; sp.long_cap = h->n_rec;
 	sp.n_ref = (int32_t)h->ref_names.size();
@@ -436,7 +438,8 @@ int64_t ngsqc_n_records(ngsqc_handle* h) { int rc = guarded(h, [&] { do_decode(h
 int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { do_decode(h); }); }
 int ngsqc_drop_decoded(ngsqc_handle* h)
 {
-	return guarded(h, [&] { h->d_infl.release(); h->d_recoff.release(); h->d_status.release(); h->decoded = false; h->depth_ready = false; h->n_rec = 0; });
+	// buffers stay allocated (re-used by the next decode); only the decoded STATE is dropped, so the next scan redoes K1+K2
+	return guarded(h, [&] { h->decoded = false; h->depth_ready = false; h->n_rec = 0; });
 }
 
 int ngsqc_copy_inflated(ngsqc_handle* h, uint8_t* out, int64_t cap)
