@@ -136,6 +136,8 @@ typedef struct ngsqc_timings {
 	int64_t compressed_bytes, inflated_bytes, n_records;
 	double scan_kernel_ms;            /* K3-K5 kernels only (HIP events around the scan launches on the handle's stream) */
 	double depth_kernel_ms;           /* K6 prefix sum + histogram kernels */
+	double inflate_huff_ms;           /* K1 phase 1: huff_tokens_kernel (0 when the group kernel ran) */
+	double inflate_lz77_ms;           /* K1 phase 2: lz77_resolve_kernel */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

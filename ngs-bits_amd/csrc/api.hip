@@ -124,7 +124,11 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, uint8_t* d_out_b
 			if (h->d_tok_cnt.n < (size_t)n + 8) h->d_tok_cnt.alloc((size_t)n + 8);
 			h->tok_first = first; h->tok_n = n;
 		}
-		launch_inflate_two_phase(h->d_comp.p, h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		Timer tp(h->stream); tp.start();
+		launch_huff_tokens(h->d_comp.p, h->d_blocks.p + first, n, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		h->tm.inflate_huff_ms = tp.stop(); tp.start();
+		launch_lz77_resolve(h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		h->tm.inflate_lz77_ms = tp.stop();
 		if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
 		HIPCHK(hipMemcpyAsync(h->h_status.data(), h->d_status.p + first, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));

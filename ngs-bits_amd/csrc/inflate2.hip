@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 // ---------------------------------------------------------------------------------------------------------------- phase 2
 constexpr int P2_BMAX = 1024;   // max output bytes resolved per batch (LDS staging)
 
-struct P2Lds { uint32_t end[64]; uint16_t src[P2_BMAX + 64]; uint8_t val[P2_BMAX + 64]; };
+struct P2Lds { unsigned long long endmask[P2_BMAX / 64]; uint16_t src[P2_BMAX + 64]; uint8_t val[P2_BMAX + 64]; };
 
 __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
                                                            const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
@@ -475,23 +475,31 @@ __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __res
 			const uint32_t B = (uint32_t)__shfl((int)end, (int)ntake - 1);
 			const uint32_t start = end - len;
 			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
-			S.end[lane] = (uint32_t)lane < ntake ? end : 0xffffffffu;
 			// stores of earlier batches must be complete before this batch gathers from the window
 			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
 			bool any_unres = false;
+			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
+			if (lane < P2_BMAX / 64) S.endmask[lane] = 0ull;
+			__builtin_amdgcn_wave_barrier();
+			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
+			__builtin_amdgcn_wave_barrier();
+			uint32_t ta = 0;   // tokens that end at or before the current chunk start
 			for (uint32_t j0 = 0; j0 < B; j0 += 64)
 			{
 				const uint32_t j = j0 + (uint32_t)lane;
-				// owner = first token whose end > j
-				uint32_t lo = 0, hi = 63;
-				#pragma unroll
-				for (int it = 0; it < 6; ++it) { uint32_t mid = (lo + hi) >> 1; bool right = S.end[mid] <= j; lo = right ? mid + 1 : lo; hi = right ? hi : mid; }
-				const uint32_t o = lo;
-				const uint32_t tko = (uint32_t)__shfl((int)tk, (int)o);
-				const uint32_t sto = (uint32_t)__shfl((int)start, (int)o);
+				// owner token of byte j = ta + #tokens ending inside the chunk at or before j. The token ends inside the chunk
+				// are strictly increasing, so they form a 64-bit mask (bit p <-> some token ends at j0 + p + 1), read from the
+				// batch's end bitmap; a popcount of the bits below (j - j0) ranks the byte.
+				const uint64_t m = S.endmask[j0 >> 6];
+				const uint32_t pj = (uint32_t)lane;   // j - j0
+				const uint32_t o = ta + (uint32_t)__popcll(m & ((1ull << pj) - 1ull));
+				ta += (uint32_t)__popcll(m);
+				const uint32_t tko = (uint32_t)__shfl((int)tk, (int)(o & 63u));
+				const uint32_t sto = (uint32_t)__shfl((int)start, (int)(o & 63u));
+				uint32_t sidx = 0xffffu;
 				if (j < B)
 				{
-					uint32_t v = tko & 255u; uint32_t sidx = 0xffffu;
+					uint32_t v = tko & 255u;
 					if (tko >> 31)
 					{
 						const uint32_t d = (tko & 0x7fffu) + 1u, off = j - sto;
@@ -538,16 +546,22 @@ __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __res
 	}
 }
 
-void launch_inflate_two_phase(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
-                              const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, hipStream_t s)
+void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
+                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, hipStream_t s)
 {
-	// d_tok_count has n_blocks + 4 entries: the last 8 bytes (8-byte aligned) are the phase-1 work counter
+	if (n_blocks <= 0) return;
+	// d_tok_count has n_blocks + 8 entries: the last 8 bytes (8-byte aligned) are the phase-1 work counter
 	unsigned long long* d_work = (unsigned long long*)(d_tok_count + ((n_blocks + 1) & ~1ll));
 	hipMemsetAsync(d_work, 0, sizeof(unsigned long long), s);
-	if (n_blocks <= 0) return;
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < 256 * 6 ? wgs : 256 * 6);   // 6 one-wave workgroups fit a CU (24.8 KB LDS each)
 	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work);
+}
+
+void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
+                         const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s)
+{
+	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
 	int grid2 = (int)(wg2 < 256 * 8 ? wg2 : 256 * 8);
 	hipLaunchKernelGGL(lz77_resolve_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
