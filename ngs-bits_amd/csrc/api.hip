@@ -61,7 +61,11 @@ struct ngsqc_handle
 	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth;
 	bool depth_ready = false;
 	std::vector<BlockStatus> h_status; std::vector<int32_t> h_start; std::vector<int64_t> h_next;   // host scratch reused across decodes (no per-step page faults)
-	DevBuf<int64_t> d_long;
+	DevBuf<int64_t> d_long; DevBuf<unsigned long long> d_counters; DevBuf<BlockDesc> d_tile_blocks; DevBuf<uint8_t> d_carry_tmp;
+	// tiling: the inflated stream is processed in member ranges that fit HBM; tile-local offsets everywhere on the device
+	std::vector<std::pair<int64_t, int64_t>> tiles;   // (first member, count)
+	int cur_tile = -1; int64_t tile_prefix = 0, tile_total = 0, tile_u_lo = 0, tile_ord_base = 0;
+	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0; int64_t n_rec_total = -1;
 	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
 	ngsqc_timings tm{};
 };
@@ -109,8 +113,9 @@ void check_status(ngsqc_handle* h, int64_t n_blocks)
 
 // K1 dispatcher. Default: two-phase (lane-per-member Huffman -> tokens, wave-per-member LZ77 resolve). A member whose
 // token stream overflows its budget (clen + 64 tokens) makes the whole range fall back to the group kernel.
-bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, uint8_t* d_out_base)
+bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc* d_desc, uint8_t* d_out_base)
 {
+	BlockStatus* d_st = h->d_status.p;   // status of the n members of this call
 	const char* ev = getenv("NGSQC_INFLATE_VARIANT"); const int variant = ev ? atoi(ev) : 20;
 	if (n <= 0) return true;
 	if (variant >= 20)
@@ -125,19 +130,19 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, uint8_t* d_out_b
 			h->tok_first = first; h->tok_n = n;
 		}
 		Timer tp(h->stream); tp.start();
-		launch_huff_tokens(h->d_comp.p, h->d_blocks.p + first, n, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
-		h->tm.inflate_huff_ms = tp.stop(); tp.start();
-		launch_lz77_resolve(h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
-		h->tm.inflate_lz77_ms = tp.stop();
+		launch_huff_tokens(h->d_comp.p, d_desc, n, d_st, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		h->tm.inflate_huff_ms += tp.stop(); tp.start();
+		launch_lz77_resolve(d_desc, n, d_out_base, d_st, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
+		h->tm.inflate_lz77_ms += tp.stop();
 		if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
-		HIPCHK(hipMemcpyAsync(h->h_status.data(), h->d_status.p + first, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(h->h_status.data(), d_st, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		bool overflow = false; for (int64_t i = 0; i < n; ++i) if (h->h_status[(size_t)i].error == 100) overflow = true;
 		if (!overflow) { check_status(h, n); return true; }
 	}
-	launch_inflate(h->d_comp.p, h->d_blocks.p + first, n, d_out_base, h->d_status.p + first, h->stream);
+	launch_inflate(h->d_comp.p, d_desc, n, d_out_base, d_st, h->stream);
 	if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
-	HIPCHK(hipMemcpyAsync(h->h_status.data(), h->d_status.p + first, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(h->h_status.data(), d_st, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	check_status(h, n);
 	return true;
@@ -152,7 +157,7 @@ void read_header(ngsqc_handle* h)
 		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
 		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
 		h->d_status.ensure((size_t)std::max<int64_t>(k, 1));
-		inflate_members(h, 0, k, tmp.p);
+		inflate_members(h, 0, k, h->d_blocks.p, tmp.p);
 		std::vector<uint8_t> hb((size_t)bytes);
 		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
 		bool complete = false;
@@ -196,91 +201,144 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device)
 	read_header(h);
 }
 
-void do_decode(ngsqc_handle* h)
+// Member ranges ("tiles") whose inflated bytes + token scratch + record index fit the device. NGSQC_TILE_MEMBERS overrides
+// (tests use tiny tiles to exercise the carry logic).
+void plan_tiles(ngsqc_handle* h)
 {
-	if (h->decoded) return;
-	HIPCHK(hipSetDevice(h->device));
+	if (!h->tiles.empty() || h->blocks.empty()) return;
 	const int64_t nb = (int64_t)h->blocks.size();
-	Timer t(h->stream);
-	const bool dbg0 = getenv("NGSQC_DEBUG") != nullptr;
-	auto lap0 = [&](const char* what) { if (dbg0) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
-	lap0("decode begin");
-	// ---- K1 ----
-	h->d_infl.ensure((size_t)h->total + 64);
-	lap0("alloc infl");
-	h->d_status.ensure((size_t)std::max<int64_t>(nb, 1));
-	t.start();
-	inflate_members(h, 0, nb, h->d_infl.p);
-	h->tm.inflate_ms = t.stop(); h->tm.inflate_launches = 1;
-	lap0("inflate");
-	// ---- K2 ----
-	t.start();
-	std::vector<int32_t>& start = h->h_start; if (start.size() < (size_t)nb) start.resize((size_t)nb);
-	for (int64_t b = 0; b < nb; ++b)
+	int64_t per_tile = nb;
+	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) per_tile = std::max<int64_t>(1, atoll(e));
+	else
 	{
-		int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
-		start[b] = hi <= h->first_rec ? -1 : (lo <= h->first_rec ? (int32_t)(h->first_rec - lo) : -2);
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+		{
+			const double per_member = 65536.0 + 4.0 * (65536.0 / 3.0 + 64.0) + 2.0 * 8.0 * 400.0;   // inflated + tokens + record index / long list
+			int64_t fit = (int64_t)((double)free_b * 0.80 / per_member);
+			per_tile = std::max<int64_t>(4096, std::min<int64_t>(nb, fit));
+		}
 	}
+	for (int64_t f = 0; f < nb; f += per_tile) h->tiles.emplace_back(f, std::min<int64_t>(per_tile, nb - f));
+}
+
+// K1 + K2 for tile t. Tiles must be decoded in order (t == 0 or t == cur_tile + 1): a record that starts in one tile and
+// ends in the next is carried as a prefix in front of the next tile's members.
+void decode_tile(ngsqc_handle* h, int t)
+{
+	HIPCHK(hipSetDevice(h->device));
+	plan_tiles(h);
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
-	auto lap = [&](const char* what) { if (dbg) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc] %-24s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
-	lap("k2 begin");
-	DevBuf<int32_t> d_start; d_start.alloc((size_t)nb); HIPCHK(hipMemcpyAsync(d_start.p, start.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)nb + 1);
-	DevBuf<int64_t> d_next; d_next.alloc((size_t)nb + 1);
+	if (t == h->cur_tile && h->decoded) return;
+	if (t != 0 && t != h->cur_tile + 1) throw std::runtime_error("internal: tiles must be decoded in order");
+	const bool last = t == (int)h->tiles.size() - 1;
+	const int64_t first = h->tiles[(size_t)t].first, nm = h->tiles[(size_t)t].second;
+	if (t == 0) { h->carry_len = 0; h->next_ord_base = 0; h->expected_abs = h->first_rec; }
+	const int64_t u_lo = (int64_t)h->blocks[(size_t)first].upos;
+	const int64_t u_hi = (int64_t)h->blocks[(size_t)(first + nm - 1)].upos + h->blocks[(size_t)(first + nm - 1)].usize;
+	const int64_t prefix = h->carry_len;
+	const int64_t total = prefix + (u_hi - u_lo);
+	Timer tmr(h->stream);
+	// ---- buffers ----
+	h->d_infl.ensure((size_t)total + 64);   // (the carried prefix was staged in d_carry_tmp by finish_tile)
+	if (prefix) HIPCHK(hipMemcpyAsync(h->d_infl.p, h->d_carry_tmp.p, (size_t)prefix, hipMemcpyDeviceToDevice, h->stream));
+	// tile-local member descriptors: [0] = pseudo member covering the carried prefix (not inflated), then the members
+	std::vector<BlockDesc> loc((size_t)nm + 1);
+	loc[0] = BlockDesc{0, 0, 0, (uint32_t)prefix};
+	for (int64_t i = 0; i < nm; ++i) { BlockDesc d = h->blocks[(size_t)(first + i)]; d.upos = (uint64_t)(prefix + ((int64_t)d.upos - u_lo)); loc[(size_t)i + 1] = d; }
+	h->d_tile_blocks.ensure((size_t)nm + 1);
+	HIPCHK(hipMemcpyAsync(h->d_tile_blocks.p, loc.data(), loc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, h->stream));
+	h->d_status.ensure((size_t)nm + 1);
+	// ---- K1 ----
+	tmr.start();
+	inflate_members(h, first, nm, h->d_tile_blocks.p + 1, h->d_infl.p);
+	h->tm.inflate_ms += tmr.stop(); h->tm.inflate_launches++;
+	// ---- K2 (tile-local coordinates; entry 0 is the prefix pseudo member) ----
+	tmr.start();
+	const int64_t ne = nm + 1;
+	std::vector<int32_t>& start = h->h_start; if (start.size() < (size_t)ne) start.resize((size_t)ne);
+	std::vector<int64_t>& next = h->h_next; if (next.size() < (size_t)ne) next.resize((size_t)ne);
+	const int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
+	for (int64_t b = 0; b < ne; ++b)
+	{
+		const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
+		start[(size_t)b] = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2);
+	}
+	DevBuf<int32_t> d_start; d_start.alloc((size_t)ne); HIPCHK(hipMemcpyAsync(d_start.p, start.data(), (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)ne + 1);
+	DevBuf<int64_t> d_next; d_next.alloc((size_t)ne + 1);
 	DevBuf<uint32_t> d_bad; d_bad.alloc(1);
-	std::vector<int64_t>& next = h->h_next; if (next.size() < (size_t)nb) next.resize((size_t)nb);
-	int64_t from = 0; int rounds = 0;
-	while (nb > 0)
+	int64_t from = 0; int rounds = 0; int64_t straddle = -1;
+	while (true)
 	{
 		HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), h->stream));
-		launch_index_count(h->d_infl.p, h->total, h->d_blocks.p + from, nb - from, d_start.p + from, d_cnt.p + from, d_next.p + from, d_bad.p, (int32_t)h->ref_names.size(), h->stream);
-		HIPCHK(hipMemcpyAsync(start.data() + from, d_start.p + from, (size_t)(nb - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(nb - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+		launch_index_count(h->d_infl.p, total, h->d_tile_blocks.p + from, ne - from, d_start.p + from, d_cnt.p + from, d_next.p + from, d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+		HIPCHK(hipMemcpyAsync(start.data() + from, d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(ne - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		lap("k2 count+d2h");
 		// exact verification of the chain: every member's exit must land on the next member's start
-		int64_t expected = h->first_rec; int64_t mismatch = -1;
-		for (int64_t b = 0; b < nb; ++b)
+		int64_t expected = exp0; int64_t mismatch = -1; straddle = -1;
+		for (int64_t b = 0; b < ne; ++b)
 		{
-			int64_t lo = (int64_t)h->blocks[b].upos, hi = lo + h->blocks[b].usize;
-			int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
-			if (start[b] != want)
-			{
-				if (dbg && rounds < 3) fprintf(stderr, "[ngsqc] member %lld: start=%d want=%d expected=%lld lo=%lld hi=%lld prev_next=%lld prev_start=%d\n", (long long)b, start[b], want, (long long)expected, (long long)lo, (long long)hi, b ? (long long)next[b - 1] : -9LL, b ? start[b - 1] : -9);
-				mismatch = b; start[b] = want; break;
-			}
+			const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
+			const int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
+			if (start[(size_t)b] != want) { mismatch = b; start[(size_t)b] = want; break; }
 			if (want >= 0)
 			{
-				if (next[b] == -2) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
-				expected = next[b];
+				const int64_t nx = next[(size_t)b];
+				if (nx == -2) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
+				if (nx <= -10) { straddle = -(nx + 10); expected = INT64_MAX / 2; }   // the rest of the tile belongs to this record
+				else expected = nx;
 			}
 		}
 		if (mismatch < 0)
 		{
-			if (expected != h->total) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
+			if (straddle < 0 && expected != total && !(expected == INT64_MAX / 2)) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (record chain does not end at a member boundary)");
+			if (straddle >= 0 && last) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 			break;
 		}
-		if (dbg) fprintf(stderr, "[ngsqc] chain mismatch at member %lld (round %d)\n", (long long)mismatch, rounds);
+		if (dbg) fprintf(stderr, "[ngsqc] tile %d: chain mismatch at entry %lld (round %d)\n", t, (long long)mismatch, rounds);
 		if (++rounds > 100000) throw FormatError("could not resolve the BAM record chain");
-		HIPCHK(hipMemcpyAsync(d_start.p + mismatch, &start[mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(d_start.p + mismatch, &start[(size_t)mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 		from = mismatch;
 	}
-	lap("k2 verify");
-	DevBuf<int64_t> d_base; d_base.alloc((size_t)nb + 1);
-	DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(nb) + 64);
-	launch_scan_counts(d_cnt.p, nb, d_base.p, d_tmp.p, h->stream);
+	DevBuf<int64_t> d_base; d_base.alloc((size_t)ne + 1);
+	DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(ne) + 64);
+	launch_scan_counts(d_cnt.p, ne, d_base.p, d_tmp.p, h->stream);
 	int64_t n_rec = 0;
-	HIPCHK(hipMemcpyAsync(&n_rec, d_base.p + nb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(&n_rec, d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	h->n_rec = n_rec;
-	lap("k2 scan");
 	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec, 1));
-	lap("k2 alloc recoff");
-	launch_index_write(h->d_infl.p, h->d_blocks.p, nb, d_start.p, d_base.p, h->d_recoff.p, h->stream);
-	h->tm.index_ms = t.stop();
-	lap("k2 write");
-	h->tm.n_records = n_rec;
+	launch_index_write(h->d_infl.p, total, h->d_tile_blocks.p, ne, d_start.p, d_base.p, h->d_recoff.p, h->stream);
+	h->tm.index_ms += tmr.stop();
+	// ---- publish tile state ----
+	h->cur_tile = t; h->tile_prefix = prefix; h->tile_total = total; h->tile_u_lo = u_lo; h->tile_ord_base = h->next_ord_base;
+	h->n_rec = n_rec; h->tm.n_records += n_rec;
+	h->carry_src = straddle; h->carry_len = straddle >= 0 ? total - straddle : 0;
+	h->expected_abs = u_hi;   // only meaningful when nothing is carried (the next record starts at the next tile's first byte)
 	h->decoded = true;
+}
+
+// Called after a tile has been consumed and before the next one is decoded: stage the bytes of the straddling record.
+void finish_tile(ngsqc_handle* h)
+{
+	if (h->carry_len > 0)
+	{
+		h->d_carry_tmp.ensure((size_t)h->carry_len + 64);
+		HIPCHK(hipMemcpyAsync(h->d_carry_tmp.p, h->d_infl.p + h->carry_src, (size_t)h->carry_len, hipMemcpyDeviceToDevice, h->stream));
+	}
+	h->next_ord_base = h->tile_ord_base + h->n_rec;
+}
+
+void reset_decode_timings(ngsqc_handle* h) { h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0; }
+
+// whole-file convenience used by the single-tile fast path and the test hooks
+void do_decode(ngsqc_handle* h)
+{
+	plan_tiles(h);
+	if (h->tiles.empty()) { h->decoded = true; h->n_rec = 0; return; }
+	if (h->tiles.size() == 1) { if (!(h->decoded && h->cur_tile == 0)) { reset_decode_timings(h); decode_tile(h, 0); } return; }
+	throw std::runtime_error("internal: do_decode on a multi-tile file");
 }
 
 // regions -> device tables. Regions must be sorted by start within a tid, non-overlapping, and each tid contiguous.
@@ -327,26 +385,53 @@ void finalize_depth(ngsqc_handle* h)
 
 struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 
+// Visit every tile in file order with the tile resident in HBM (K1+K2 done). A single-tile file that is already decoded
+// is visited without redoing K1/K2 (the reference re-reads the file for every pass; we keep it).
+template <class F> void for_each_tile(ngsqc_handle* h, F f)
+{
+	plan_tiles(h);
+	const int nt = (int)h->tiles.size();
+	if (nt == 0) return;
+	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(0); return; }
+	reset_decode_timings(h);
+	for (int t = 0; t < nt; ++t)
+	{
+		decode_tile(h, t);
+		const bool go_on = f(t);
+		if (!go_on) break;
+		if (t + 1 < nt) finish_tile(h);
+	}
+}
+
 void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev)
 {
-	DevBuf<unsigned long long> d_counters; d_counters.alloc(A_DEV_TOTAL);
+	h->d_counters.ensure(A_DEV_TOTAL);
 	std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
-	HIPCHK(hipMemcpyAsync(d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1)); DevBuf<int64_t>& d_long = h->d_long;
-	sp.infl = h->d_infl.p; sp.total = h->total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec;
-	sp.counters = d_counters.p; sp.diff = h->d_depth.p; sp.long_list = d_long.p; sp.long_cap = h->n_rec;
-	sp.n_ref = (int32_t)h->ref_names.size();
-	Timer t(h->stream); t.start();
-	Timer tk(h->stream); tk.start();
-	launch_scan(sp, h->stream);
-	h->tm.scan_kernel_ms = tk.stop();
-	unsigned long long n_long = 0;
-	HIPCHK(hipMemcpyAsync(&n_long, d_counters.p + A_LONG_COUNT, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	h->tm.scan_launches = 1;
-	if (n_long) { tk.start(); launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_kernel_ms += tk.stop(); h->tm.scan_launches++; }
+	HIPCHK(hipMemcpyAsync(h->d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+	sp.counters = h->d_counters.p; sp.diff = h->d_depth.p; sp.n_ref = (int32_t)h->ref_names.size();
+	h->tm.scan_kernel_ms = 0; h->tm.scan_launches = 0; h->tm.scan_ms = 0;
+	auto bind_tile = [&]() {
+		h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
+		sp.infl = h->d_infl.p; sp.total = h->tile_total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec; sp.ord_base = h->tile_ord_base;
+		sp.long_list = h->d_long.p; sp.long_cap = h->n_rec;
+	};
+	for_each_tile(h, [&](int) {
+		bind_tile();
+		Timer t(h->stream); t.start();
+		HIPCHK(hipMemsetAsync(h->d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
+		Timer tk(h->stream); tk.start();
+		launch_scan(sp, h->stream);
+		h->tm.scan_kernel_ms += tk.stop();
+		unsigned long long n_long = 0;
+		HIPCHK(hipMemcpyAsync(&n_long, h->d_counters.p + A_LONG_COUNT, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		h->tm.scan_launches++;
+		if (n_long) { tk.start(); launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_kernel_ms += tk.stop(); h->tm.scan_launches++; }
+		h->tm.scan_ms += t.stop();
+		return true;
+	});
 	dev.assign(A_DEV_TOTAL, 0ull);
-	HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	if (sp.mode != MODE_DEPTH)
 	{
@@ -357,12 +442,21 @@ void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& 
 		const int64_t pidx = (sp.mode != NGSQC_MODE_ROI && dev[A_FIRST_PAIRED] != ~0ull) ? (int64_t)dev[A_FIRST_PAIRED] : 0;
 		if (f > 0 || pidx > 0)
 		{
-			launch_prefix_fix(sp, f, pidx, gmax, h->stream);
-			HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			Timer t(h->stream); t.start();
+			const int64_t upto = std::max(f, pidx);
+			// visit the tiles that hold records [0, upto) again (normally only tile 0, usually still resident)
+			for_each_tile(h, [&](int) {
+				bind_tile();
+				const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - h->tile_ord_base, 0), h->n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - h->tile_ord_base, 0), h->n_rec);
+				launch_prefix_fix(sp, lf, lp, gmax, h->stream);
+				HIPCHK(hipStreamSynchronize(h->stream));
+				return h->tile_ord_base + h->n_rec < upto;
+			});
+			HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipStreamSynchronize(h->stream));
+			h->tm.scan_ms += t.stop();
 		}
 	}
-	h->tm.scan_ms = t.stop();
 	h->tm.scan_algorithmic_bytes = (int64_t)dev[A_ALG_BYTES];
 }
 
@@ -437,22 +531,45 @@ int64_t ngsqc_ref_len(const ngsqc_handle* h, int tid) { return (h && tid >= 0 &&
 int64_t ngsqc_n_bgzf_blocks(const ngsqc_handle* h) { return h ? (int64_t)h->blocks.size() : 0; }
 int64_t ngsqc_compressed_size(const ngsqc_handle* h) { return h ? (int64_t)h->csize : 0; }
 int64_t ngsqc_inflated_size(ngsqc_handle* h) { return h ? h->total : 0; }
-int64_t ngsqc_n_records(ngsqc_handle* h) { int rc = guarded(h, [&] { do_decode(h); }); return rc == NGSQC_OK ? h->n_rec : (int64_t)rc; }
+int64_t ngsqc_n_records(ngsqc_handle* h)
+{
+	int64_t n = 0;
+	int rc = guarded(h, [&] { for_each_tile(h, [&](int) { n += h->n_rec; return true; }); });
+	return rc == NGSQC_OK ? n : (int64_t)rc;
+}
 
-int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { do_decode(h); }); }
+int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { for_each_tile(h, [&](int) { return true; }); }); }
 int ngsqc_drop_decoded(ngsqc_handle* h)
 {
 	// buffers stay allocated (re-used by the next decode); only the decoded STATE is dropped, so the next scan redoes K1+K2
-	return guarded(h, [&] { h->decoded = false; h->depth_ready = false; h->n_rec = 0; });
+	return guarded(h, [&] { h->decoded = false; h->cur_tile = -1; h->depth_ready = false; h->n_rec = 0; });
 }
 
 int ngsqc_copy_inflated(ngsqc_handle* h, uint8_t* out, int64_t cap)
 {
-	return guarded(h, [&] { do_decode(h); int64_t n = std::min(cap, h->total); if (n > 0) HIPCHK(hipMemcpy(out, h->d_infl.p, (size_t)n, hipMemcpyDeviceToHost)); });
+	return guarded(h, [&] {
+		for_each_tile(h, [&](int) {
+			const int64_t lo = h->tile_u_lo, n = std::min(cap, lo + (h->tile_total - h->tile_prefix)) - lo;   // this tile's own bytes (without the carried prefix)
+			if (n > 0) HIPCHK(hipMemcpy(out + lo, h->d_infl.p + h->tile_prefix, (size_t)n, hipMemcpyDeviceToHost));
+			return true;
+		});
+	});
 }
 int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap)
 {
-	return guarded(h, [&] { do_decode(h); int64_t n = std::min(cap, h->n_rec); if (n > 0) HIPCHK(hipMemcpy(out, h->d_recoff.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost)); });
+	return guarded(h, [&] {
+		int64_t done = 0;
+		for_each_tile(h, [&](int) {
+			const int64_t n = std::min(cap - done, h->n_rec);
+			if (n > 0)
+			{
+				HIPCHK(hipMemcpy(out + done, h->d_recoff.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+				for (int64_t i = 0; i < n; ++i) out[done + i] += h->tile_u_lo - h->tile_prefix;   // tile-local -> stream offset
+				done += n;
+			}
+			return true;
+		});
+	});
 }
 
 int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* counters, double* gc_reads)
@@ -465,8 +582,6 @@ int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* 
 		const bool dbgs = getenv("NGSQC_DEBUG") != nullptr;
 		auto laps = [&](const char* what) { if (dbgs) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc:scan] %-20s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
 		laps("begin");
-		do_decode(h);
-		laps("decode");
 		const int n_ref = (int)h->ref_names.size();
 		const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
 		setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
@@ -561,7 +676,6 @@ int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p)
 	return guarded(h, [&] {
 		if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
 		Timer total(h->stream); total.start();
-		do_decode(h);
 		setup_regions(h, p->regions, p->n_regions);
 		ScanParams sp{};
 		sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;

@@ -29,7 +29,7 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 // ---- K2 ----
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s);
-void launch_index_write(const uint8_t* d_infl, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
                         const int64_t* d_base, int64_t* d_recoff, hipStream_t s);
 void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
 void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
@@ -44,7 +44,7 @@ constexpr int MODE_DEPTH = 3;
 enum { A_TOTAL, A_MAPPED, A_ONTARGET, A_NEAR, A_DUP, A_PP, A_INS_CNT, A_SUM_LEN, A_BASES_MAPPED, A_CLIPPED, A_INS_SUM,
        A_USABLE, A_NO_OVERLAP, A_USABLE_RAW, A_USABLE_ROI, A_DP0, A_DP1, A_DP2, A_DP3, A_DP4, A_DD0, A_DD1, A_DD2, A_DD3,
        A_READS_X, A_READS_Y, A_ALG_BYTES, A_COUNT,
-       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
+       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
 
 struct ScanParams
 {
@@ -61,7 +61,8 @@ struct ScanParams
 	const int32_t* gc_start; const int32_t* gc_end; const int32_t* gc_bin;
 	const int32_t* tid_gc_first; const int32_t* tid_gc_last; int64_t n_gc;
 	// data
-	const uint8_t* infl; int64_t total; const int64_t* recoff; int64_t n_rec;
+	const uint8_t* infl; int64_t total; const int64_t* recoff; int64_t n_rec;   // the resident tile (offsets are tile-local)
+	int64_t ord_base;              // file ordinal of the tile's first record
 	// outputs
 	unsigned long long* counters;  // [A_DEV_TOTAL]
 	int32_t* diff;                 // difference array -> depth

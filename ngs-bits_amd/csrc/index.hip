@@ -55,19 +55,22 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 		start[b] = s;
 	}
 	if (s < 0) { cnt[b] = 0; next_abs[b] = -1; return; }
-	int64_t o = lo + s; uint32_t n = 0; bool ok = true;
+	// next_abs: >= 0 chain exit; -2 corrupt record; <= -10 a record starts at o = -(next_abs + 10) but extends past the end
+	// of the resident tile (it is carried into the next tile, not counted here)
+	int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
 	while (o < hi)
 	{
-		if (o + 4 > total) { ok = false; break; }
+		if (o + 4 > total) { res = -(o + 10); stop = true; break; }
 		uint32_t bs = ld32u(infl + o);
-		if (bs < 32 || o + 4 + (int64_t)bs > total) { ok = false; break; }
+		if (bs < 32) { res = -2; stop = true; break; }
+		if (o + 4 + (int64_t)bs > total) { res = -(o + 10); stop = true; break; }
 		++n; o += 4 + (int64_t)bs;
 	}
-	cnt[b] = n; next_abs[b] = ok ? o : -2;
-	if (!ok) atomicAdd(bad, 1u);
+	cnt[b] = n; next_abs[b] = stop ? res : o;
+	if (stop && res == -2) atomicAdd(bad, 1u);
 }
 
-__global__ void index_write_kernel(const uint8_t* __restrict__ infl, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+__global__ void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                    const int32_t* __restrict__ start, const int64_t* __restrict__ base, int64_t* __restrict__ recoff)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +80,13 @@ __global__ void index_write_kernel(const uint8_t* __restrict__ infl, const Block
 	const BlockDesc bd = blocks[b];
 	const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
 	int64_t o = lo + s; int64_t k = base[b];
-	while (o < hi) { recoff[k++] = o; o += 4 + (int64_t)ld32u(infl + o); }
+	while (o < hi)
+	{
+		if (o + 4 > total) break;
+		int64_t nx = o + 4 + (int64_t)ld32u(infl + o);
+		if (nx > total) break;   // straddles the tile end: belongs to the next tile
+		recoff[k++] = o; o = nx;
+	}
 }
 
 // ---- generic 3-kernel exclusive scans (u32 -> i64) and in-place inclusive (i32) ----
@@ -146,12 +155,12 @@ void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_cnt, d_next_abs, d_bad, n_ref);
 }
 
-void launch_index_write(const uint8_t* d_infl, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
                         const int64_t* d_base, int64_t* d_recoff, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
 	int grid = (int)((n_blocks + 63) / 64);
-	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, d_blocks, n_blocks, d_start, d_base, d_recoff);
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_base, d_recoff);
 }
 
 // exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).

@@ -316,9 +316,10 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
 	__syncthreads();
 	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
 	const long long stride = (long long)gridDim.x * blockDim.x;
-	for (long long ord = (long long)blockIdx.x * blockDim.x + threadIdx.x; ord < p.n_rec; ord += stride)
+	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < p.n_rec; li += stride)
 	{
-		RecView r = load_rec(p.infl, p.recoff[ord]);
+		const long long ord = p.ord_base + li;   // ordinal in the file; li = index inside the resident tile
+		RecView r = load_rec(p.infl, p.recoff[li]);
 		bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
 		if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
 		{
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
 		if (defer)
 		{
 			unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
-			if ((long long)k < p.long_cap) p.long_list[k] = ord;
+			if ((long long)k < p.long_cap) p.long_list[k] = li;
 			continue;
 		}
 		long long ref_len = 0, clip = 0; bool spliced = false;
@@ -357,8 +358,8 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 	const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
 	for (long long w = wave; w < n_long; w += n_waves)
 	{
-		long long ord = p.long_list[w];
-		RecView r = load_rec(p.infl, p.recoff[ord]);
+		const long long li = p.long_list[w]; const long long ord = p.ord_base + li;
+		RecView r = load_rec(p.infl, p.recoff[li]);
 		// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries
 		if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
 		{
@@ -442,9 +443,9 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired, int gmax)
 {
 	__shared__ int sh[256]; __shared__ int carry;
-	if (threadIdx.x == 0) carry = 0;
+	if (threadIdx.x == 0) carry = (int)p.counters[A_FIX_CARRY];   // running maximum carried in from earlier tiles
 	__syncthreads();
-	long long upto = upto_max > upto_paired ? upto_max : upto_paired;
+	long long upto = upto_max > upto_paired ? upto_max : upto_paired;   // tile-local limits
 	long long s_trim = 0, s_len = 0;
 	for (long long base = 0; base < upto; base += 256)
 	{
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, lon
 		if (threadIdx.x == 255) carry = run;
 		__syncthreads();
 	}
+	if (threadIdx.x == 0) p.counters[A_FIX_CARRY] = (unsigned long long)carry;
 	s_trim = wave_sum(s_trim); s_len = wave_sum(s_len);
 	if ((threadIdx.x & 63) == 0) { if (s_trim) atomicAdd(&p.counters[A_FIX_TRIM], (unsigned long long)s_trim); if (s_len) atomicAdd(&p.counters[A_FIX_LEN], (unsigned long long)s_len); }
 }

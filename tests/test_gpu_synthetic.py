@@ -77,3 +77,18 @@ def test_roi_mode_exome_like(tmp_path):
     cov, _, _ = O.avg_coverage(ob, str(bed), min_mapq=1, random_access=False)
     assert np.array_equal(h.region_sums(lines), cov)
     h.close()
+
+
+@pytest.mark.parametrize("tile_members", [1, 3, 7])
+def test_tiled_processing_matches_single_tile(tmp_path, monkeypatch, tile_members):
+    """Files larger than HBM are processed in member ranges ("tiles"); records straddling tile borders are carried.
+    Tiny tiles on unaligned / long-read inputs exercise every carry path; results must be identical."""
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    _check(tmp_path, "t_unaligned.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=30_000, seed=12, aligned=False, start_pos=15_900_000)
+    _check(tmp_path, "t_ont.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=400, seed=13, mode=1, depth=40.0, start_pos=15_900_000)
+    _check(tmp_path, "t_noroi.bam", None, ngsqc.MODE_NOROI, 0, n_reads=20_000, seed=14, first_contig=22, start_pos=156_000_000, depth=2.0)
+    # inflated stream of a multi-tile file through the test hook
+    path = str(tmp_path / "t_unaligned.bam")
+    h = ngsqc.Handle(path=path)
+    assert np.array_equal(h.inflated(), O.Bam(path).inflated())
+    h.close()
