@@ -15,6 +15,7 @@
 //
 // Same output as inflate.hip (bit-exact; tests/test_gpu_parity.py). Integer / bit-serial work, no MFMA.
 #include "common.h"
+#include <cstdlib>
 
 namespace ngsqc {
 
@@ -96,7 +97,7 @@ __device__ __forceinline__ int canon_decode(uint32_t bits, const CNT& c, uint32_
 // For code length l (1..15) the word holds
 //   limit_l = (first_code_l + count_l) << (15 - l)   (upper bound, left-aligned to 15 bits; non-decreasing in l)
 //   delta_l = offset_l - first_code_l                (index of the length's first symbol in the sorted array minus its first code)
-// With v = the next 15 stream bits MSB-first: length = 1 + #{l : v >= limit_l}, index = (v >> (15 - length)) + delta.
+// With v = the next 15 stream bits MSB-first: length = 1 + #{l : v >= limit_l}, index = (v >> (15 - length)) + delta_length.
 struct DistSyms
 {
 	uint64_t q[3];
@@ -117,16 +118,29 @@ struct DistSyms
 
 struct LimTab
 {
-	uint32_t w[15];
+	uint32_t w[15];   // (limit_l << 16) | (delta_l & 0xffff) for l = 1..15
+	// With vx = (v << 16) | 0xffff a plain 32-bit compare vx >= w[l] is v >= limit_l. The limits are non-decreasing, so
+	// n = #{l : v >= limit_l} is found by a 4-level binary search whose pivots are picked with v_cndmask from the 15
+	// registers (4 compares + 11 selects instead of 15 compares + 30 selects); the last pivot the search went LEFT of
+	// is w[n], the word of the code's own length, which carries the delta.
 	__device__ __forceinline__ int decode(uint32_t bits, uint32_t& len_out) const
 	{
-		const uint32_t v = __brev(bits) >> 17;
-		uint32_t n = 0, sel = 0;
-		#pragma unroll
-		for (int l = 14; l >= 0; --l) { const bool ge = v >= (w[l] & 0xffffu); n += ge ? 1u : 0u; sel = ge ? sel : w[l]; }   // sel ends as the word of the smallest l with v < limit_l
+		const uint32_t vx = ((__brev(bits) >> 1) & 0x7fff0000u) | 0xffffu;
+		const bool c1 = vx >= w[7];
+		const uint32_t p2 = c1 ? w[11] : w[3];
+		const bool c2 = vx >= p2;
+		const uint32_t p3a = c2 ? w[5] : w[1], p3b = c2 ? w[13] : w[9];
+		const uint32_t p3 = c1 ? p3b : p3a;
+		const bool c3 = vx >= p3;
+		const uint32_t q0 = c3 ? w[2] : w[0], q1 = c3 ? w[6] : w[4], q2 = c3 ? w[10] : w[8], q3 = c3 ? w[14] : w[12];
+		const uint32_t r0 = c2 ? q1 : q0, r1 = c2 ? q3 : q2;
+		const uint32_t p4 = c1 ? r1 : r0;
+		const bool c4 = vx >= p4;
+		uint32_t n = c1 ? 1u : 0u; n = 2 * n + (c2 ? 1u : 0u); n = 2 * n + (c3 ? 1u : 0u); n = 2 * n + (c4 ? 1u : 0u);
+		uint32_t sel = c1 ? 0u : w[7]; sel = c2 ? sel : p2; sel = c3 ? sel : p3; sel = c4 ? sel : p4;
 		len_out = n + 1;
-		if (n >= 15) return -1;
-		return (int)(v >> (14 - n)) + (int)(int16_t)(sel >> 16);
+		const int idx = (int)((vx >> 16) >> (14 - (n & 15u) < 15u ? 14 - (n & 15u) : 0u)) + (int)(int16_t)(sel & 0xffffu);
+		return n >= 15 ? -1 : idx;
 	}
 	template <class CNT> __device__ __forceinline__ void build(const CNT& c)
 	{
@@ -136,7 +150,7 @@ struct LimTab
 		{
 			const uint32_t cnt = c.get_const(l - 1);
 			uint32_t lim = (code + cnt) << (15 - l); if (lim > 0x8000u) lim = 0x8000u;   // over-subscribed codes are rejected by the index checks
-			w[l - 1] = lim | (((o - code) & 0xffffu) << 16);
+			w[l - 1] = (lim << 16) | ((o - code) & 0xffffu);
 			o += cnt; code = (code + cnt) << 1;
 		}
 	}
@@ -144,7 +158,7 @@ struct LimTab
 
 __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
-                                                          BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter)
+                                                          BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, int park_hi)
 {
 	__shared__ uint32_t lds[P1_LANE_W * 64];
 	const int lane = threadIdx.x;
@@ -175,12 +189,13 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	uint32_t h_i = 0, h_n = 0, h_nlit = 0, h_prev = 0, hdr_bits = 0; uint32_t stored_left = 0;
 
 	auto exhausted = [&]() -> bool { return rd == wr && next_q >= n_q && !pf_valid; };
-	auto refill = [&]() {   // top the bit buffer up from the ring; past the end of the member zero bits are appended
-		if (bitcnt <= 32)
-		{
-			if (rd != wr) { bitbuf |= (uint64_t)L.ring(rd) << bitcnt; bitcnt += 32; ++rd; }
-			else if (next_q >= n_q && !pf_valid) bitcnt += 32;
-		}
+	auto refill = [&]() {   // top the bit buffer up from the ring (branch-free); past the end of the member zero bits are appended
+		const bool t = bitcnt <= 32, a = rd != wr, ex = next_q >= n_q && !pf_valid;
+		uint32_t w = L.ring(rd);
+		w = (t && a) ? w : 0u;
+		bitbuf |= (uint64_t)w << (bitcnt & 63u);
+		bitcnt += (t && (a || ex)) ? 32u : 0u;
+		rd += (t && a) ? 1u : 0u;
 	};
 	auto ready = [&](uint32_t words) -> bool { return wr - rd >= words || (next_q >= n_q && !pf_valid); };
 	auto take = [&](uint32_t n) -> uint32_t { uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u); bitbuf >>= n; bitcnt -= n; bits_used += n; return v; };   // n <= 16
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	};
 	auto emit = [&](uint32_t t) { if (tok_n >= tok_cap) { err = TOK_ERR_OVERFLOW; state = S_FINISH; } else { L.tok(tok_n) = t; ++tok_n; } };
 
-	int trip = 0;
+	int trip = 0; bool slow_mode = false;
 	while (true)
 	{
 		// ================= service block: commit prefetched input, flush tokens, issue the next prefetch =================
@@ -219,54 +234,66 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 		}
 		++trip;
 
-		if (state == S_SYM)
+		// Symbol decode (the common state) and header / bookkeeping states never run in the same trip: a lane that reaches
+		// a header parks until park_hi lanes are parked (or no lane decodes symbols), then the wave runs ONLY the slow states
+		// until every parked lane is back in S_SYM. Otherwise nearly every trip would pay for both code paths (with 64 lanes
+		// each ~4 % of its time in a header, some lane is in one ~90 % of the time). park_hi == 0: no parking (both per trip).
 		{
-			if (ready(2))   // both refills of this symbol are guaranteed (or the stream is exhausted: zeros follow)
+			const uint64_t slow_m = __builtin_amdgcn_ballot_w64(state != S_SYM && state != S_STORED && state != S_DONE);
+			if (!slow_mode)
+			{
+				if (slow_m != 0 && ((int)__popcll(slow_m) >= park_hi || __builtin_amdgcn_ballot_w64(state == S_SYM || state == S_STORED) == 0)) slow_mode = true;
+			}
+			else if (slow_m == 0) slow_mode = false;
+		}
+		const bool run_fast = !slow_mode || park_hi == 0, run_slow = slow_mode || park_hi == 0;
+
+		if (run_fast && state == S_SYM && ready(2))   // both refills of this symbol are guaranteed (or the stream is exhausted: zeros follow)
+		{
+			// few exec regions: everything is computed unconditionally (indices clamped), errors are collected in e
+			refill();
+			uint32_t len;
+			const int idx = limL.decode((uint32_t)bitbuf, len);
+			uint32_t e = (uint32_t)idx < 288u ? 0u : 9u;
+			const uint32_t s = L.litsym((uint32_t)idx < 288u ? (uint32_t)idx : 287u);
+			bitbuf >>= len; bitcnt -= len; bits_used += len;
+			uint32_t tokv = s, add = 1;
+			if (s > 256)
+			{
+				const uint32_t ls = s - 257;
+				if (ls >= 29) e = 10;
+				const uint32_t eb = ls < 8 ? 0u : (ls == 28 ? 0u : (ls - 4) >> 2);
+				const uint32_t base = ls < 8 ? ls + 3 : (ls == 28 ? 258u : ((4u + ((ls - 4) & 3u)) << eb) + 3u);
+				const uint32_t mlen = base + take(eb);
+				refill();
+				uint32_t dl;
+				const int di = limD.decode((uint32_t)bitbuf, dl);
+				if ((uint32_t)di >= 30u) e = 11;
+				const uint32_t ds = dsym.get((uint32_t)di < 30u ? (uint32_t)di : 29u);
+				bitbuf >>= dl; bitcnt -= dl; bits_used += dl;
+				if (ds >= 30) e = 12;
+				const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+				const uint32_t dbase = ds < 4 ? ds + 1 : ((2u + (ds & 1u)) << deb) + 1u;
+				const uint32_t mdist = dbase + take(deb);
+				if (mdist > out_n) e = 13;
+				tokv = 0x80000000u | (((mlen - 3) & 255u) << 23) | ((mdist - 1) & 0x7fffu); add = mlen;
+			}
+			if (e == 0 && s != 256 && out_n + add > usize) e = s < 256 ? 3u : 13u;
+			if (e) { err = e; state = S_FINISH; }
+			else if (s == 256) state = bfinal ? S_FINISH : S_HDR;
+			else { emit(tokv); out_n += add; }
+		}
+		else if (run_fast && state == S_STORED)
+		{
+			if (ready(1))
 			{
 				refill();
-				uint32_t len;
-				int idx = limL.decode((uint32_t)bitbuf, len);
-				if (idx < 0 || idx >= 288) { err = 9; state = S_FINISH; }
-				else
-				{
-					uint32_t s = L.litsym((uint32_t)idx);
-					bitbuf >>= len; bitcnt -= len; bits_used += len;
-					if (s < 256) { emit(s); ++out_n; }
-					else if (s == 256) { state = bfinal ? S_FINISH : S_HDR; }
-					else
-					{
-						s -= 257;
-						if (s >= 29) { err = 10; state = S_FINISH; }
-						else
-						{
-							uint32_t eb = s < 8 ? 0u : (s == 28 ? 0u : (s - 4) >> 2);
-							uint32_t base = s < 8 ? s + 3 : (s == 28 ? 258u : ((4u + ((s - 4) & 3u)) << eb) + 3u);
-							uint32_t mlen = base + take(eb);
-							refill();
-							uint32_t dl;
-							int di = limD.decode((uint32_t)bitbuf, dl);
-							if (di < 0 || di >= 30) { err = 11; state = S_FINISH; }
-							else
-							{
-								uint32_t ds = dsym.get((uint32_t)di);
-								bitbuf >>= dl; bitcnt -= dl; bits_used += dl;
-								if (ds >= 30) { err = 12; state = S_FINISH; }
-								else
-								{
-									uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
-									uint32_t dbase = ds < 4 ? ds + 1 : ((2u + (ds & 1u)) << deb) + 1u;
-									uint32_t mdist = dbase + take(deb);
-									if (mdist > out_n || out_n + mlen > usize) { err = 13; state = S_FINISH; }
-									else { emit(0x80000000u | ((mlen - 3) << 23) | (mdist - 1)); out_n += mlen; }
-								}
-							}
-						}
-					}
-					if (out_n > usize) { err = 3; state = S_FINISH; }
-				}
+				if (out_n >= usize) { err = 3; state = S_FINISH; }
+				else { emit(take(8)); ++out_n; if (--stored_left == 0 && state == S_STORED) state = bfinal ? S_FINISH : S_HDR; }
 			}
 		}
-		else if (state == S_P1 || state == S_P2)
+		if (!run_slow) continue;
+		if (state == S_P1 || state == S_P2)
 		{
 			// one code-length-alphabet symbol per trip (RFC 1951 §3.2.7); pass 1 counts, pass 2 places symbols
 			if (ready(1))
@@ -400,15 +427,6 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 				else { err = 4; state = S_FINISH; }
 			}
 		}
-		else if (state == S_STORED)
-		{
-			if (ready(1))
-			{
-				refill();
-				if (out_n >= usize) { err = 3; state = S_FINISH; }
-				else { emit(take(8)); ++out_n; if (--stored_left == 0 && state == S_STORED) state = bfinal ? S_FINISH : S_HDR; }
-			}
-		}
 		else if (state == S_FINISH)
 		{
 			// flush the tail of the token ring, publish counts
@@ -443,6 +461,241 @@ constexpr int P2_BMAX = 1024;   // max output bytes resolved per batch (LDS stag
 
 struct P2Lds { unsigned long long endmask[P2_BMAX / 64]; uint16_t src[P2_BMAX + 64]; uint8_t val[P2_BMAX + 64]; };
 
+// Default phase 2. Same batching as lz77_resolve_kernel (kept below as NGSQC_P2_VARIANT=0), but the batch is resolved
+// front to back in 64-byte chunks so that no separate dependency passes are needed: a byte whose source lies
+//   * before the batch            -> gathered from HBM (earlier batches of the same wave; stores drained by vmcnt(0)),
+//   * in an earlier chunk         -> read from the LDS staging bytes (already final),
+//   * in the same chunk           -> taken from the source LANE (ds_bpermute), iterating only while some lane's source is
+//                                    itself still pending (sources are always lower lanes, so the loop terminates; the
+//                                    periodic form i mod dist makes the depth the number of chained TOKENS, not bytes).
+// Every byte is written once to LDS and once to HBM (64 consecutive bytes per store instruction).
+struct P2bLds { unsigned long long endmask[P2_BMAX / 64]; alignas(8) uint8_t val[P2_BMAX + 64]; };
+
+// STAGED: the batch is stored from the LDS staging bytes after the chunk loop as aligned dwords (the staging index is shifted
+// by the output address's misalignment), so no store sits between the gathers of consecutive chunks.
+template <bool STAGED>
+__global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
+                                                         const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
+{
+	__shared__ P2bLds lds[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	P2bLds& S = lds[wv];
+	constexpr int WAIT_VM0 = 0x0F70;
+	const uint64_t lane_lt = (1ull << lane) - 1ull;
+	const int64_t n_waves = (int64_t)gridDim.x * 4;
+	for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_blocks; b += n_waves)
+	{
+		if (status[b].error) continue;
+		const uint32_t n = tok_count[b];
+		const uint32_t* T = tok + tok_off[b];
+		uint8_t* out = out_base + blocks[b].upos;
+		const uint32_t usize = blocks[b].usize;
+		uint32_t P = 0;   // bytes written so far
+		for (uint32_t t0 = 0; t0 < n;)
+		{
+			const uint32_t i = t0 + (uint32_t)lane;
+			const uint32_t tk = i < n ? T[i] : 0u;
+			const bool is_m = tk >> 31;
+			const uint32_t len = i < n ? (is_m ? ((tk >> 23) & 255u) + 3u : 1u) : 0u;
+			uint32_t end = len;
+			#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(end, o); if (lane >= o) end += t; }
+			// take the longest token prefix whose output fits the staging buffer
+			const uint64_t fit = __builtin_amdgcn_ballot_w64(i < n && end <= (uint32_t)P2_BMAX);
+			uint32_t ntake = (uint32_t)__popcll(fit); if (ntake == 0) ntake = 1;
+			const uint32_t B = (uint32_t)__shfl((int)end, (int)ntake - 1);
+			const uint32_t start = end - len;
+			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
+			// what a byte needs from its owner token: match flag, the token's start inside the batch, dist-1 or the literal
+			const uint32_t pk = (tk & 0x80000000u) | ((start & 0x7ffu) << 20) | (is_m ? (tk & 0x7fffu) : (tk & 255u));
+			// stores of earlier batches must be complete before this batch gathers from the window
+			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
+			if (lane < P2_BMAX / 64) S.endmask[lane] = 0ull;
+			__builtin_amdgcn_wave_barrier();
+			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
+			__builtin_amdgcn_wave_barrier();
+			uint32_t ta = 0;   // tokens that end at or before the current chunk start
+			const uint32_t sh = STAGED ? (uint32_t)((uintptr_t)(out + P) & 3u) : 0u;
+			for (uint32_t j0 = 0; j0 < B; j0 += 64)
+			{
+				const uint32_t j = j0 + (uint32_t)lane;
+				// owner token of byte j = ta + #tokens ending inside the chunk before j (popcount over the end bitmap)
+				const uint64_t m = S.endmask[j0 >> 6];
+				const uint32_t o = ta + (uint32_t)__popcll(m & lane_lt);
+				ta += (uint32_t)__popcll(m);
+				const uint32_t pko = (uint32_t)__shfl((int)pk, (int)(o & 63u));
+				uint32_t vv = pko & 255u;        // bit 8 = still waiting for a lower lane of this chunk
+				uint32_t rel = (uint32_t)lane;
+				if (j < B && (pko >> 31))
+				{
+					const uint32_t sto = (pko >> 20) & 0x7ffu, d = (pko & 0x7fffu) + 1u, off = j - sto;
+					uint32_t r = off;
+					if (off >= d)
+					{
+						uint32_t q = (uint32_t)((float)off * __builtin_amdgcn_rcpf((float)d)); int rr = (int)off - (int)(q * d);   // q is off by at most 1
+						if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
+						r = (uint32_t)rr;
+					}
+					const int src = (int)sto - (int)d + (int)r;   // relative to P
+					if (src < 0) vv = out[(int64_t)P + src];
+					else if ((uint32_t)src < j0) vv = S.val[sh + (uint32_t)src];
+					else { vv = 0x100u; rel = (uint32_t)src - j0; }
+				}
+				uint64_t pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
+				while (pend)
+				{
+					const uint32_t sv = (uint32_t)__shfl((int)vv, (int)rel);
+					if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
+					pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
+				}
+				if (j < B) { S.val[sh + j] = (uint8_t)vv; if (!STAGED) out[P + j] = (uint8_t)vv; }
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (STAGED)
+			{
+				// shifted byte x of the staging buffer lives at out + P - sh + x; whole dwords where all four bytes are in [sh, sh + B)
+				uint8_t* const o4 = out + P - sh; const uint32_t hi = sh + B;
+				for (uint32_t x = 4u * (uint32_t)lane; x < hi; x += 256)
+				{
+					if (x >= sh && x + 4 <= hi) *(uint32_t*)(o4 + x) = *(const uint32_t*)&S.val[x];
+					else { for (uint32_t k = x; k < x + 4; ++k) if (k >= sh && k < hi) o4[k] = S.val[k]; }
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			P += B; t0 += ntake;
+		}
+		if (lane == 0 && status[b].error == 0 && P != usize) status[b].error = 17;
+		if (lane == 0) status[b].produced = P;
+	}
+}
+
+// Inclusive wave prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each 16-lane row
+// (row_shr:1/2/4/8, out-of-row sources read as 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+
+// Phase 2 with the HBM gathers of a whole batch in flight at once (NGSQC_P2_VARIANT=3). Pass A walks the chunks, finds every
+// byte's owner token and source and ISSUES the gathers for sources that precede the batch (one register per chunk keeps
+// either the final byte, the gathered byte, or the in-batch source index); pass B then resolves chunk by chunk as
+// lz77_chunk_kernel does. The gather latency is paid once per batch instead of once per 64-byte chunk.
+constexpr int P2_NCH = P2_BMAX / 64;
+
+__global__ __launch_bounds__(256) void lz77_pipe_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
+                                                        const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
+{
+	__shared__ P2bLds lds[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	P2bLds& S = lds[wv];
+	constexpr int WAIT_VM0 = 0x0F70;
+	const uint64_t lane_lt = (1ull << lane) - 1ull;
+	const int64_t n_waves = (int64_t)gridDim.x * 4;
+	for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_blocks; b += n_waves)
+	{
+		if (status[b].error) continue;
+		const uint32_t n = tok_count[b];
+		const uint32_t* T = tok + tok_off[b];
+		uint8_t* out = out_base + blocks[b].upos;
+		const uint32_t usize = blocks[b].usize;
+		uint32_t P = 0;   // bytes written so far
+		uint32_t tk_next = (uint32_t)lane < n ? T[lane] : 0u;
+		for (uint32_t t0 = 0; t0 < n;)
+		{
+			const uint32_t i = t0 + (uint32_t)lane;
+			const uint32_t tk = tk_next;
+			const bool is_m = tk >> 31;
+			const uint32_t len = i < n ? (is_m ? ((tk >> 23) & 255u) + 3u : 1u) : 0u;
+			const uint32_t end = wave_scan_incl(len);
+			// take the longest token prefix whose output fits the staging buffer
+			const uint64_t fit = __builtin_amdgcn_ballot_w64(i < n && end <= (uint32_t)P2_BMAX);
+			uint32_t ntake = (uint32_t)__popcll(fit); if (ntake == 0) ntake = 1;
+			const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)ntake - 1);
+			const uint32_t start = end - len;
+			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
+			// the next batch's tokens are requested now; they arrive while this batch is resolved
+			{ const uint32_t i2 = t0 + ntake + (uint32_t)lane; tk_next = i2 < n ? T[i2] : 0u; }
+			// what a byte needs from its owner token: match flag, the token's start inside the batch, dist-1 or the literal
+			const uint32_t pk = (tk & 0x80000000u) | ((start & 0x7ffu) << 20) | (is_m ? (tk & 0x7fffu) : (tk & 255u));
+			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
+			if (lane < P2_NCH) S.endmask[lane] = 0ull;
+			__builtin_amdgcn_wave_barrier();
+			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
+			__builtin_amdgcn_wave_barrier();
+			// stores of earlier batches must be complete before this batch gathers from the window
+			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+			uint32_t x[P2_NCH];
+			uint32_t ta = 0;   // tokens that end at or before the current chunk start
+			// ---- pass A: owners, sources, gathers ----
+			#pragma unroll
+			for (int c = 0; c < P2_NCH; ++c)
+			{
+				const uint32_t j0 = 64u * (uint32_t)c;
+				x[c] = 0;
+				if (j0 < B)   // (no early exit: a constant trip count keeps x[] in registers with static indices)
+				{
+				const uint32_t j = j0 + (uint32_t)lane;
+				const uint64_t m = S.endmask[c];
+				const uint32_t o = ta + (uint32_t)__popcll(m & lane_lt);
+				ta += (uint32_t)__popcll(m);
+				const uint32_t pko = (uint32_t)__shfl((int)pk, (int)(o & 63u));
+				uint32_t v = pko & 255u;
+				if (j < B && (pko >> 31))
+				{
+					const uint32_t sto = (pko >> 20) & 0x7ffu, d = (pko & 0x7fffu) + 1u, off = j - sto;
+					uint32_t r = off;
+					if (off >= d)
+					{
+						uint32_t q = (uint32_t)((float)off * __builtin_amdgcn_rcpf((float)d)); int rr = (int)off - (int)(q * d);   // q is off by at most 1
+						if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
+						r = (uint32_t)rr;
+					}
+					const int src = (int)sto - (int)d + (int)r;   // relative to P
+					if (src < 0) v = out[(int64_t)P + src];
+					else v = 0x80000000u | (uint32_t)src;
+				}
+				x[c] = v;
+				}
+			}
+			// ---- pass B: resolve front to back, store ----
+			#pragma unroll
+			for (int c = 0; c < P2_NCH; ++c)
+			{
+				const uint32_t j0 = 64u * (uint32_t)c;
+				if (j0 >= B) break;
+				const uint32_t j = j0 + (uint32_t)lane;
+				uint32_t vv = x[c], rel = (uint32_t)lane;
+				if (vv >> 31)
+				{
+					const uint32_t src = vv & 0x7ffu;
+					if (src < j0) vv = S.val[src];
+					else { vv = 0x100u; rel = src - j0; }
+				}
+				uint64_t pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
+				while (pend)
+				{
+					const uint32_t sv = (uint32_t)__shfl((int)vv, (int)rel);
+					if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
+					pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
+				}
+				if (j < B) { S.val[j] = (uint8_t)vv; out[P + j] = (uint8_t)vv; }
+				__builtin_amdgcn_wave_barrier();
+			}
+			P += B; t0 += ntake;
+		}
+		if (lane == 0 && status[b].error == 0 && P != usize) status[b].error = 17;
+		if (lane == 0) status[b].produced = P;
+	}
+}
+
+// First phase-2 design (NGSQC_P2_VARIANT=0): all bytes staged, then whole-batch dependency passes in LDS.
 __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
                                                            const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
 {
@@ -555,7 +808,8 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	hipMemsetAsync(d_work, 0, sizeof(unsigned long long), s);
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < 256 * 6 ? wgs : 256 * 6);   // 6 one-wave workgroups fit a CU (24.8 KB LDS each)
-	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work);
+	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
+	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, park_hi);
 }
 
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
@@ -564,7 +818,11 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
 	int grid2 = (int)(wg2 < 256 * 8 ? wg2 : 256 * 8);
-	hipLaunchKernelGGL(lz77_resolve_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
+	const char* ve = getenv("NGSQC_P2_VARIANT"); const int variant = ve ? atoi(ve) : 2;
+	if (variant == 0) hipLaunchKernelGGL(lz77_resolve_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
+	else if (variant == 3) hipLaunchKernelGGL(lz77_pipe_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
+	else if (variant == 2) hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
+	else hipLaunchKernelGGL(lz77_chunk_kernel<true>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
 }
 
 } // namespace ngsqc
