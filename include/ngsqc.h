@@ -136,8 +136,9 @@ typedef struct ngsqc_timings {
 	int64_t compressed_bytes, inflated_bytes, n_records;
 	double scan_kernel_ms;            /* K3-K5 kernels only (HIP events around the scan launches on the handle's stream) */
 	double depth_kernel_ms;           /* K6 prefix sum + histogram kernels */
-	double inflate_huff_ms;           /* K1 phase 1: huff_tokens_kernel (0 when the group kernel ran) */
-	double inflate_lz77_ms;           /* K1 phase 2: lz77_resolve_kernel */
+	double inflate_huff_ms;           /* K1 phase 1: huff_tokens_kernel, sum over its launches (0 when the group kernel ran) */
+	double inflate_lz77_ms;           /* K1 phase 2: lz77 resolve kernel (sum over its launches; overlaps phase 1 of the next member chunk) */
+	int64_t inflate_huff_launches;    /* K1 phase-1 launches of the last decode (member chunks of one "round" of decoder lanes) */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

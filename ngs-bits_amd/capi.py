@@ -48,7 +48,8 @@ class Timings(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("inflate_ms", C.c_double), ("index_ms", C.c_double), ("scan_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("total_ms", C.c_double), ("inflate_launches", C.c_int64),
                 ("scan_launches", C.c_int64), ("scan_algorithmic_bytes", C.c_int64), ("compressed_bytes", C.c_int64),
-                ("inflated_bytes", C.c_int64), ("n_records", C.c_int64), ("scan_kernel_ms", C.c_double), ("depth_kernel_ms", C.c_double), ("inflate_huff_ms", C.c_double), ("inflate_lz77_ms", C.c_double)]
+                ("inflated_bytes", C.c_int64), ("n_records", C.c_int64), ("scan_kernel_ms", C.c_double), ("depth_kernel_ms", C.c_double), ("inflate_huff_ms", C.c_double), ("inflate_lz77_ms", C.c_double),
+                ("inflate_huff_launches", C.c_int64)]
 
 
 def lib_path():

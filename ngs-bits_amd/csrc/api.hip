@@ -48,7 +48,8 @@ uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) 
 struct ngsqc_handle
 {
 	std::string err, path;
-	int device = 0; hipStream_t stream = nullptr;
+	int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; int n_cu = 256;
+	std::vector<hipEvent_t> k1_events; DevBuf<unsigned long long> d_k1_work;   // K1 pipeline: 4 events + one queue head per member chunk
 	size_t csize = 0;
 	std::vector<BlockDesc> blocks; int64_t total = 0;
 	DevBuf<uint8_t> d_comp; DevBuf<BlockDesc> d_blocks;
@@ -103,6 +104,8 @@ void init_device(ngsqc_handle* h, int device)
 	h->device = device;
 	HIPCHK(hipSetDevice(device));
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+	int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cu = cu;
 }
 
 void check_status(ngsqc_handle* h, int64_t n_blocks)
@@ -129,14 +132,42 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 			if (h->d_tok_cnt.n < (size_t)n + 8) h->d_tok_cnt.alloc((size_t)n + 8);
 			h->tok_first = first; h->tok_n = n;
 		}
-		Timer tp(h->stream); tp.start();
-		launch_huff_tokens(h->d_comp.p, d_desc, n, d_st, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
-		h->tm.inflate_huff_ms += tp.stop(); tp.start();
-		launch_lz77_resolve(d_desc, n, d_out_base, d_st, h->d_tok_off.p, h->d_tok.p, h->d_tok_cnt.p, h->stream);
-		h->tm.inflate_lz77_ms += tp.stop();
+		// Phase 1 decodes one member per LANE, so a launch lasts as long as its slowest lane: members are cut into chunks of at
+		// most one "round" (every decoder lane gets one member) and phase 2 of chunk c runs on a second stream while phase 1
+		// of chunk c+1 decodes - the two kernels bound on different things (dependent-issue latency at 1.5 waves/SIMD vs VALU
+		// throughput), and a ragged last round no longer idles the chip. 6 phase-1 waves per CU leave LDS for phase 2.
+		const char* pe = getenv("NGSQC_K1_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;
+		const int64_t lanes = (int64_t)h->n_cu * (pipelined ? 6 : 7) * 64;
+		const int64_t nch0 = pipelined ? std::max<int64_t>(1, (n + lanes - 1) / lanes) : 1;
+		const int64_t chunk = (((n + nch0 - 1) / nch0) + 63) & ~63ll;   // equal chunks, whole waves
+		const int64_t nch = (n + chunk - 1) / chunk;
+		while ((int64_t)h->k1_events.size() < 4 * nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->k1_events.push_back(e); }
+		h->d_k1_work.ensure((size_t)nch);
+		HIPCHK(hipMemsetAsync(h->d_k1_work.p, 0, (size_t)nch * sizeof(unsigned long long), h->stream));
+		for (int64_t c = 0; c < nch; ++c)
+		{
+			const int64_t c0 = c * chunk, cn = std::min<int64_t>(chunk, n - c0);
+			hipEvent_t* e4 = &h->k1_events[(size_t)(4 * c)];
+			HIPCHK(hipEventRecord(e4[0], h->stream));
+			launch_huff_tokens(h->d_comp.p, d_desc + c0, cn, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_k1_work.p + c, h->n_cu * (pipelined ? 6 : 7), h->stream);
+			HIPCHK(hipEventRecord(e4[1], h->stream));
+			hipStream_t s2 = pipelined ? h->stream2 : h->stream;
+			if (pipelined) HIPCHK(hipStreamWaitEvent(s2, e4[1], 0));
+			HIPCHK(hipEventRecord(e4[2], s2));
+			launch_lz77_resolve(d_desc + c0, cn, d_out_base, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, s2);
+			HIPCHK(hipEventRecord(e4[3], s2));
+		}
+		if (pipelined) HIPCHK(hipStreamWaitEvent(h->stream, h->k1_events[(size_t)(4 * (nch - 1) + 3)], 0));
 		if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
 		HIPCHK(hipMemcpyAsync(h->h_status.data(), d_st, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
+		for (int64_t c = 0; c < nch; ++c)
+		{
+			float ms = 0; hipEvent_t* e4 = &h->k1_events[(size_t)(4 * c)];
+			HIPCHK(hipEventElapsedTime(&ms, e4[0], e4[1])); h->tm.inflate_huff_ms += ms;
+			HIPCHK(hipEventElapsedTime(&ms, e4[2], e4[3])); h->tm.inflate_lz77_ms += ms;
+		}
+		h->tm.inflate_huff_launches += nch;
 		bool overflow = false; for (int64_t i = 0; i < n; ++i) if (h->h_status[(size_t)i].error == 100) overflow = true;
 		if (!overflow) { check_status(h, n); return true; }
 	}
@@ -330,7 +361,7 @@ void finish_tile(ngsqc_handle* h)
 	h->next_ord_base = h->tile_ord_base + h->n_rec;
 }
 
-void reset_decode_timings(ngsqc_handle* h) { h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0; }
+void reset_decode_timings(ngsqc_handle* h) { h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0; h->tm.inflate_huff_launches = 0; }
 
 // whole-file convenience used by the single-tile fast path and the test hooks
 void do_decode(ngsqc_handle* h)
@@ -521,6 +552,8 @@ void ngsqc_close(ngsqc_handle* h)
 {
 	if (!h) return;
 	if (h->stream) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+	if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+	for (hipEvent_t e : h->k1_events) (void)hipEventDestroy(e);
 	delete h;
 }
 

@@ -22,8 +22,7 @@ namespace ngsqc {
 // ---------------------------------------------------------------------------------------------------------------- phase 1
 constexpr int P1_SYM_W = 81;     // lit_sym : 288 x 9 bit as a byte plane (72 words) + a bit plane (9 words)
 constexpr int P1_RING_W = 8;     // compressed input ring (32 B)
-constexpr int P1_TOK_W = 8;      // token ring
-constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W + P1_TOK_W;   // 97 words per lane (24.8 KB per wave -> 6 waves per CU)
+constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W;   // 89 words per lane (22.8 KB per wave -> 7 waves per CU); tokens wait in registers
 constexpr int P1_SERVICE = 4;    // symbols between service blocks
 
 enum { S_NEXT = 0, S_HDR = 1, S_P1 = 2, S_P2 = 3, S_SYM = 4, S_STORED = 5, S_FINISH = 6, S_DONE = 7 };
@@ -44,7 +43,6 @@ struct P1Lds
 		uint32_t& hi = at(72 + (int)(i >> 5)); hi = (hi & ~(1u << (i & 31))) | ((s >> 8) << (i & 31));
 	}
 	__device__ __forceinline__ uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
-	__device__ __forceinline__ uint32_t& tok(uint32_t i) const { return at(P1_SYM_W + P1_RING_W + (int)(i & (P1_TOK_W - 1))); }
 };
 
 // packed per-length counters: FW bits per field, 32/FW fields per register (FW = 10 for lit/len, 5+1 for dist/CL -> use 6)
@@ -176,6 +174,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	uint32_t bits_used = 0;                                // payload bits consumed so far (for byte alignment / re-seek)
 	uint4 pf = make_uint4(0, 0, 0, 0); bool pf_valid = false;
 	uint32_t* tok_ptr = nullptr; uint32_t tok_cap = 0, tok_n = 0, tok_flushed = 0;
+	uint32_t tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, tq6 = 0;   // unflushed tokens, newest first (a shift register: at most 3 left over + 4 new between services)
 	uint32_t out_n = 0, err = 0; int bfinal = 0;
 	LimTab limL, limD;                                       // decode tables of the current deflate block (registers)
 	DistSyms dsym; dsym.clear();                             // distance symbols sorted by (len, sym)
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 		bitbuf = (uint64_t)L.ring(rd) >> sh; bitcnt = 32 - sh; ++rd; bits_used = bitpos;
 		refill();
 	};
-	auto emit = [&](uint32_t t) { if (tok_n >= tok_cap) { err = TOK_ERR_OVERFLOW; state = S_FINISH; } else { L.tok(tok_n) = t; ++tok_n; } };
+	auto emit = [&](uint32_t t) { if (tok_n >= tok_cap) { err = TOK_ERR_OVERFLOW; state = S_FINISH; } else { tq6 = tq5; tq5 = tq4; tq4 = tq3; tq3 = tq2; tq2 = tq1; tq1 = tq0; tq0 = t; ++tok_n; } };
 
 	int trip = 0; bool slow_mode = false;
 	while (true)
@@ -226,7 +225,13 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 			{
 				if (tok_n - tok_flushed >= 4)
 				{
-					uint4 t4 = make_uint4(L.tok(tok_flushed), L.tok(tok_flushed + 1), L.tok(tok_flushed + 2), L.tok(tok_flushed + 3));
+					// the four oldest of cnt = 4..7 waiting tokens are tq[cnt-1] .. tq[cnt-4]
+					const uint32_t k = tok_n - tok_flushed - 4;
+					uint4 t4;
+					t4.x = k == 0 ? tq3 : (k == 1 ? tq4 : (k == 2 ? tq5 : tq6));
+					t4.y = k == 0 ? tq2 : (k == 1 ? tq3 : (k == 2 ? tq4 : tq5));
+					t4.z = k == 0 ? tq1 : (k == 1 ? tq2 : (k == 2 ? tq3 : tq4));
+					t4.w = k == 0 ? tq0 : (k == 1 ? tq1 : (k == 2 ? tq2 : tq3));
 					*(uint4*)(tok_ptr + tok_flushed) = t4; tok_flushed += 4;
 				}
 				if (wr - rd <= (uint32_t)(P1_RING_W - 4) && next_q < n_q) { pf = comp_q[q0 + next_q]; ++next_q; pf_valid = true; }
@@ -430,7 +435,17 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 		else if (state == S_FINISH)
 		{
 			// flush the tail of the token ring, publish counts
-			if (err != TOK_ERR_OVERFLOW) for (uint32_t i = tok_flushed; i < tok_n; ++i) tok_ptr[i] = L.tok(i);
+			if (err != TOK_ERR_OVERFLOW)
+			{
+				const uint32_t cnt = tok_n - tok_flushed;   // <= 7; tq_i is the token at stream position tok_n - 1 - i
+				if (cnt > 0) tok_ptr[tok_n - 1] = tq0;
+				if (cnt > 1) tok_ptr[tok_n - 2] = tq1;
+				if (cnt > 2) tok_ptr[tok_n - 3] = tq2;
+				if (cnt > 3) tok_ptr[tok_n - 4] = tq3;
+				if (cnt > 4) tok_ptr[tok_n - 5] = tq4;
+				if (cnt > 5) tok_ptr[tok_n - 6] = tq5;
+				if (cnt > 6) tok_ptr[tok_n - 7] = tq6;
+			}
 			if (!err && out_n != usize) err = 14;
 			tok_count[b] = tok_n; status[b].produced = out_n; status[b].error = err;
 			state = S_NEXT;
@@ -471,6 +486,28 @@ struct P2Lds { unsigned long long endmask[P2_BMAX / 64]; uint16_t src[P2_BMAX + 
 // Every byte is written once to LDS and once to HBM (64 consecutive bytes per store instruction).
 struct P2bLds { unsigned long long endmask[P2_BMAX / 64]; alignas(8) uint8_t val[P2_BMAX + 64]; };
 
+// Inclusive wave prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each 16-lane row
+// (row_shr:1/2/4/8, out-of-row sources read as 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+
+// Buffer resource over one member's output: 32-bit offsets (one VALU add per address instead of a 64-bit add chain) and
+// hardware bounds clamping. The descriptor lives in SGPRs, so its inputs are made provably wave-uniform first.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t member_rsrc(uint8_t* p, uint32_t bytes)
+{
+	const uint64_t a = (uint64_t)p;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+	return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 // STAGED: the batch is stored from the LDS staging bytes after the chunk loop as aligned dwords (the staging index is shifted
 // by the output address's misalignment), so no store sits between the gathers of consecutive chunks.
 template <bool STAGED>
@@ -490,31 +527,33 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 		const uint32_t* T = tok + tok_off[b];
 		uint8_t* out = out_base + blocks[b].upos;
 		const uint32_t usize = blocks[b].usize;
+		const __amdgpu_buffer_rsrc_t rs = member_rsrc(out, usize);
 		uint32_t P = 0;   // bytes written so far
+		uint32_t tk_next = (uint32_t)lane < n ? T[lane] : 0u;
 		for (uint32_t t0 = 0; t0 < n;)
 		{
 			const uint32_t i = t0 + (uint32_t)lane;
-			const uint32_t tk = i < n ? T[i] : 0u;
+			const uint32_t tk = tk_next;
 			const bool is_m = tk >> 31;
 			const uint32_t len = i < n ? (is_m ? ((tk >> 23) & 255u) + 3u : 1u) : 0u;
-			uint32_t end = len;
-			#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(end, o); if (lane >= o) end += t; }
+			const uint32_t end = wave_scan_incl(len);
 			// take the longest token prefix whose output fits the staging buffer
 			const uint64_t fit = __builtin_amdgcn_ballot_w64(i < n && end <= (uint32_t)P2_BMAX);
 			uint32_t ntake = (uint32_t)__popcll(fit); if (ntake == 0) ntake = 1;
-			const uint32_t B = (uint32_t)__shfl((int)end, (int)ntake - 1);
+			const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)ntake - 1);
 			const uint32_t start = end - len;
 			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
 			// what a byte needs from its owner token: match flag, the token's start inside the batch, dist-1 or the literal
 			const uint32_t pk = (tk & 0x80000000u) | ((start & 0x7ffu) << 20) | (is_m ? (tk & 0x7fffu) : (tk & 255u));
-			// stores of earlier batches must be complete before this batch gathers from the window
-			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
 			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
 			if (lane < P2_BMAX / 64) S.endmask[lane] = 0ull;
 			__builtin_amdgcn_wave_barrier();
 			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
 			__builtin_amdgcn_wave_barrier();
+			// stores of earlier batches must be complete before this batch gathers from the window
+			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
+			// the next batch's tokens are requested now; they arrive while this batch is resolved
+			{ const uint32_t i2 = t0 + ntake + (uint32_t)lane; tk_next = i2 < n ? T[i2] : 0u; }
 			uint32_t ta = 0;   // tokens that end at or before the current chunk start
 			const uint32_t sh = STAGED ? (uint32_t)((uintptr_t)(out + P) & 3u) : 0u;
 			for (uint32_t j0 = 0; j0 < B; j0 += 64)
@@ -538,7 +577,7 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 						r = (uint32_t)rr;
 					}
 					const int src = (int)sto - (int)d + (int)r;   // relative to P
-					if (src < 0) vv = out[(int64_t)P + src];
+					if (src < 0) vv = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)P + src, 0, 0);
 					else if ((uint32_t)src < j0) vv = S.val[sh + (uint32_t)src];
 					else { vv = 0x100u; rel = (uint32_t)src - j0; }
 				}
@@ -549,7 +588,7 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 					if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
 					pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
 				}
-				if (j < B) { S.val[sh + j] = (uint8_t)vv; if (!STAGED) out[P + j] = (uint8_t)vv; }
+				if (j < B) { S.val[sh + j] = (uint8_t)vv; if (!STAGED) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vv, rs, (int)(P + j), 0, 0); }
 				__builtin_amdgcn_wave_barrier();
 			}
 			if (STAGED)
@@ -568,19 +607,6 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 		if (lane == 0 && status[b].error == 0 && P != usize) status[b].error = 17;
 		if (lane == 0) status[b].produced = P;
 	}
-}
-
-// Inclusive wave prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each 16-lane row
-// (row_shr:1/2/4/8, out-of-row sources read as 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3.
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
-{
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-	return x;
 }
 
 // Phase 2 with the HBM gathers of a whole batch in flight at once (NGSQC_P2_VARIANT=3). Pass A walks the chunks, finds every
@@ -800,14 +826,12 @@ __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __res
 }
 
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
-                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, hipStream_t s)
+                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, int max_wgs, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	// d_tok_count has n_blocks + 8 entries: the last 8 bytes (8-byte aligned) are the phase-1 work counter
-	unsigned long long* d_work = (unsigned long long*)(d_tok_count + ((n_blocks + 1) & ~1ll));
-	hipMemsetAsync(d_work, 0, sizeof(unsigned long long), s);
+	// d_work: the launch's member queue head (zeroed by the caller). One-wave workgroups; 7 fit a CU (22.8 KB LDS each).
 	int64_t wgs = (n_blocks + 63) / 64;
-	int grid1 = (int)(wgs < 256 * 6 ? wgs : 256 * 6);   // 6 one-wave workgroups fit a CU (24.8 KB LDS each)
+	int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
 	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
 	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, park_hi);
 }
