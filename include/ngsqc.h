@@ -128,6 +128,46 @@ typedef struct ngsqc_run { int64_t line; int32_t start; int32_t end; } ngsqc_run
 int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int32_t cutoff, int32_t is_high,
                        int32_t saturate254, ngsqc_run* runs, int64_t cap, int64_t* n_runs);
 
+/* ---- one BAM sharded over several handles / GPUs --------------------------------------------------
+ * The reference reads a BAM with one sequential reader (BamReader::getNextAlignment, src/cppNGS/BamReader.h:386-398); its
+ * loop bodies (Statistics.cpp:416-574, :830-917, :1068-1183) are independent per record except for two carries: the
+ * running maximum read length behind bases_trimmed (:428-429,:565-568) and "a paired read has been seen" (:879,:1115).
+ * A shard handle owns the records that START inside its contiguous range of BGZF members (equal compressed bytes, cut at
+ * member starts); the members behind the range are inflated only to complete its last record. Protocol per shard:
+ *   ngsqc_open_shard -> ngsqc_scan_mapping_partial (local scan) -> exchange the summaries (all-gather, 48 bytes each) ->
+ *   ngsqc_plan_shard_fix (pure host logic, also verifies the record chain across shards) -> ngsqc_scan_mapping_finish
+ *   (local fix-up on the record prefix the carries touch; returns ADDITIVE counters) -> SUM all-reduce of the counters
+ *   (MAX for max_length / paired_end / yx_valid) and of the difference array (ngsqc_depth_device, in place) ->
+ *   ngsqc_depth_finalize -> ngsqc_depth_stats on the summed array.                                                   */
+int ngsqc_open_shard(const char* bam_path, int device, int shard, int n_shards, ngsqc_handle** out);
+int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, int shard, int n_shards, ngsqc_handle** out);
+
+typedef struct ngsqc_shard_summary {
+	int64_t n_records;         /* records owned by the shard */
+	int64_t first_abs;         /* inflated-stream offset (whole file) of the first record owned; -1: no record starts in the shard */
+	int64_t exit_abs;          /* offset of the first record behind the shard (= the next shard's first_abs); -1 with first_abs */
+	int64_t max_len;           /* longest l_seq among counted (not secondary / supplementary) records, 0 = none */
+	int64_t first_max_ord;     /* shard-local ordinal of the first counted record of that length, -1 = none */
+	int64_t first_paired_ord;  /* shard-local ordinal of the first record that sets paired_end, -1 = none */
+} ngsqc_shard_summary;
+typedef struct ngsqc_shard_fix {
+	int64_t gmax;              /* max over shards of max_len */
+	int64_t floor_max;         /* max of max_len over EARLIER shards (running maximum carried into this shard) */
+	int64_t trim_upto;         /* local ordinals [0, trim_upto) precede the BAM's first record of length gmax */
+	int64_t paired_upto;       /* local ordinals [0, paired_upto) precede the BAM's first paired record */
+	int32_t paired_end;        /* some shard saw a paired read */
+	int32_t reserved;
+} ngsqc_shard_fix;
+int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_shard_summary* out);
+/* returns NGSQC_E_FORMAT (message via ngsqc_last_error(NULL)) when the shards' record chains do not join */
+int ngsqc_plan_shard_fix(const ngsqc_shard_summary* all, int n_shards, int shard, ngsqc_shard_fix* out);
+int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64_t* counters, double* gc_reads);
+/* the un-prefixed difference array (int32[n_slots], device memory owned by the handle) for an in-place SUM all-reduce */
+int ngsqc_depth_device(ngsqc_handle* h, void** dev_ptr, int64_t* n_slots);
+int ngsqc_depth_diff_copy(ngsqc_handle* h, int32_t* out, int64_t cap);       /* host copy of the same array (CPU collectives) */
+int ngsqc_depth_diff_set(ngsqc_handle* h, const int32_t* in, int64_t n);
+int ngsqc_depth_finalize(ngsqc_handle* h);                                    /* difference array -> per-base depth (K6 prefix sum) */
+
 /* ---- measurement: HIP-event timings (ms) of the stages of the last job on this handle ---- */
 typedef struct ngsqc_timings {
 	double h2d_ms, inflate_ms, index_ms, scan_ms, finalize_ms, total_ms;

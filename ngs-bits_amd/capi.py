@@ -52,6 +52,19 @@ class Timings(C.Structure):
                 ("inflate_huff_launches", C.c_int64)]
 
 
+class ShardSummary(C.Structure):
+    _fields_ = [("n_records", C.c_int64), ("first_abs", C.c_int64), ("exit_abs", C.c_int64), ("max_len", C.c_int64),
+                ("first_max_ord", C.c_int64), ("first_paired_ord", C.c_int64)]
+
+
+class ShardFix(C.Structure):
+    _fields_ = [("gmax", C.c_int64), ("floor_max", C.c_int64), ("trim_upto", C.c_int64), ("paired_upto", C.c_int64),
+                ("paired_end", C.c_int32), ("reserved", C.c_int32)]
+
+
+SUMMARY_FIELDS = [f for f, _ in ShardSummary._fields_]
+
+
 def lib_path():
     return os.path.join(PKG_DIR, "libngsqc_hip.so")
 
@@ -98,6 +111,15 @@ def lib():
         L.ngsqc_lowhigh_runs.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, i64, C.POINTER(i64)]
         L.ngsqc_get_timings.restype = i32; L.ngsqc_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ngsqc_version.restype = cp
+        L.ngsqc_open_shard.restype = i32; L.ngsqc_open_shard.argtypes = [cp, i32, i32, i32, C.POINTER(vp)]
+        L.ngsqc_open_memory_shard.restype = i32; L.ngsqc_open_memory_shard.argtypes = [vp, C.c_size_t, i32, i32, i32, C.POINTER(vp)]
+        L.ngsqc_scan_mapping_partial.restype = i32; L.ngsqc_scan_mapping_partial.argtypes = [vp, C.POINTER(MappingParams), C.POINTER(ShardSummary)]
+        L.ngsqc_plan_shard_fix.restype = i32; L.ngsqc_plan_shard_fix.argtypes = [C.POINTER(ShardSummary), i32, i32, C.POINTER(ShardFix)]
+        L.ngsqc_scan_mapping_finish.restype = i32; L.ngsqc_scan_mapping_finish.argtypes = [vp, C.POINTER(ShardFix), vp, vp]
+        L.ngsqc_depth_device.restype = i32; L.ngsqc_depth_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.ngsqc_depth_diff_copy.restype = i32; L.ngsqc_depth_diff_copy.argtypes = [vp, vp, i64]
+        L.ngsqc_depth_diff_set.restype = i32; L.ngsqc_depth_diff_set.argtypes = [vp, vp, i64]
+        L.ngsqc_depth_finalize.restype = i32; L.ngsqc_depth_finalize.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -107,7 +129,24 @@ EXPORTS = [
     "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
     "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
+    "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
+    "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
 ]
+
+
+def plan_shard_fix(summaries, shard):
+    """summaries: int64 array [n_shards, 6] (SUMMARY_FIELDS order, file order). Pure host logic of the library (no device):
+    returns the ShardFix of `shard`; raises NgsqcError when the shards' record chains do not join."""
+    a = np.ascontiguousarray(summaries, dtype=np.int64).reshape(-1, len(SUMMARY_FIELDS))
+    arr = (ShardSummary * a.shape[0])()
+    for i in range(a.shape[0]):
+        for j, f in enumerate(SUMMARY_FIELDS):
+            setattr(arr[i], f, int(a[i, j]))
+    fix = ShardFix()
+    rc = lib().ngsqc_plan_shard_fix(arr, a.shape[0], int(shard), C.byref(fix))
+    if rc != 0:
+        raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+    return fix
 
 
 def _regions_array(regions):
@@ -120,14 +159,18 @@ def _regions_array(regions):
 class Handle:
     """One open BAM on one GPU (ngsqc_handle)."""
 
-    def __init__(self, path=None, data=None, device=0):
+    def __init__(self, path=None, data=None, device=0, shard=None):
+        """shard=(i, n): own the records that start inside the i-th of n contiguous BGZF-member ranges of the BAM."""
         L = lib()
         h = C.c_void_p()
+        si, sn = (int(shard[0]), int(shard[1])) if shard is not None else (0, 1)
+        self.shard = (si, sn)
         if path is not None:
-            rc = L.ngsqc_open(os.fsencode(path), device, C.byref(h))
+            rc = L.ngsqc_open_shard(os.fsencode(path), device, si, sn, C.byref(h)) if shard is not None else L.ngsqc_open(os.fsencode(path), device, C.byref(h))
         else:
             buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
-            rc = L.ngsqc_open_memory(buf.ctypes.data, buf.size, device, C.byref(h))
+            rc = (L.ngsqc_open_memory_shard(buf.ctypes.data, buf.size, device, si, sn, C.byref(h)) if shard is not None
+                  else L.ngsqc_open_memory(buf.ctypes.data, buf.size, device, C.byref(h)))
         if rc != 0:
             raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
         self.h = h
@@ -175,8 +218,7 @@ class Handle:
         self._chk(lib().ngsqc_copy_record_offsets(self.h, a.ctypes.data, a.size))
         return a
 
-    def scan_mapping(self, mode, regions=None, min_mapq=1, tid_x=-1, tid_y=-1, nonspecial=None, gc_chunks=None, gc_bin=None):
-        """regions / gc_chunks: lists of (tid, start, end), 1-based closed, merged+sorted. Returns (counters, gc_reads)."""
+    def _mapping_params(self, mode, regions=None, min_mapq=1, tid_x=-1, tid_y=-1, nonspecial=None, gc_chunks=None, gc_bin=None):
         p = MappingParams()
         p.mode, p.min_mapq, p.tid_x, p.tid_y = mode, min_mapq, tid_x, tid_y
         n_ref = len(self.refs)
@@ -189,10 +231,49 @@ class Handle:
         if gc_chunks:
             ga = _regions_array(gc_chunks); gb = np.ascontiguousarray(gc_bin, dtype=np.int32); keep += [ga, gb]
             p.gc_chunks = C.cast(ga, C.c_void_p).value; p.gc_bin = gb.ctypes.data; p.n_gc_chunks = len(gc_chunks)
+        return p, keep
+
+    def scan_mapping(self, mode, regions=None, min_mapq=1, tid_x=-1, tid_y=-1, nonspecial=None, gc_chunks=None, gc_bin=None):
+        """regions / gc_chunks: lists of (tid, start, end), 1-based closed, merged+sorted. Returns (counters, gc_reads)."""
+        p, keep = self._mapping_params(mode, regions, min_mapq, tid_x, tid_y, nonspecial, gc_chunks, gc_bin)
         counters = np.zeros(NCOUNTERS, dtype=np.int64)
         gc = np.zeros(101, dtype=np.float64)
         self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
         return counters, gc
+
+    # ---- one BAM sharded over several handles (include/ngsqc.h, "sharded" section) ----
+    def scan_mapping_partial(self, mode, **kw):
+        """Local scan of a shard. Returns its summary as int64[6] (SUMMARY_FIELDS order)."""
+        p, keep = self._mapping_params(mode, **kw)
+        sm = ShardSummary()
+        self._chk(lib().ngsqc_scan_mapping_partial(self.h, C.byref(p), C.byref(sm)))
+        return np.array([getattr(sm, f) for f in SUMMARY_FIELDS], dtype=np.int64)
+
+    def scan_mapping_finish(self, fix):
+        """Local fix-up after the summaries were exchanged. Returns ADDITIVE (counters, gc_reads) of this shard."""
+        counters = np.zeros(NCOUNTERS, dtype=np.int64)
+        gc = np.zeros(101, dtype=np.float64)
+        self._chk(lib().ngsqc_scan_mapping_finish(self.h, C.byref(fix), counters.ctypes.data, gc.ctypes.data))
+        return counters, gc
+
+    def depth_device(self):
+        """(device pointer, n_slots) of the un-prefixed int32 difference array (for an in-place all-reduce)."""
+        ptr = C.c_void_p(); n = C.c_int64(0)
+        self._chk(lib().ngsqc_depth_device(self.h, C.byref(ptr), C.byref(n)))
+        return (ptr.value or 0), int(n.value)
+
+    def depth_diff(self):
+        _, n = self.depth_device()
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(lib().ngsqc_depth_diff_copy(self.h, a.ctypes.data, n))
+        return a[:n]
+
+    def depth_diff_set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        self._chk(lib().ngsqc_depth_diff_set(self.h, a.ctypes.data, a.size))
+
+    def depth_finalize(self):
+        self._chk(lib().ngsqc_depth_finalize(self.h))
 
     def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False):
         p = DepthParams()

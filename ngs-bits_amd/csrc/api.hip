@@ -69,6 +69,15 @@ struct ngsqc_handle
 	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0; int64_t n_rec_total = -1;
 	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
 	ngsqc_timings tm{};
+	// one BAM sharded over several handles: this handle owns the records that START inside members
+	// [0, shard_own_members) of its (rebased) member table; the members behind them are only there to complete the last record
+	int shard = 0, n_shards = 1;
+	int64_t shard_own_members = -1;        // -1: not a shard (every record of the table is owned)
+	int64_t shard_limit = -1;              // rebased inflated offset of the first byte that is NOT owned
+	int64_t shard_u_base = 0;              // inflated offset (whole file) of the handle's first member
+	int64_t shard_first_abs = -1, shard_exit_abs = -1; int shard_last_tile = -1;
+	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
+	Partial* partial = nullptr;
 };
 
 namespace {
@@ -180,9 +189,12 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 }
 
 // inflate the first members until the BAM header (magic, text, reference table) is complete; parse it
-void read_header(ngsqc_handle* h)
+// avail: number of leading members whose compressed bytes are resident in d_comp (all of them for an unsharded handle).
+// Returns false when more members are needed than are resident.
+bool read_header(ngsqc_handle* h, int64_t avail)
 {
-	int64_t k = std::min<int64_t>(8, (int64_t)h->blocks.size());
+	int64_t k = std::min<int64_t>(std::min<int64_t>(8, avail), (int64_t)h->blocks.size());
+	if (avail < (int64_t)h->blocks.size()) k = avail;
 	while (true)
 	{
 		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
@@ -211,25 +223,85 @@ void read_header(ngsqc_handle* h)
 			if (!ok) break;
 			h->ref_names.swap(names); h->ref_lens.swap(lens); h->first_rec = (int64_t)o; complete = true;
 		} while (false);
-		if (complete) return;
+		if (complete) return true;
 		if (k >= (int64_t)h->blocks.size()) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
-		k = std::min<int64_t>(k * 4, (int64_t)h->blocks.size());
+		if (k >= avail) return false;
+		k = std::min<int64_t>(std::min<int64_t>(k * 4, avail), (int64_t)h->blocks.size());
 	}
 }
 
-void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device)
+void upload_compressed(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 {
+	const size_t n = end - beg;
+	h->d_comp.alloc(n + 1024);
+	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
+	if (n) HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes + beg, n, hipMemcpyHostToDevice, h->stream));
+}
+
+constexpr int64_t SHARD_TAIL_MEMBERS = 64;   // members behind a shard that are inflated to complete its last record (NGSQC_SHARD_TAIL_MEMBERS)
+
+void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, int shard, int n_shards)
+{
+	if (n_shards < 1 || shard < 0 || shard >= n_shards) throw ArgError("invalid shard index");
 	h->csize = n;
 	scan_bgzf(bytes, n, h->blocks, h->total);
 	init_device(h, device);
 	Timer t(h->stream); t.start();
-	h->d_comp.alloc(n + 1024);
-	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
-	if (n) HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes, n, hipMemcpyHostToDevice, h->stream));
+	h->shard = shard; h->n_shards = n_shards;
+	if (n_shards == 1)
+	{
+		upload_compressed(h, bytes, 0, n);
+		h->d_blocks.upload(h->blocks, h->stream);
+		h->tm.h2d_ms = t.stop();
+		h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
+		read_header(h, (int64_t)h->blocks.size());
+		return;
+	}
+	// ---- header: only the first members are sent to the device ----
+	const int64_t nb = (int64_t)h->blocks.size();
+	for (int64_t k = std::min<int64_t>(8, nb);; k = std::min<int64_t>(k * 4, nb))
+	{
+		const size_t end = k ? (size_t)(h->blocks[(size_t)k - 1].cpos + h->blocks[(size_t)k - 1].clen) : 0;
+		upload_compressed(h, bytes, 0, end);
+		std::vector<BlockDesc> head(h->blocks.begin(), h->blocks.begin() + k);
+		h->d_blocks.upload(head, h->stream);
+		if (read_header(h, k)) break;
+		if (k >= nb) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
+	}
+	h->tok_first = -1; h->tok_n = -1;
+	// ---- member range of this shard: equal compressed bytes, cut at member starts ----
+	auto first_member_at = [&](int s) -> int64_t {
+		if (s <= 0) return 0;
+		if (s >= n_shards) return nb;
+		const uint64_t target = (uint64_t)((double)n * (double)s / (double)n_shards);
+		int64_t lo = 0, hi = nb;
+		while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (h->blocks[(size_t)mid].cpos < target) lo = mid + 1; else hi = mid; }
+		return lo;
+	};
+	const int64_t m0 = first_member_at(shard), m1 = first_member_at(shard + 1);
+	int64_t tail = SHARD_TAIL_MEMBERS; if (const char* e = getenv("NGSQC_SHARD_TAIL_MEMBERS")) tail = std::max<int64_t>(0, atoll(e));
+	const int64_t m_end = std::min<int64_t>(nb, m1 + (m1 > m0 ? tail : 0));
+	std::vector<BlockDesc> own;
+	size_t cbeg = 0, cend = 0; int64_t u0 = 0, u_own = 0, u_all = 0;
+	if (m1 > m0)
+	{
+		cbeg = (size_t)(h->blocks[(size_t)m0].cpos & ~15ull);
+		cend = (size_t)(h->blocks[(size_t)m_end - 1].cpos + h->blocks[(size_t)m_end - 1].clen);
+		u0 = (int64_t)h->blocks[(size_t)m0].upos;
+		u_own = (m1 < nb ? (int64_t)h->blocks[(size_t)m1].upos : h->total) - u0;
+		u_all = (m_end < nb ? (int64_t)h->blocks[(size_t)m_end].upos : h->total) - u0;
+		for (int64_t i = m0; i < m_end; ++i) { BlockDesc d = h->blocks[(size_t)i]; d.cpos -= cbeg; d.upos -= (uint64_t)u0; own.push_back(d); }
+	}
+	const int64_t first_rec_abs = h->first_rec;
+	h->blocks.swap(own);
+	h->shard_own_members = m1 - m0; h->shard_limit = u_own; h->shard_u_base = u0; h->total = u_all;
+	h->first_rec = first_rec_abs >= u0 ? first_rec_abs - u0 : -1;   // shards behind the header: unknown, guessed by K2 and verified across shards
+	if (m1 > m0 && first_rec_abs >= u0 + u_own) { h->blocks.clear(); h->shard_own_members = 0; h->shard_limit = 0; h->total = 0; cbeg = cend = 0; }   // header only: owns no record
+	upload_compressed(h, bytes, cbeg, cend);
+	h->csize = cend - cbeg;
 	h->d_blocks.upload(h->blocks, h->stream);
 	h->tm.h2d_ms = t.stop();
-	h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
-	read_header(h);
+	h->tm.compressed_bytes = (int64_t)(cend - cbeg); h->tm.inflated_bytes = u_own;
 }
 
 // Member ranges ("tiles") whose inflated bytes + token scratch + record index fit the device. NGSQC_TILE_MEMBERS overrides
@@ -289,17 +361,21 @@ void decode_tile(ngsqc_handle* h, int t)
 	const int64_t ne = nm + 1;
 	std::vector<int32_t>& start = h->h_start; if (start.size() < (size_t)ne) start.resize((size_t)ne);
 	std::vector<int64_t>& next = h->h_next; if (next.size() < (size_t)ne) next.resize((size_t)ne);
-	const int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
+	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
+	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
+	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
+	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	for (int64_t b = 0; b < ne; ++b)
 	{
 		const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
-		start[(size_t)b] = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2);
+		start[(size_t)b] = anchor_by_guess ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
 	}
 	DevBuf<int32_t> d_start; d_start.alloc((size_t)ne); HIPCHK(hipMemcpyAsync(d_start.p, start.data(), (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)ne + 1);
 	DevBuf<int64_t> d_next; d_next.alloc((size_t)ne + 1);
 	DevBuf<uint32_t> d_bad; d_bad.alloc(1);
-	int64_t from = 0; int rounds = 0; int64_t straddle = -1;
+	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess;
+	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
 	while (true)
 	{
 		HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), h->stream));
@@ -308,10 +384,15 @@ void decode_tile(ngsqc_handle* h, int t)
 		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(ne - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		// exact verification of the chain: every member's exit must land on the next member's start
-		int64_t expected = exp0; int64_t mismatch = -1; straddle = -1;
+		int64_t expected = exp0; int64_t mismatch = -1; straddle = -1; bool anchored = !anchor_by_guess;
 		for (int64_t b = 0; b < ne; ++b)
 		{
 			const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
+			if (!anchored)
+			{
+				if (start[(size_t)b] < 0) continue;          // no plausible record start inside this member
+				anchored = true; expected = lo + start[(size_t)b]; exp0 = expected;
+			}
 			const int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
 			if (start[(size_t)b] != want) { mismatch = b; start[(size_t)b] = want; break; }
 			if (want >= 0)
@@ -324,8 +405,10 @@ void decode_tile(ngsqc_handle* h, int t)
 		}
 		if (mismatch < 0)
 		{
+			found_start = anchored;
+			if (!anchored) { expected = total; exp0 = total; }   // no record starts in this tile at all
 			if (straddle < 0 && expected != total && !(expected == INT64_MAX / 2)) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (record chain does not end at a member boundary)");
-			if (straddle >= 0 && last) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
+			if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 			break;
 		}
 		if (dbg) fprintf(stderr, "[ngsqc] tile %d: chain mismatch at entry %lld (round %d)\n", t, (long long)mismatch, rounds);
@@ -341,6 +424,34 @@ void decode_tile(ngsqc_handle* h, int t)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec, 1));
 	launch_index_write(h->d_infl.p, total, h->d_tile_blocks.p, ne, d_start.p, d_base.p, h->d_recoff.p, h->stream);
+	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
+	if (h->shard_own_members >= 0)
+	{
+		// records that start at or behind the shard limit belong to the next shard (recoff is ascending)
+		const int64_t lim = prefix + (h->shard_limit - u_lo);
+		if (lim <= total)
+		{
+			int64_t lo = 0, hi = n_rec;
+			while (lo < hi)
+			{
+				const int64_t mid = (lo + hi) / 2; int64_t v = 0;
+				HIPCHK(hipMemcpyAsync(&v, h->d_recoff.p + mid, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+				if (v < lim) lo = mid + 1; else hi = mid;
+			}
+			int64_t exit_local = -1;
+			if (lo < n_rec) { HIPCHK(hipMemcpyAsync(&exit_local, h->d_recoff.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+			else if (straddle >= 0 && straddle >= lim) exit_local = straddle;
+			else if (straddle < 0 && last) exit_local = total;
+			if (!found_start && last) { h->shard_exit_abs = -1; h->shard_last_tile = t; n_rec = 0; straddle = -1; }   // nothing starts here: a longer record covers the shard
+			else if (exit_local >= 0 || last)
+			{
+				if (exit_local < 0) throw FormatError("a record at the end of shard " + std::to_string(h->shard) + " is longer than the members read behind the shard (raise NGSQC_SHARD_TAIL_MEMBERS)");
+				h->shard_exit_abs = h->shard_u_base + u_lo + (exit_local - prefix); h->shard_last_tile = t;
+				if (lo < n_rec || (straddle >= 0 && straddle >= lim)) straddle = -1;   // whatever straddles the end of this tile is not ours
+				n_rec = lo;
+			}
+		}
+	}
 	h->tm.index_ms += tmr.stop();
 	// ---- publish tile state ----
 	h->cur_tile = t; h->tile_prefix = prefix; h->tile_total = total; h->tile_u_lo = u_lo; h->tile_ord_base = h->next_ord_base;
@@ -429,12 +540,36 @@ template <class F> void for_each_tile(ngsqc_handle* h, F f)
 	{
 		decode_tile(h, t);
 		const bool go_on = f(t);
-		if (!go_on) break;
+		if (!go_on || t == h->shard_last_tile) break;   // (a shard stops at the tile that holds the first record of the next shard)
 		if (t + 1 < nt) finish_tile(h);
 	}
 }
 
-void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev)
+// Order-dependent carries (running maximum of the read length, "a paired read has been seen") on the record prefix
+// [0, f) / [0, pidx) of this handle; floor_max = running maximum carried in from earlier shards of the same BAM.
+void run_prefix_fix(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev, int64_t f, int64_t pidx, int gmax, int floor_max)
+{
+	if (f <= 0 && pidx <= 0) return;
+	Timer t(h->stream); t.start();
+	const unsigned long long carry0 = (unsigned long long)std::max(floor_max, 0);
+	HIPCHK(hipMemcpyAsync(h->d_counters.p + A_FIX_CARRY, &carry0, sizeof(carry0), hipMemcpyHostToDevice, h->stream));
+	const int64_t upto = std::max(f, pidx);
+	// visit the tiles that hold records [0, upto) again (normally only tile 0, usually still resident)
+	for_each_tile(h, [&](int) {
+		h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
+		sp.infl = h->d_infl.p; sp.total = h->tile_total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec; sp.ord_base = h->tile_ord_base;
+		sp.long_list = h->d_long.p; sp.long_cap = h->n_rec;
+		const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - h->tile_ord_base, 0), h->n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - h->tile_ord_base, 0), h->n_rec);
+		launch_prefix_fix(sp, lf, lp, gmax, h->stream);
+		HIPCHK(hipStreamSynchronize(h->stream));
+		return h->tile_ord_base + h->n_rec < upto;
+	});
+	HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	h->tm.scan_ms += t.stop();
+}
+
+void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev, bool do_fix = true)
 {
 	h->d_counters.ensure(A_DEV_TOTAL);
 	std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
@@ -464,29 +599,13 @@ void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& 
 	dev.assign(A_DEV_TOTAL, 0ull);
 	HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	if (sp.mode != MODE_DEPTH)
+	if (sp.mode != MODE_DEPTH && do_fix)
 	{
-		// order-dependent carries: running maximum of the read length and "a paired read has been seen"
 		const unsigned long long key = dev[A_FIRST_MAX_KEY];
 		const int gmax = (int)(key >> 40);
 		const int64_t f = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : 0;
 		const int64_t pidx = (sp.mode != NGSQC_MODE_ROI && dev[A_FIRST_PAIRED] != ~0ull) ? (int64_t)dev[A_FIRST_PAIRED] : 0;
-		if (f > 0 || pidx > 0)
-		{
-			Timer t(h->stream); t.start();
-			const int64_t upto = std::max(f, pidx);
-			// visit the tiles that hold records [0, upto) again (normally only tile 0, usually still resident)
-			for_each_tile(h, [&](int) {
-				bind_tile();
-				const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - h->tile_ord_base, 0), h->n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - h->tile_ord_base, 0), h->n_rec);
-				launch_prefix_fix(sp, lf, lp, gmax, h->stream);
-				HIPCHK(hipStreamSynchronize(h->stream));
-				return h->tile_ord_base + h->n_rec < upto;
-			});
-			HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-			h->tm.scan_ms += t.stop();
-		}
+		run_prefix_fix(h, sp, dev, f, pidx, gmax, 0);
 	}
 	h->tm.scan_algorithmic_bytes = (int64_t)dev[A_ALG_BYTES];
 }
@@ -502,7 +621,7 @@ template <typename F> int guarded(ngsqc_handle* h, F f)
 	catch (std::exception& e) { h->err = e.what(); return NGSQC_E_DEVICE; }
 }
 
-int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n, int device)
+int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n, int device, int shard = 0, int n_shards = 1)
 {
 	if (!out) return NGSQC_E_ARG;
 	*out = nullptr;
@@ -527,7 +646,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		}
 		else h->path = "<memory>";
 		if (!bytes && n) throw ArgError("null BAM buffer");
-		open_common(h, (const uint8_t*)bytes, n, device);
+		open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
 	}
 	catch (FormatError& e) { g_open_error = e.what(); rc = NGSQC_E_FORMAT; }
 	catch (ArgError& e) { g_open_error = e.what(); rc = NGSQC_E_ARG; }
@@ -543,10 +662,107 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 
 } // namespace
 
+struct ngsqc_handle::Partial
+{
+	int mode = 0; bool yx = false; ScanParams sp{}; DevBuf<uint8_t> d_ns; GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
+	std::vector<unsigned long long> dev;
+};
+
+namespace {
+void mapping_setup(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_handle::Partial& st)
+{
+	if (!p) throw ArgError("null argument");
+	if (p->mode < NGSQC_MODE_ROI || p->mode > NGSQC_MODE_WGS) throw ArgError("invalid mode");
+	if (p->mode == NGSQC_MODE_ROI && (!p->regions || p->n_regions <= 0)) throw ArgError("target-region mode needs regions");
+	const int n_ref = (int)h->ref_names.size();
+	const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
+	setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
+	ScanParams& sp = st.sp; sp = ScanParams{};
+	sp.mode = p->mode; sp.min_mapq = p->min_mapq; sp.min_baseq = 0; sp.skip_mismapped = 0;
+	sp.tid_x = p->tid_x; sp.tid_y = p->tid_y;
+	st.mode = p->mode; const bool yx = st.yx = p->tid_x >= 0 && p->tid_x < n_ref && p->tid_y >= 0 && p->tid_y < n_ref;
+	if (!yx) { sp.tid_x = -2; sp.tid_y = -2; }
+	sp.len_x = yx ? h->ref_lens[p->tid_x] : 0; sp.len_y = yx ? h->ref_lens[p->tid_y] : 0;
+	std::vector<uint8_t> ns((size_t)std::max(n_ref, 1), 0);
+	if (p->tid_nonspecial) for (int i = 0; i < n_ref; ++i) ns[i] = p->tid_nonspecial[i];
+	st.d_ns.upload(ns, h->stream); sp.tid_nonspecial = st.d_ns.p;
+	sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
+	sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
+	// GC chunks
+	GcTables& gc = st.gc; DevBuf<unsigned long long>& d_gctab = st.d_gctab; DevBuf<double>& d_gcover = st.d_gcover;
+	const bool use_gc = use_regions && p->gc_chunks && p->gc_bin && p->n_gc_chunks > 0;
+	d_gctab.alloc(101 * GC_NMAX); d_gcover.alloc(101);
+	HIPCHK(hipMemsetAsync(d_gctab.p, 0, 101 * GC_NMAX * sizeof(unsigned long long), h->stream));
+	HIPCHK(hipMemsetAsync(d_gcover.p, 0, 101 * sizeof(double), h->stream));
+	if (use_gc)
+	{
+		const int64_t n = p->n_gc_chunks;
+		std::vector<int32_t> s((size_t)n), e((size_t)n), b((size_t)n), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
+		for (int64_t i = 0; i < n; ++i)
+		{
+			const ngsqc_region& r = p->gc_chunks[i];
+			if (r.tid < 0 || r.tid >= n_ref) throw ArgError("GC chunk with invalid reference id");
+			if (i == 0 || p->gc_chunks[i - 1].tid != r.tid) tf[r.tid] = (int32_t)i;
+			tl[r.tid] = (int32_t)i + 1;
+			s[i] = r.start; e[i] = r.end; b[i] = p->gc_bin[i] > 100 ? -1 : p->gc_bin[i];
+		}
+		gc.start.upload(s, h->stream); gc.end.upload(e, h->stream); gc.bin.upload(b, h->stream); gc.tf.upload(tf, h->stream); gc.tl.upload(tl, h->stream);
+		sp.gc_start = gc.start.p; sp.gc_end = gc.end.p; sp.gc_bin = gc.bin.p; sp.tid_gc_first = gc.tf.p; sp.tid_gc_last = gc.tl.p; sp.n_gc = n;
+	}
+	sp.gc_tab = d_gctab.p; sp.gc_over = d_gcover.p;
+}
+
+// device accumulators -> the reference's counters. gmax / paired_end: of the whole BAM (== this handle's unless it is a shard)
+void mapping_counters(ngsqc_handle* h, ngsqc_handle::Partial& st, int gmax, bool paired_end, int64_t* counters, double* gc_reads)
+{
+	const std::vector<unsigned long long>& dev = st.dev; const bool yx = st.yx;
+		// ---- device accumulators -> the reference's counters ----
+	auto S = [&](int i) { return (int64_t)dev[i]; };
+	for (int i = 0; i < NGSQC_NCOUNTERS; ++i) counters[i] = 0;
+	counters[NGSQC_C_AL_TOTAL] = S(A_TOTAL); counters[NGSQC_C_AL_MAPPED] = S(A_MAPPED); counters[NGSQC_C_AL_ONTARGET] = S(A_ONTARGET);
+	counters[NGSQC_C_AL_NEARTARGET] = S(A_NEAR); counters[NGSQC_C_AL_DUP] = S(A_DUP); counters[NGSQC_C_AL_PROPER_PAIRED] = S(A_PP);
+	counters[NGSQC_C_INSERT_SIZE_READ_COUNT] = S(A_INS_CNT);
+	counters[NGSQC_C_BASES_TRIMMED] = S(A_TOTAL) * gmax - S(A_SUM_LEN) - S(A_FIX_TRIM);
+	counters[NGSQC_C_BASES_MAPPED] = S(A_BASES_MAPPED); counters[NGSQC_C_BASES_CLIPPED] = S(A_CLIPPED); counters[NGSQC_C_INSERT_SIZE_SUM] = S(A_INS_SUM);
+	if (st.mode == NGSQC_MODE_ROI)
+	{
+		counters[NGSQC_C_BASES_USABLE] = S(A_USABLE);
+		counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = S(A_NO_OVERLAP);
+	}
+	else
+	{
+		counters[NGSQC_C_BASES_USABLE] = S(A_USABLE) - S(A_CLIPPED);                        // Statistics.cpp:917 / :1183
+		counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = (paired_end ? S(A_USABLE) - S(A_FIX_LEN) : 0) + S(A_NO_OVERLAP); // :879,:898-901
+	}
+	counters[NGSQC_C_BASES_USABLE_RAW] = S(A_USABLE_RAW); counters[NGSQC_C_BASES_USABLE_ROI] = S(A_USABLE_ROI);
+	for (int i = 0; i < 5; ++i) counters[NGSQC_C_BASES_USABLE_DP0 + i] = S(A_DP0 + i);
+	for (int i = 0; i < 4; ++i) counters[NGSQC_C_DP_DIST0 + i] = S(A_DD0 + i);
+	counters[NGSQC_C_MAX_LENGTH] = gmax; counters[NGSQC_C_PAIRED_END] = paired_end ? 1 : 0;
+	counters[NGSQC_C_ROI_BASES] = h->roi_bases;
+	counters[NGSQC_C_READS_X] = yx ? S(A_READS_X) : 0; counters[NGSQC_C_READS_Y] = yx ? S(A_READS_Y) : 0;
+	counters[NGSQC_C_YX_VALID] = (yx && S(A_READS_X) != 0) ? 1 : 0;
+	for (int i = 0; i < 1000; ++i) counters[NGSQC_C_INSERT_HIST0 + i] = S(A_HIST0 + i);
+	if (gc_reads)
+	{
+		std::vector<unsigned long long> tab(101 * GC_NMAX); std::vector<double> over(101);
+		HIPCHK(hipMemcpy(tab.data(), st.d_gctab.p, tab.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(over.data(), st.d_gcover.p, over.size() * sizeof(double), hipMemcpyDeviceToHost));
+		for (int b = 0; b <= 100; ++b)
+		{
+			double v = over[b];
+			for (int n = 1; n < GC_NMAX; ++n) if (tab[(size_t)b * GC_NMAX + n]) v += (double)tab[(size_t)b * GC_NMAX + n] * (1.0 / (double)n);
+			gc_reads[b] = v;
+		}
+	}
+}
+} // namespace
+
 extern "C" {
 
 int ngsqc_open(const char* bam_path, int device, ngsqc_handle** out) { if (!bam_path) return NGSQC_E_ARG; return open_impl(out, bam_path, nullptr, 0, device); }
 int ngsqc_open_memory(const void* bam_bytes, size_t n_bytes, int device, ngsqc_handle** out) { return open_impl(out, nullptr, bam_bytes, n_bytes, device); }
+int ngsqc_open_shard(const char* bam_path, int device, int shard, int n_shards, ngsqc_handle** out) { if (!bam_path) return NGSQC_E_ARG; return open_impl(out, bam_path, nullptr, 0, device, shard, n_shards); }
+int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, int shard, int n_shards, ngsqc_handle** out) { return open_impl(out, nullptr, bam_bytes, n_bytes, device, shard, n_shards); }
 
 void ngsqc_close(ngsqc_handle* h)
 {
@@ -554,6 +770,7 @@ void ngsqc_close(ngsqc_handle* h)
 	if (h->stream) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
 	if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
 	for (hipEvent_t e : h->k1_events) (void)hipEventDestroy(e);
+	delete h->partial;
 	delete h;
 }
 
@@ -609,99 +826,110 @@ int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* 
 {
 	return guarded(h, [&] {
 		if (!p || !counters) throw ArgError("null argument");
-		if (p->mode < NGSQC_MODE_ROI || p->mode > NGSQC_MODE_WGS) throw ArgError("invalid mode");
-		if (p->mode == NGSQC_MODE_ROI && (!p->regions || p->n_regions <= 0)) throw ArgError("target-region mode needs regions");
 		Timer total(h->stream); total.start();
-		const bool dbgs = getenv("NGSQC_DEBUG") != nullptr;
-		auto laps = [&](const char* what) { if (dbgs) { (void)hipStreamSynchronize(h->stream); static double last = 0; double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); fprintf(stderr, "[ngsqc:scan] %-20s %.3f ms\n", what, last ? (now - last) * 1e3 : 0.0); last = now; } };
-		laps("begin");
-		const int n_ref = (int)h->ref_names.size();
-		const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
-		setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
-		ScanParams sp{};
-		sp.mode = p->mode; sp.min_mapq = p->min_mapq; sp.min_baseq = 0; sp.skip_mismapped = 0;
-		sp.tid_x = p->tid_x; sp.tid_y = p->tid_y;
-		const bool yx = p->tid_x >= 0 && p->tid_x < n_ref && p->tid_y >= 0 && p->tid_y < n_ref;
-		if (!yx) { sp.tid_x = -2; sp.tid_y = -2; }
-		sp.len_x = yx ? h->ref_lens[p->tid_x] : 0; sp.len_y = yx ? h->ref_lens[p->tid_y] : 0;
-		std::vector<uint8_t> ns((size_t)std::max(n_ref, 1), 0);
-		if (p->tid_nonspecial) for (int i = 0; i < n_ref; ++i) ns[i] = p->tid_nonspecial[i];
-		DevBuf<uint8_t> d_ns; d_ns.upload(ns, h->stream); sp.tid_nonspecial = d_ns.p;
-		sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
-		sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
-		// GC chunks
-		GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
-		const bool use_gc = use_regions && p->gc_chunks && p->gc_bin && p->n_gc_chunks > 0;
-		d_gctab.alloc(101 * GC_NMAX); d_gcover.alloc(101);
-		HIPCHK(hipMemsetAsync(d_gctab.p, 0, 101 * GC_NMAX * sizeof(unsigned long long), h->stream));
-		HIPCHK(hipMemsetAsync(d_gcover.p, 0, 101 * sizeof(double), h->stream));
-		if (use_gc)
-		{
-			const int64_t n = p->n_gc_chunks;
-			std::vector<int32_t> s((size_t)n), e((size_t)n), b((size_t)n), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
-			for (int64_t i = 0; i < n; ++i)
-			{
-				const ngsqc_region& r = p->gc_chunks[i];
-				if (r.tid < 0 || r.tid >= n_ref) throw ArgError("GC chunk with invalid reference id");
-				if (i == 0 || p->gc_chunks[i - 1].tid != r.tid) tf[r.tid] = (int32_t)i;
-				tl[r.tid] = (int32_t)i + 1;
-				s[i] = r.start; e[i] = r.end; b[i] = p->gc_bin[i] > 100 ? -1 : p->gc_bin[i];
-			}
-			gc.start.upload(s, h->stream); gc.end.upload(e, h->stream); gc.bin.upload(b, h->stream); gc.tf.upload(tf, h->stream); gc.tl.upload(tl, h->stream);
-			sp.gc_start = gc.start.p; sp.gc_end = gc.end.p; sp.gc_bin = gc.bin.p; sp.tid_gc_first = gc.tf.p; sp.tid_gc_last = gc.tl.p; sp.n_gc = n;
-		}
-		sp.gc_tab = d_gctab.p; sp.gc_over = d_gcover.p;
-		std::vector<unsigned long long> dev;
-		laps("setup");
-		run_scan(h, sp, dev);
-		laps("run_scan");
+		ngsqc_handle::Partial st;
+		mapping_setup(h, p, st);
+		run_scan(h, st.sp, st.dev);
 		Timer fin(h->stream); fin.start();
 		finalize_depth(h);
 		h->tm.finalize_ms = fin.stop();
-		laps("finalize");
-
-		// ---- device accumulators -> the reference's counters ----
-		auto S = [&](int i) { return (int64_t)dev[i]; };
-		for (int i = 0; i < NGSQC_NCOUNTERS; ++i) counters[i] = 0;
-		const int gmax = (int)(dev[A_FIRST_MAX_KEY] >> 40);
-		const bool paired_end = dev[A_FIRST_PAIRED] != ~0ull;
-		counters[NGSQC_C_AL_TOTAL] = S(A_TOTAL); counters[NGSQC_C_AL_MAPPED] = S(A_MAPPED); counters[NGSQC_C_AL_ONTARGET] = S(A_ONTARGET);
-		counters[NGSQC_C_AL_NEARTARGET] = S(A_NEAR); counters[NGSQC_C_AL_DUP] = S(A_DUP); counters[NGSQC_C_AL_PROPER_PAIRED] = S(A_PP);
-		counters[NGSQC_C_INSERT_SIZE_READ_COUNT] = S(A_INS_CNT);
-		counters[NGSQC_C_BASES_TRIMMED] = S(A_TOTAL) * gmax - S(A_SUM_LEN) - S(A_FIX_TRIM);
-		counters[NGSQC_C_BASES_MAPPED] = S(A_BASES_MAPPED); counters[NGSQC_C_BASES_CLIPPED] = S(A_CLIPPED); counters[NGSQC_C_INSERT_SIZE_SUM] = S(A_INS_SUM);
-		if (p->mode == NGSQC_MODE_ROI)
-		{
-			counters[NGSQC_C_BASES_USABLE] = S(A_USABLE);
-			counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = S(A_NO_OVERLAP);
-		}
-		else
-		{
-			counters[NGSQC_C_BASES_USABLE] = S(A_USABLE) - S(A_CLIPPED);                        // Statistics.cpp:917 / :1183
-			counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = (paired_end ? S(A_USABLE) - S(A_FIX_LEN) : 0) + S(A_NO_OVERLAP); // :879,:898-901
-		}
-		counters[NGSQC_C_BASES_USABLE_RAW] = S(A_USABLE_RAW); counters[NGSQC_C_BASES_USABLE_ROI] = S(A_USABLE_ROI);
-		for (int i = 0; i < 5; ++i) counters[NGSQC_C_BASES_USABLE_DP0 + i] = S(A_DP0 + i);
-		for (int i = 0; i < 4; ++i) counters[NGSQC_C_DP_DIST0 + i] = S(A_DD0 + i);
-		counters[NGSQC_C_MAX_LENGTH] = gmax; counters[NGSQC_C_PAIRED_END] = paired_end ? 1 : 0;
-		counters[NGSQC_C_ROI_BASES] = h->roi_bases;
-		counters[NGSQC_C_READS_X] = yx ? S(A_READS_X) : 0; counters[NGSQC_C_READS_Y] = yx ? S(A_READS_Y) : 0;
-		counters[NGSQC_C_YX_VALID] = (yx && S(A_READS_X) != 0) ? 1 : 0;
-		for (int i = 0; i < 1000; ++i) counters[NGSQC_C_INSERT_HIST0 + i] = S(A_HIST0 + i);
-		if (gc_reads)
-		{
-			std::vector<unsigned long long> tab(101 * GC_NMAX); std::vector<double> over(101);
-			HIPCHK(hipMemcpy(tab.data(), d_gctab.p, tab.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-			HIPCHK(hipMemcpy(over.data(), d_gcover.p, over.size() * sizeof(double), hipMemcpyDeviceToHost));
-			for (int b = 0; b <= 100; ++b)
-			{
-				double v = over[b];
-				for (int n = 1; n < GC_NMAX; ++n) if (tab[(size_t)b * GC_NMAX + n]) v += (double)tab[(size_t)b * GC_NMAX + n] * (1.0 / (double)n);
-				gc_reads[b] = v;
-			}
-		}
+		mapping_counters(h, st, (int)(st.dev[A_FIRST_MAX_KEY] >> 40), st.dev[A_FIRST_PAIRED] != ~0ull, counters, gc_reads);
 		h->tm.total_ms = total.stop();
 	});
+}
+
+// ---- one BAM sharded over several handles: local scan, tiny exchange, local fix-up, additive counters ----
+int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_shard_summary* out)
+{
+	return guarded(h, [&] {
+		if (!p || !out) throw ArgError("null argument");
+		Timer total(h->stream); total.start();
+		delete h->partial; h->partial = new ngsqc_handle::Partial();
+		ngsqc_handle::Partial& st = *h->partial;
+		mapping_setup(h, p, st);
+		run_scan(h, st.sp, st.dev, false);
+		const unsigned long long key = st.dev[A_FIRST_MAX_KEY];
+		out->n_records = h->tm.n_records;
+		out->first_abs = h->shard_own_members >= 0 ? h->shard_first_abs : (h->tm.n_records ? h->first_rec : -1);
+		out->exit_abs = h->shard_own_members >= 0 ? h->shard_exit_abs : (h->tm.n_records ? h->total : -1);
+		out->max_len = (int64_t)(key >> 40);
+		out->first_max_ord = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : -1;
+		out->first_paired_ord = st.dev[A_FIRST_PAIRED] != ~0ull ? (int64_t)st.dev[A_FIRST_PAIRED] : -1;
+		h->tm.total_ms = total.stop();
+	});
+}
+
+int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64_t* counters, double* gc_reads)
+{
+	return guarded(h, [&] {
+		if (!fix || !counters) throw ArgError("null argument");
+		if (!h->partial) throw ArgError("ngsqc_scan_mapping_finish without ngsqc_scan_mapping_partial");
+		ngsqc_handle::Partial& st = *h->partial;
+		Timer total(h->stream); total.start();
+		run_prefix_fix(h, st.sp, st.dev, fix->trim_upto, st.mode != NGSQC_MODE_ROI ? fix->paired_upto : 0, (int)fix->gmax, (int)fix->floor_max);
+		mapping_counters(h, st, (int)fix->gmax, fix->paired_end != 0, counters, gc_reads);
+		h->tm.total_ms += total.stop();
+	});
+}
+
+int ngsqc_depth_device(ngsqc_handle* h, void** dev_ptr, int64_t* n_slots)
+{
+	return guarded(h, [&] {
+		if (!dev_ptr || !n_slots) throw ArgError("null argument");
+		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		HIPCHK(hipStreamSynchronize(h->stream));
+		*dev_ptr = h->d_depth.p; *n_slots = h->n_slots;
+	});
+}
+int ngsqc_depth_diff_copy(ngsqc_handle* h, int32_t* out, int64_t cap)
+{
+	return guarded(h, [&] {
+		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		if (cap < h->n_slots || (!out && h->n_slots)) throw ArgError("depth buffer too small");
+		if (h->n_slots) HIPCHK(hipMemcpyAsync(out, h->d_depth.p, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+int ngsqc_depth_diff_set(ngsqc_handle* h, const int32_t* in, int64_t n)
+{
+	return guarded(h, [&] {
+		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		if (n != h->n_slots || (!in && n)) throw ArgError("depth buffer size mismatch");
+		if (n) HIPCHK(hipMemcpyAsync(h->d_depth.p, in, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+int ngsqc_depth_finalize(ngsqc_handle* h)
+{
+	return guarded(h, [&] {
+		if (h->depth_ready) return;
+		Timer fin(h->stream); fin.start();
+		finalize_depth(h);
+		h->tm.finalize_ms = fin.stop();
+	});
+}
+
+// Pure host logic (no device): what shard `shard` needs for its fix-up, from the summaries of all shards in file order.
+// Also verifies the record chain across shards: a shard's guessed first record must be the previous shard's chain exit.
+int ngsqc_plan_shard_fix(const ngsqc_shard_summary* all, int n_shards, int shard, ngsqc_shard_fix* out)
+{
+	if (!all || !out || n_shards < 1 || shard < 0 || shard >= n_shards) return NGSQC_E_ARG;
+	int64_t cur = -1;
+	for (int s = 0; s < n_shards; ++s)
+	{
+		if (all[s].first_abs < 0) continue;
+		if (cur >= 0 && all[s].first_abs != cur) { g_open_error = "shard " + std::to_string(s) + " starts at inflated offset " + std::to_string(all[s].first_abs) + " but the previous shard's record chain ends at " + std::to_string(cur); return NGSQC_E_FORMAT; }
+		cur = all[s].exit_abs;
+	}
+	int64_t gmax = 0; int s_max = -1, s_paired = -1;
+	for (int s = 0; s < n_shards; ++s) if (all[s].max_len > gmax) { gmax = all[s].max_len; }
+	for (int s = 0; s < n_shards; ++s) if (s_max < 0 && gmax > 0 && all[s].max_len == gmax) s_max = s;
+	for (int s = 0; s < n_shards; ++s) if (s_paired < 0 && all[s].first_paired_ord >= 0) s_paired = s;
+	int64_t floor_max = 0; for (int s = 0; s < shard; ++s) floor_max = std::max(floor_max, all[s].max_len);
+	out->gmax = gmax; out->floor_max = floor_max; out->paired_end = s_paired >= 0 ? 1 : 0;
+	out->trim_upto = s_max < 0 ? 0 : (shard < s_max ? all[shard].n_records : (shard == s_max ? all[shard].first_max_ord : 0));
+	out->paired_upto = s_paired < 0 ? 0 : (shard < s_paired ? all[shard].n_records : (shard == s_paired ? all[shard].first_paired_ord : 0));
+	return NGSQC_OK;
 }
 
 int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p)

@@ -1,13 +1,13 @@
 """Multi-GPU plumbing: one process per GPU, counter vectors combined with ONE collective over RCCL/xGMI.
 
 The hot path shards embarrassingly (one BAM — or one BGZF range of a BAM — per GPU); the only exchange is the reduction
-of the ~8 KB int64 counter vector (SUM for counts and histograms, MAX for max_length / paired_end / yx_valid).
+of the ~8 KB int64 counter vector (SUM for counts and histograms, MAX for max_length / paired_end / roi_bases / yx_valid).
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
 """
 import numpy as np
 
-IDX_MAX_LENGTH, IDX_PAIRED_END, IDX_HALF_DEPTH, IDX_YX_VALID = 24, 25, 27, 31
-MAX_REDUCED = (IDX_MAX_LENGTH, IDX_PAIRED_END, IDX_HALF_DEPTH, IDX_YX_VALID)
+IDX_MAX_LENGTH, IDX_PAIRED_END, IDX_ROI_BASES, IDX_HALF_DEPTH, IDX_YX_VALID = 24, 25, 26, 27, 31
+MAX_REDUCED = (IDX_MAX_LENGTH, IDX_PAIRED_END, IDX_ROI_BASES, IDX_HALF_DEPTH, IDX_YX_VALID)   # identical or max-like on every rank: not additive
 
 
 def combine_counters_local(vectors):
@@ -22,7 +22,7 @@ def combine_counters_local(vectors):
 def allreduce_counters(counters, device=None, group=None):
     """All-reduce one rank's NGSQC counter vector across the process group. Returns a numpy int64 array.
 
-    Two tiny collectives on the same tensor layout: SUM over everything, then MAX over the 4 non-additive slots.
+    Two tiny collectives on the same tensor layout: SUM over everything, then MAX over the non-additive slots.
     """
     import torch
     import torch.distributed as dist
@@ -42,3 +42,83 @@ def shard_blocks(n_blocks, world_size, rank):
     base, rem = divmod(n_blocks, world_size)
     b0 = rank * base + min(rank, rem)
     return b0, b0 + base + (1 if rank < rem else 0)
+
+
+# ---- one BAM sharded over the ranks (protocol in include/ngsqc.h) ----
+
+class _DeviceInt32:
+    """Aliases library-owned device memory as a torch tensor (no copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def scan_mapping_sharded(handle, mode, device=None, group=None, **scan_kw):
+    """Rank-side driver: `handle` is this rank's shard (Handle(..., shard=(rank, world))). Every rank returns the same
+    (counters, gc_reads) of the WHOLE BAM; afterwards handle.depth_stats()/depth() see the whole BAM's depth array.
+
+    Collectives: all-gather of the 48-byte summaries, SUM/MAX all-reduce of the 8 KB counter vector, SUM all-reduce of
+    gc_reads (808 B) and - when there is a target region - one in-place SUM all-reduce of the int32 difference array
+    (device memory of the library; RCCL over xGMI with backend "nccl", host copy with "gloo")."""
+    import torch
+    import torch.distributed as dist
+    from .capi import plan_shard_fix
+
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = handle.scan_mapping_partial(mode, **scan_kw)
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.int64, device=device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        summaries = np.stack([x.cpu().numpy() for x in parts])
+    else:
+        summaries = mine[None, :]
+    fix = plan_shard_fix(summaries, rank)
+    counters, gc = handle.scan_mapping_finish(fix)
+    counters = allreduce_counters(counters, device=device, group=group)
+    ptr, n = handle.depth_device()
+    if world > 1:
+        g = torch.tensor(gc, dtype=torch.float64, device=device)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        gc = g.cpu().numpy()
+        if n > 0:
+            done = False
+            if device is not None and str(device).startswith("cuda"):
+                try:
+                    d = torch.as_tensor(_DeviceInt32(ptr, n), device=device)
+                    dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+                    torch.cuda.synchronize()
+                    done = True
+                except (TypeError, RuntimeError, ValueError):
+                    done = False
+            if not done:
+                d = torch.from_numpy(handle.depth_diff().copy())
+                if device is not None and str(device).startswith("cuda"):
+                    d = d.to(device)
+                dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+                handle.depth_diff_set(d.cpu().numpy())
+    handle.depth_finalize()
+    return counters, gc, summaries
+
+
+def scan_mapping_sharded_local(handles, mode, **scan_kw):
+    """The same protocol inside ONE process for a list of shard handles in file order (tests; several shards on one GPU).
+    Returns (counters, gc_reads, summaries); handles[0] ends up holding the whole BAM's finalized depth array."""
+    from .capi import plan_shard_fix
+
+    summaries = np.stack([h.scan_mapping_partial(mode, **scan_kw) for h in handles])
+    parts, gcs = [], []
+    for i, h in enumerate(handles):
+        c, g = h.scan_mapping_finish(plan_shard_fix(summaries, i))
+        parts.append(c); gcs.append(g)
+    counters = combine_counters_local(parts)
+    gc = np.sum(np.stack(gcs), axis=0)
+    _, n = handles[0].depth_device()
+    if n > 0:
+        total = handles[0].depth_diff().astype(np.int64)
+        for h in handles[1:]:
+            total += h.depth_diff()
+        handles[0].depth_diff_set(total.astype(np.int32))
+    handles[0].depth_finalize()
+    return counters, gc, summaries

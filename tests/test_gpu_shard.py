@@ -1,0 +1,131 @@
+"""One BAM sharded over several handles on the GPU: N shard handles on device 0 run the protocol of
+include/ngsqc.h ("sharded" section) in one process; counters, per-base depth and the depth histogram must be identical
+to the oracle's sequential pass over the whole file — for htslib-style members, members that cut records (records
+straddle shard borders), ONT-like records longer than several members, multi-tile shards, more shards than members, and a
+crafted BAM whose first full-length and first paired reads appear late in the file (the carries cross shards)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import bamgen_lib as G
+import hostprep as H
+import oracle_lib as O
+from conftest import RESOURCES
+from test_gpu_inflate import rebgzf
+
+pytestmark = pytest.mark.gpu
+ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+OMIM = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
+SKIP = {O.COUNTER_NAMES.index("half_depth"), O.COUNTER_NAMES.index("bases_covered_half")}
+
+
+def _sharded_vs_oracle(path, bed, qc_mode, merge_mode, n_shards, by_path=False):
+    ob = O.Bam(path)
+    exp = O.mapping(ob, qc_mode, bed, merge_bed=(merge_mode == 1))
+    data = None if by_path else np.fromfile(path, dtype=np.uint8)
+    hs = [ngsqc.Handle(path=path, shard=(i, n_shards)) if by_path else ngsqc.Handle(data=data, shard=(i, n_shards)) for i in range(n_shards)]
+    try:
+        regs = None
+        if bed:
+            regs, _ = H.bed_regions(bed, hs[0].refs, merge_mode)
+        tx, ty = H.xy_tids(hs[0].refs)
+        counters, gc, summaries = ngsqc.scan_mapping_sharded_local(hs, qc_mode, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(hs[0].refs))
+        assert int(summaries[:, 0].sum()) == ob.count, summaries
+        for i in range(len(counters)):
+            if i not in SKIP:
+                assert int(counters[i]) == int(exp.counters[i]), (O.COUNTER_NAMES[i] if i < 32 else f"insert_hist[{i - 32}]", int(counters[i]), int(exp.counters[i]), summaries)
+        if regs:
+            assert np.array_equal(hs[0].depth(int(counters[26])), exp.depth)
+            # the histogram of the summed array equals the one an unsharded handle computes
+            whole = ngsqc.Handle(path=path)
+            whole.scan_mapping(qc_mode, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(whole.refs))
+            a, b = hs[0].depth_stats(599, 7), whole.depth_stats(599, 7)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+            whole.close()
+        return summaries
+    finally:
+        for h in hs:
+            h.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_short_reads_aligned_members(tmp_path, n_shards):
+    path = str(tmp_path / "wgs.bam")
+    G.write(path, n_reads=200_000, seed=21, start_pos=15_900_000)
+    s = _sharded_vs_oracle(path, OMIM, ngsqc.MODE_WGS, 3, n_shards, by_path=(n_shards == 3))
+    assert (s[:, 0] > 0).all()
+
+
+@pytest.mark.parametrize("n_shards", [2, 5])
+def test_records_straddle_shard_borders(tmp_path, n_shards):
+    path = str(tmp_path / "unaligned.bam")
+    G.write(path, n_reads=90_000, seed=22, aligned=False, start_pos=15_900_000)
+    _sharded_vs_oracle(path, OMIM, ngsqc.MODE_WGS, 3, n_shards)
+    _sharded_vs_oracle(path, None, ngsqc.MODE_NOROI, 0, n_shards)
+
+
+def test_long_reads_longer_than_members(tmp_path):
+    path = str(tmp_path / "ont.bam")
+    G.write(path, n_reads=1200, seed=23, mode=1, depth=40.0, start_pos=15_900_000)
+    bed = tmp_path / "chr1.bed"
+    bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3)
+
+
+def test_multi_tile_shards(tmp_path, monkeypatch):
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", "3")
+    path = str(tmp_path / "tiles.bam")
+    G.write(path, n_reads=40_000, seed=24, aligned=False, start_pos=15_900_000)
+    _sharded_vs_oracle(path, OMIM, ngsqc.MODE_WGS, 3, 3)
+
+
+def test_more_shards_than_members(tmp_path):
+    path = str(tmp_path / "tiny.bam")
+    G.write(path, n_reads=700, seed=25, start_pos=15_900_000)     # a handful of members
+    s = _sharded_vs_oracle(path, None, ngsqc.MODE_NOROI, 0, 16)
+    assert (s[:, 0] == 0).any()                                   # some shards own nothing
+
+
+def _crafted_bam(path, n, first_full, first_paired, member_sizes):
+    """chr1 reads whose length only reaches 150 at record `first_full`, paired flag from `first_paired` on."""
+    rng = np.random.default_rng(9)
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n"
+    raw = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\x00" + struct.pack("<i", 248956422))
+    pos = 16_000_000
+    for i in range(n):
+        l_seq = 150 if i >= first_full and (i == first_full or rng.random() < 0.6) else int(rng.integers(40, 100 + min(49, i // 40)))
+        flag = 0
+        if i >= first_paired and (i == first_paired or rng.random() < 0.8):
+            flag |= 0x1 | 0x2 | (0x40 if i % 2 == 0 else 0x80)
+        if rng.random() < 0.05:
+            flag |= 0x400
+        if rng.random() < 0.03:
+            flag |= 0x100
+        name = b"r%07d\x00" % i
+        cigar = struct.pack("<I", (l_seq << 4) | 0)
+        seq = bytes(rng.integers(0, 256, (l_seq + 1) // 2, dtype=np.uint8))
+        qual = bytes(rng.integers(2, 40, l_seq, dtype=np.uint8))
+        mapq = int(rng.choice([0, 20, 60], p=[0.1, 0.1, 0.8]))
+        tlen = 300 if flag & 0x1 else 0
+        core = struct.pack("<iiBBHHHiiii", 0, pos, len(name), mapq, 4681, 1, flag, l_seq, 0 if flag & 1 else -1, pos + 150 if flag & 1 else -1, tlen)
+        rec = core + name + cigar + seq + qual
+        raw += struct.pack("<i", len(rec)) + rec
+        pos += int(rng.integers(1, 30))
+    open(path, "wb").write(rebgzf(bytes(raw), member_sizes))
+
+
+@pytest.mark.parametrize("first_full,first_paired", [(0, 0), (3100, 4200), (5900, 2), (2500, 6000)])
+def test_carries_cross_shards(tmp_path, first_full, first_paired):
+    path = str(tmp_path / "crafted.bam")
+    _crafted_bam(path, 6000, first_full, first_paired, [20_000, 33_333, 7_000])
+    for n_shards in (2, 4, 7):
+        s = _sharded_vs_oracle(path, None, ngsqc.MODE_NOROI, 0, n_shards)
+        if first_full > 3000 and n_shards >= 4:
+            assert s[0, 3] < 150                               # shard 0 never sees a full-length read: the carry really crosses shards
+    bed = tmp_path / "chr1.bed"
+    bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3)
