@@ -1,4 +1,5 @@
 #include "Statistics.hpp"
+#include <thread>
 #include <zlib.h>
 
 namespace ngsbits {
@@ -6,20 +7,30 @@ namespace ngsbits {
 const char* const NO_REF = "<none>";
 
 // ---------------------------------------------------------------- BamReader
-BamReader::BamReader(const std::string& bam_file, const std::string&) : bam_file_(bam_file)
+BamReader::BamReader(const std::string& bam_file, const std::string&, bool allow_shards) : bam_file_(bam_file)
 {
 	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
-	int rc = ngsqc_open(bam_file.c_str(), dev, &h_);
-	if (rc != NGSQC_OK)
+	int n_shards = 1; if (allow_shards) if (const char* e = getenv("NGSQC_SHARDS")) n_shards = std::max(1, atoi(e));
+	int n_dev = 1; if (n_shards > 1) if (const char* e = getenv("NGSQC_DEVICES")) n_dev = std::max(1, atoi(e));
+	for (int s = 0; s < n_shards; ++s)
 	{
-		std::string msg = ngsqc_last_error(nullptr);
-		if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file);   // BamReader.cpp:467
-		if (rc == NGSQC_E_DEVICE) NB_THROW(Exception, "GPU backend unavailable: " + msg);
-		NB_THROW(FileAccessException, msg);
+		ngsqc_handle* h = nullptr;
+		int rc = n_shards == 1 ? ngsqc_open(bam_file.c_str(), dev, &h) : ngsqc_open_shard(bam_file.c_str(), dev + s % n_dev, s, n_shards, &h);
+		if (rc != NGSQC_OK)
+		{
+			std::string msg = ngsqc_last_error(nullptr);
+			for (ngsqc_handle* o : shards_) ngsqc_close(o);
+			shards_.clear();
+			if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file);   // BamReader.cpp:467
+			if (rc == NGSQC_E_DEVICE) NB_THROW(Exception, "GPU backend unavailable: " + msg);
+			NB_THROW(FileAccessException, msg);
+		}
+		shards_.push_back(h);
 	}
+	h_ = shards_[0];
 	for (int i = 0; i < ngsqc_n_ref(h_); ++i) { chrs_.emplace_back(ngsqc_ref_name(h_, i)); sizes_.push_back(ngsqc_ref_len(h_, i)); }
 }
-BamReader::~BamReader() { if (h_) ngsqc_close(h_); }
+BamReader::~BamReader() { for (ngsqc_handle* h : shards_) ngsqc_close(h); }
 int BamReader::chromosomeID(const Chromosome& chr) const { for (size_t i = 0; i < chrs_.size(); ++i) if (chrs_[i] == chr) return (int)i; return -1; }
 int BamReader::chromosomeSize(const Chromosome& chr) const
 {
@@ -165,7 +176,50 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 		for (long long i = 0; i < gc->dropout.count(); ++i) { int tid = reader.chromosomeID(gc->dropout[i].chr()); if (tid < 0) continue; chunks.push_back(ngsqc_region{tid, gc->dropout[i].start(), gc->dropout[i].end()}); bins.push_back(gc->bin[(size_t)i]); }
 		p.gc_chunks = chunks.data(); p.gc_bin = bins.data(); p.n_gc_chunks = (int64_t)chunks.size();
 	}
-	reader.check(ngsqc_scan_mapping(reader.handle(), &p, s.c.data(), s.gc_reads.data()));
+	const std::vector<ngsqc_handle*>& sh = reader.shards();
+	if (sh.size() == 1) { reader.check(ngsqc_scan_mapping(reader.handle(), &p, s.c.data(), s.gc_reads.data())); return s; }
+
+	// ---- one BAM sharded over several handles / GPUs (include/ngsqc.h, "sharded" section): local scans run concurrently ----
+	const int n = (int)sh.size();
+	auto checkShard = [&](ngsqc_handle* h, int rc) {
+		if (rc == NGSQC_OK) return;
+		std::string msg = ngsqc_last_error(h);
+		if (rc == NGSQC_E_ARG) NB_THROW(ArgumentException, msg);
+		if (rc == NGSQC_E_FORMAT) NB_THROW(FileAccessException, msg);
+		NB_THROW(Exception, msg);
+	};
+	std::vector<ngsqc_shard_summary> sum((size_t)n); std::vector<int> rcs((size_t)n, NGSQC_OK);
+	{
+		std::vector<std::thread> th;
+		for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[(size_t)i] = ngsqc_scan_mapping_partial(sh[(size_t)i], &p, &sum[(size_t)i]); });
+		for (auto& t : th) t.join();
+	}
+	for (int i = 0; i < n; ++i) checkShard(sh[(size_t)i], rcs[(size_t)i]);
+	std::vector<int32_t> diff_sum, diff;
+	for (int i = 0; i < n; ++i)
+	{
+		ngsqc_shard_fix fix{};
+		if (ngsqc_plan_shard_fix(sum.data(), n, i, &fix) != NGSQC_OK) NB_THROW(FileAccessException, std::string(ngsqc_last_error(nullptr)));
+		std::vector<int64_t> c((size_t)NGSQC_NCOUNTERS, 0); std::vector<double> g(101, 0.0);
+		checkShard(sh[(size_t)i], ngsqc_scan_mapping_finish(sh[(size_t)i], &fix, c.data(), g.data()));
+		for (int k = 0; k < NGSQC_NCOUNTERS; ++k)
+		{
+			const bool max_like = k == NGSQC_C_MAX_LENGTH || k == NGSQC_C_PAIRED_END || k == NGSQC_C_ROI_BASES || k == NGSQC_C_YX_VALID;
+			s.c[(size_t)k] = max_like ? std::max(s.c[(size_t)k], c[(size_t)k]) : s.c[(size_t)k] + c[(size_t)k];
+		}
+		for (int k = 0; k < 101; ++k) s.gc_reads[(size_t)k] += g[(size_t)k];
+		// difference arrays are additive: summed on the host here (a multi-process deployment all-reduces them over RCCL instead)
+		void* dptr = nullptr; int64_t slots = 0;
+		checkShard(sh[(size_t)i], ngsqc_depth_device(sh[(size_t)i], &dptr, &slots));
+		if (slots > 0)
+		{
+			diff.resize((size_t)slots);
+			checkShard(sh[(size_t)i], ngsqc_depth_diff_copy(sh[(size_t)i], diff.data(), slots));
+			if (diff_sum.empty()) diff_sum = diff; else for (int64_t k = 0; k < slots; ++k) diff_sum[(size_t)k] += diff[(size_t)k];
+		}
+	}
+	if (!diff_sum.empty()) checkShard(sh[0], ngsqc_depth_diff_set(sh[0], diff_sum.data(), (int64_t)diff_sum.size()));
+	checkShard(sh[0], ngsqc_depth_finalize(sh[0]));
 	return s;
 }
 
@@ -210,7 +264,7 @@ QCCollection Statistics::mapping(const BedFile& bed_file, const std::string& bam
 	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
 	long long roi_bases = bed_file.baseCount();
 	GcPrep gc(bed_file, fa.get());
-	BamReader reader(bam_file, ref_file);
+	BamReader reader(bam_file, ref_file, true);
 	// ROI lines on chromosomes the BAM does not know never match a read in the reference (ChromosomalIndex lookup by name)
 	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
 	Scan s = runScan(reader, NGSQC_MODE_ROI, min_mapq, regions, &gc, &bed_file);
@@ -323,7 +377,7 @@ double nBases(const BamReader& reader, FastaFileIndex* fa) { double n = 0; if (f
 // ---------------------------------------------------------------- Statistics::mapping(bam, ref, min_mapq)   Statistics.cpp:805-988
 QCCollection Statistics::mapping(const std::string& bam_file, const std::string& ref_file, int min_mapq)
 {
-	BamReader reader(bam_file, ref_file);
+	BamReader reader(bam_file, ref_file, true);
 	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
 	Scan s = runScan(reader, NGSQC_MODE_NOROI, min_mapq, {}, nullptr, nullptr);
 	QCCollection output;
@@ -341,7 +395,7 @@ QCCollection Statistics::mapping(const std::string& bam_file, const std::string&
 // ---------------------------------------------------------------- Statistics::mapping_wgs   Statistics.cpp:990-1359
 QCCollection Statistics::mapping_wgs(const std::string& bam_file, const std::string& bedpath, int min_mapq, const std::string& ref_file)
 {
-	BamReader reader(bam_file, ref_file);
+	BamReader reader(bam_file, ref_file, true);
 	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
 	bool roi_available = false; BedFile roi;
 	if (!bedpath.empty())

@@ -11,19 +11,22 @@ namespace ngsbits {
 class BamReader
 {
 public:
-	BamReader(const std::string& bam_file, const std::string& ref_genome = "");
+	// allow_shards: honour NGSQC_SHARDS=N (an extension): the BAM is split into N BGZF-member ranges, one handle each, spread
+	// round-robin over the visible GPUs; only the mapping-QC scans (runScan) know how to combine shards.
+	BamReader(const std::string& bam_file, const std::string& ref_genome = "", bool allow_shards = false);
 	~BamReader();
 	BamReader(const BamReader&) = delete; BamReader& operator=(const BamReader&) = delete;
 	const std::vector<Chromosome>& chromosomes() const { return chrs_; }
 	int chromosomeID(const Chromosome& chr) const;              // tid or -1
 	int chromosomeSize(const Chromosome& chr) const;
 	double genomeSize(bool include_special_chromosomes) const; // BamReader.cpp:789-800
-	ngsqc_handle* handle() const { return h_; }
+	ngsqc_handle* handle() const { return h_; }                 // shard 0 when sharded (holds the combined depth array after a scan)
+	const std::vector<ngsqc_handle*>& shards() const { return shards_; }   // all shard handles in file order (size 1 when not sharded)
 	const std::string& fileName() const { return bam_file_; }
 	void requireIndex() const;                                  // setRegion's "Could not load index" (BamReader.cpp:742-746)
 	void check(int rc) const;
 private:
-	std::string bam_file_; ngsqc_handle* h_ = nullptr; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
+	std::string bam_file_; ngsqc_handle* h_ = nullptr; std::vector<ngsqc_handle*> shards_; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
 };
 
 class Statistics

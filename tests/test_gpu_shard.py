@@ -129,3 +129,41 @@ def test_carries_cross_shards(tmp_path, first_full, first_paired):
     bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
     _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4)
     _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3)
+
+
+_ALIAS = r"""
+import importlib, sys
+import numpy as np
+import torch
+torch.cuda.init()                      # torch's HIP runtime first (as in bench.py), then the library
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+ngsqc = importlib.import_module("ngs-bits_amd")
+dist_mod = importlib.import_module("ngs-bits_amd.dist")
+import hostprep as H
+h = ngsqc.Handle(path=sys.argv[2], shard=(0, 1))
+regs, _ = H.bed_regions(sys.argv[3], h.refs, 3)
+h.scan_mapping_partial(ngsqc.MODE_WGS, regions=regs, nonspecial=H.nonspecial(h.refs))
+ptr, n = h.depth_device()
+before = h.depth_diff().copy()
+t = torch.as_tensor(dist_mod._DeviceInt32(ptr, n), device="cuda:0")
+assert t.dtype == torch.int32 and t.numel() == n and t.data_ptr() == ptr, (t.dtype, t.numel(), n, t.data_ptr(), ptr)
+assert int(t.to(torch.int64).sum().item()) == int(before.astype(np.int64).sum())
+t += 3                                 # what an in-place all-reduce does
+torch.cuda.synchronize()
+assert np.array_equal(h.depth_diff(), before + 3)
+h.close()
+print("alias ok")
+"""
+
+
+def test_difference_array_is_aliased_for_the_collective(tmp_path):
+    """The RCCL all-reduce runs IN PLACE on the library's device memory: the torch view must alias it (no copy).
+    (Own process: torch has to bring up its HIP runtime before the library does, as in bench.py.)"""
+    import subprocess
+    import sys
+    path = str(tmp_path / "alias.bam")
+    G.write(path, n_reads=50_000, seed=31, start_pos=15_900_000)
+    script = tmp_path / "alias.py"
+    script.write_text(_ALIAS)
+    p = subprocess.run([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, OMIM], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "alias ok" in p.stdout, p.stderr[-3000:]

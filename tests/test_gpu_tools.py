@@ -16,8 +16,8 @@ BIN = os.path.join(ROOT, "ngs-bits_amd", "bin")
 STRIP = re.compile(r"creation |<binary>|AT dropout|GC dropout|SNV allele frequency deviation")
 
 
-def run(tool, *args):
-    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True)
+def run(tool, *args, env=None):
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr
     return p
 
@@ -43,6 +43,25 @@ def test_mappingqc_matches_reference_expected_output(tmp_path, args, expected):
     got, exp = _lines(out), _lines(os.path.join(GO, expected))
     if expected.endswith(".txt"):
         exp = [ln for ln in exp if ln]  # the TXT file ends with the (empty) contamination block
+        got = [ln for ln in got if ln]
+    assert got == exp
+
+
+@pytest.mark.parametrize("shards", ["2", "5"])
+@pytest.mark.parametrize("args,expected", [
+    (["-in", "MappingQC_in2.bam", "-roi", "MappingQC_in2.bed", "-build", "hg19", "-txt"], "MappingQC_test02_out.txt"),
+    (["-in", "MappingQC_in1.bam", "-wgs", "-build", "hg19"], "MappingQC_test05_out.qcML"),
+    (["-in", "MappingQC_in3.bam", "-rna", "-build", "hg19"], "MappingQC_test07_out.qcML"),
+])
+def test_mappingqc_sharded_over_several_handles(tmp_path, args, expected, shards):
+    """NGSQC_SHARDS=N: the tool splits the BAM into N BGZF-member ranges (one handle each, concurrent local scans, the
+    shard protocol of include/ngsqc.h) — the output must stay byte-identical to the reference's expected files."""
+    a = [os.path.join(GI, x) if x.endswith((".bam", ".bed")) else x for x in args]
+    out = str(tmp_path / expected)
+    run("MappingQC", *a, "-out", out, "-no_ref", env={"NGSQC_SHARDS": shards})
+    got, exp = _lines(out), _lines(os.path.join(GO, expected))
+    if expected.endswith(".txt"):
+        exp = [ln for ln in exp if ln]
         got = [ln for ln in got if ln]
     assert got == exp
 
