@@ -1,28 +1,53 @@
-"""Turns the rocprofv3 sqlite outputs under gpurun_out/ into the text summaries committed under profiles/."""
-import json
+"""Turns the rocprofv3 sqlite outputs under gpurun_out/ into the text summaries committed under profiles/.
+
+  rocprofv3 --kernel-trace --stats -d gpurun_out/r1_trace -o t -- <cmd>
+  rocprofv3 --pmc FETCH_SIZE        -d gpurun_out/r1_fetch -o f -- <cmd>      (separate passes, no trace domains)
+  rocprofv3 --pmc WRITE_SIZE        -d gpurun_out/r1_write -o w -- <cmd>
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d gpurun_out/r1_sq -o s -- <cmd>
+  <cmd> = python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+"""
+import os
 import sqlite3
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+CMD = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)"
 out = open(f"profiles/{tag}_kernel_stats.txt", "w")
 c = sqlite3.connect("gpurun_out/r1_trace/t_results.db")
-out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)\n")
+out.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}\n")
 out.write("# name\tcalls\ttotal_ms\tavg_ms\tpercent\n")
 for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     out.write(f"{r[0]}\t{r[1]}\t{r[2]/1e3:.3f}\t{r[3]/1e3:.4f}\t{r[4]:.2f}\n")
 out.close()
 pm = open(f"profiles/{tag}_hbm_traffic_pmc.txt", "w")
-pm.write("# separate passes: rocprofv3 --pmc FETCH_SIZE -- <cmd> ; rocprofv3 --pmc WRITE_SIZE -- <cmd>  (same command as above)\n")
+pm.write(f"# separate passes: rocprofv3 --pmc FETCH_SIZE -- <cmd> ; rocprofv3 --pmc WRITE_SIZE -- <cmd> ; <cmd> = {CMD}\n")
 pm.write("# per-kernel SUM over dispatches / number of dispatches = per-launch value; rocprofv3 reports these in KiB.\n")
 pm.write("# gfx950 note (MI355X_MICROARCH.md HBM section): FETCH_SIZE counts 64 B per 128 B request for wide coalesced streams (x2 correction);\n")
 pm.write("# other access widths (the scan kernel's sparse 4-byte gathers, the inflate kernels' byte traffic) are uncalibrated.\n")
-pm.write("# kernel\tcounter\tdispatches\tsum\tper_launch\n")
-res = {}
+pm.write("# kernel\tcounter\tdispatches\tsum_KiB\tper_launch\n")
 for db, ctr in (("gpurun_out/r1_fetch/f_results.db", "FETCH_SIZE"), ("gpurun_out/r1_write/w_results.db", "WRITE_SIZE")):
+    if not os.path.exists(db):
+        continue
     c = sqlite3.connect(db)
     for r in c.execute("select kernel_name, count(*), sum(value), max(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
-        pm.write(f"{r[0][:70]}\t{ctr}\t{r[1]}\t{r[2]:.1f}\tmax_launch={r[3]:.1f}\n")
-        res[(r[0][:30], ctr)] = (r[1], r[2], r[3])
+        pm.write(f"{r[0][:70]}\t{ctr}\t{r[1]}\t{r[2]:.1f}\tavg_launch={r[2]/r[1]:.1f}\n")
 pm.close()
-print(open(f"profiles/{tag}_kernel_stats.txt").read()[:1500])
+if os.path.exists("gpurun_out/r1_sq/s_results.db"):
+    sq = open(f"profiles/{tag}_sq_counters.txt", "w")
+    sq.write(f"# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -- {CMD}\n")
+    sq.write("# SQ_INSTS_* count wave-level instructions, the *_CYCLES counters tick in quad-cycles (one wave64 VALU instruction = one tick);\n")
+    sq.write("# the counters see about 3/4 of the waves of a dispatch on this part (SQ_WAVES vs the launched grid), ratios are unaffected.\n")
+    sq.write("# derived: valu_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's lifetime spent issuing VALU)\n")
+    sq.write("# kernel\tcounter\tdispatches\tsum_over_dispatches\n")
+    c = sqlite3.connect("gpurun_out/r1_sq/s_results.db")
+    acc = {}
+    for k, cn, n, s in c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        sq.write(f"{k[:60]}\t{cn}\t{n}\t{s:.4e}\n")
+        acc.setdefault(k[:60], {})[cn] = s
+    sq.write("# kernel\tvalu_issue_share\tany_issue_share\tvalu_per_salu\n")
+    for k, v in acc.items():
+        if v.get("SQ_WAVE_CYCLES"):
+            sq.write(f"{k}\t{v.get('SQ_ACTIVE_INST_VALU', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_ACTIVE_INST_ANY', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_INSTS_VALU', 0)/max(v.get('SQ_INSTS_SALU', 1), 1):.2f}\n")
+    sq.close()
+print(open(f"profiles/{tag}_kernel_stats.txt").read()[:1800])
 print(open(f"profiles/{tag}_hbm_traffic_pmc.txt").read()[:3000])
