@@ -1,6 +1,6 @@
 // MappingQC — drop-in for src/MappingQC/main.cpp:21-188 on the MI355X path: same flags, defaults, checks and output
-// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): the contamination check (-no_cont is implied),
-// -somatic_custom_bed and -read_qc; they are accepted and reported as not implemented instead of silently ignored.
+// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): the contamination check (-no_cont is implied) and
+// -read_qc (accepted and reported as not implemented instead of silently ignored).
 #include "Statistics.hpp"
 using namespace ngsbits;
 
@@ -42,7 +42,6 @@ public:
 		if (parameters_set != 1) NB_THROW(CommandLineParsingException, "You have to use exactly one of the parameters 'roi', 'wgs', or 'rna' !");
 		if (cfdna && roi_file == "") NB_THROW(CommandLineParsingException, "The flag 'cfdna' can only be used with parameter 'roi'!");
 		if (getOutfile("read_qc") != "") NB_THROW(NotImplementedException, "'-read_qc' is not available in the MI355X build yet (StatisticsReads is a 'next' row of the hot-path scope).");
-		if (getInfile("somatic_custom_bed") != "") NB_THROW(NotImplementedException, "'-somatic_custom_bed' is not available in the MI355X build yet (somaticCustomDepth is a 'next' row of the hot-path scope).");
 
 		std::vector<std::string> parameters; QCCollection metrics;
 		if (wgs)
@@ -62,6 +61,14 @@ public:
 		}
 		// sample contamination (Statistics::contamination, main.cpp:146-151): not on the GPU path yet -> behaves like -no_cont
 		QCCollection metrics_cont;
+		// somatic sub-panel depth (main.cpp:153-165)
+		std::string somatic_custom_roi_file = getInfile("somatic_custom_bed");
+		if (somatic_custom_roi_file != "")
+		{
+			BedFile custom_bed; custom_bed.load(somatic_custom_roi_file); custom_bed.merge();
+			metrics.insert(Statistics::somaticCustomDepth(custom_bed, in, ref_file, min_mapq));
+			parameters.push_back("-somatic_custom_bed " + somatic_custom_roi_file);
+		}
 		if (getFlag("single_end")) parameters.push_back("-single_end");
 		std::string out = getOutfile("out");
 		if (getFlag("txt"))

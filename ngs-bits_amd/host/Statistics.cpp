@@ -458,6 +458,52 @@ std::vector<ngsqc_region> unionRegions(const BedFile& bed, const BamReader& read
 }
 }
 
+// Statistics.cpp:1574-1710. The reference keeps a QMap<position, depth> per chromosome; the read filter (no secondary /
+// supplementary / unmapped / duplicate, MAPQ >= min_mapq) and the whole-reference-span increment are those of the coverage
+// tools, so the GPU side is ngsqc_scan_depth on the (merged) sub-panel: bases_usable = sum of the per-base depths, the
+// histogram comes from the exact per-depth counts of K6.
+QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::string& bam_file, const std::string& ref_file, int min_mapq)
+{
+	if (!bed_file.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for depth details statistics!");   // :1577-1580
+	long long roi_bases = bed_file.baseCount();
+	BamReader reader(bam_file, ref_file);
+	long long bases_usable = 0;
+	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
+	if (!regions.empty())
+	{
+		ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
+		reader.check(ngsqc_scan_depth(reader.handle(), &p));
+		std::vector<int64_t> sums(regions.size(), 0);
+		reader.check(ngsqc_region_sums(reader.handle(), regions.data(), (int64_t)regions.size(), sums.data()));
+		for (int64_t v : sums) bases_usable += v;
+	}
+	double avg_depth = (double)bases_usable / roi_bases;
+	int hist_max = 599, hist_step = 5;                                                                  // :1657-1670
+	if (avg_depth > 200) { hist_max += 400; hist_step += 5; }
+	if (avg_depth > 500) hist_max += 500;
+	if (avg_depth > 1000) hist_max += 1000;
+	Histogram depth_dist(0, hist_max, hist_step);
+	long long in_bam = 0;
+	if (!regions.empty())
+	{
+		long long covered = 0;
+		depth_dist = depthHistogram(reader, hist_max, hist_step, 0, covered);
+		for (auto& r : regions) in_bam += r.end - r.start + 1;
+	}
+	if (roi_bases > in_bam) depth_dist.inc(0, true, (double)(roi_bases - in_bam));   // positions on chromosomes the BAM does not know stay at depth 0
+	QCCollection output;
+	addQcValue(output, "QC:2000097", "somatic custom target region read depth", avg_depth);
+	const int depths[8] = {10, 20, 30, 50, 60, 100, 200, 500};
+	const char* accessions[8] = {"QC:2000090", "QC:2000091", "QC:2000092", "QC:2000093", "QC:2000098", "QC:2000094", "QC:2000095", "QC:2000096"};
+	for (int i = 0; i < 8; ++i)
+	{
+		double cov_bases = 0.0;
+		for (int bin = depth_dist.binIndex(depths[i]); bin < depth_dist.binCount(); ++bin) cov_bases += depth_dist.binValue(bin);
+		addQcValue(output, accessions[i], "somatic custom target " + std::to_string(depths[i]) + "x percentage", 100.0 * cov_bases / roi_bases);
+	}
+	return output;
+}
+
 void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");

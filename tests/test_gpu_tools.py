@@ -33,10 +33,11 @@ def _lines(path):
     (["-in", "MappingQC_in1.bam", "-wgs", "-build", "hg19"], "MappingQC_test05_out.qcML"),
     (["-in", "MappingQC_in3.bam", "-rna", "-build", "hg19"], "MappingQC_test07_out.qcML"),
     (["-in", "MappingQC_in4.bam", "-roi", "MappingQC_in3.bed", "-cfdna", "-build", "hg19"], "MappingQC_test08_out.qcML"),
+    (["-in", "MappingQC_in2.bam", "-somatic_custom_bed", "MappingQC_in2_custom_subpanel.bed", "-roi", "MappingQC_in2.bed", "-build", "hg19"], "MappingQC_test09_out.qcML"),
     (["-in", "MappingQC_in5.bam", "-wgs", "-build", "hg38"], "MappingQC_test10_out.qcML"),
 ])
 def test_mappingqc_matches_reference_expected_output(tmp_path, args, expected):
-    """src/tools-TEST/MappingQC_Test.cpp test02/03/04/05/07/08/10, byte-compared after the reference's own REMOVE_LINES."""
+    """src/tools-TEST/MappingQC_Test.cpp test02/03/04/05/07/08/09/10, byte-compared after the reference's own REMOVE_LINES."""
     a = [os.path.join(GI, x) if x.endswith((".bam", ".bed")) else x for x in args]
     out = str(tmp_path / expected)
     run("MappingQC", *a, "-out", out, "-no_ref")
