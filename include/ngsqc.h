@@ -128,6 +128,16 @@ typedef struct ngsqc_run { int64_t line; int32_t start; int32_t end; } ngsqc_run
 int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int32_t cutoff, int32_t is_high,
                        int32_t saturate254, ngsqc_run* runs, int64_t cap, int64_t* n_runs);
 
+/* ---- site pileup: BamReader::getPileup (src/cppNGS/BamReader.cpp:809-885; SNP counts, indel_window = -1,
+ * count_fragments = false) for a table of known sites, e.g. the common SNPs of Statistics::contamination
+ * (Statistics.cpp:2333-2386). Sites: (tid, pos) with start == end == pos (1-based), sorted by tid then pos, each tid
+ * contiguous. counts[8*i + 0..5] = A, C, G, T, N, deletion at site i after the reference's filters (not secondary /
+ * supplementary / duplicate / unmapped, proper pair unless include_not_properly_paired, MAPQ >= min_mapq, base quality
+ * >= min_baseq; a deleted base passes with quality 255); [6] = bases Pileup::inc throws on (IUPAC codes other than
+ * ACGTN), [7] = reads whose CIGAR does not reach the site (the reference throws "Could not find position"). */
+int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_sites, int32_t min_mapq, int32_t min_baseq,
+                      int32_t include_not_properly_paired, int64_t* counts);
+
 /* ---- one BAM sharded over several handles / GPUs --------------------------------------------------
  * The reference reads a BAM with one sequential reader (BamReader::getNextAlignment, src/cppNGS/BamReader.h:386-398); its
  * loop bodies (Statistics.cpp:416-574, :830-917, :1068-1183) are independent per record except for two carries: the

@@ -111,6 +111,7 @@ def lib():
         L.ngsqc_lowhigh_runs.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, i64, C.POINTER(i64)]
         L.ngsqc_get_timings.restype = i32; L.ngsqc_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ngsqc_version.restype = cp
+        L.ngsqc_site_pileup.restype = i32; L.ngsqc_site_pileup.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp]
         L.ngsqc_open_shard.restype = i32; L.ngsqc_open_shard.argtypes = [cp, i32, i32, i32, C.POINTER(vp)]
         L.ngsqc_open_memory_shard.restype = i32; L.ngsqc_open_memory_shard.argtypes = [vp, C.c_size_t, i32, i32, i32, C.POINTER(vp)]
         L.ngsqc_scan_mapping_partial.restype = i32; L.ngsqc_scan_mapping_partial.argtypes = [vp, C.POINTER(MappingParams), C.POINTER(ShardSummary)]
@@ -129,7 +130,7 @@ EXPORTS = [
     "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
     "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
-    "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
+    "ngsqc_site_pileup", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
 ]
 
@@ -240,6 +241,13 @@ class Handle:
         gc = np.zeros(101, dtype=np.float64)
         self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
         return counters, gc
+
+    def site_pileup(self, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):
+        """sites: list of (tid, pos) sorted by tid then pos. Returns int64[n, 8]: A, C, G, T, N, deletion, other-letter, not-found."""
+        ra = _regions_array([(t, p, p) for t, p in sites])
+        out = np.zeros((max(len(sites), 1), 8), dtype=np.int64)
+        self._chk(lib().ngsqc_site_pileup(self.h, C.cast(ra, C.c_void_p), len(sites), min_mapq, min_baseq, int(include_not_properly_paired), out.ctypes.data))
+        return out[:len(sites)]
 
     # ---- one BAM sharded over several handles (include/ngsqc.h, "sharded" section) ----
     def scan_mapping_partial(self, mode, **kw):

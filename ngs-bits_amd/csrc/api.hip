@@ -932,6 +932,38 @@ int ngsqc_plan_shard_fix(const ngsqc_shard_summary* all, int n_shards, int shard
 	return NGSQC_OK;
 }
 
+int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_sites, int32_t min_mapq, int32_t min_baseq, int32_t include_not_properly_paired, int64_t* counts)
+{
+	return guarded(h, [&] {
+		if (n_sites < 0 || (n_sites && (!sites || !counts))) throw ArgError("null argument");
+		if (n_sites == 0) return;
+		const int n_ref = (int)h->ref_names.size();
+		std::vector<int32_t> pos((size_t)n_sites), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
+		std::vector<uint8_t> seen((size_t)std::max(n_ref, 1), 0);
+		for (int64_t i = 0; i < n_sites; ++i)
+		{
+			const ngsqc_region& r = sites[i];
+			if (r.tid < 0 || r.tid >= n_ref) throw ArgError("site with invalid reference id");
+			if (r.start < 1 || r.end != r.start) throw ArgError("a site is a single 1-based position (start == end)");
+			if (i > 0 && sites[i - 1].tid == r.tid) { if (sites[i - 1].start > r.start) throw ArgError("sites must be sorted by position within a reference"); }
+			else { if (seen[(size_t)r.tid]) throw ArgError("sites of one reference must be contiguous"); seen[(size_t)r.tid] = 1; tf[(size_t)r.tid] = (int32_t)i; }
+			tl[(size_t)r.tid] = (int32_t)i + 1; pos[(size_t)i] = r.start;
+		}
+		DevBuf<int32_t> d_pos, d_tf, d_tl; d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream);
+		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_sites * 8);
+		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_sites * 8 * sizeof(uint32_t), h->stream));
+		for_each_tile(h, [&](int) {
+			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->stream);
+			HIPCHK(hipStreamSynchronize(h->stream));
+			return true;
+		});
+		std::vector<uint32_t> out((size_t)n_sites * 8);
+		HIPCHK(hipMemcpyAsync(out.data(), d_cnt.p, out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		for (size_t i = 0; i < out.size(); ++i) counts[i] = (int64_t)out[i];
+	});
+}
+
 int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p)
 {
 	return guarded(h, [&] {

@@ -75,6 +75,10 @@ void launch_scan(const ScanParams& p, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, int32_t gmax, hipStream_t s);
 
+// site pileup (BamReader::getPileup SNP counts for a table of sites; counts = u32[n_sites][8])
+void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
+                   int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s);
+
 // ---- K6 ----
 void launch_depth_mark_spare(int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, hipStream_t s);
 void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int64_t half, unsigned long long* d_hist, unsigned long long* d_cov, hipStream_t s);

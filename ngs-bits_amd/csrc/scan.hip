@@ -13,6 +13,7 @@
 // the reference increments the whole reference span [start,end] of a read (RegionDepth::incrementRegion,
 // Statistics.cpp:45-53), which is exactly a prefix sum over these differences. All arithmetic is integer.
 #include "common.h"
+#include <algorithm>
 
 namespace ngsqc {
 
@@ -514,6 +515,94 @@ void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paire
 {
 	if (upto_max <= 0 && upto_paired <= 0) return;
 	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, gmax);
+}
+
+// ---- site pileup: BamReader::getPileup (src/cppNGS/BamReader.cpp:809-885, SNP counts) for a table of known sites ----
+// The reference runs one indexed query per site (10^5 for Statistics::contamination, Statistics.cpp:2333-2386) and extracts
+// the base of every overlapping read with BamAlignment::extractBaseByCIGAR (BamReader.cpp:307-374). Here every record
+// looks up the sites inside its reference span (binary search in the per-tid sorted site table: a short read meets a
+// site with probability ~0.5 %) and walks its CIGAR once per hit. counts[site][0..5] = A, C, G, T, N, deletion;
+// [6] = a base Pileup::inc would throw on (other IUPAC codes), [7] = a position the CIGAR walk could not find.
+// (single exit, no early returns inside the loops: the straightforward version with returns was miscompiled by hipcc 7.2 -
+// three out of four reads came back as "nothing to count")
+__device__ static int pileup_base(const RecView& r, int pos, int& qual_out)   // 0..4 = A,C,G,T,N; 5 = deletion; 6 = other letter; -1 = nothing to count; -2 = not found
+{
+	uint32_t other_ops = 0;                  // cigarIsOnlyInsertion looks at the CORE cigar (BamReader.cpp:90-100)
+	for (uint32_t k = 0; k < r.n_cigar_raw; ++k) { const uint32_t op = ld32(r.core + 32 + r.l_name + 4ull * k) & 15u; other_ops |= (op != 1u && op != 4u) ? 1u : 0u; }
+	int res = other_ops ? -2 : -1, q = -1;
+	bool done = other_ops == 0;
+	int read_pos = 0, genome_pos = r.pos;   // start() - 1
+	for (uint32_t k = 0; k < r.n_cigar; ++k)
+	{
+		if (!done)
+		{
+			const uint32_t c = ld32(r.cigar + 4ull * k); const uint32_t op = c & 15u; const int len = (int)(c >> 4);
+			const bool ref_op = op == 0 || op == 2 || op == 3 || op == 7 || op == 8, read_op = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+			genome_pos += ref_op ? len : 0; read_pos += read_op ? len : 0;
+			if (op == 2 && genome_pos >= pos) { res = 5; q = 255; done = true; }
+			else if (op == 3 && genome_pos >= pos) { res = -1; done = true; }
+			else if (op == 4 && read_pos >= r.l_seq) { res = -1; done = true; }
+			else if (op == 6 || op > 8) { res = -2; done = true; }
+			else if (genome_pos >= pos)
+			{
+				const int ap = read_pos - (genome_pos + 1 - pos);
+				const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
+				const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15;
+				q = rec_qual(r)[ap];
+				res = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
+				done = true;
+			}
+		}
+	}
+	qual_out = q;
+	return res;
+}
+
+__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, long long n_rec, int n_ref,
+                                                     const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_first, const int32_t* __restrict__ tid_last,
+                                                     int min_mapq, int min_baseq, int include_npp, uint32_t* __restrict__ counts)
+{
+	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < n_rec; li += (long long)gridDim.x * blockDim.x)
+	{
+		RecView r = load_rec(infl, recoff[li]);
+		const uint32_t flag = r.flag;
+		if (flag & (0x100 | 0x800 | 0x400 | 0x4)) continue;                 // BamReader.cpp:830
+		if (!(flag & 0x2) && !include_npp) continue;                         // :831
+		if ((int)r.mapq < min_mapq) continue;                                // :836
+		if (r.tid < 0 || r.tid >= n_ref) continue;
+		const int first = tid_first[r.tid], last = tid_last[r.tid];
+		if (first >= last) continue;
+		// CG:B,I long CIGAR (htslib bam_tag2cigar)
+		if (r.n_cigar_raw > 0 && r.pos >= 0)
+		{
+			const uint32_t c0 = ld32(r.cigar);
+			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq)
+			{
+				const uint8_t* t = aux_find(rec_aux(r), rec_end(r), 'C', 'G');
+				if (t && t[0] == 'B' && t[1] == 'I') { const uint32_t n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) { r.cigar = t + 6; r.n_cigar = n; } }
+			}
+		}
+		long long ref_len = 0;
+		for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
+		if (ref_len == 0) ref_len = 1;                                        // bam_endpos
+		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
+		int a = first, b = last;                                              // first site with pos >= start1
+		while (a < b) { const int m = (a + b) >> 1; if (site_pos[m] < start1) a = m + 1; else b = m; }
+		for (int i = a; i < last && site_pos[i] <= end1; ++i)
+		{
+			int q; const int base = pileup_base(r, site_pos[i], q);
+			if (base == -2) atomicAdd(&counts[8ull * i + 7], 1u);
+			else if (base >= 0 && q >= min_baseq) atomicAdd(&counts[8ull * i + base], 1u);
+		}
+	}
+}
+
+void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
+                   int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s)
+{
+	if (n_rec <= 0) return;
+	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 32);
+	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, min_mapq, min_baseq, include_npp, counts);
 }
 
 } // namespace ngsqc

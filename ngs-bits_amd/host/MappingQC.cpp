@@ -1,6 +1,6 @@
 // MappingQC — drop-in for src/MappingQC/main.cpp:21-188 on the MI355X path: same flags, defaults, checks and output
-// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): the contamination check (-no_cont is implied) and
-// -read_qc (accepted and reported as not implemented instead of silently ignored).
+// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): -read_qc (accepted and reported as not implemented
+// instead of silently ignored).
 #include "Statistics.hpp"
 using namespace ngsbits;
 
@@ -59,8 +59,9 @@ public:
 			parameters.push_back("-roi"); parameters.push_back(fileName(roi_file));
 			if (cfdna) parameters.push_back("-cfdna");
 		}
-		// sample contamination (Statistics::contamination, main.cpp:146-151): not on the GPU path yet -> behaves like -no_cont
+		// sample contamination (main.cpp:143-151)
 		QCCollection metrics_cont;
+		if (!getFlag("no_cont") && getEnum("build") != "non_human") metrics_cont = Statistics::contamination(getEnum("build"), in, ref_file, roi_file, getFlag("debug"), 20, 50, getFlag("single_end"));
 		// somatic sub-panel depth (main.cpp:153-165)
 		std::string somatic_custom_roi_file = getInfile("somatic_custom_bed");
 		if (somatic_custom_roi_file != "")

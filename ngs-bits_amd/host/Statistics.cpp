@@ -504,6 +504,89 @@ QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::
 	return output;
 }
 
+// Statistics.cpp:2333-2386 + NGSHelper::getKnownVariants (NGSHelper.cpp:22-94) + BamReader::getPileup (BamReader.cpp:809-885).
+// The reference runs one indexed pileup query per known SNP; here all sites go to the GPU in one table (ngsqc_site_pileup).
+QCCollection Statistics::contamination(const std::string& build, const std::string& bam, const std::string& ref_file, const std::string& roi_file, bool debug, int min_cov, int min_snps, bool include_not_properly_paired)
+{
+	BamReader reader(bam, ref_file);
+	// target region: variants whose [pos, pos + len(ref) - 1] overlaps a line are kept (VcfFile::setRegion / VcfFile.cpp:131-136)
+	std::map<int, std::vector<std::pair<int, int>>> roi_by_chr; std::map<int, std::vector<int>> roi_pmax;
+	if (roi_file != "")
+	{
+		BedFile roi; roi.load(roi_file); roi.sort();
+		for (long long i = 0; i < roi.count(); ++i) roi_by_chr[roi[i].chr().num()].push_back({roi[i].start(), roi[i].end()});
+		for (auto& kv : roi_by_chr) { std::vector<int>& pm = roi_pmax[kv.first]; int m = 0; for (auto& se : kv.second) { m = std::max(m, se.second); pm.push_back(m); } }
+	}
+	auto in_roi = [&](const Chromosome& chr, int s, int e) {
+		auto it = roi_by_chr.find(chr.num()); if (it == roi_by_chr.end()) return false;
+		const auto& v = it->second; const auto& pm = roi_pmax[chr.num()];
+		size_t hi = (size_t)(std::upper_bound(v.begin(), v.end(), std::make_pair(e, std::numeric_limits<int>::max())) - v.begin());   // lines with start <= e
+		return hi > 0 && pm[hi - 1] >= s;
+	};
+	// known variants: SNVs with 0.2 <= AF <= 0.8 (getKnownVariants(build, true, [roi,] 0.2, 0.8))
+	std::string res = resourceDir() + "/" + build + "_snps.tsv";
+	std::ifstream f(res);
+	if (!f) NB_THROW(ProgrammingException, "Unsupported genome build '" + build + "'!");   // NGSHelper.cpp copyFromResource
+	struct Snp { Chromosome chr; int pos; char ref, alt; };
+	std::vector<Snp> snps; std::string line;
+	while (std::getline(f, line))
+	{
+		std::vector<std::string> c = split(line, '\t');
+		if (c.size() < 5) continue;
+		const int pos = atoi(c[1].c_str());
+		Chromosome chr(c[0]);
+		if (roi_file != "" && !in_roi(chr, pos, pos + (int)c[2].size() - 1)) continue;
+		char* end = nullptr; double af = c[4].empty() ? 0.0 : strtod(c[4].c_str(), &end); if (c[4].empty() || *end) af = 0.0;   // QByteArray::toDouble
+		if (!(af >= 0.2 && af <= 0.8)) continue;
+		std::string alt0 = c[3].substr(0, c[3].find(','));
+		for (auto& ch : alt0) ch = (char)toupper(ch);
+		if (!(alt0.size() == 1 && c[2].size() == 1 && alt0 != "-" && c[2] != "-")) continue;                                    // VcfLine::isSNV
+		snps.push_back(Snp{chr, pos, c[2][0], alt0[0]});
+	}
+	// site table for the GPU: (tid, pos), grouped by tid in position order
+	std::vector<ngsqc_region> sites; std::vector<size_t> order;
+	if (!snps.empty()) reader.requireIndex();                                                                                  // getPileup -> setRegion (BamReader.cpp:740-746)
+	std::vector<int> tids(snps.size());
+	for (size_t i = 0; i < snps.size(); ++i)
+	{
+		tids[i] = reader.chromosomeID(snps[i].chr);
+		if (tids[i] < 0) NB_THROW(FileAccessException, "Could not find chromosome '" + snps[i].chr.str() + "' in BAM/CRAM file " + bam);   // BamReader.cpp:750-754
+		order.push_back(i);
+	}
+	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tids[a] != tids[b] ? tids[a] < tids[b] : snps[a].pos < snps[b].pos; });
+	for (size_t k : order) sites.push_back(ngsqc_region{tids[k], snps[k].pos, snps[k].pos});
+	std::vector<int64_t> counts(sites.size() * 8, 0);
+	if (!sites.empty()) reader.check(ngsqc_site_pileup(reader.handle(), sites.data(), (int64_t)sites.size(), 1, 13, include_not_properly_paired ? 1 : 0, counts.data()));
+	Histogram hist(0, 1, 0.05);
+	int passed = 0; double passed_depth_sum = 0.0;
+	std::vector<size_t> slot(snps.size()); for (size_t j = 0; j < order.size(); ++j) slot[order[j]] = j;
+	for (size_t i = 0; i < snps.size(); ++i)                                                                                   // file order, as the reference
+	{
+		const int64_t* c = &counts[slot[i] * 8];
+		if (c[6]) NB_THROW(ArgumentException, "Unknown base in pileup!");                                                      // Pileup.cpp:31
+		if (c[7]) NB_THROW(Exception, "Could not find position " + std::to_string(snps[i].pos) + " in read!");                 // BamReader.cpp:366
+		const long long depth = c[0] + c[1] + c[2] + c[3];
+		if (depth < min_cov) continue;
+		auto cnt = [&](char b) -> double { b = (char)toupper(b); return b == 'A' ? (double)c[0] : b == 'C' ? (double)c[1] : b == 'G' ? (double)c[2] : b == 'T' ? (double)c[3] : b == 'N' ? (double)c[4] : -1.0; };
+		const double w = cnt(snps[i].ref), m = cnt(snps[i].alt);
+		if (w < 0) NB_THROW(ArgumentException, std::string("Unknown wild-type base '") + snps[i].ref + "' in frequency calculation!");
+		if (m < 0) NB_THROW(ArgumentException, std::string("Unknown mutant base '") + snps[i].alt + "' in frequency calculation!");
+		if (w + m == 0) continue;
+		++passed; passed_depth_sum += (double)depth;
+		hist.inc(m / (w + m), false);
+	}
+	if (debug)
+	{
+		printf("Contamination debug output:\n%d of %zu SNPs passed quality filters\nAverage depth of passed SNPs: %s\n", passed, snps.size(), number(passed_depth_sum / passed, 2).c_str());
+	}
+	double off = 0.0;
+	for (int i = 1; i <= 5; ++i) off += hist.binValue(i, true);
+	for (int i = 14; i <= 18; ++i) off += hist.binValue(i, true);
+	QCCollection output;
+	addQcValue(output, "QC:2000051", "SNV allele frequency deviation", passed < min_snps ? std::string("n/a") : number(off, 2));
+	return output;
+}
+
 void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");

@@ -40,6 +40,8 @@ public:
 	static QCCollection mapping_wgs(const std::string& bam_file, const std::string& bedpath, int min_mapq, const std::string& ref_file);
 	// Statistics.cpp:1574  — MappingQC -somatic_custom_bed: depth metrics on a sub-panel
 	static QCCollection somaticCustomDepth(const BedFile& bed_file, const std::string& bam_file, const std::string& ref_file, int min_mapq = 1);
+	// Statistics.cpp:2333  — sample contamination check on the known common SNPs (MappingQC default, switched off by -no_cont)
+	static QCCollection contamination(const std::string& build, const std::string& bam, const std::string& ref_file, const std::string& roi_file = "", bool debug = false, int min_cov = 20, int min_snps = 50, bool include_not_properly_paired = false);
 	// Statistics.cpp:2698 / 2693 / 2806
 	static void avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq = 1, int threads = 1, int decimals = 2, const std::string& ref_file = "", bool random_access = false, bool skip_mismapped = false, bool debug = false);
 	static BedFile lowCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq = 1, int min_baseq = 0, int threads = 1, const std::string& ref_file = "", bool random_access = true, bool debug = false);

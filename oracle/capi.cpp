@@ -180,4 +180,34 @@ int64_t orc_bed_roundtrip(const char* bed, int merge_mode, char* out, int64_t ca
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
 }
 
+// Site pileup (BamReader::getPileup SNP counts) for a list of (tid, pos): out[6*i .. 6*i+5] = A, C, G, T, N, deletion.
+int orc_site_pileup(void* bam, const int32_t* tid, const int32_t* pos, int64_t n, int min_mapq, int include_not_properly_paired, int min_baseq, int64_t* out, char* err, int errlen)
+{
+	try
+	{
+		for (int64_t i=0; i<n; ++i)
+		{
+			SiteCounts c = site_pileup(*(BamFile*)bam, tid[i], pos[i], min_mapq, include_not_properly_paired!=0, min_baseq);
+			out[6*i] = c.a; out[6*i+1] = c.c; out[6*i+2] = c.g; out[6*i+3] = c.t; out[6*i+4] = c.n; out[6*i+5] = c.del;
+		}
+		return 0;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
+}
+// Statistics::contamination on (tid, pos, ref, alt) known SNVs; writes the QC value string ("n/a" or "%.2f") to out.
+int orc_contamination(void* bam, const int32_t* tid, const int32_t* pos, const char* ref, const char* alt, int64_t n, int include_not_properly_paired, char* out, int outlen, char* err, int errlen)
+{
+	try
+	{
+		std::vector<KnownSnp> snps((size_t)n);
+		for (int64_t i=0; i<n; ++i) snps[(size_t)i] = KnownSnp{tid[i], pos[i], ref[i], alt[i]};
+		std::string v = contamination_value(*(BamFile*)bam, snps, include_not_properly_paired!=0);
+		snprintf(out, (size_t)outlen, "%s", v.c_str());
+		return 0;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
+}
+
 } // extern "C"
+
+

@@ -8,6 +8,8 @@
 //   Statistics::avgCoverage + workers  src/cppNGS/Statistics.cpp:2698-2804, WorkerAverageCoverage.cpp:17-173
 //   Statistics::lowOrHighCoverage      src/cppNGS/Statistics.cpp:2534-2657, WorkerLowOrHighCoverage.cpp:18-252
 //   BamAlignment::qualities            src/cppNGS/BamReader.cpp:210-255
+//   BamReader::getPileup + BamAlignment::extractBaseByCIGAR  src/cppNGS/BamReader.cpp:809-885, 307-374 -> site_pileup()
+//   Statistics::contamination          src/cppNGS/Statistics.cpp:2333-2386 -> contamination_value()
 //   FastaFileIndex::seq / n            src/cppNGS/FastaFileIndex.cpp:72-131 ; Sequence::gcContent Sequence.cpp:86-101
 // Written as the straight sequential loops of the reference on purpose: this is the checker, not the product.
 // ============================================================================
@@ -645,6 +647,86 @@ static inline BedFile low_high_coverage(const BedFile& bed, const BamFile& bam, 
 	}
 	output.merge(true, true, true); // Statistics.cpp:2655
 	return output;
+}
+
+// ---------------------------------------------------------------- site pileup (BamReader::getPileup, SNP part only)
+// BamAlignment::extractBaseByCIGAR (BamReader.cpp:307-374). Returns the base character ('~' = nothing to count, '-' =
+// deleted) and the quality of that base (255 for a deletion, -1 for '~'). pos is 1-based.
+static inline std::pair<char,int> extract_base_by_cigar(const Rec& al, int pos)
+{
+	int read_pos = 0, genome_pos = al.start() - 1;
+	{
+		// cigarIsOnlyInsertion (BamReader.cpp:90-100) looks at the CORE cigar ops; an empty CIGAR counts as "only insertions"
+		bool only = true;
+		for (uint32_t i=0; i<al.n_cigar; ++i) { uint32_t op = al.cigarOp(i); if (op!=1 && op!=4) { only = false; break; } }
+		if (only) return {'~', -1};
+	}
+	for (uint32_t i=0; i<al.n_cigar; ++i)
+	{
+		const uint32_t op = al.cigarOp(i); const int len = (int)al.cigarLen(i);
+		if (op==0 || op==7 || op==8) { genome_pos += len; read_pos += len; }
+		else if (op==1) read_pos += len;
+		else if (op==2) { genome_pos += len; if (genome_pos>=pos) return {'-', 255}; }
+		else if (op==3) { genome_pos += len; if (genome_pos>=pos) return {'~', -1}; }
+		else if (op==4) { read_pos += len; if (read_pos>=al.length()) return {'~', -1}; }
+		else if (op==5) {}
+		else throw Error("Unknown CIGAR operation!");
+		if (genome_pos>=pos)
+		{
+			const int actual_pos = read_pos - (genome_pos + 1 - pos);
+			const int nib = (al.seq[actual_pos>>1] >> ((~actual_pos & 1) << 2)) & 0xf;
+			return {"=ACMGRSVTWYHKDBN"[nib], (int)al.qual[actual_pos]};
+		}
+	}
+	throw Error("Could not find position " + std::to_string(pos) + " in read with start position " + std::to_string(al.start()) + "!");
+}
+
+// counts per site: A, C, G, T, N, deletion (Pileup::inc, Pileup.cpp:17-32); any other IUPAC letter throws like the reference
+struct SiteCounts { int64_t a=0, c=0, g=0, t=0, n=0, del=0; };
+static inline SiteCounts site_pileup(const BamFile& bam, int tid, int pos, int min_mapq, bool include_not_properly_paired, int min_baseq)
+{
+	SiteCounts out;
+	bam.forRegion(tid, pos, pos, [&](const Rec& al) {
+		if (al.isSecondary() || al.isSupplementary() || al.isDuplicate() || al.isUnmapped()) return;   // BamReader.cpp:830
+		if (!al.isProperPair() && !include_not_properly_paired) return;                                 // :831
+		if ((int)al.mapq < min_mapq) return;                                                            // :836
+		auto base = extract_base_by_cigar(al, pos);                                                     // :866
+		if (base.second >= min_baseq)
+		{
+			switch (base.first)
+			{
+				case 'A': ++out.a; break; case 'C': ++out.c; break; case 'G': ++out.g; break; case 'T': ++out.t; break; case 'N': ++out.n; break;
+				case '-': ++out.del; break; case '~': break;
+				default: throw Error(std::string("Unknown base '") + base.first + "' in pileup!");
+			}
+		}
+	});
+	return out;
+}
+
+// Statistics::contamination (Statistics.cpp:2333-2386) on a list of known SNVs (tid, pos, ref, alt) already filtered by
+// allele frequency / SNV / target region (NGSHelper::getKnownVariants). Returns the QC value string.
+struct KnownSnp { int tid; int pos; char ref; char alt; };
+static inline std::string contamination_value(const BamFile& bam, const std::vector<KnownSnp>& snps, bool include_not_properly_paired, int min_cov = 20, int min_snps = 50)
+{
+	Histogram hist(0, 1, 0.05);
+	int passed = 0;
+	for (const KnownSnp& s : snps)
+	{
+		SiteCounts p = site_pileup(bam, s.tid, s.pos, 1, include_not_properly_paired, 13);
+		const int64_t depth = p.a + p.c + p.g + p.t;                      // Pileup::depth(false)
+		if (depth < min_cov) continue;
+		auto cnt = [&](char b) -> double { b = (char)toupper(b); return b=='A' ? p.a : b=='C' ? p.c : b=='G' ? p.g : b=='T' ? p.t : b=='N' ? p.n : -1; };
+		const double w = cnt(s.ref), m = cnt(s.alt);
+		if (w < 0 || m < 0) throw Error("Unknown base in frequency calculation!");
+		if (w + m == 0) continue;                                          // NaN frequency: non-informative
+		++passed;
+		hist.inc(m / (w + m), false);
+	}
+	double off = 0.0;   // Histogram::binValue(i, true): percentage of all counted values
+	for (int i=1; i<=5; ++i) off += 100.0 * hist.binValue(i) / hist.binSum();
+	for (int i=14; i<=18; ++i) off += 100.0 * hist.binValue(i) / hist.binSum();
+	return passed < min_snps ? std::string("n/a") : fmt(off, 2);
 }
 
 } // namespace orc

@@ -204,3 +204,31 @@ def baseline_wgs_stream(image, bed=None, min_mapq=1, max_records=-1):
     if secs < 0:
         raise OracleError(err.value.decode())
     return counters, {"n_records": int(st[0]), "inflated": int(st[1]), "compressed": int(st[2])}, secs
+
+
+def site_pileup(bam, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):
+    """BamReader::getPileup SNP counts for (tid, pos) sites: int64[n, 6] = A, C, G, T, N, deletion."""
+    n = len(sites)
+    tid = np.ascontiguousarray([t for t, _ in sites], dtype=np.int32); pos = np.ascontiguousarray([p for _, p in sites], dtype=np.int32)
+    out = np.zeros((max(n, 1), 6), dtype=np.int64)
+    err = C.create_string_buffer(1024)
+    L = lib()
+    L.orc_site_pileup.restype = C.c_int
+    L.orc_site_pileup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    if L.orc_site_pileup(bam.h, tid.ctypes.data, pos.ctypes.data, n, min_mapq, int(include_not_properly_paired), min_baseq, out.ctypes.data, err, 1024) != 0:
+        raise OracleError(err.value.decode())
+    return out[:n]
+
+
+def contamination(bam, snps, include_not_properly_paired=False):
+    """Statistics::contamination on known SNVs [(tid, pos, ref, alt)] (already AF / SNV / ROI filtered). Returns the QC value string."""
+    n = len(snps)
+    tid = np.ascontiguousarray([s[0] for s in snps], dtype=np.int32); pos = np.ascontiguousarray([s[1] for s in snps], dtype=np.int32)
+    ref = bytes(ord(s[2]) for s in snps); alt = bytes(ord(s[3]) for s in snps)
+    out = C.create_string_buffer(64); err = C.create_string_buffer(1024)
+    L = lib()
+    L.orc_contamination.restype = C.c_int
+    L.orc_contamination.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    if L.orc_contamination(bam.h, tid.ctypes.data, pos.ctypes.data, ref, alt, n, int(include_not_properly_paired), out, 64, err, 1024) != 0:
+        raise OracleError(err.value.decode())
+    return out.value.decode()

@@ -146,3 +146,27 @@ def test_bam_reader_accessors():  # BamReader_Test.cpp: CIGAR with thousands of 
     assert b.count > 0 and b.n_blocks > 0
     offs = b.record_offsets()
     assert offs[0] == b.first_record_offset and np.all(np.diff(offs) > 36)
+
+
+def _pile(ob, chrom, pos, **kw):
+    import hostprep as H
+    refs = ob.refs
+    tid = H.tid_map(refs)[H.chr_num(chrom)]
+    a, c, g, t, n, d = (int(x) for x in O.site_pileup(ob, [(tid, pos)], **kw)[0])
+    return dict(A=a, C=c, G=g, T=t, N=n, d=d, depth=a + c + g + t, depth_del=a + c + g + t + d)
+
+
+def test_pileup_known_answers_rna():  # BamReader_Test.cpp:256-275 (CIGARs with S and N operations)
+    ob = O.Bam(os.path.join(GI, "BamReader_rna.bam"))
+    p = _pile(ob, "chr10", 90974727)
+    assert p["depth_del"] == 132 and abs(p["C"] / (p["A"] + p["C"]) - 0.4621) < 0.001
+    assert _pile(ob, "chr10", 92675287)["depth_del"] == 23
+    assert _pile(ob, "chr11", 92675295)["depth_del"] == 0
+
+
+def test_pileup_known_answers_insert_only():  # BamReader_Test.cpp:278-292 (reads whose CIGAR is insertions / soft-clips only)
+    ob = O.Bam(os.path.join(GI, "BamReader_insert_only.bam"))
+    p = _pile(ob, "chr19", 5787214)
+    assert p["depth_del"] == 111 and abs(p["C"] / (p["T"] + p["C"]) - 0.556) < 0.001
+    p = _pile(ob, "chr19", 5787215)
+    assert p["depth_del"] == 118 and abs(p["A"] / (p["G"] + p["A"]) - 0.389) < 0.001

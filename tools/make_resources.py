@@ -4,6 +4,8 @@ Runs only where /root/reference exists (this container); the generated files are
   ngs-bits_amd/resources/qcml_terms.tsv : accession<TAB>name<TAB>definition for the qcML terms the hot path emits
                                           (from src/cppNGS/Resources/qcML.obo; looked up by Statistics::addQcValue,
                                           Statistics.cpp:2904-2922)
+  ngs-bits_amd/resources/hg19_snps.tsv, hg38_snps.tsv : CHROM POS REF ALT AF of the reference's known-variant resources
+                                          (src/cppNGS/Resources/hg*_snps.vcf; NGSHelper::getKnownVariants)
   ngs-bits_amd/resources/qcml_tail.txt  : the fixed cvList + XSL stylesheet block every qcML file ends with
                                           (QCCollection.cpp:260-336), cut from the reference's own expected output
                                           src/tools-TEST/data_out/MappingQC_test10_out.qcML
@@ -37,6 +39,21 @@ def main():
     with open(os.path.join(RES, "qcml_tail.txt"), "w", encoding="utf-8") as f:
         f.write(tail)
     print(len(rows), "terms;", len(tail), "bytes of tail")
+    # known common variants of NGSHelper::getKnownVariants (resources hg19_snps.vcf / hg38_snps.vcf): the five columns the
+    # contamination check reads (CHROM, POS, REF, ALT, INFO/AF), one line per VCF record, order kept
+    for build in ("hg19", "hg38"):
+        n = 0
+        with open(os.path.join(RES, f"{build}_snps.tsv"), "w") as f:
+            for ln in open(os.path.join(REF, f"src/cppNGS/Resources/{build}_snps.vcf")):
+                if ln.startswith("#"):
+                    continue
+                c = ln.rstrip("\n").split("\t")
+                af = ""
+                for kv in c[7].split(";"):
+                    if kv.startswith("AF="):
+                        af = kv[3:]
+                f.write("\t".join([c[0], c[1], c[3], c[4], af]) + "\n"); n += 1
+        print(build, n, "known variants")
 
 
 if __name__ == "__main__":
