@@ -138,6 +138,26 @@ int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lin
 int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_sites, int32_t min_mapq, int32_t min_baseq,
                       int32_t include_not_properly_paired, int64_t* counts);
 
+/* ---- raw-read QC pass: StatisticsReads::update(const BamAlignment&) (src/cppNGS/StatisticsReads.cpp:83-158), the loop
+ * of `MappingQC -read_qc` (src/MappingQC/main.cpp:83-98). Secondary / supplementary records are skipped; single_end
+ * counts every read as forward (otherwise read1 = forward). The reference throws on bases other than A/C/G/T/N and on
+ * qualities >= 100: such records are counted in n_unknown_base / n_quality_out_of_range for the caller to throw. */
+typedef struct ngsqc_read_stats {
+	int64_t c_forward, c_reverse, bases_sequenced;
+	int64_t bases[5];                                   /* A, C, G, T, N over all cycles (sum of the per-cycle pileups) */
+	int64_t base_qualities[100];                        /* bases per quality value */
+	int64_t read_qualities[100];                        /* reads per round(mean quality)  (StatisticsReads.cpp:151) */
+	int64_t qscore_dist_r1[60], qscore_dist_r2[60];     /* Histogram(0,60,1) of the mean quality, forward / reverse reads (:152-153) */
+	int64_t max_cycles;                                 /* longest counted read */
+	int64_t n_unknown_base, n_quality_out_of_range;
+} ngsqc_read_stats;
+int ngsqc_scan_reads(ngsqc_handle* h, int32_t single_end, ngsqc_read_stats* st);
+/* after ngsqc_scan_reads: reads per length 0..max_cycles (cap >= max_cycles + 1) */
+int ngsqc_read_length_hist(ngsqc_handle* h, int64_t* out, int64_t cap);
+/* after ngsqc_scan_reads: per cycle A, C, G, T, N counts and the quality sums of forward / reverse reads, out[7 * cycle + k],
+ * for the first min(n_cycles, 320) cycles (per-cycle statistics only feed plots; longer reads are covered by the totals) */
+int ngsqc_read_cycle_stats(ngsqc_handle* h, int64_t* out, int64_t n_cycles);
+
 /* ---- one BAM sharded over several handles / GPUs --------------------------------------------------
  * The reference reads a BAM with one sequential reader (BamReader::getNextAlignment, src/cppNGS/BamReader.h:386-398); its
  * loop bodies (Statistics.cpp:416-574, :830-917, :1068-1183) are independent per record except for two carries: the

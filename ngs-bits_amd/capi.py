@@ -65,6 +65,12 @@ class ShardFix(C.Structure):
 SUMMARY_FIELDS = [f for f, _ in ShardSummary._fields_]
 
 
+class ReadStats(C.Structure):
+    _fields_ = [("c_forward", C.c_int64), ("c_reverse", C.c_int64), ("bases_sequenced", C.c_int64), ("bases", C.c_int64 * 5),
+                ("base_qualities", C.c_int64 * 100), ("read_qualities", C.c_int64 * 100), ("qscore_dist_r1", C.c_int64 * 60),
+                ("qscore_dist_r2", C.c_int64 * 60), ("max_cycles", C.c_int64), ("n_unknown_base", C.c_int64), ("n_quality_out_of_range", C.c_int64)]
+
+
 def lib_path():
     return os.path.join(PKG_DIR, "libngsqc_hip.so")
 
@@ -112,6 +118,9 @@ def lib():
         L.ngsqc_get_timings.restype = i32; L.ngsqc_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ngsqc_version.restype = cp
         L.ngsqc_site_pileup.restype = i32; L.ngsqc_site_pileup.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.ngsqc_scan_reads.restype = i32; L.ngsqc_scan_reads.argtypes = [vp, C.c_int32, C.POINTER(ReadStats)]
+        L.ngsqc_read_length_hist.restype = i32; L.ngsqc_read_length_hist.argtypes = [vp, vp, i64]
+        L.ngsqc_read_cycle_stats.restype = i32; L.ngsqc_read_cycle_stats.argtypes = [vp, vp, i64]
         L.ngsqc_open_shard.restype = i32; L.ngsqc_open_shard.argtypes = [cp, i32, i32, i32, C.POINTER(vp)]
         L.ngsqc_open_memory_shard.restype = i32; L.ngsqc_open_memory_shard.argtypes = [vp, C.c_size_t, i32, i32, i32, C.POINTER(vp)]
         L.ngsqc_scan_mapping_partial.restype = i32; L.ngsqc_scan_mapping_partial.argtypes = [vp, C.POINTER(MappingParams), C.POINTER(ShardSummary)]
@@ -130,7 +139,7 @@ EXPORTS = [
     "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
     "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
-    "ngsqc_site_pileup", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
+    "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
 ]
 
@@ -241,6 +250,19 @@ class Handle:
         gc = np.zeros(101, dtype=np.float64)
         self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
         return counters, gc
+
+    def scan_reads(self, single_end=False, n_cycles=320):
+        """StatisticsReads::update over the whole BAM. Returns a dict of numpy arrays / ints (layout of ngsqc_read_stats) plus
+        'read_lengths' (reads per length) and 'cycles' ([n, 7]: A, C, G, T, N, quality sum forward, quality sum reverse)."""
+        st = ReadStats()
+        self._chk(lib().ngsqc_scan_reads(self.h, int(single_end), C.byref(st)))
+        out = {f: (np.array(getattr(st, f), dtype=np.int64) if hasattr(getattr(st, f), "__len__") else int(getattr(st, f))) for f, _ in ReadStats._fields_}
+        lens = np.zeros(out["max_cycles"] + 1, dtype=np.int64)
+        self._chk(lib().ngsqc_read_length_hist(self.h, lens.ctypes.data, lens.size))
+        cyc = np.zeros((max(n_cycles, 1), 7), dtype=np.int64)
+        self._chk(lib().ngsqc_read_cycle_stats(self.h, cyc.ctypes.data, n_cycles))
+        out["read_lengths"] = lens; out["cycles"] = cyc[:n_cycles]
+        return out
 
     def site_pileup(self, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):
         """sites: list of (tid, pos) sorted by tid then pos. Returns int64[n, 8]: A, C, G, T, N, deletion, other-letter, not-found."""

@@ -76,6 +76,7 @@ struct ngsqc_handle
 	int64_t shard_limit = -1;              // rebased inflated offset of the first byte that is NOT owned
 	int64_t shard_u_base = 0;              // inflated offset (whole file) of the handle's first member
 	int64_t shard_first_abs = -1, shard_exit_abs = -1; int shard_last_tile = -1;
+	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last ngsqc_scan_reads
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
 	Partial* partial = nullptr;
 };
@@ -961,6 +962,56 @@ int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_site
 		HIPCHK(hipMemcpyAsync(out.data(), d_cnt.p, out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		for (size_t i = 0; i < out.size(); ++i) counts[i] = (int64_t)out[i];
+	});
+}
+
+int ngsqc_scan_reads(ngsqc_handle* h, int32_t single_end, ngsqc_read_stats* st)
+{
+	return guarded(h, [&] {
+		if (!st) throw ArgError("null argument");
+		// pass 1: longest counted read (sizes the read-length histogram)
+		DevBuf<unsigned long long> d_max; d_max.alloc(1);
+		HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned long long), h->stream));
+		for_each_tile(h, [&](int) { launch_reads_max(h->d_infl.p, h->d_recoff.p, h->n_rec, d_max.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); return true; });
+		unsigned long long mx = 0;
+		HIPCHK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+		const int64_t len_cap = (int64_t)mx;
+		DevBuf<unsigned long long> d_acc, d_len, d_cyc; d_acc.alloc(RA_TOTAL); d_len.alloc((size_t)len_cap + 1); d_cyc.alloc((size_t)RQ_CYC * 7);
+		HIPCHK(hipMemsetAsync(d_acc.p, 0, RA_TOTAL * sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_len.p, 0, ((size_t)len_cap + 1) * sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_cyc.p, 0, (size_t)RQ_CYC * 7 * sizeof(unsigned long long), h->stream));
+		// pass 2
+		for_each_tile(h, [&](int) { launch_reads(h->d_infl.p, h->d_recoff.p, h->n_rec, single_end ? 1 : 0, d_acc.p, d_len.p, len_cap, d_cyc.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); return true; });
+		std::vector<unsigned long long> acc(RA_TOTAL), len((size_t)len_cap + 1), cyc((size_t)RQ_CYC * 7);
+		HIPCHK(hipMemcpyAsync(acc.data(), d_acc.p, acc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(len.data(), d_len.p, len.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(cyc.data(), d_cyc.p, cyc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		memset(st, 0, sizeof(*st));
+		st->c_forward = (int64_t)acc[RA_FWD]; st->c_reverse = (int64_t)acc[RA_REV]; st->bases_sequenced = (int64_t)acc[RA_BASES];
+		for (int i = 0; i < 5; ++i) st->bases[i] = (int64_t)acc[RA_A + i];
+		for (int i = 0; i < 100; ++i) { st->base_qualities[i] = (int64_t)acc[RA_BQ0 + i]; st->read_qualities[i] = (int64_t)acc[RA_RQ0 + i]; }
+		for (int i = 0; i < 60; ++i) { st->qscore_dist_r1[i] = (int64_t)acc[RA_QD0 + i]; st->qscore_dist_r2[i] = (int64_t)acc[RA_QD0 + 60 + i]; }
+		st->max_cycles = len_cap; st->n_unknown_base = (int64_t)acc[RA_BAD_BASE]; st->n_quality_out_of_range = (int64_t)acc[RA_BAD_QUAL];
+		h->rq_len_hist.assign(len.begin(), len.end()); h->rq_cyc.assign(cyc.begin(), cyc.end());
+	});
+}
+int ngsqc_read_length_hist(ngsqc_handle* h, int64_t* out, int64_t cap)
+{
+	return guarded(h, [&] {
+		if (h->rq_len_hist.empty()) throw ArgError("no read statistics: run ngsqc_scan_reads first");
+		if (!out || cap < (int64_t)h->rq_len_hist.size()) throw ArgError("read-length buffer too small");
+		std::copy(h->rq_len_hist.begin(), h->rq_len_hist.end(), out);
+	});
+}
+int ngsqc_read_cycle_stats(ngsqc_handle* h, int64_t* out, int64_t n_cycles)
+{
+	return guarded(h, [&] {
+		if (h->rq_cyc.empty()) throw ArgError("no read statistics: run ngsqc_scan_reads first");
+		if (!out || n_cycles < 0) throw ArgError("invalid cycle buffer");
+		const int64_t n = std::min<int64_t>(n_cycles, RQ_CYC);
+		std::copy(h->rq_cyc.begin(), h->rq_cyc.begin() + 7 * n, out);
+		for (int64_t i = 7 * n; i < 7 * n_cycles; ++i) out[i] = 0;
 	});
 }
 

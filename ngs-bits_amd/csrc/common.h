@@ -79,6 +79,13 @@ void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paire
 void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
                    int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s);
 
+// ---- raw-read QC pass (reads.hip): StatisticsReads::update(BamAlignment) ----
+constexpr int RQ_PASSES = 5, RQ_CYC = RQ_PASSES * 64;   // per-cycle statistics are kept for the first 320 cycles (every Illumina read length)
+enum { RA_FWD, RA_REV, RA_BASES, RA_A, RA_C, RA_G, RA_T, RA_N, RA_BAD_BASE, RA_BAD_QUAL, RA_BQ0, RA_RQ0 = RA_BQ0 + 100, RA_QD0 = RA_RQ0 + 100, RA_TOTAL = RA_QD0 + 120 };
+void launch_reads_max(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, unsigned long long* d_max, hipStream_t s);
+void launch_reads(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int single_end, unsigned long long* d_acc, unsigned long long* d_len_hist, int64_t len_cap,
+                  unsigned long long* d_cyc /* [RQ_CYC][7]: A,C,G,T,N, quality sum forward, quality sum reverse */, hipStream_t s);
+
 // ---- K6 ----
 void launch_depth_mark_spare(int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, hipStream_t s);
 void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int64_t half, unsigned long long* d_hist, unsigned long long* d_cov, hipStream_t s);

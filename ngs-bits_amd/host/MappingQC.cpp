@@ -1,6 +1,5 @@
 // MappingQC — drop-in for src/MappingQC/main.cpp:21-188 on the MI355X path: same flags, defaults, checks and output
-// (qcML / TXT). Not yet on the GPU path (SURVEY.md §8f "next"): -read_qc (accepted and reported as not implemented
-// instead of silently ignored).
+// (qcML / TXT), including the contamination check, -somatic_custom_bed and -read_qc.
 #include "Statistics.hpp"
 using namespace ngsbits;
 
@@ -41,7 +40,15 @@ public:
 		int parameters_set = (roi_file != "" ? 1 : 0) + wgs + rna;
 		if (parameters_set != 1) NB_THROW(CommandLineParsingException, "You have to use exactly one of the parameters 'roi', 'wgs', or 'rna' !");
 		if (cfdna && roi_file == "") NB_THROW(CommandLineParsingException, "The flag 'cfdna' can only be used with parameter 'roi'!");
-		if (getOutfile("read_qc") != "") NB_THROW(NotImplementedException, "'-read_qc' is not available in the MI355X build yet (StatisticsReads is a 'next' row of the hot-path scope).");
+		// raw read QC (main.cpp:80-98)
+		std::string read_qc = trimmed(getOutfile("read_qc"));
+		if (!read_qc.empty())
+		{
+			StatisticsReads stats(getFlag("single_end"));
+			BamReader reader(in, ref_file);
+			stats.update(reader);
+			stats.getResult().storeToQCML(read_qc, {in}, "", "MappingQC", version());
+		}
 
 		std::vector<std::string> parameters; QCCollection metrics;
 		if (wgs)

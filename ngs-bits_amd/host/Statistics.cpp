@@ -504,6 +504,118 @@ QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::
 	return output;
 }
 
+// ---------------------------------------------------------------- StatisticsReads (StatisticsReads.cpp:83-442)
+void StatisticsReads::update(BamReader& reader)
+{
+	reader.check(ngsqc_scan_reads(reader.handle(), single_end_ ? 1 : 0, &st_));
+	if (st_.n_unknown_base) NB_THROW(ProgrammingException, "Unknown base in StatisticsReads::update!");                                    // :131
+	if (st_.n_quality_out_of_range) NB_THROW(ArgumentException, "Base quality > 100. This should not happen!");                            // :141
+	read_lengths_.assign((size_t)st_.max_cycles + 1, 0);
+	reader.check(ngsqc_read_length_hist(reader.handle(), read_lengths_.data(), (int64_t)read_lengths_.size()));
+	const int64_t n_cyc = std::min<int64_t>(st_.max_cycles, 320);
+	cycles_.assign((size_t)n_cyc * 7, 0);
+	if (n_cyc) reader.check(ngsqc_read_cycle_stats(reader.handle(), cycles_.data(), n_cyc));
+	have_ = true;
+}
+
+QCCollection StatisticsReads::getResult()
+{
+	QCCollection output;
+	auto put = [&](const std::string& name, const std::string& value, const std::string& desc, const std::string& acc) { QCValue v; v.name = name; v.accession = acc; v.description = desc; v.type = QCValueType::STRING; v.s = value; output.insert(v); };
+	auto putd = [&](const std::string& name, double value, const std::string& desc, const std::string& acc) { QCValue v; v.name = name; v.accession = acc; v.description = desc; v.type = QCValueType::DOUBLE; v.d = value; output.insert(v); };
+	auto putp = [&](const std::string& name, const std::vector<double>& x, const std::vector<std::vector<double>>& lines, const std::string& desc, const std::string& acc) { QCValue v; v.name = name; v.accession = acc; v.description = desc; v.type = QCValueType::IMAGE; v.s = plotPng(x, lines); output.insert(v); };
+	const long long c_forward = st_.c_forward, c_reverse = st_.c_reverse, bases_sequenced = st_.bases_sequenced;
+	const long long total_reads = c_forward + c_reverse;
+	const long long c_base_n = st_.bases[4], c_base_gc = st_.bases[1] + st_.bases[2];
+	const long long bases_total = st_.bases[0] + st_.bases[1] + st_.bases[2] + st_.bases[3] + st_.bases[4];       // sum of pileup.depth(false, true)
+	long long c_base_q20 = 0, c_base_q30 = 0, c_read_q20 = 0;
+	for (int q = 20; q < 100; ++q) c_base_q20 += st_.base_qualities[q];
+	for (int q = 30; q < 100; ++q) c_base_q30 += st_.base_qualities[q];
+	for (int b = 20; b < 60; ++b) c_read_q20 += st_.qscore_dist_r1[b] + st_.qscore_dist_r2[b];                  // mean >= 20  <=>  bin >= 20 of Histogram(0,60,1)
+	std::vector<int> tmp; for (size_t l = 0; l < read_lengths_.size(); ++l) if (read_lengths_[l]) tmp.push_back((int)l);          // read_lengths_.keys()
+	if (tmp.empty()) tmp.push_back(0);
+	const int longest_read = tmp.back();
+	const bool is_longread = single_end_ && longest_read >= 10000;
+	put("read count", std::to_string(total_reads), "Total number of reads (forward and reverse reads of paired-end sequencing count as two reads).", "QC:2000005");
+	std::string lengths;
+	if (tmp.size() < 4) { lengths = std::to_string(tmp[0]); for (size_t i = 1; i < tmp.size(); ++i) lengths += ", " + std::to_string(tmp[i]); }
+	else lengths = std::to_string(tmp[0]) + "-" + std::to_string(longest_read);
+	put("read length", lengths, "Raw read length of a single read before trimming. Comma-separated list of lenghs or length range, if reads have different lengths.", "QC:2000006");
+	putd("bases sequenced (MB)", (double)bases_sequenced / 1000000.0, "Bases sequenced in total (in megabases).", "QC:2000049");
+	putd("Q20 read percentage", 100.0 * c_read_q20 / total_reads, "The percentage of reads with a mean base quality score greater than Q20.", "QC:2000007");
+	putd("Q20 base percentage", 100.0 * c_base_q20 / bases_total, "The percentage of bases with a minimum quality score of Q20.", "QC:2000148");
+	putd("Q30 base percentage", 100.0 * c_base_q30 / bases_total, "The percentage of bases with a minimum quality score of Q30.", "QC:2000008");
+	putd("no base call percentage", 100.0 * c_base_n / bases_total, "The percentage of bases without base call (N).", "QC:2000009");
+	putd("gc content percentage", 100.0 * c_base_gc / (bases_total - c_base_n), "The percentage of bases that are called to be G or C.", "QC:2000010");
+	if (single_end_)   // N50 (:190-208)
+	{
+		long long bases = 0; int n50 = 0;
+		for (size_t k = tmp.size(); k-- > 0;) { bases += (long long)tmp[k] * read_lengths_[(size_t)tmp[k]]; if (bases > bases_sequenced / 2) { n50 = tmp[k]; break; } }
+		put("N50 read length (bp)", std::to_string(n50), "Minimum read length to reach 50% of sequenced bases.", "QC:2000131");
+	}
+	int n95 = -1;      // :211-237
+	if (is_longread)
+	{
+		long long bases = 0;
+		for (int l : tmp) { bases += (long long)l * read_lengths_[(size_t)l]; if (bases > 0.95 * bases_sequenced) { n95 = l; break; } }
+		if (longest_read <= 100000) n95 = (int)(std::ceil(n95 / 1000.0) * 1000); else n95 = (int)(std::ceil(n95 / 10000.0) * 10000);
+	}
+	// per-cycle plots (the GPU pass keeps per-cycle statistics for the first 320 cycles)
+	int cycles = longest_read; if (is_longread) cycles = std::min(n95, cycles);
+	cycles = std::min<int>(cycles, (int)(cycles_.size() / 7));
+	std::vector<double> la, lc, lg, lt, ln, lgc, lx, q1, q2;
+	for (int i = 0; i < cycles; ++i)
+	{
+		const int64_t* c = &cycles_[(size_t)i * 7];
+		const double depth_no_n = (double)(c[0] + c[1] + c[2] + c[3]);
+		la.push_back(100.0 * c[0] / depth_no_n); lc.push_back(100.0 * c[1] / depth_no_n); lg.push_back(100.0 * c[2] / depth_no_n); lt.push_back(100.0 * c[3] / depth_no_n);
+		ln.push_back(100.0 * c[4] / (depth_no_n + c[4])); lgc.push_back(lg.back() + lc.back()); lx.push_back(i + 1);
+		long long depth = c[0] + c[1] + c[2] + c[3] + c[4]; if (c_reverse > 0) depth /= 2;
+		q1.push_back((double)c[5] / depth); q2.push_back((double)c[6] / depth);
+	}
+	putp("base distribution plot", lx, {la, lc, lg, lt, ln, lgc}, "Base distribution plot per cycle.", "QC:2000011");
+	if (c_reverse > 0) putp("Q score plot", lx, {q1, q2}, "Mean Q score per cycle for forward/reverse reads.", "QC:2000012");
+	else putp("Q score plot", lx, {q1}, "Mean Q score per cycle for forward/reverse reads.", "QC:2000012");
+	{
+		std::vector<double> x, y1, y2; long long s1 = 0, s2 = 0;
+		for (int b = 0; b < 60; ++b) { s1 += st_.qscore_dist_r1[b]; s2 += st_.qscore_dist_r2[b]; }
+		for (int b = 0; b < 60; ++b) { x.push_back(b + 0.5); y1.push_back(100.0 * st_.qscore_dist_r1[b] / s1); y2.push_back(100.0 * st_.qscore_dist_r2[b] / s2); }
+		if (c_reverse > 0) putp("read Q score distribution", x, {y1, y2}, "Distrubition of the mean forward/reverse Q score for each read.", "QC:2000138");
+		else putp("read Q score distribution", x, {y1}, "Distrubition of the mean forward/reverse Q score for each read.", "QC:2000138");
+	}
+	if (single_end_)   // :342-438
+	{
+		const int hist_min = std::max(0, tmp.front() - 20), hist_max = (is_longread ? n95 : longest_read) + 20;
+		const int step = std::max(1, (hist_max - hist_min) / 60);
+		Histogram read_length_hist(hist_min, hist_max, step);
+		for (int l : tmp) read_length_hist.inc(l, true, (double)read_lengths_[(size_t)l]);
+		putp("Read length histogram", read_length_hist.xCoords(), {read_length_hist.yCoords(true)}, "Histogram of read lengths", "QC:2000132");
+		std::vector<double> xs, values; long long max_count = 0, bases_checked = 0; int mode_base_q_score = 0, median_base_q_score = -1;
+		for (int i = 0; i <= 60; ++i)
+		{
+			const long long base_count = st_.base_qualities[i];
+			xs.push_back(i); values.push_back((100.0 * base_count) / bases_sequenced);
+			if (base_count >= max_count) { max_count = base_count; if (i < 50) mode_base_q_score = i; }
+			bases_checked += base_count;
+			if (median_base_q_score == -1 && bases_checked * 2 >= bases_sequenced) median_base_q_score = i;
+		}
+		putp("base Q score histogram", xs, {values}, "Histogram of base Q scores.", "QC:2000143");
+		put("median base Q score", std::to_string(median_base_q_score), "Median Q score of all bases of the sample.", "QC:2000144");
+		put("mode base Q score", std::to_string(mode_base_q_score), "Most frequent Q score of all bases of the sample.", "QC:2000145");
+		max_count = 0; int mode_read_q_score = 0, median_read_q_score = -1; long long reads_checked = 0;
+		for (int i = 0; i < 100; ++i)
+		{
+			const long long read_count = st_.read_qualities[i];
+			if (read_count >= max_count) { max_count = read_count; mode_read_q_score = i; }
+			reads_checked += read_count;
+			if (median_read_q_score == -1 && reads_checked * 2 >= c_forward) median_read_q_score = i;
+		}
+		put("median read Q score", std::to_string(median_read_q_score), "Median Q score of all reads of the sample.", "QC:2000146");
+		put("mode read Q score", std::to_string(mode_read_q_score), "Most frequent Q score of all reads of the sample.", "QC:2000147");
+	}
+	return output;
+}
+
 // Statistics.cpp:2333-2386 + NGSHelper::getKnownVariants (NGSHelper.cpp:22-94) + BamReader::getPileup (BamReader.cpp:809-885).
 // The reference runs one indexed pileup query per known SNP; here all sites go to the GPU in one table (ngsqc_site_pileup).
 QCCollection Statistics::contamination(const std::string& build, const std::string& bam, const std::string& ref_file, const std::string& roi_file, bool debug, int min_cov, int min_snps, bool include_not_properly_paired)

@@ -54,6 +54,19 @@ private:
 	static BedFile lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access);
 };
 
+// Raw-read QC of a BAM (src/cppNGS/StatisticsReads.h; MappingQC -read_qc, src/MappingQC/main.cpp:83-98). The reference feeds
+// every alignment to update(const BamAlignment&); here update(reader) runs that loop over the whole BAM on the GPU
+// (ngsqc_scan_reads) and getResult() is the reference's post-processing of the same counters.
+class StatisticsReads
+{
+public:
+	explicit StatisticsReads(bool single_end = false) : single_end_(single_end) {}
+	void update(BamReader& reader);
+	QCCollection getResult();
+private:
+	bool single_end_; ngsqc_read_stats st_{}; std::vector<int64_t> read_lengths_, cycles_; bool have_ = false;
+};
+
 // ref_file == NO_REF: run without a reference genome (an extension for genome-less test boxes; GC/AT dropout become
 // "n/a" and the N-base correction of the WGS depth denominators is skipped). The reference always needs a FASTA.
 extern const char* const NO_REF;

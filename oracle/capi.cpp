@@ -208,6 +208,27 @@ int orc_contamination(void* bam, const int32_t* tid, const int32_t* pos, const c
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
 }
 
+// Raw-read QC: out[0..7] = c_forward, c_reverse, bases_sequenced, c_read_q20, c_base_q20, c_base_q30, max_cycles, n_lengths;
+// out[8..107] base_qualities, out[108..207] read_qualities, out[208..267] qscore_dist_r1, out[268..327] qscore_dist_r2,
+// out[328..332] total A, C, G, T, N. len_hist[l] for l <= len_cap; cyc[7*i+k] = A,C,G,T,N,qsum fwd,qsum rev for i < n_cyc.
+int orc_reads_qc(void* bam, int single_end, int64_t* out, int64_t* len_hist, int64_t len_cap, int64_t* cyc, int64_t n_cyc, char* err, int errlen)
+{
+	try
+	{
+		ReadsQc q = reads_qc(*(BamFile*)bam, single_end != 0);
+		out[0] = q.c_forward; out[1] = q.c_reverse; out[2] = q.bases_sequenced; out[3] = q.c_read_q20; out[4] = q.c_base_q20; out[5] = q.c_base_q30;
+		out[6] = (int64_t)q.pileups.size(); out[7] = (int64_t)q.read_lengths.size();
+		for (int i=0;i<100;++i) { out[8+i] = q.base_qualities[(size_t)i]; out[108+i] = q.read_qualities[(size_t)i]; }
+		for (int i=0;i<60;++i) { out[208+i] = (int64_t)q.qscore_dist_r1.binValue(i); out[268+i] = (int64_t)q.qscore_dist_r2.binValue(i); }
+		for (int k=0;k<5;++k) { int64_t t = 0; for (auto& p : q.pileups) t += p[(size_t)k]; out[328+k] = t; }
+		if (len_hist) { for (int64_t l=0;l<=len_cap;++l) len_hist[l] = 0; for (auto& kv : q.read_lengths) if (kv.first <= len_cap) len_hist[kv.first] = kv.second; }
+		if (cyc) for (int64_t i=0;i<n_cyc;++i) for (int k=0;k<7;++k)
+			cyc[7*i+k] = (size_t)i < q.pileups.size() ? (k<5 ? q.pileups[(size_t)i][(size_t)k] : (int64_t)(k==5 ? q.qualities1[(size_t)i] : q.qualities2[(size_t)i])) : 0;
+		return 0;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
+}
+
 } // extern "C"
 
 

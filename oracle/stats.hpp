@@ -10,10 +10,12 @@
 //   BamAlignment::qualities            src/cppNGS/BamReader.cpp:210-255
 //   BamReader::getPileup + BamAlignment::extractBaseByCIGAR  src/cppNGS/BamReader.cpp:809-885, 307-374 -> site_pileup()
 //   Statistics::contamination          src/cppNGS/Statistics.cpp:2333-2386 -> contamination_value()
+//   StatisticsReads::update(BamAlignment) src/cppNGS/StatisticsReads.cpp:83-158 -> reads_qc()
 //   FastaFileIndex::seq / n            src/cppNGS/FastaFileIndex.cpp:72-131 ; Sequence::gcContent Sequence.cpp:86-101
 // Written as the straight sequential loops of the reference on purpose: this is the checker, not the product.
 // ============================================================================
 #pragma once
+#include <array>
 #include <cinttypes>
 #include <numeric>
 #include <limits>
@@ -727,6 +729,58 @@ static inline std::string contamination_value(const BamFile& bam, const std::vec
 	for (int i=1; i<=5; ++i) off += 100.0 * hist.binValue(i) / hist.binSum();
 	for (int i=14; i<=18; ++i) off += 100.0 * hist.binValue(i) / hist.binSum();
 	return passed < min_snps ? std::string("n/a") : fmt(off, 2);
+}
+
+// ---------------------------------------------------------------- raw-read QC (StatisticsReads::update(const BamAlignment&))
+struct ReadsQc
+{
+	int64_t c_forward = 0, c_reverse = 0, bases_sequenced = 0, c_read_q20 = 0, c_base_q20 = 0, c_base_q30 = 0;
+	std::map<int, int64_t> read_lengths;
+	std::vector<std::array<int64_t,5>> pileups;            // per cycle: A, C, G, T, N
+	std::vector<double> qualities1, qualities2;            // per cycle quality sums, forward / reverse
+	std::vector<int64_t> base_qualities = std::vector<int64_t>(100, 0), read_qualities = std::vector<int64_t>(100, 0);
+	Histogram qscore_dist_r1 = Histogram(0, 60, 1), qscore_dist_r2 = Histogram(0, 60, 1);
+};
+static inline ReadsQc reads_qc(const BamFile& bam, bool single_end)
+{
+	ReadsQc o;
+	for (size_t n = 0; n < bam.count(); ++n)
+	{
+		const Rec al = bam.rec(n);
+		if (al.isSupplementary() || al.isSecondary()) continue;                                   // :86
+		bool is_forward;
+		if (single_end) { is_forward = true; ++o.c_forward; }
+		else { is_forward = al.isRead1(); if (is_forward) ++o.c_forward; else ++o.c_reverse; }    // :90-106
+		const int cycles = al.length();
+		o.bases_sequenced += cycles; o.read_lengths[cycles]++;
+		if (cycles > (int)o.pileups.size()) { o.pileups.resize((size_t)cycles, {0,0,0,0,0}); o.qualities1.resize((size_t)cycles, 0.0); o.qualities2.resize((size_t)cycles, 0.0); }
+		for (int i = 0; i < cycles; ++i)
+		{
+			const int base = (al.seq[i>>1] >> ((~i & 1) << 2)) & 0xf;                              // baseIntegers(): A=1, C=2, G=4, T=8, N=15
+			if (base==1) o.pileups[(size_t)i][0]++; else if (base==2) o.pileups[(size_t)i][1]++; else if (base==4) o.pileups[(size_t)i][2]++;
+			else if (base==8) o.pileups[(size_t)i][3]++; else if (base==15) o.pileups[(size_t)i][4]++;
+			else throw Error("Unknown base '" + std::to_string(base) + "' in StatisticsReads::update!");
+		}
+		double q_sum = 0.0;
+		for (int i = 0; i < cycles; ++i)
+		{
+			const int q = al.qual[i];
+			q_sum += q;
+			if (q >= 20.0) ++o.c_base_q20;
+			if (q >= 30.0) ++o.c_base_q30;
+			if (q >= (int)o.base_qualities.size()) throw Error("Base quality > 100 (" + std::to_string(q) + "). This should not happen!");
+			o.base_qualities[(size_t)q]++;
+			if (is_forward) o.qualities1[(size_t)i] += q; else o.qualities2[(size_t)i] += q;
+		}
+		const double mean_qscore = q_sum / cycles;
+		if (mean_qscore == mean_qscore)
+		{
+			o.read_qualities[(size_t)std::round(mean_qscore)]++;
+			if (is_forward) o.qscore_dist_r1.inc(mean_qscore, true); else o.qscore_dist_r2.inc(mean_qscore, true);
+			if (mean_qscore >= 20.0) ++o.c_read_q20;
+		}
+	}
+	return o;
 }
 
 } // namespace orc

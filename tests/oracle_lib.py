@@ -232,3 +232,20 @@ def contamination(bam, snps, include_not_properly_paired=False):
     if L.orc_contamination(bam.h, tid.ctypes.data, pos.ctypes.data, ref, alt, n, int(include_not_properly_paired), out, 64, err, 1024) != 0:
         raise OracleError(err.value.decode())
     return out.value.decode()
+
+
+def reads_qc(bam, single_end=False, len_cap=None, n_cycles=320):
+    """StatisticsReads::update(BamAlignment) over the whole BAM: dict in the layout of ngs-bits_amd Handle.scan_reads()."""
+    L = lib()
+    L.orc_reads_qc.restype = C.c_int
+    L.orc_reads_qc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int]
+    out = np.zeros(333, dtype=np.int64); err = C.create_string_buffer(1024)
+    if L.orc_reads_qc(bam.h, int(single_end), out.ctypes.data, None, 0, None, 0, err, 1024) != 0:
+        raise OracleError(err.value.decode())
+    cap = int(out[6]) if len_cap is None else len_cap
+    lens = np.zeros(cap + 1, dtype=np.int64); cyc = np.zeros((max(n_cycles, 1), 7), dtype=np.int64)
+    if L.orc_reads_qc(bam.h, int(single_end), out.ctypes.data, lens.ctypes.data, cap, cyc.ctypes.data, n_cycles, err, 1024) != 0:
+        raise OracleError(err.value.decode())
+    return dict(c_forward=int(out[0]), c_reverse=int(out[1]), bases_sequenced=int(out[2]), c_read_q20=int(out[3]), c_base_q20=int(out[4]),
+                c_base_q30=int(out[5]), max_cycles=int(out[6]), base_qualities=out[8:108].copy(), read_qualities=out[108:208].copy(),
+                qscore_dist_r1=out[208:268].copy(), qscore_dist_r2=out[268:328].copy(), bases=out[328:333].copy(), read_lengths=lens, cycles=cyc[:n_cycles])

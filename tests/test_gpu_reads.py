@@ -1,0 +1,67 @@
+"""Raw-read QC pass on the GPU (ngsqc_scan_reads = StatisticsReads::update over the whole BAM, the loop of
+`MappingQC -read_qc`): every counter and histogram bit-exact vs the oracle on the fixture BAMs (short reads, RNA, long
+reads, paired and single-end mode), on synthetic short-read / ONT-like (reads far longer than the per-cycle window) and
+multi-tile inputs, and the tool's qcML file vs the reference's expected output MappingQC_test11_out.qcML."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import bamgen_lib as G
+import oracle_lib as O
+from conftest import GOLDEN_IN as GI, GOLDEN_OUT as GO, ROOT
+
+pytestmark = pytest.mark.gpu
+ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+STRIP = re.compile(r"creation |<binary>")
+
+
+def _compare(path, single_end):
+    ob = O.Bam(path)
+    exp = O.reads_qc(ob, single_end)
+    h = ngsqc.Handle(path=path)
+    try:
+        got = h.scan_reads(single_end)
+    finally:
+        h.close()
+    assert got["n_unknown_base"] == 0 and got["n_quality_out_of_range"] == 0
+    for k in ("c_forward", "c_reverse", "bases_sequenced", "max_cycles"):
+        assert got[k] == exp[k], (k, got[k], exp[k])
+    for k in ("bases", "base_qualities", "read_qualities", "qscore_dist_r1", "qscore_dist_r2", "read_lengths", "cycles"):
+        assert np.array_equal(got[k], exp[k]), (k, np.nonzero(np.asarray(got[k]) != np.asarray(exp[k]))[0][:5])
+    return exp
+
+
+@pytest.mark.parametrize("bam", ["MappingQC_in1.bam", "MappingQC_in3.bam", "MappingQC_in5.bam", "BamReader_rna.bam", "BamReader_lr.bam",
+                                 "Statistics_longread.bam", "BamReader_insert_only.bam", "sry.bam"])
+@pytest.mark.parametrize("single_end", [False, True])
+def test_fixture_bams_match_the_oracle(bam, single_end):
+    exp = _compare(os.path.join(GI, bam), single_end)
+    assert exp["c_forward"] + exp["c_reverse"] > 0
+
+
+def test_synthetic_short_long_and_tiled(tmp_path, monkeypatch):
+    p1 = str(tmp_path / "sr.bam"); G.write(p1, n_reads=150_000, seed=51, start_pos=15_900_000)
+    p2 = str(tmp_path / "ont.bam"); G.write(p2, n_reads=900, seed=52, mode=1, depth=40.0, start_pos=15_900_000)
+    p3 = str(tmp_path / "un.bam"); G.write(p3, n_reads=40_000, seed=53, aligned=False, start_pos=15_900_000)
+    assert _compare(p1, False)["c_reverse"] > 0
+    assert _compare(p2, True)["max_cycles"] > 5000          # reads far longer than the 320-cycle window: totals + first 320 cycles
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", "3")
+    _compare(p3, False); _compare(p2, True)
+
+
+def _lines(path):
+    return [ln for ln in open(path, encoding="latin-1").read().splitlines() if not STRIP.search(ln)]
+
+
+def test_tool_read_qc_matches_reference_expected_output(tmp_path):
+    """src/tools-TEST/MappingQC_Test.cpp:78-91 (wgs_with_raw_read_qc): both outputs of one run."""
+    out1, out2 = str(tmp_path / "MappingQC_test10_out.qcML"), str(tmp_path / "MappingQC_test11_out.qcML")
+    p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", os.path.join(GI, "MappingQC_in5.bam"), "-wgs", "-build", "hg38",
+                        "-out", out1, "-read_qc", out2, "-no_ref"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert _lines(out2) == _lines(os.path.join(GO, "MappingQC_test11_out.qcML"))
+    drop = re.compile(r"AT dropout|GC dropout")            # need a genome FASTA
+    assert [ln for ln in _lines(out1) if not drop.search(ln)] == [ln for ln in _lines(os.path.join(GO, "MappingQC_test10_out.qcML")) if not drop.search(ln)]

@@ -170,3 +170,20 @@ def test_pileup_known_answers_insert_only():  # BamReader_Test.cpp:278-292 (read
     assert p["depth_del"] == 111 and abs(p["C"] / (p["T"] + p["C"]) - 0.556) < 0.001
     p = _pile(ob, "chr19", 5787215)
     assert p["depth_del"] == 118 and abs(p["A"] / (p["G"] + p["A"]) - 0.389) < 0.001
+
+
+def test_reads_qc_known_answers():  # src/tools-TEST/MappingQC_Test.cpp:78-91 -> data_out/MappingQC_test11_out.qcML (read_qc of MappingQC_in5.bam)
+    q = O.reads_qc(O.Bam(os.path.join(GI, "MappingQC_in5.bam")))
+    exp = dict(re.findall(r'name="([^"]+)" description="[^"]*" value="([^"]*)"', open(os.path.join(GO, "MappingQC_test11_out.qcML"), encoding="latin-1").read()))
+    total = q["c_forward"] + q["c_reverse"]; bases_total = int(q["bases"].sum()); lens = np.nonzero(q["read_lengths"])[0]
+    assert str(total) == exp["read count"]
+    assert (f"{lens[0]}-{lens[-1]}" if lens.size >= 4 else ", ".join(str(x) for x in lens)) == exp["read length"]
+    assert f"{q['bases_sequenced'] / 1e6:.2f}" == exp["bases sequenced (MB)"]
+    assert f"{100.0 * q['c_read_q20'] / total:.2f}" == exp["Q20 read percentage"]
+    assert f"{100.0 * q['c_base_q20'] / bases_total:.2f}" == exp["Q20 base percentage"]
+    assert f"{100.0 * q['c_base_q30'] / bases_total:.2f}" == exp["Q30 base percentage"]
+    assert f"{100.0 * q['bases'][4] / bases_total:.2f}" == exp["no base call percentage"]
+    assert f"{100.0 * (q['bases'][1] + q['bases'][2]) / (bases_total - q['bases'][4]):.2f}" == exp["gc content percentage"]
+    # internal consistency of the derived counters the GPU side does not transfer
+    assert q["c_base_q20"] == q["base_qualities"][20:].sum() and q["c_base_q30"] == q["base_qualities"][30:].sum()
+    assert q["c_read_q20"] == q["qscore_dist_r1"][20:].sum() + q["qscore_dist_r2"][20:].sum()

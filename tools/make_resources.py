@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RES = os.path.join(ROOT, "ngs-bits_amd", "resources")
 WANTED = set(["QC:1000002", "QC:1000003", "QC:1000004", "QC:1000005", "QC:1000006"] +
              ["QC:20000%02d" % i for i in list(range(19, 33)) + [37, 38, 50, 51, 52, 57, 58, 59, 60, 61] + list(range(65, 77)) + list(range(90, 99)) + [99]] +
-             ["QC:2000139", "QC:2000150"] + ["QC:20001%02d" % i for i in range(0, 10)])
+             ["QC:20000%02d" % i for i in range(5, 13)] + ["QC:2000131", "QC:2000132", "QC:2000138"] + ["QC:20001%02d" % i for i in range(43, 49)] + ["QC:2000139", "QC:2000150"] + ["QC:20001%02d" % i for i in range(0, 10)])
 
 
 def main():
