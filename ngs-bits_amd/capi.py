@@ -266,10 +266,14 @@ class Handle:
 
     def site_pileup(self, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):
         """sites: list of (tid, pos) sorted by tid then pos. Returns int64[n, 8]: A, C, G, T, N, deletion, other-letter, not-found."""
-        ra = _regions_array([(t, p, p) for t, p in sites])
-        out = np.zeros((max(len(sites), 1), 8), dtype=np.int64)
-        self._chk(lib().ngsqc_site_pileup(self.h, C.cast(ra, C.c_void_p), len(sites), min_mapq, min_baseq, int(include_not_properly_paired), out.ctypes.data))
-        return out[:len(sites)]
+        # sites may also be an int32 array [n, 3] of (tid, pos, pos) rows (the C layout), e.g. prepared once for repeated calls
+        if isinstance(sites, np.ndarray):
+            arr = np.ascontiguousarray(sites, dtype=np.int32); n = arr.shape[0]; ptr = arr.ctypes.data
+        else:
+            arr = _regions_array([(t, p, p) for t, p in sites]); n = len(sites); ptr = C.cast(arr, C.c_void_p)
+        out = np.zeros((max(n, 1), 8), dtype=np.int64)
+        self._chk(lib().ngsqc_site_pileup(self.h, ptr, n, min_mapq, min_baseq, int(include_not_properly_paired), out.ctypes.data))
+        return out[:n]
 
     # ---- one BAM sharded over several handles (include/ngsqc.h, "sharded" section) ----
     def scan_mapping_partial(self, mode, **kw):

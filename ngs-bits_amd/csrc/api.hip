@@ -950,11 +950,24 @@ int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_site
 			else { if (seen[(size_t)r.tid]) throw ArgError("sites of one reference must be contiguous"); seen[(size_t)r.tid] = 1; tf[(size_t)r.tid] = (int32_t)i; }
 			tl[(size_t)r.tid] = (int32_t)i + 1; pos[(size_t)i] = r.start;
 		}
-		DevBuf<int32_t> d_pos, d_tf, d_tl; d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream);
+		// 64 kb position buckets per reference (only references that have sites get buckets)
+		std::vector<int64_t> tb0((size_t)n_ref + 1, 0); std::vector<int32_t> bucket;
+		for (int t = 0; t < n_ref; ++t)
+		{
+			tb0[(size_t)t] = (int64_t)bucket.size();
+			if (tf[(size_t)t] >= tl[(size_t)t]) continue;
+			const int64_t nb = (std::max<int64_t>(h->ref_lens[(size_t)t], pos[(size_t)tl[(size_t)t] - 1]) >> PILEUP_BUCKET_SHIFT) + 2;
+			int32_t i = tf[(size_t)t];
+			for (int64_t b = 0; b < nb; ++b) { const int64_t lo = b << PILEUP_BUCKET_SHIFT; while (i < tl[(size_t)t] && pos[(size_t)i] < lo) ++i; bucket.push_back(i); }
+		}
+		tb0[(size_t)n_ref] = (int64_t)bucket.size();
+		if (bucket.empty()) bucket.push_back(0);
+		DevBuf<int32_t> d_pos, d_tf, d_tl, d_bucket; DevBuf<int64_t> d_tb0;
+		d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream); d_bucket.upload(bucket, h->stream); d_tb0.upload(tb0, h->stream);
 		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_sites * 8);
 		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_sites * 8 * sizeof(uint32_t), h->stream));
 		for_each_tile(h, [&](int) {
-			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->stream);
+			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->stream);
 			HIPCHK(hipStreamSynchronize(h->stream));
 			return true;
 		});

@@ -560,6 +560,7 @@ __device__ static int pileup_base(const RecView& r, int pos, int& qual_out)   //
 
 __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, long long n_rec, int n_ref,
                                                      const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_first, const int32_t* __restrict__ tid_last,
+                                                     const int32_t* __restrict__ bucket, const int64_t* __restrict__ tid_bucket0,
                                                      int min_mapq, int min_baseq, int include_npp, uint32_t* __restrict__ counts)
 {
 	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < n_rec; li += (long long)gridDim.x * blockDim.x)
@@ -586,8 +587,11 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 		for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
 		if (ref_len == 0) ref_len = 1;                                        // bam_endpos
 		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
-		int a = first, b = last;                                              // first site with pos >= start1
-		while (a < b) { const int m = (a + b) >> 1; if (site_pos[m] < start1) a = m + 1; else b = m; }
+		// first site with pos >= start1: bucket[tid][start1 >> 16] = first site at or behind the bucket's first position, then a short scan
+		const int64_t b0 = tid_bucket0[r.tid], nbk = tid_bucket0[r.tid + 1] - b0;
+		int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
+		int a = bucket[b0 + bi];
+		while (a < last && site_pos[a] < start1) ++a;
 		for (int i = a; i < last && site_pos[i] <= end1; ++i)
 		{
 			int q; const int base = pileup_base(r, site_pos[i], q);
@@ -598,11 +602,11 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 }
 
 void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
-                   int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s)
+                   const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s)
 {
 	if (n_rec <= 0) return;
 	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 32);
-	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, min_mapq, min_baseq, include_npp, counts);
+	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts);
 }
 
 } // namespace ngsqc
