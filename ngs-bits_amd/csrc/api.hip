@@ -68,6 +68,7 @@ struct ngsqc_handle
 	int cur_tile = -1; int64_t tile_prefix = 0, tile_total = 0, tile_u_lo = 0, tile_ord_base = 0;
 	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0; int64_t n_rec_total = -1;
 	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
+	DevBuf<uint32_t> d_k1_order; int64_t k1_order_chunk = -1;   // queue order of the members inside each K1 chunk (largest first)
 	ngsqc_timings tm{};
 	// one BAM sharded over several handles: this handle owns the records that START inside members
 	// [0, shard_own_members) of its (rebased) member table; the members behind them are only there to complete the last record
@@ -133,8 +134,10 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 	if (n <= 0) return true;
 	if (variant >= 20)
 	{
+		bool order_dirty = false;
 		if (h->tok_first != first || h->tok_n != n)
 		{
+			order_dirty = true;
 			std::vector<uint64_t> off((size_t)n + 1, 0);
 			for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] = off[(size_t)i] + (((uint64_t)h->blocks[(size_t)(first + i)].clen + 64 + 3) & ~3ull);
 			h->d_tok_off.upload(off, h->stream);
@@ -147,11 +150,24 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 		// of chunk c+1 decodes - the two kernels bound on different things (dependent-issue latency at 1.5 waves/SIMD vs VALU
 		// throughput), and a ragged last round no longer idles the chip. 6 phase-1 waves per CU leave LDS for phase 2.
 		const char* pe = getenv("NGSQC_K1_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;
+		const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
 		const int64_t lanes = (int64_t)h->n_cu * (pipelined ? 6 : 7) * 64;
 		const int64_t nch0 = pipelined ? std::max<int64_t>(1, (n + lanes - 1) / lanes) : 1;
 		const int64_t chunk = (((n + nch0 - 1) / nch0) + 63) & ~63ll;   // equal chunks, whole waves
 		const int64_t nch = (n + chunk - 1) / chunk;
 		while ((int64_t)h->k1_events.size() < 4 * nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->k1_events.push_back(e); }
+		if (h->k1_order_chunk != chunk || h->d_k1_order.n < (size_t)n || order_dirty)
+		{
+			// queue order inside every chunk: largest compressed size first (chunk-local indices)
+			std::vector<uint32_t> ord((size_t)n);
+			for (int64_t c0 = 0; c0 < n; c0 += chunk)
+			{
+				const int64_t cn = std::min<int64_t>(chunk, n - c0);
+				for (int64_t i = 0; i < cn; ++i) ord[(size_t)(c0 + i)] = (uint32_t)i;
+				std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(first + c0 + a)].clen > h->blocks[(size_t)(first + c0 + b)].clen; });
+			}
+			h->d_k1_order.upload(ord, h->stream); h->k1_order_chunk = chunk;
+		}
 		h->d_k1_work.ensure((size_t)nch);
 		HIPCHK(hipMemsetAsync(h->d_k1_work.p, 0, (size_t)nch * sizeof(unsigned long long), h->stream));
 		for (int64_t c = 0; c < nch; ++c)
@@ -159,7 +175,7 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 			const int64_t c0 = c * chunk, cn = std::min<int64_t>(chunk, n - c0);
 			hipEvent_t* e4 = &h->k1_events[(size_t)(4 * c)];
 			HIPCHK(hipEventRecord(e4[0], h->stream));
-			launch_huff_tokens(h->d_comp.p, d_desc + c0, cn, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_k1_work.p + c, h->n_cu * (pipelined ? 6 : 7), h->stream);
+			launch_huff_tokens(h->d_comp.p, d_desc + c0, cn, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_k1_work.p + c, sorted_queue ? h->d_k1_order.p + c0 : nullptr, h->n_cu * (pipelined ? 6 : 7), h->stream);
 			HIPCHK(hipEventRecord(e4[1], h->stream));
 			hipStream_t s2 = pipelined ? h->stream2 : h->stream;
 			if (pipelined) HIPCHK(hipStreamWaitEvent(s2, e4[1], 0));

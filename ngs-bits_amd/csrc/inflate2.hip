@@ -156,7 +156,7 @@ struct LimTab
 
 __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
-                                                          BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, int park_hi)
+                                                          BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)
 {
 	__shared__ uint32_t lds[P1_LANE_W * 64];
 	const int lane = threadIdx.x;
@@ -452,10 +452,13 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 		}
 		else if (state == S_NEXT)
 		{
+			// members leave the queue in the caller's order (largest compressed size first): the 64 lanes of a wave decode members of
+			// nearly equal size and finish together, and the launch ends with its smallest members
 			b = (int64_t)atomicAdd(work_counter, 1ull);
 			if (b >= n_blocks) state = S_DONE;
 			else
 			{
+				if (order) b = (int64_t)order[b];
 				const BlockDesc bd = blocks[b];
 				const uint64_t to = tok_off[b], to1 = tok_off[b + 1];
 				__builtin_amdgcn_s_waitcnt(WAIT_VM0);
@@ -826,14 +829,14 @@ __global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __res
 }
 
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
-                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, int max_wgs, hipStream_t s)
+                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
 	// d_work: the launch's member queue head (zeroed by the caller). One-wave workgroups; 7 fit a CU (22.8 KB LDS each).
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
 	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
-	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, park_hi);
+	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
 }
 
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
