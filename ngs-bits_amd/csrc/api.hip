@@ -982,9 +982,15 @@ int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_site
 		d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream); d_bucket.upload(bucket, h->stream); d_tb0.upload(tb0, h->stream);
 		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_sites * 8);
 		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_sites * 8 * sizeof(uint32_t), h->stream));
+		DevBuf<unsigned long long> d_nlong; d_nlong.alloc(1);
 		for_each_tile(h, [&](int) {
-			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->stream);
+			h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
+			HIPCHK(hipMemsetAsync(d_nlong.p, 0, sizeof(unsigned long long), h->stream));
+			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->d_long.p, d_nlong.p, h->stream);
+			unsigned long long n_long = 0;
+			HIPCHK(hipMemcpyAsync(&n_long, d_nlong.p, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipStreamSynchronize(h->stream));
+			if (n_long) { launch_pileup_long(h->d_infl.p, h->d_recoff.p, h->d_long.p, (int64_t)n_long, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); }
 			return true;
 		});
 		std::vector<uint32_t> out((size_t)n_sites * 8);

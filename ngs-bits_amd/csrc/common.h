@@ -78,7 +78,10 @@ void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paire
 // site pileup (BamReader::getPileup SNP counts for a table of sites; counts = u32[n_sites][8])
 constexpr int PILEUP_BUCKET_SHIFT = 16;   // 64 kb position buckets per reference: bucket -> first site at or behind the bucket start
 void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
-                   const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s);
+                   const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts,
+                   int64_t* long_list, unsigned long long* long_count, hipStream_t s);
+void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, int64_t n_long, const int32_t* site_pos, const int32_t* tid_last,
+                        const int32_t* bucket, const int64_t* tid_bucket0, int min_baseq, uint32_t* counts, hipStream_t s);
 
 // ---- raw-read QC pass (reads.hip): StatisticsReads::update(BamAlignment) ----
 constexpr int RQ_PASSES = 5, RQ_CYC = RQ_PASSES * 64;   // per-cycle statistics are kept for the first 320 cycles (every Illumina read length)

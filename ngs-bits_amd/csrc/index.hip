@@ -32,6 +32,43 @@ __device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total
 	return true;
 }
 
+// Guessing the first record of a member, one WAVE per member: 64 consecutive offsets are tested per step (two coalesced
+// 4-byte loads reject almost every offset before the full plausibility check), so a member that lies inside one long record
+// (ONT: most members) costs 1 k steps instead of a 65 k-step scalar scan per thread. Members whose start is already known
+// (>= 0 or -1) are skipped; a member without any plausible start gets -1.
+__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+                                                          int32_t* start, int32_t n_ref)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+	for (int64_t b = wave; b < n_blocks; b += n_waves)
+	{
+		if (start[b] != -2) continue;
+		const BlockDesc bd = blocks[b];
+		const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+		int32_t found = -1;
+		for (int64_t base = lo; base < hi; base += 64)
+		{
+			const int64_t o = base + lane;
+			bool ok = false;
+			if (o < hi && o + 36 <= total)
+			{
+				const uint32_t bs = ld32u(infl + o); const int32_t tid = (int32_t)ld32u(infl + o + 4);
+				ok = bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref;
+			}
+			if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+			if (ok)
+			{
+				ok = plausible(infl, total, o, n_ref);
+				if (ok) { const int64_t o2 = o + 4 + ld32u(infl + o); if (o2 < total && !plausible(infl, total, o2, n_ref)) ok = false; }   // chain one more record
+			}
+			const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+			if (m) { found = (int32_t)(base + __builtin_ctzll(m) - lo); break; }
+		}
+		if (lane == 0) start[b] = found;
+	}
+}
+
 // start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
 __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
@@ -151,6 +188,11 @@ void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
+	{
+		// resolve the guesses wave-cooperatively first (the count kernel keeps its scalar guess loop only as a fallback)
+		const int64_t wg = (n_blocks + 3) / 4;
+		hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_blocks, d_start, n_ref);
+	}
 	int grid = (int)((n_blocks + 63) / 64);
 	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_cnt, d_next_abs, d_bad, n_ref);
 }

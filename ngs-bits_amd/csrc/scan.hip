@@ -561,7 +561,8 @@ __device__ static int pileup_base(const RecView& r, int pos, int& qual_out)   //
 __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, long long n_rec, int n_ref,
                                                      const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_first, const int32_t* __restrict__ tid_last,
                                                      const int32_t* __restrict__ bucket, const int64_t* __restrict__ tid_bucket0,
-                                                     int min_mapq, int min_baseq, int include_npp, uint32_t* __restrict__ counts)
+                                                     int min_mapq, int min_baseq, int include_npp, uint32_t* __restrict__ counts,
+                                                     int64_t* __restrict__ long_list, unsigned long long* __restrict__ long_count)
 {
 	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < n_rec; li += (long long)gridDim.x * blockDim.x)
 	{
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 				if (t && t[0] == 'B' && t[1] == 'I') { const uint32_t n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) { r.cigar = t + 6; r.n_cigar = n; } }
 			}
 		}
+		if (r.n_cigar > (uint32_t)LONG_CIGAR) { long_list[atomicAdd(long_count, 1ull)] = li; continue; }   // wave-per-record path (pileup_long_kernel)
 		long long ref_len = 0;
 		for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
 		if (ref_len == 0) ref_len = 1;                                        // bam_endpos
@@ -601,12 +603,102 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 	}
 }
 
+// Records with long CIGARs (ONT: ~1 op per 12 bp, thousands of ops): ONE WAVE PER RECORD. Every lane owns a contiguous
+// slice of the ops; a wave prefix sum gives each slice its genome / read position, then for every site inside the read each
+// lane looks for the first op of its slice that carries the genome position to or past the site (and for a soft clip that
+// exhausts the read, BamReader.cpp:346-353); the earliest such op of the wave decides, exactly as the sequential walk does.
+__global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, const int64_t* __restrict__ long_list, long long n_long,
+                                                          const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_last,
+                                                          const int32_t* __restrict__ bucket, const int64_t* __restrict__ tid_bucket0,
+                                                          int min_baseq, uint32_t* __restrict__ counts)
+{
+	const int lane = threadIdx.x & 63;
+	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+	for (long long w = wave; w < n_long; w += n_waves)
+	{
+		RecView r = load_rec(infl, recoff[long_list[w]]);      // (passed the read filters in pileup_kernel)
+		if (r.n_cigar_raw > 0 && r.pos >= 0)
+		{
+			const uint32_t c0 = ld32(r.cigar);
+			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq)
+			{
+				unsigned long long cg = 0; uint32_t n = 0;
+				if (lane == 0)
+				{
+					const uint8_t* t = aux_find(rec_aux(r), rec_end(r), 'C', 'G');
+					if (t && t[0] == 'B' && t[1] == 'I') { n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) cg = (unsigned long long)(uintptr_t)(t + 6); }
+				}
+				cg = __shfl(cg, 0); n = __shfl(n, 0);
+				if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; }
+			}
+		}
+		const uint32_t per = (r.n_cigar + 63) / 64, k0 = min((uint32_t)lane * per, r.n_cigar), k1 = min(k0 + per, r.n_cigar);
+		long long s_ref = 0, s_read = 0;
+		for (uint32_t k = k0; k < k1; ++k)
+		{
+			const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u; const long long len = c >> 4;
+			if ((0x18Du >> op) & 1u) s_ref += len;
+			if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) s_read += len;
+		}
+		long long p_ref = s_ref, p_read = s_read;   // inclusive wave scan -> exclusive prefix
+		#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const long long a = __shfl_up(p_ref, o), b = __shfl_up(p_read, o); if (lane >= o) { p_ref += a; p_read += b; } }
+		long long ref_len = __shfl(p_ref, 63); if (ref_len == 0) ref_len = 1;
+		p_ref -= s_ref; p_read -= s_read;
+		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
+		const int last = tid_last[r.tid];
+		const int64_t b0 = tid_bucket0[r.tid], nbk = tid_bucket0[r.tid + 1] - b0;
+		int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
+		int a = bucket[b0 + bi];
+		while (a < last && site_pos[a] < start1) ++a;
+		for (int i = a; i < last && site_pos[i] <= end1; ++i)
+		{
+			const int pos = site_pos[i];
+			long long g = r.pos + p_ref, rp = p_read;
+			uint32_t hit_k = 0xffffffffu, hit_op = 0, s_k = 0xffffffffu; long long hit_g = 0, hit_rp = 0;
+			for (uint32_t k = k0; k < k1; ++k)
+			{
+				const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u; const long long len = c >> 4;
+				if ((0x18Du >> op) & 1u) g += len;
+				if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) rp += len;
+				if (op == 4 && rp >= r.l_seq && s_k == 0xffffffffu) s_k = k;
+				if (((0x18Du >> op) & 1u) && g >= pos && hit_k == 0xffffffffu) { hit_k = k; hit_op = op; hit_g = g; hit_rp = rp; }
+			}
+			uint32_t first_hit = hit_k, first_s = s_k;
+			#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { first_hit = min(first_hit, (uint32_t)__shfl_xor((int)first_hit, o)); first_s = min(first_s, (uint32_t)__shfl_xor((int)first_s, o)); }
+			if (first_hit == 0xffffffffu) { if (lane == 0) atomicAdd(&counts[8ull * i + 7], 1u); continue; }   // "Could not find position"
+			if (first_s < first_hit) continue;                                                                  // '~'
+			if (hit_k == first_hit)   // exactly one lane
+			{
+				if (hit_op == 2) atomicAdd(&counts[8ull * i + 5], 1u);                                          // deleted base, quality 255
+				else if (hit_op != 3)
+				{
+					const long long ap = hit_rp - (hit_g + 1 - pos);
+					const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
+					const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15, q = rec_qual(r)[ap];
+					const int base = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
+					if (q >= min_baseq) atomicAdd(&counts[8ull * i + base], 1u);
+				}
+			}
+		}
+	}
+}
+
 void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
-                   const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts, hipStream_t s)
+                   const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts,
+                   int64_t* long_list, unsigned long long* long_count, hipStream_t s)
 {
 	if (n_rec <= 0) return;
 	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 32);
-	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts);
+	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts, long_list, long_count);
+}
+void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, int64_t n_long, const int32_t* site_pos, const int32_t* tid_last,
+                        const int32_t* bucket, const int64_t* tid_bucket0, int min_baseq, uint32_t* counts, hipStream_t s)
+{
+	if (n_long <= 0) return;
+	const int grid = (int)std::min<int64_t>((n_long + 3) / 4, 256 * 16);
+	hipLaunchKernelGGL(pileup_long_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, long_list, (long long)n_long, site_pos, tid_last, bucket, tid_bucket0, min_baseq, counts);
 }
 
 } // namespace ngsqc
