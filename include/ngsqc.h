@@ -189,6 +189,8 @@ typedef struct ngsqc_shard_fix {
 	int32_t reserved;
 } ngsqc_shard_fix;
 int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_shard_summary* out);
+/* coverage tools on a shard: ngsqc_scan_depth without the final prefix sum (the depth scan has no order-dependent carries) */
+int ngsqc_scan_depth_partial(ngsqc_handle* h, const ngsqc_depth_params* p);
 /* returns NGSQC_E_FORMAT (message via ngsqc_last_error(NULL)) when the shards' record chains do not join */
 int ngsqc_plan_shard_fix(const ngsqc_shard_summary* all, int n_shards, int shard, ngsqc_shard_fix* out);
 int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64_t* counters, double* gc_reads);

@@ -8,4 +8,4 @@ from .capi import (  # noqa: F401
     NgsqcError, Handle, Region, MappingParams, lib, lib_path, build_library,
     MODE_ROI, MODE_NOROI, MODE_WGS, NCOUNTERS, COUNTER_NAMES, ShardSummary, ShardFix, SUMMARY_FIELDS, plan_shard_fix,
 )
-from .dist import allreduce_counters, combine_counters_local, shard_blocks, scan_mapping_sharded, scan_mapping_sharded_local  # noqa: F401,E402
+from .dist import allreduce_counters, combine_counters_local, shard_blocks, scan_mapping_sharded, scan_mapping_sharded_local, scan_depth_sharded_local  # noqa: F401,E402

@@ -110,6 +110,7 @@ def lib():
         L.ngsqc_copy_record_offsets.restype = i32; L.ngsqc_copy_record_offsets.argtypes = [vp, vp, i64]
         L.ngsqc_scan_mapping.restype = i32; L.ngsqc_scan_mapping.argtypes = [vp, C.POINTER(MappingParams), vp, vp]
         L.ngsqc_scan_depth.restype = i32; L.ngsqc_scan_depth.argtypes = [vp, C.POINTER(DepthParams)]
+        L.ngsqc_scan_depth_partial.restype = i32; L.ngsqc_scan_depth_partial.argtypes = [vp, C.POINTER(DepthParams)]
         L.ngsqc_depth_stats.restype = i32; L.ngsqc_depth_stats.argtypes = [vp, C.c_int32, i64, vp, vp]
         L.ngsqc_depth_copy.restype = i32; L.ngsqc_depth_copy.argtypes = [vp, vp, i64]
         L.ngsqc_region_sums.restype = i32; L.ngsqc_region_sums.argtypes = [vp, vp, i64, vp]
@@ -139,7 +140,7 @@ EXPORTS = [
     "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
     "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
-    "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
+    "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
 ]
 
@@ -309,12 +310,13 @@ class Handle:
     def depth_finalize(self):
         self._chk(lib().ngsqc_depth_finalize(self.h))
 
-    def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False):
+    def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False, partial=False):
+        """partial=True: shard variant that leaves the additive difference array (see depth_diff / depth_finalize)."""
         p = DepthParams()
         ra = _regions_array(regions)
         p.min_mapq, p.min_baseq, p.skip_mismapped = min_mapq, min_baseq, int(skip_mismapped)
         p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions)
-        self._chk(lib().ngsqc_scan_depth(self.h, C.byref(p)))
+        self._chk((lib().ngsqc_scan_depth_partial if partial else lib().ngsqc_scan_depth)(self.h, C.byref(p)))
 
     def depth_stats(self, hist_cap, half_depth):
         hist = np.zeros(hist_cap + 1, dtype=np.int64)

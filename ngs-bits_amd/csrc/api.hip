@@ -1050,25 +1050,27 @@ int ngsqc_read_cycle_stats(ngsqc_handle* h, int64_t* out, int64_t n_cycles)
 	});
 }
 
-int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p)
+namespace {
+void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 {
-	return guarded(h, [&] {
-		if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
-		Timer total(h->stream); total.start();
-		setup_regions(h, p->regions, p->n_regions);
-		ScanParams sp{};
-		sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;
-		sp.tid_x = -2; sp.tid_y = -2;
-		sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
-		sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
-		std::vector<unsigned long long> dev;
-		run_scan(h, sp, dev);
-		Timer fin(h->stream); fin.start();
-		finalize_depth(h);
-		h->tm.finalize_ms = fin.stop();
-		h->tm.total_ms = total.stop();
-	});
+	if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
+	Timer total(h->stream); total.start();
+	setup_regions(h, p->regions, p->n_regions);
+	ScanParams sp{};
+	sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;
+	sp.tid_x = -2; sp.tid_y = -2;
+	sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
+	sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
+	std::vector<unsigned long long> dev;
+	run_scan(h, sp, dev);
+	if (finalize) { Timer fin(h->stream); fin.start(); finalize_depth(h); h->tm.finalize_ms = fin.stop(); }
+	h->tm.total_ms = total.stop();
 }
+} // namespace
+
+int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, true); }); }
+// shard variant: leaves the un-prefixed difference array (additive over shards: ngsqc_depth_device / _diff_copy / _diff_set, then ngsqc_depth_finalize)
+int ngsqc_scan_depth_partial(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, false); }); }
 
 int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int64_t* hist, int64_t* covered)
 {

@@ -122,3 +122,15 @@ def scan_mapping_sharded_local(handles, mode, **scan_kw):
         handles[0].depth_diff_set(total.astype(np.int32))
     handles[0].depth_finalize()
     return counters, gc, summaries
+
+
+def scan_depth_sharded_local(handles, regions, **kw):
+    """Coverage-tool depth scan over shard handles in one process: handles[0] ends up with the whole BAM's depth array."""
+    for h in handles:
+        h.scan_depth(regions, partial=True, **kw)
+    total = handles[0].depth_diff().astype(np.int64)
+    for h in handles[1:]:
+        total += h.depth_diff()
+    handles[0].depth_diff_set(total.astype(np.int32))
+    handles[0].depth_finalize()
+    return handles[0]

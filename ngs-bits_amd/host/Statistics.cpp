@@ -223,6 +223,32 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 	return s;
 }
 
+// coverage-tool depth scan (ngsqc_scan_depth); with NGSQC_SHARDS the shards scan concurrently and their difference arrays are summed
+void runDepthScan(BamReader& reader, const ngsqc_depth_params& p)
+{
+	const std::vector<ngsqc_handle*>& sh = reader.shards();
+	if (sh.size() == 1) { reader.check(ngsqc_scan_depth(reader.handle(), &p)); return; }
+	const int n = (int)sh.size(); std::vector<int> rcs((size_t)n, NGSQC_OK);
+	{
+		std::vector<std::thread> th;
+		for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[(size_t)i] = ngsqc_scan_depth_partial(sh[(size_t)i], &p); });
+		for (auto& t : th) t.join();
+	}
+	auto chk = [&](ngsqc_handle* h, int rc) { if (rc == NGSQC_OK) return; std::string msg = ngsqc_last_error(h); if (rc == NGSQC_E_ARG) NB_THROW(ArgumentException, msg); if (rc == NGSQC_E_FORMAT) NB_THROW(FileAccessException, msg); NB_THROW(Exception, msg); };
+	std::vector<int32_t> sum, diff;
+	for (int i = 0; i < n; ++i)
+	{
+		chk(sh[(size_t)i], rcs[(size_t)i]);
+		void* dptr = nullptr; int64_t slots = 0;
+		chk(sh[(size_t)i], ngsqc_depth_device(sh[(size_t)i], &dptr, &slots));
+		diff.resize((size_t)slots);
+		if (slots) chk(sh[(size_t)i], ngsqc_depth_diff_copy(sh[(size_t)i], diff.data(), slots));
+		if (sum.empty()) sum = diff; else for (int64_t k = 0; k < slots; ++k) sum[(size_t)k] += diff[(size_t)k];
+	}
+	if (!sum.empty()) chk(sh[0], ngsqc_depth_diff_set(sh[0], sum.data(), (int64_t)sum.size()));
+	chk(sh[0], ngsqc_depth_finalize(sh[0]));
+}
+
 // Statistics.cpp:576-604
 void dropoutValues(const std::vector<double>& gc_roi, const std::vector<double>& gc_reads, double& at, double& gc, std::vector<double>& roi_perc, std::vector<double>& read_perc)
 {
@@ -466,13 +492,13 @@ QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::
 {
 	if (!bed_file.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for depth details statistics!");   // :1577-1580
 	long long roi_bases = bed_file.baseCount();
-	BamReader reader(bam_file, ref_file);
+	BamReader reader(bam_file, ref_file, true);
 	long long bases_usable = 0;
 	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
 	if (!regions.empty())
 	{
 		ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
-		reader.check(ngsqc_scan_depth(reader.handle(), &p));
+		runDepthScan(reader, p);
 		std::vector<int64_t> sums(regions.size(), 0);
 		reader.check(ngsqc_region_sums(reader.handle(), regions.data(), (int64_t)regions.size(), sums.data()));
 		for (int64_t v : sums) bases_usable += v;
@@ -703,11 +729,11 @@ void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
 	if (bed_file.count() == 0) return;
-	BamReader reader(bam_file, ref_file);
+	BamReader reader(bam_file, ref_file, true);
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
 	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = skip_mismapped ? 1 : 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
-	reader.check(ngsqc_scan_depth(reader.handle(), &p));
+	runDepthScan(reader, p);
 	std::vector<ngsqc_region> lines = toRegions(bed_file, reader, true);
 	std::vector<int64_t> sums(lines.size(), 0);
 	reader.check(ngsqc_region_sums(reader.handle(), lines.data(), (int64_t)lines.size(), sums.data()));
@@ -721,11 +747,11 @@ BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string
 	if (!random_access && cutoff > 255) NB_THROW(ArgumentException, "Cutoff cannot be bigger than 255!");   // WorkerLowOrHighCoverage.cpp:149
 	BedFile output;
 	if (bed_file.count() == 0) return output;
-	BamReader reader(bam_file, "");
+	BamReader reader(bam_file, "", true);
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
 	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = min_baseq; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
-	reader.check(ngsqc_scan_depth(reader.handle(), &p));
+	runDepthScan(reader, p);
 	std::vector<ngsqc_region> lines = toRegions(bed_file, reader, true);
 	int64_t n_runs = 0;
 	reader.check(ngsqc_lowhigh_runs(reader.handle(), lines.data(), (int64_t)lines.size(), cutoff, is_high ? 1 : 0, random_access ? 0 : 1, nullptr, 0, &n_runs));

@@ -12,7 +12,7 @@ class BamReader
 {
 public:
 	// allow_shards: honour NGSQC_SHARDS=N (an extension): the BAM is split into N BGZF-member ranges, one handle each, spread
-	// round-robin over the visible GPUs; only the mapping-QC scans (runScan) know how to combine shards.
+	// round-robin over the visible GPUs (mapping scans: shard protocol of include/ngsqc.h; depth scans: summed difference arrays).
 	BamReader(const std::string& bam_file, const std::string& ref_genome = "", bool allow_shards = false);
 	~BamReader();
 	BamReader(const BamReader&) = delete; BamReader& operator=(const BamReader&) = delete;

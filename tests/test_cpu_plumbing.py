@@ -38,7 +38,7 @@ def _tool(name, *args):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "ngs-bits_amd", "host"), "-s"])
-    return subprocess.run([exe] + list(args), capture_output=True, text=True)
+    return subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
 
 
 def test_tool_cli_contract():

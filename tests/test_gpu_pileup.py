@@ -111,10 +111,10 @@ def test_contamination_value_of_the_tool_matches_the_oracle(tmp_path):
     want = O.contamination(ob, _known_snvs("hg38", ob.refs))
     assert want != "n/a"                                     # enough informative SNPs: the numeric branch is exercised
     out = str(tmp_path / "cont.qcML")
-    p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", path, "-wgs", "-build", "hg38", "-no_ref", "-out", out], capture_output=True, text=True)
+    p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", path, "-wgs", "-build", "hg38", "-no_ref", "-out", out], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     m = re.search(r'name="SNV allele frequency deviation"[^>]*value="([^"]*)"', open(out).read())
     assert m and m.group(1) == want, (m and m.group(1), want)
     # -no_cont leaves the value out
-    p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", path, "-wgs", "-build", "hg38", "-no_ref", "-no_cont", "-out", out], capture_output=True, text=True)
+    p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", path, "-wgs", "-build", "hg38", "-no_ref", "-no_cont", "-out", out], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "SNV allele frequency deviation" not in open(out).read()

@@ -60,7 +60,7 @@ def test_tool_read_qc_matches_reference_expected_output(tmp_path):
     """src/tools-TEST/MappingQC_Test.cpp:78-91 (wgs_with_raw_read_qc): both outputs of one run."""
     out1, out2 = str(tmp_path / "MappingQC_test10_out.qcML"), str(tmp_path / "MappingQC_test11_out.qcML")
     p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", os.path.join(GI, "MappingQC_in5.bam"), "-wgs", "-build", "hg38",
-                        "-out", out1, "-read_qc", out2, "-no_ref"], capture_output=True, text=True)
+                        "-out", out1, "-read_qc", out2, "-no_ref"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert _lines(out2) == _lines(os.path.join(GO, "MappingQC_test11_out.qcML"))
     drop = re.compile(r"AT dropout|GC dropout")            # need a genome FASTA

@@ -167,3 +167,27 @@ def test_difference_array_is_aliased_for_the_collective(tmp_path):
     script.write_text(_ALIAS)
     p = subprocess.run([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, OMIM], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "alias ok" in p.stdout, p.stderr[-3000:]
+
+
+def test_coverage_depth_scan_over_shards(tmp_path):
+    """The coverage tools' depth scan has no carries: the shards' difference arrays just add up (incl. the -min_baseq decrements)."""
+    path = str(tmp_path / "cov.bam")
+    G.write(path, n_reads=120_000, seed=33, aligned=False, start_pos=15_900_000)
+    bed = tmp_path / "exome.bed"
+    rng = np.random.default_rng(5)
+    starts = np.sort(rng.integers(16_000_000, 16_550_000, 400))
+    bed.write_text("".join(f"chr1\t{s}\t{s + int(rng.integers(60, 900))}\tex{s}\n" for s in starts))
+    ob = O.Bam(path)
+    data = np.fromfile(path, dtype=np.uint8)
+    for baseq in (0, 20):
+        hs = [ngsqc.Handle(data=data, shard=(i, 4)) for i in range(4)]
+        regs, _ = H.bed_regions(str(bed), hs[0].refs, 2)
+        h0 = ngsqc.scan_depth_sharded_local(hs, regs, min_mapq=1, min_baseq=baseq)
+        exp = O.low_high_coverage(ob, str(bed), 20, 1, baseq, is_high=False, random_access=True, tool_merge=1)
+        assert np.array_equal(h0.depth(exp["roi_bases"]), exp["depth"]), baseq
+        if baseq == 0:
+            lines, _ = H.bed_regions(str(bed), h0.refs, 0)
+            cov, _, _ = O.avg_coverage(ob, str(bed), min_mapq=1, random_access=False)
+            assert np.array_equal(h0.region_sums(lines), cov)
+        for h in hs:
+            h.close()

@@ -17,7 +17,7 @@ STRIP = re.compile(r"creation |<binary>|AT dropout|GC dropout")
 
 
 def run(tool, *args, env=None):
-    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=300)
     assert p.returncode == 0, p.stderr
     return p
 
@@ -67,7 +67,10 @@ def test_mappingqc_sharded_over_several_handles(tmp_path, args, expected, shards
     assert got == exp
 
 
-def test_coverage_tools_match_oracle(tmp_path):
+@pytest.mark.parametrize("shards", [None, "3"])
+def test_coverage_tools_match_oracle(tmp_path, shards, monkeypatch):
+    if shards:
+        monkeypatch.setenv("NGSQC_SHARDS", shards)   # the tools split the BAM into member ranges and sum the shards' difference arrays
     bam, bed = os.path.join(GI, "close_exons.bam"), os.path.join(GI, "close_exons.bed")
     ob = O.Bam(bam)
     out = str(tmp_path / "cov.tsv")
@@ -86,7 +89,7 @@ def test_coverage_tools_match_oracle(tmp_path):
 
 
 def test_tool_errors():
-    p = subprocess.run([os.path.join(BIN, "MappingQC"), "-in", os.path.join(GI, "close_exons.bam"), "-wgs", "-rna", "-no_ref"], capture_output=True, text=True)
+    p = subprocess.run([os.path.join(BIN, "MappingQC"), "-in", os.path.join(GI, "close_exons.bam"), "-wgs", "-rna", "-no_ref"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "exactly one of the parameters 'roi', 'wgs', or 'rna'" in p.stderr
-    p = subprocess.run([os.path.join(BIN, "BedLowCoverage"), "-bam", os.path.join(GI, "close_exons.bam"), "-in", os.path.join(GI, "close_exons.bed"), "-cutoff", "300"], capture_output=True, text=True)
+    p = subprocess.run([os.path.join(BIN, "BedLowCoverage"), "-bam", os.path.join(GI, "close_exons.bam"), "-in", os.path.join(GI, "close_exons.bed"), "-cutoff", "300"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "Cutoff cannot be bigger than 255!" in p.stderr
