@@ -3,17 +3,21 @@
 //   phase 1  huff_tokens_kernel : ONE LANE PER BGZF MEMBER. Every lane Huffman-decodes its own raw-DEFLATE stream into a
 //            token stream (literal byte | match{len,dist}); 64 members advance per wave instruction, so the VALU issue
 //            slots that the group kernel (inflate.hip) spends on 16 redundant lanes carry 64 independent decoders.
-//            Canonical Huffman decode runs out of REGISTERS (code-length counts packed 10/5 bits per field); LDS only
-//            holds the symbol-order arrays, a 64-byte input ring and an 8-token output ring per lane, all laid out
-//            element-major (word k of lane l at k*64+l) so that any per-lane access pattern is bank-conflict free.
+//            Canonical Huffman decode runs out of REGISTERS (per code length one limit|delta word, the length found by a
+//            4-level binary search with v_cndmask-selected pivots); LDS only holds the symbol-order planes and a 32-byte
+//            input ring per lane, laid out element-major (word k of lane l at k*64+l) so that any per-lane access
+//            pattern is bank-conflict free; waiting tokens sit in a 7-register shift register.
 //            Input refill and token flush happen in a "service" block every 4 symbols: 16-byte loads prefetched one
-//            service ahead, 16-byte token stores, one s_waitcnt per service.
-//   phase 2  lz77_resolve_kernel : ONE WAVE PER MEMBER. Tokens are taken 64 at a time; a wave prefix-sum gives every
-//            token its output range, then every OUTPUT BYTE of the batch gets a lane: owner token by binary search,
-//            source position in periodic form (i mod dist), bytes whose source lies before the batch are gathered from
-//            HBM, the (few) in-batch dependencies are resolved by iterating in LDS, and the batch is stored coalesced.
+//            service ahead, 16-byte token stores, one s_waitcnt per service. Header states are parked (see the loop).
+//   phase 2  lz77_chunk_kernel : ONE WAVE PER MEMBER. Tokens are taken 64 at a time; a wave prefix-sum gives every
+//            token its output range, then the batch is resolved front to back in 64-byte chunks: every OUTPUT BYTE gets a
+//            lane (owner token by popcount over a token-end bitmap), its source in periodic form (i mod dist) is
+//            gathered from HBM (before the batch), read from the LDS staging bytes (earlier chunk) or taken from the
+//            source lane (same chunk). lz77_resolve_kernel / lz77_pipe_kernel are earlier variants kept for the tests.
+//   The host side (api.hip:inflate_members) cuts the members into chunks of one decoder "round" and overlaps phase 2 of a
+//   chunk with phase 1 of the next one on a second stream.
 //
-// Same output as inflate.hip (bit-exact; tests/test_gpu_parity.py). Integer / bit-serial work, no MFMA.
+// Same output as inflate.hip (bit-exact; tests/test_gpu_parity.py, tests/test_gpu_inflate.py). Integer work, no MFMA.
 #include "common.h"
 #include <cstdlib>
 
