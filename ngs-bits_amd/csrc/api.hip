@@ -147,8 +147,8 @@ bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc*
 		}
 		// Phase 1 decodes one member per LANE, so a launch lasts as long as its slowest lane: members are cut into chunks of at
 		// most one "round" (every decoder lane gets one member) and phase 2 of chunk c runs on a second stream while phase 1
-		// of chunk c+1 decodes - the two kernels bound on different things (dependent-issue latency at 1.5 waves/SIMD vs VALU
-		// throughput), and a ragged last round no longer idles the chip. 6 phase-1 waves per CU leave LDS for phase 2.
+		// of chunk c+1 decodes: a ragged last round no longer idles the chip (both kernels are VALU-bound, so the overlap itself
+		// gains little). 6 phase-1 waves per CU leave LDS for the phase-2 workgroups.
 		const char* pe = getenv("NGSQC_K1_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;
 		const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
 		const int64_t lanes = (int64_t)h->n_cu * (pipelined ? 6 : 7) * 64;
