@@ -229,6 +229,20 @@ int orc_reads_qc(void* bam, int single_end, int64_t* out, int64_t* len_hist, int
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
 }
 
+// All-cores form of the bench baseline (throughput only, see stream.hpp). out_stats: {n_records, inflated, compressed}. Returns seconds.
+double orc_baseline_wgs_stream_mt(const uint8_t* image, int64_t n, const char* bed, int min_mapq, int threads, int64_t* out_stats, char* err, int errlen)
+{
+	try
+	{
+		BedFile roi; bool have = bed && *bed; if (have) roi.load(bed);
+		StreamStats st;
+		double secs = mapping_wgs_stream_mt(image, (size_t)n, have ? &roi : nullptr, min_mapq, threads, st);
+		if (out_stats) { out_stats[0] = st.n_records; out_stats[1] = st.inflated; out_stats[2] = st.compressed; }
+		return secs;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }
+}
+
 } // extern "C"
 
 

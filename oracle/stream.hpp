@@ -10,12 +10,18 @@
 // ============================================================================
 #pragma once
 #include "stats.hpp"
+#include <chrono>
+#include <thread>
 
 namespace orc {
 
 struct StreamStats { int64_t n_records = 0, inflated = 0, compressed = 0; double seconds = 0; };
 
-inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int64_t max_records, StreamStats& st)
+// begin_off / end_off (multi-threaded baseline only): process the members in [begin_off, end_off) after reading the header
+// from the start of the file; begin_off must be the offset of a member at which a record starts (true for every member of an
+// htslib-style "aligned" BAM such as bench.py's synthetic input). shared_depth: depth array shared by the threads (atomic adds).
+inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int64_t max_records, StreamStats& st,
+                                        size_t begin_off = 0, size_t end_off = (size_t)-1, int32_t* shared_depth = nullptr)
 {
 	MappingResult r;
 	std::vector<uint8_t> fv; // bgzf_scan works on a vector; avoid the copy by scanning headers inline
@@ -27,7 +33,8 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 	if (roi_available && !roi.isMergedAndSorted()) { roi.sort(); roi.merge(); }
 	std::vector<size_t> doff(roi.count() + 1, 0);
 	for (size_t i = 0; i < roi.count(); ++i) doff[i + 1] = doff[i] + roi.lines[i].length();
-	r.depth.assign(doff.back(), 0); r.roi_bases = (int64_t)doff.back();
+	if (!shared_depth) r.depth.assign(doff.back(), 0);
+	r.roi_bases = (int64_t)doff.back();
 	std::unique_ptr<ChrIndex> roi_index; if (roi_available) roi_index.reset(new ChrIndex(roi));
 	uint8_t out[65536 + 8]; size_t consumed = 0; // bytes of buf already parsed
 	auto process = [&](const Rec& al)
@@ -48,8 +55,8 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 					r.bases_usable_roi += al.length();
 					const BedLine& reg = roi.lines[i];
 					int a = std::max(al.start(), reg.start), b = std::min(al.end(), reg.end);
-					int* d = r.depth.data() + doff[i] - reg.start;
-					for (int p = a; p <= b; ++p) d[p] += 1;
+					if (shared_depth) { int32_t* d = shared_depth + doff[i] - reg.start; for (int p = a; p <= b; ++p) __atomic_fetch_add(d + p, 1, __ATOMIC_RELAXED); }
+					else { int* d = r.depth.data() + doff[i] - reg.start; for (int p = a; p <= b; ++p) d[p] += 1; }
 				}
 			});
 		}
@@ -86,7 +93,7 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 		if (al.isDuplicate()) ++r.al_dup;
 	};
 	bool stop = false;
-	while (off < n && !stop)
+	while (off < n && off < end_off && !stop)
 	{
 		if (off + 18 > n) throw Error("Truncated BGZF header");
 		const uint8_t* p = file + off;
@@ -128,6 +135,7 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 					for (auto& nme : names) num.push_back(chr_num(nme));
 					for (size_t i = 0; i < num.size(); ++i) { if (num[i] == 1001 && tid_x < 0) tid_x = (int)i; if (num[i] == 1002 && tid_y < 0) tid_y = (int)i; }
 				} while (false);
+				if (header_done && begin_off > 0) { buf.clear(); consumed = 0; off = begin_off; st.inflated = 0; continue; }   // jump to this thread's member range
 			}
 			if (header_done)
 			{
@@ -143,16 +151,53 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 		}
 		off += bsize;
 	}
-	st.compressed = (int64_t)off;
+	st.compressed = (int64_t)(off - begin_off);
 	r.bases_usable -= r.bases_clipped;
 	r.yx_valid = (tid_x >= 0 && tid_y >= 0 && r.reads_x != 0) ? 1 : 0;
-	if (r.roi_bases > 0)
+	if (r.roi_bases > 0 && !shared_depth)
 	{
 		double avg_depth = (double)r.bases_usable_roi / (double)r.roi_bases;
 		int half = (int)std::round(0.5 * avg_depth); r.half_depth = half;
 		for (int32_t d : r.depth) if (d >= half) ++r.bases_covered_half;
 	}
 	return r;
+}
+
+// All-cores form of the baseline: T threads, each over a contiguous range of BGZF members (equal compressed bytes), one
+// shared depth array. Throughput only: the two order-dependent counters (bases_trimmed, bases_usable_no_overlap) are summed
+// without the cross-range carries, so the counters of this form are NOT used for parity.
+inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int threads, StreamStats& total)
+{
+	std::vector<size_t> member_off;
+	for (size_t off = 0; off + 18 <= n;)
+	{
+		const uint8_t* p = file + off; uint16_t xlen = rd16(p + 10); uint32_t bsize = 0; size_t x = 12, xend = 12 + xlen;
+		while (x + 4 <= xend) { uint16_t slen = rd16(p + x + 2); if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = rd16(p + x + 4) + 1u; x += 4 + slen; }
+		if (!bsize) throw Error("Invalid BGZF block");
+		member_off.push_back(off); off += bsize;
+	}
+	threads = std::max(1, std::min<int>(threads, (int)member_off.size()));
+	BedFile roi; if (roi_in) { roi = *roi_in; if (!roi.isMergedAndSorted()) { roi.sort(); roi.merge(); } }
+	size_t slots = 0; for (size_t i = 0; i < roi.count(); ++i) slots += roi.lines[i].length();
+	std::vector<int32_t> depth(slots, 0);
+	std::vector<StreamStats> st((size_t)threads); std::vector<std::string> errs((size_t)threads);
+	std::vector<std::thread> th;
+	auto t0 = std::chrono::steady_clock::now();
+	for (int t = 0; t < threads; ++t)
+		th.emplace_back([&, t] {
+			try
+			{
+				const size_t a = member_off[member_off.size() * (size_t)t / (size_t)threads];
+				const size_t b = t + 1 == threads ? n : member_off[member_off.size() * (size_t)(t + 1) / (size_t)threads];
+				mapping_wgs_stream(file, n, roi_in ? &roi : nullptr, min_mapq, -1, st[(size_t)t], a, b, roi_in ? depth.data() : nullptr);
+			}
+			catch (std::exception& e) { errs[(size_t)t] = e.what(); }
+		});
+	for (auto& x : th) x.join();
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	for (int t = 0; t < threads; ++t) { if (!errs[(size_t)t].empty()) throw Error(errs[(size_t)t]); total.n_records += st[(size_t)t].n_records; total.inflated += st[(size_t)t].inflated; total.compressed += st[(size_t)t].compressed; }
+	total.seconds = secs;
+	return secs;
 }
 
 } // namespace orc

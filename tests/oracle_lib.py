@@ -249,3 +249,17 @@ def reads_qc(bam, single_end=False, len_cap=None, n_cycles=320):
     return dict(c_forward=int(out[0]), c_reverse=int(out[1]), bases_sequenced=int(out[2]), c_read_q20=int(out[3]), c_base_q20=int(out[4]),
                 c_base_q30=int(out[5]), max_cycles=int(out[6]), base_qualities=out[8:108].copy(), read_qualities=out[108:208].copy(),
                 qscore_dist_r1=out[208:268].copy(), qscore_dist_r2=out[268:328].copy(), bases=out[328:333].copy(), read_lengths=lens, cycles=cyc[:n_cycles])
+
+
+def baseline_wgs_stream_mt(image, bed=None, min_mapq=1, threads=0):
+    """All-cores form of the bench baseline (throughput only). Returns (stats dict, seconds)."""
+    import os as _os
+    L = lib()
+    L.orc_baseline_wgs_stream_mt.restype = C.c_double
+    L.orc_baseline_wgs_stream_mt.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    buf = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8))
+    st = np.zeros(3, dtype=np.int64); err = C.create_string_buffer(1024)
+    secs = L.orc_baseline_wgs_stream_mt(buf.ctypes.data, buf.size, _b(bed), min_mapq, threads or (_os.cpu_count() or 1), st.ctypes.data, err, 1024)
+    if secs < 0:
+        raise OracleError(err.value.decode())
+    return dict(n_records=int(st[0]), inflated=int(st[1]), compressed=int(st[2])), secs

@@ -23,3 +23,14 @@ def test_stream_equals_oracle(bam, bed):
         keep[27:29] = False  # half depth is undefined without a ROI (0/0 in the reference)
     assert np.array_equal(got[keep], exp.counters[keep])
     assert st["n_records"] == O.Bam(path).count and secs >= 0
+
+
+def test_all_cores_baseline_visits_every_record_once():
+    """bench.py's cpu_baseline_all_cores: member ranges per thread must cover every record exactly once."""
+    import bamgen_lib as G
+    img = G.generate(150_000, seed=8, start_pos=15_900_000)
+    bed = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
+    _, st1, _ = O.baseline_wgs_stream(img, bed, 1, -1)
+    for threads in (1, 3, 8):
+        st, secs = O.baseline_wgs_stream_mt(img, bed, 1, threads)
+        assert st["n_records"] == st1["n_records"] == 150_000 and st["inflated"] == st1["inflated"] and secs > 0, (threads, st, st1)
