@@ -18,21 +18,34 @@ def lib():
         if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
             subprocess.check_call(["make", "-C", TOOLS, "-s"])
         L = C.CDLL(so)
-        L.bamgen_generate.restype = C.c_void_p
-        L.bamgen_generate.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-        L.bamgen_free.argtypes = [C.c_void_p]
+        L.bamgen_generate_map.restype = C.c_void_p
+        L.bamgen_generate_map.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.bamgen_release.argtypes = [C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
 
+class _Mapping:
+    """Owner of the generator's anonymous mapping: the numpy view keeps it alive through its base chain."""
+
+    def __init__(self, ptr, n, cap):
+        self.ptr, self.n, self.cap = ptr, n, cap
+        self.__array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        if self.ptr:
+            lib().bamgen_release(self.ptr, self.cap)
+            self.ptr = None
+
+
 def generate(n_reads, seed=20260821, mode=0, depth=30.0, first_contig=0, start_pos=0, level=6, aligned=True, threads=0):
-    """Returns the BAM file image as a numpy uint8 array. mode 0 = short-read WGS, 1 = ONT-like long reads."""
-    n = C.c_size_t(0)
-    p = lib().bamgen_generate(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, C.byref(n))
-    try:
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
-    finally:
-        lib().bamgen_free(p)
+    """Returns the BAM file image as a numpy uint8 array (a zero-copy view of the generator's buffer).
+    mode 0 = short-read WGS, 1 = ONT-like long reads."""
+    n, cap = C.c_size_t(0), C.c_size_t(0)
+    p = lib().bamgen_generate_map(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, C.byref(n), C.byref(cap))
+    if not p:
+        raise MemoryError(f"bamgen: could not map {cap.value} bytes for {n_reads} reads")
+    return np.asarray(_Mapping(p, n.value, cap.value))
 
 
 def write(path, **kw):

@@ -14,6 +14,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
 #include <zlib.h>
 
 namespace {
@@ -37,15 +38,25 @@ struct Params
 void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); v.push_back((x >> 16) & 255); v.push_back((x >> 24) & 255); }
 void put16(std::vector<uint8_t>& v, uint16_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); }
 
-// one BGZF member
+// one BGZF member. The z_stream is kept per thread and reset per member (deflateInit2 allocates ~260 KB: with a fresh stream per
+// member the generator spent most of its time in mmap / page faults); deflateReset gives the same bytes as a fresh stream.
+struct ZCache { z_stream zs; int level = -99; bool live = false; ~ZCache() { if (live) deflateEnd(&zs); } };
 void bgzf_block(const uint8_t* data, size_t n, int level, std::vector<uint8_t>& out)
 {
-	uint8_t buf[70000];
-	z_stream zs; memset(&zs, 0, sizeof(zs));
-	deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+	static thread_local ZCache zc;
+	static thread_local uint8_t buf[70000];
+	z_stream& zs = zc.zs;
+	if (!zc.live || zc.level != level)
+	{
+		if (zc.live) deflateEnd(&zs);
+		memset(&zs, 0, sizeof(zs));
+		deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+		zc.live = true; zc.level = level;
+	}
+	else deflateReset(&zs);
 	zs.next_in = const_cast<uint8_t*>(data); zs.avail_in = (uInt)n; zs.next_out = buf; zs.avail_out = sizeof(buf);
 	deflate(&zs, Z_FINISH);
-	size_t clen = zs.total_out; deflateEnd(&zs);
+	size_t clen = zs.total_out;
 	static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
 	out.insert(out.end(), hdr, hdr + 12);
 	out.push_back('B'); out.push_back('C'); put16(out, 2); put16(out, (uint16_t)(clen + 25));
@@ -204,78 +215,108 @@ std::vector<uint8_t> header_bytes()
 
 constexpr int64_t CHUNK = 32768; // reads per chunk (short); long-read mode uses CHUNK/64
 
-std::vector<uint8_t> generate(const Params& P)
+// The image is assembled in one anonymous mapping sized from an upper bound (untouched pages cost nothing), so the
+// caller gets it without another copy. Chunks are generated in segments of a few chunks per thread: the threads compress
+// into per-slot buffers that are reused from segment to segment, then copy their slots to the final offsets in parallel
+// (peak memory = the image + one segment; a full 30x WGS image is ~60 GB).
+struct Image { uint8_t* p = nullptr; size_t n = 0, cap = 0; };
+
+Image generate(const Params& P)
 {
 	const int64_t chunk = P.mode == 0 ? CHUNK : CHUNK / 64;
 	const int64_t n_chunks = (P.n_reads + chunk - 1) / chunk;
 	const double mean_len = P.mode == 0 ? 147.0 : std::exp(9.6 + 0.75 * 0.75 / 2);
 	const double gap = mean_len / P.depth; // mean distance between read starts
 	// chunk c covers genomic offsets [c*chunk*gap, (c+1)*chunk*gap) of the concatenated genome starting at (first_contig,start_pos)
-	std::vector<std::vector<uint8_t>> parts((size_t)n_chunks);
-	std::atomic<int64_t> next(0);
-	auto worker = [&] {
-		std::vector<uint8_t> rec;
-		while (true)
-		{
-			int64_t c = next.fetch_add(1); if (c >= n_chunks) break;
-			Rng g(P.seed * 1000003ull + (uint64_t)c);
+	const int T = P.threads > 0 ? P.threads : (int)std::max(1u, std::thread::hardware_concurrency());
+	std::vector<uint8_t> head;
+	{ Bgzf z(P.level, 1); auto h = header_bytes(); z.write(h.data(), h.size(), false); z.flush(); head.swap(z.out); }
+	static const uint8_t eof[28] = {0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0,0x1b,0,0x03,0,0,0,0,0,0,0,0,0};
+	// upper bound of the image: stored-block worst case of every member (inflated size + 5 bytes per 64 KB + 26 bytes of BGZF frame)
+	// on top of a generous bound of the inflated record bytes
+	const double rec_bound = P.mode == 0 ? 420.0 : 1.3 * 1.6e6;   // bytes per record, far above the mean (long reads: capped lengths, ~13 bytes per 12 bp)
+	size_t cap = head.size() + 28 + (size_t)((double)P.n_reads * (P.mode == 0 ? rec_bound : std::min(rec_bound, 40.0 * mean_len))) + (size_t)n_chunks * 70000 + (1u << 20);
+	Image img; img.cap = cap;
+	void* m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (m == MAP_FAILED) return img;
+	img.p = (uint8_t*)m;
+	memcpy(img.p, head.data(), head.size());
+	size_t pos = head.size();
+	const int64_t seg = std::max<int64_t>(1, std::min<int64_t>(n_chunks, (int64_t)T * 4));
+	std::vector<std::vector<uint8_t>> slot((size_t)seg);
+	std::vector<size_t> off((size_t)seg + 1);
+	bool overflow = false;
+	for (int64_t c0 = 0; c0 < n_chunks && !overflow; c0 += seg)
+	{
+		const int64_t cn = std::min(seg, n_chunks - c0);
+		std::atomic<int64_t> next(0);
+		auto worker = [&] {
+			std::vector<uint8_t> rec;
 			Bgzf z(P.level, P.aligned);
-			int64_t n = std::min(chunk, P.n_reads - c * chunk);
-			double off = (double)c * (double)chunk * gap, span = (double)n * gap;
-			// sorted offsets inside the chunk: sorted uniforms
-			std::vector<double> offs((size_t)n); for (auto& o : offs) o = off + g.uni() * span;
-			std::sort(offs.begin(), offs.end());
-			for (int64_t i = 0; i < n; ++i)
+			while (true)
 			{
-				int64_t o = (int64_t)offs[i] + P.start_pos; int tid = P.first_contig;
-				while (tid < 24 && o >= HG38_LENS[tid]) { o -= HG38_LENS[tid]; ++tid; }
-				if (o >= HG38_LENS[tid]) o = HG38_LENS[tid] - 1;
-				uint64_t serial = (uint64_t)(c * chunk + i);
-				if (P.mode == 0) short_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial); else long_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial);
-				z.write(rec.data(), rec.size(), true);
+				const int64_t k = next.fetch_add(1); if (k >= cn) break;
+				const int64_t c = c0 + k;
+				Rng g(P.seed * 1000003ull + (uint64_t)c);
+				z.out.swap(slot[(size_t)k]); z.out.clear(); z.cur.clear();
+				int64_t n = std::min(chunk, P.n_reads - c * chunk);
+				double o0 = (double)c * (double)chunk * gap, span = (double)n * gap;
+				// sorted offsets inside the chunk: sorted uniforms
+				std::vector<double> offs((size_t)n); for (auto& o : offs) o = o0 + g.uni() * span;
+				std::sort(offs.begin(), offs.end());
+				for (int64_t i = 0; i < n; ++i)
+				{
+					int64_t o = (int64_t)offs[i] + P.start_pos; int tid = P.first_contig;
+					while (tid < 24 && o >= HG38_LENS[tid]) { o -= HG38_LENS[tid]; ++tid; }
+					if (o >= HG38_LENS[tid]) o = HG38_LENS[tid] - 1;
+					uint64_t serial = (uint64_t)(c * chunk + i);
+					if (P.mode == 0) short_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial); else long_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial);
+					z.write(rec.data(), rec.size(), true);
+				}
+				z.flush();
+				z.out.swap(slot[(size_t)k]);
 			}
-			z.flush();
-			parts[(size_t)c].swap(z.out);
-		}
-	};
-	int T = P.threads > 0 ? P.threads : (int)std::max(1u, std::thread::hardware_concurrency());
-	std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(worker);
-	for (auto& t : th) t.join();
+		};
+		{ std::vector<std::thread> th; for (int t = 0; t < std::min<int64_t>(T, cn); ++t) th.emplace_back(worker); for (auto& t : th) t.join(); }
+		off[0] = pos; for (int64_t k = 0; k < cn; ++k) off[(size_t)k + 1] = off[(size_t)k] + slot[(size_t)k].size();
+		if (off[(size_t)cn] + 28 > cap) { overflow = true; break; }
+		std::atomic<int64_t> nx(0);
+		auto copier = [&] { while (true) { const int64_t k = nx.fetch_add(1); if (k >= cn) break; memcpy(img.p + off[(size_t)k], slot[(size_t)k].data(), slot[(size_t)k].size()); } };
+		{ std::vector<std::thread> th; for (int t = 0; t < std::min<int64_t>(T, cn); ++t) th.emplace_back(copier); for (auto& t : th) t.join(); }
+		pos = off[(size_t)cn];
+	}
+	if (overflow) { munmap(img.p, img.cap); img.p = nullptr; return img; }
 	// NOTE: clamping a read to the contig end can move it before its predecessor by < 1 read length at contig ends;
 	// records stay sorted by (tid, original offset); the QC path does not depend on strict order.
-	std::vector<uint8_t> out;
-	{ Bgzf z(P.level, 1); auto h = header_bytes(); z.write(h.data(), h.size(), false); z.flush(); out.swap(z.out); }
-	size_t total = out.size() + 28; for (auto& p : parts) total += p.size();
-	out.reserve(total);
-	for (auto& p : parts) { out.insert(out.end(), p.begin(), p.end()); std::vector<uint8_t>().swap(p); }
-	static const uint8_t eof[28] = {0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0,0x1b,0,0x03,0,0,0,0,0,0,0,0,0};
-	out.insert(out.end(), eof, eof + 28);
-	return out;
+	memcpy(img.p + pos, eof, 28); pos += 28;
+	img.n = pos;
+	return img;
 }
 
 } // namespace
 
 extern "C" {
-// returns malloc'ed buffer (free with bamgen_free); mode 0 short-read WGS, 1 long-read; aligned=1 htslib-style member alignment
-uint8_t* bamgen_generate(int64_t n_reads, uint64_t seed, int mode, double depth, int first_contig, int64_t start_pos, int level, int aligned, int threads, size_t* n_out)
+// returns an anonymous mapping of *cap_out bytes whose first *n_out bytes are the BAM image (release with bamgen_release);
+// mode 0 short-read WGS, 1 long-read; aligned=1 htslib-style member alignment. NULL when memory could not be mapped.
+uint8_t* bamgen_generate_map(int64_t n_reads, uint64_t seed, int mode, double depth, int first_contig, int64_t start_pos, int level, int aligned, int threads, size_t* n_out, size_t* cap_out)
 {
 	Params P{n_reads, seed, mode, depth, first_contig, level, aligned, threads, start_pos};
-	std::vector<uint8_t> v = generate(P);
-	uint8_t* p = (uint8_t*)malloc(v.size() ? v.size() : 1);
-	memcpy(p, v.data(), v.size()); *n_out = v.size();
-	return p;
+	Image img = generate(P);
+	*n_out = img.n; *cap_out = img.cap;
+	return img.p;
 }
-void bamgen_free(uint8_t* p) { free(p); }
+void bamgen_release(uint8_t* p, size_t cap) { if (p) munmap(p, cap); }
 }
 
 #ifdef BAMGEN_MAIN
 int main(int argc, char** argv)
 {
 	if (argc < 3) { fprintf(stderr, "usage: bamgen OUT.bam N_READS [seed=20260821] [mode=0] [depth=30] [first_contig=0] [level=6] [aligned=1]\n"); return 2; }
-	size_t n = 0;
-	uint8_t* p = bamgen_generate(atoll(argv[2]), argc > 3 ? strtoull(argv[3], 0, 10) : 20260821ull, argc > 4 ? atoi(argv[4]) : 0, argc > 5 ? atof(argv[5]) : 30.0,
-	                             argc > 6 ? atoi(argv[6]) : 0, 0, argc > 7 ? atoi(argv[7]) : 6, argc > 8 ? atoi(argv[8]) : 1, 0, &n);
-	FILE* f = fopen(argv[1], "wb"); if (!f) return 1; fwrite(p, 1, n, f); fclose(f); bamgen_free(p);
+	size_t n = 0, cap = 0;
+	uint8_t* p = bamgen_generate_map(atoll(argv[2]), argc > 3 ? strtoull(argv[3], 0, 10) : 20260821ull, argc > 4 ? atoi(argv[4]) : 0, argc > 5 ? atof(argv[5]) : 30.0,
+	                                 argc > 6 ? atoi(argv[6]) : 0, 0, argc > 7 ? atoi(argv[7]) : 6, argc > 8 ? atoi(argv[8]) : 1, 0, &n, &cap);
+	if (!p) return 1;
+	FILE* f = fopen(argv[1], "wb"); if (!f) return 1; fwrite(p, 1, n, f); fclose(f); bamgen_release(p, cap);
 	return 0;
 }
 #endif
