@@ -158,6 +158,31 @@ int ngsqc_read_length_hist(ngsqc_handle* h, int64_t* out, int64_t cap);
  * for the first min(n_cycles, 320) cycles (per-cycle statistics only feed plots; longer reads are covered by the totals) */
 int ngsqc_read_cycle_stats(ngsqc_handle* h, int64_t* out, int64_t n_cycles);
 
+/* ---- fused job: ONE pass over the BAM for every consumer --------------------------------------------------------------------
+ * The reference re-reads the BAM for every pass of a tool: MappingQC runs Statistics::mapping*, then Statistics::contamination
+ * (src/MappingQC/main.cpp:100-151), optionally StatisticsReads (-read_qc, :83-98) and Statistics::somaticCustomDepth
+ * (-somatic_custom_bed, :153-165). Here every BGZF member is inflated once per job and each requested consumer sees every tile
+ * of the inflated stream while it is resident in HBM. NULL / 0 switches a consumer off. The single-purpose entry points above
+ * (ngsqc_scan_mapping, ngsqc_scan_depth, ngsqc_site_pileup, ngsqc_scan_reads) are jobs with one consumer.
+ * After the job, depth set 0 holds the mapping scan's per-base depth and depth set 1 the extra depth scan's; ngsqc_depth_select
+ * picks the one that ngsqc_depth_stats / _copy / ngsqc_region_sums / ngsqc_lowhigh_runs read (a job leaves set 0 selected when it
+ * had a mapping scan, otherwise set 1; ngsqc_scan_depth uses set 0). */
+typedef struct ngsqc_job_desc {
+	const ngsqc_mapping_params* mapping;     /* Statistics::mapping / mapping_wgs, or NULL                                      */
+	const ngsqc_depth_params* depth;         /* extra depth scan on its own regions (somaticCustomDepth), or NULL               */
+	const ngsqc_region* sites; int64_t n_sites;   /* site pileup (Statistics::contamination), n_sites == 0: off                 */
+	int32_t site_min_mapq, site_min_baseq, site_include_npp;
+	int32_t read_qc, read_qc_single_end;     /* StatisticsReads::update for every record                                         */
+	int32_t reserved;
+} ngsqc_job_desc;
+typedef struct ngsqc_job_result {
+	int64_t* counters; double* gc_reads;     /* mapping: int64[NGSQC_NCOUNTERS], double[101] (may be NULL)                       */
+	int64_t* site_counts;                    /* int64[8 * n_sites]                                                               */
+	ngsqc_read_stats* read_stats;            /* (+ ngsqc_read_length_hist / ngsqc_read_cycle_stats afterwards)                   */
+} ngsqc_job_result;
+int ngsqc_run_job(ngsqc_handle* h, const ngsqc_job_desc* job, ngsqc_job_result* result);
+int ngsqc_depth_select(ngsqc_handle* h, int32_t which);
+
 /* ---- one BAM sharded over several handles / GPUs --------------------------------------------------
  * The reference reads a BAM with one sequential reader (BamReader::getNextAlignment, src/cppNGS/BamReader.h:386-398); its
  * loop bodies (Statistics.cpp:416-574, :830-917, :1068-1183) are independent per record except for two carries: the
@@ -198,6 +223,9 @@ int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64
 int ngsqc_depth_device(ngsqc_handle* h, void** dev_ptr, int64_t* n_slots);
 int ngsqc_depth_diff_copy(ngsqc_handle* h, int32_t* out, int64_t cap);       /* host copy of the same array (CPU collectives) */
 int ngsqc_depth_diff_set(ngsqc_handle* h, const int32_t* in, int64_t n);
+/* dst's difference array += the arrays of the other shard handles; arrays on other GPUs are pulled with peer copies over xGMI
+ * (no host staging). All handles must have scanned the same regions with ngsqc_scan_*_partial. */
+int ngsqc_depth_reduce(ngsqc_handle* dst, ngsqc_handle* const* srcs, int n_srcs);
 int ngsqc_depth_finalize(ngsqc_handle* h);                                    /* difference array -> per-base depth (K6 prefix sum) */
 
 /* ---- measurement: HIP-event timings (ms) of the stages of the last job on this handle ---- */
@@ -211,6 +239,13 @@ typedef struct ngsqc_timings {
 	double inflate_huff_ms;           /* K1 phase 1: huff_tokens_kernel, sum over its launches (0 when the group kernel ran) */
 	double inflate_lz77_ms;           /* K1 phase 2: lz77 resolve kernel (sum over its launches; overlaps phase 1 of the next member chunk) */
 	int64_t inflate_huff_launches;    /* K1 phase-1 launches of the last decode (member chunks of one "round" of decoder lanes) */
+	/* tile stream (round 2): stage times are sums of HIP-event intervals on the handle's main stream; with more than one tile
+	 * they overlap K1 of the next tile, so their sum exceeds the job's wall time */
+	int64_t n_tiles;                  /* tiles of the handle's member table */
+	int64_t members_inflated;         /* BGZF members that went through K1 during the last job (== members of the tiles visited) */
+	double depth_scan_ms;             /* the extra depth scan of a job */
+	double pileup_ms, reads_ms;       /* site pileup / raw-read QC consumers */
+	double job_wall_ms;               /* host wall time of the last ngsqc_run_job (setup, all tiles, result copies) */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

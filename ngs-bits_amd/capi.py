@@ -49,7 +49,18 @@ class Timings(C.Structure):
                 ("finalize_ms", C.c_double), ("total_ms", C.c_double), ("inflate_launches", C.c_int64),
                 ("scan_launches", C.c_int64), ("scan_algorithmic_bytes", C.c_int64), ("compressed_bytes", C.c_int64),
                 ("inflated_bytes", C.c_int64), ("n_records", C.c_int64), ("scan_kernel_ms", C.c_double), ("depth_kernel_ms", C.c_double), ("inflate_huff_ms", C.c_double), ("inflate_lz77_ms", C.c_double),
-                ("inflate_huff_launches", C.c_int64)]
+                ("inflate_huff_launches", C.c_int64), ("n_tiles", C.c_int64), ("members_inflated", C.c_int64), ("depth_scan_ms", C.c_double),
+                ("pileup_ms", C.c_double), ("reads_ms", C.c_double), ("job_wall_ms", C.c_double)]
+
+
+class JobDesc(C.Structure):
+    _fields_ = [("mapping", C.c_void_p), ("depth", C.c_void_p), ("sites", C.c_void_p), ("n_sites", C.c_int64),
+                ("site_min_mapq", C.c_int32), ("site_min_baseq", C.c_int32), ("site_include_npp", C.c_int32),
+                ("read_qc", C.c_int32), ("read_qc_single_end", C.c_int32), ("reserved", C.c_int32)]
+
+
+class JobResult(C.Structure):
+    _fields_ = [("counters", C.c_void_p), ("gc_reads", C.c_void_p), ("site_counts", C.c_void_p), ("read_stats", C.c_void_p)]
 
 
 class ShardSummary(C.Structure):
@@ -131,6 +142,9 @@ def lib():
         L.ngsqc_depth_diff_copy.restype = i32; L.ngsqc_depth_diff_copy.argtypes = [vp, vp, i64]
         L.ngsqc_depth_diff_set.restype = i32; L.ngsqc_depth_diff_set.argtypes = [vp, vp, i64]
         L.ngsqc_depth_finalize.restype = i32; L.ngsqc_depth_finalize.argtypes = [vp]
+        L.ngsqc_run_job.restype = i32; L.ngsqc_run_job.argtypes = [vp, C.POINTER(JobDesc), C.POINTER(JobResult)]
+        L.ngsqc_depth_select.restype = i32; L.ngsqc_depth_select.argtypes = [vp, C.c_int32]
+        L.ngsqc_depth_reduce.restype = i32; L.ngsqc_depth_reduce.argtypes = [vp, C.POINTER(vp), i32]
         _lib = L
     return _lib
 
@@ -142,6 +156,7 @@ EXPORTS = [
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
+    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce",
 ]
 
 
@@ -252,11 +267,51 @@ class Handle:
         self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
         return counters, gc
 
-    def scan_reads(self, single_end=False, n_cycles=320):
-        """StatisticsReads::update over the whole BAM. Returns a dict of numpy arrays / ints (layout of ngsqc_read_stats) plus
-        'read_lengths' (reads per length) and 'cycles' ([n, 7]: A, C, G, T, N, quality sum forward, quality sum reverse)."""
-        st = ReadStats()
-        self._chk(lib().ngsqc_scan_reads(self.h, int(single_end), C.byref(st)))
+    def run_job(self, mapping=None, depth=None, sites=None, site_params=(1, 13, False), read_qc=None, n_cycles=320):
+        """ONE pass over the BAM for every requested consumer (ngsqc_run_job).
+        mapping: dict of scan_mapping keyword arguments incl. 'mode'; depth: dict(regions=, min_mapq=, min_baseq=, skip_mismapped=);
+        sites: list of (tid, pos) or int32 [n, 3]; read_qc: None or dict(single_end=bool).
+        Returns a dict with 'counters', 'gc_reads', 'site_counts', 'reads' for the consumers that ran."""
+        jd, jr, keep, out = JobDesc(), JobResult(), [], {}
+        if mapping is not None:
+            kw = dict(mapping); mode = kw.pop("mode")
+            p, k = self._mapping_params(mode, **kw); keep += [p, k]
+            jd.mapping = C.addressof(p)
+            out["counters"] = np.zeros(NCOUNTERS, dtype=np.int64); out["gc_reads"] = np.zeros(101, dtype=np.float64)
+            jr.counters = out["counters"].ctypes.data; jr.gc_reads = out["gc_reads"].ctypes.data
+        if depth is not None:
+            dp = DepthParams(); ra = _regions_array(depth["regions"]); keep += [dp, ra]
+            dp.min_mapq, dp.min_baseq, dp.skip_mismapped = depth.get("min_mapq", 1), depth.get("min_baseq", 0), int(depth.get("skip_mismapped", False))
+            dp.regions = C.cast(ra, C.c_void_p).value; dp.n_regions = len(depth["regions"])
+            jd.depth = C.addressof(dp)
+        if sites is not None:
+            if isinstance(sites, np.ndarray):
+                arr = np.ascontiguousarray(sites, dtype=np.int32); n = arr.shape[0]; ptr = arr.ctypes.data
+            else:
+                arr = _regions_array([(t, p_, p_) for t, p_ in sites]); n = len(sites); ptr = C.cast(arr, C.c_void_p).value
+            keep.append(arr)
+            out["site_counts"] = np.zeros((max(n, 1), 8), dtype=np.int64)
+            jd.sites = ptr; jd.n_sites = n; jd.site_min_mapq, jd.site_min_baseq, jd.site_include_npp = int(site_params[0]), int(site_params[1]), int(bool(site_params[2]))
+            jr.site_counts = out["site_counts"].ctypes.data
+        st = None
+        if read_qc is not None:
+            st = ReadStats(); jd.read_qc = 1; jd.read_qc_single_end = int(bool(read_qc.get("single_end", False))); jr.read_stats = C.addressof(st)
+        self._chk(lib().ngsqc_run_job(self.h, C.byref(jd), C.byref(jr)))
+        if sites is not None:
+            out["site_counts"] = out["site_counts"][:jd.n_sites]
+        if st is not None:
+            out["reads"] = self._read_stats_dict(st, n_cycles)
+        return out
+
+    def depth_select(self, which):
+        self._chk(lib().ngsqc_depth_select(self.h, int(which)))
+
+    def depth_reduce(self, others):
+        """this handle's difference array += the arrays of the other shard handles (peer copies, no host staging)."""
+        arr = (C.c_void_p * max(len(others), 1))(*[o.h for o in others])
+        self._chk(lib().ngsqc_depth_reduce(self.h, arr, len(others)))
+
+    def _read_stats_dict(self, st, n_cycles):
         out = {f: (np.array(getattr(st, f), dtype=np.int64) if hasattr(getattr(st, f), "__len__") else int(getattr(st, f))) for f, _ in ReadStats._fields_}
         lens = np.zeros(out["max_cycles"] + 1, dtype=np.int64)
         self._chk(lib().ngsqc_read_length_hist(self.h, lens.ctypes.data, lens.size))
@@ -264,6 +319,13 @@ class Handle:
         self._chk(lib().ngsqc_read_cycle_stats(self.h, cyc.ctypes.data, n_cycles))
         out["read_lengths"] = lens; out["cycles"] = cyc[:n_cycles]
         return out
+
+    def scan_reads(self, single_end=False, n_cycles=320):
+        """StatisticsReads::update over the whole BAM. Returns a dict of numpy arrays / ints (layout of ngsqc_read_stats) plus
+        'read_lengths' (reads per length) and 'cycles' ([n, 7]: A, C, G, T, N, quality sum forward, quality sum reverse)."""
+        st = ReadStats()
+        self._chk(lib().ngsqc_scan_reads(self.h, int(single_end), C.byref(st)))
+        return self._read_stats_dict(st, n_cycles)
 
     def site_pileup(self, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):
         """sites: list of (tid, pos) sorted by tid then pos. Returns int64[n, 8]: A, C, G, T, N, deletion, other-letter, not-found."""

@@ -1,12 +1,21 @@
-// Host side of libngsqc_hip.so: the C ABI of include/ngsqc.h on top of the HIP kernels (K1 inflate.hip, K2 index.hip,
-// K3-K5 scan.hip, K6 depth.hip). Owns the compressed image, the inflated stream, the record index and the depth array
-// in HBM; one HIP stream per handle; stage times are taken with HIP events on that stream.
-// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails with
-// NGSQC_E_DEVICE.
+// Host side of libngsqc_hip.so: the C ABI of include/ngsqc.h on top of the HIP kernels (K1 inflate2.hip + crc.hip, K2
+// index.hip, K3-K5 scan.hip / reads.hip, K6 depth.hip).
+//
+// A BAM is processed as a STREAM OF TILES (contiguous BGZF-member ranges sized to HBM):
+//   * K1 runs as one continuous stream of member chunks over the whole file on its own HIP streams (Huffman phase of chunk
+//     c+1 overlaps the LZ77 phase of chunk c; the token scratch is a ring of three chunk slots), writing into one of two
+//     tile buffers;
+//   * K2 (record index) and every consumer of a tile (mapping scan, depth scan, site pileup, raw-read QC) run on the handle's
+//     main stream while K1 already decodes the next tile: each member is inflated exactly once per job, and all consumers
+//     of a job see the tile while it is resident (ngsqc_run_job; the single-purpose entry points are jobs with one consumer).
+//   * A record that straddles two tiles is carried: its head is copied right in front of the next tile's first member
+//     (a fixed prefix area in every tile buffer, so K1 of tile t+1 does not depend on K2 of tile t).
+// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails with NGSQC_E_DEVICE.
 #include "common.h"
 #include <algorithm>
 #include <cstring>
 #include <chrono>
+#include <functional>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -27,9 +36,19 @@ template <typename T> struct DevBuf
 	void alloc(size_t count) { release(); if (count) { HIPCHK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
 	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
 	void ensure(size_t count) { if (n < count) alloc(count); }   // keep a big-enough allocation (hipMalloc/hipFree of multi-GB buffers can stall for a second)
-	void upload(const std::vector<T>& v, hipStream_t s) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
+	void upload(const std::vector<T>& v, hipStream_t s) { ensure(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
 	~DevBuf() { release(); }
 	DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// pinned host memory for the per-tile D2H / H2D exchanges (pageable copies of a few MB cost ~1 ms each)
+template <typename T> struct PinBuf
+{
+	T* p = nullptr; size_t n = 0;
+	void ensure(size_t count) { if (n >= count) return; release(); HIPCHK(hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault)); n = count; }
+	void release() { if (p) { (void)hipHostFree(p); p = nullptr; n = 0; } }
+	~PinBuf() { release(); }
+	PinBuf() = default; PinBuf(const PinBuf&) = delete; PinBuf& operator=(const PinBuf&) = delete;
 };
 
 struct Timer
@@ -41,34 +60,60 @@ struct Timer
 	double stop() { HIPCHK(hipEventRecord(b, s)); HIPCHK(hipEventSynchronize(b)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); return ms; }
 };
 
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+constexpr int K1_SLOTS = 3;          // token ring: chunk c uses slot c % 3 (phase 1 of c+1 and c+2 may run while phase 2 of c reads)
+constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
+
+// target regions + per-base depth of one scan
+struct DepthSet
+{
+	std::vector<ngsqc_region> regions; std::vector<int64_t> doff; std::vector<int32_t> rlen; int64_t n_slots = 0; int64_t roi_bases = 0;
+	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth; DevBuf<uint8_t> d_tmp;
+	bool depth_ready = false;
+};
+
+// what a consumer sees of the resident tile (offsets are tile-local; byte 0 is the first carried byte)
+struct TileCtx { const uint8_t* infl; int64_t total; const int64_t* recoff; int64_t n_rec; int64_t ord_base; int tile; bool last; };
 } // namespace
 
 struct ngsqc_handle
 {
 	std::string err, path;
-	int device = 0; hipStream_t stream = nullptr, stream2 = nullptr; int n_cu = 256;
-	std::vector<hipEvent_t> k1_events; DevBuf<unsigned long long> d_k1_work;   // K1 pipeline: 4 events + one queue head per member chunk
+	int device = 0; int n_cu = 256;
+	hipStream_t stream = nullptr;                 // main stream: K2, consumers, setup copies
+	hipStream_t s_p1[2] = {nullptr, nullptr};      // K1 phase 1 (alternating: the next chunk's waves fill in as the previous chunk's finish)
+	hipStream_t s_p2 = nullptr;                    // K1 phase 2
 	size_t csize = 0;
-	std::vector<BlockDesc> blocks; int64_t total = 0;
-	DevBuf<uint8_t> d_comp; DevBuf<BlockDesc> d_blocks;
-	// decoded state
-	bool decoded = false;
-	DevBuf<uint8_t> d_infl; DevBuf<BlockStatus> d_status; DevBuf<int64_t> d_recoff; int64_t n_rec = 0; int64_t first_rec = 0;
-	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
-	// region / depth state of the last scan
-	std::vector<ngsqc_region> regions; std::vector<int64_t> doff; std::vector<int32_t> rlen; int64_t n_slots = 0; int64_t roi_bases = 0;
-	DevBuf<int32_t> d_reg_start, d_reg_end, d_reg_len, d_tid_first, d_tid_last; DevBuf<int64_t> d_doff; DevBuf<int32_t> d_depth;
-	bool depth_ready = false;
-	std::vector<BlockStatus> h_status; std::vector<int32_t> h_start; std::vector<int64_t> h_next;   // host scratch reused across decodes (no per-step page faults)
-	DevBuf<int64_t> d_long; DevBuf<unsigned long long> d_counters; DevBuf<BlockDesc> d_tile_blocks; DevBuf<uint8_t> d_carry_tmp;
-	// tiling: the inflated stream is processed in member ranges that fit HBM; tile-local offsets everywhere on the device
-	std::vector<std::pair<int64_t, int64_t>> tiles;   // (first member, count)
-	int cur_tile = -1; int64_t tile_prefix = 0, tile_total = 0, tile_u_lo = 0, tile_ord_base = 0;
-	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0; int64_t n_rec_total = -1;
-	DevBuf<uint32_t> d_tok; DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt; int64_t tok_first = -1, tok_n = -1;   // K1 token scratch, kept across decodes
-	DevBuf<uint32_t> d_k1_order; int64_t k1_order_chunk = -1;   // queue order of the members inside each K1 chunk (largest first)
+	std::vector<BlockDesc> blocks; int64_t total = 0;   // BGZF member table of the handle (a shard: rebased to its range)
+	std::vector<uint32_t> crc;                           // CRC32 of every member's inflated bytes (from its BGZF trailer)
+	DevBuf<uint8_t> d_comp;
+	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens; int64_t first_rec = 0;
+	// ---- layout of the tile stream (plan_layout) ----
+	bool planned = false;
+	int64_t chunk = 0, nch = 0;                        // K1 chunk size (members) and count
+	std::vector<std::pair<int64_t, int64_t>> tiles;    // (first member, count); whole chunks
+	std::vector<int64_t> tile_first_chunk;             // size nt + 1
+	int64_t pfx = 0, max_tile_bytes = 0, slot_tokens = 0;
+	DevBuf<BlockDesc> d_kdesc;                         // per member: cpos into d_comp, upos relative to its tile's first member
+	DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt, d_order, d_tok, d_crc; DevBuf<unsigned long long> d_work; DevBuf<BlockStatus> d_status;
+	DevBuf<uint8_t> buf[2];                            // tile buffers: [pfx carried bytes right-aligned][members][64]
+	std::vector<hipEvent_t> ev_chunk;                  // 4 per chunk: p1 start/end, p2 start/end
+	std::vector<hipEvent_t> ev_tile;                   // 2 per tile: K1 done (status on the host), consumed
+	PinBuf<BlockStatus> p_status; PinBuf<int32_t> p_start; PinBuf<int64_t> p_next; PinBuf<unsigned long long> p_small;
+	// ---- the resident tile ----
+	bool decoded = false; int cur_tile = -1;
+	int64_t n_rec = 0; DevBuf<int64_t> d_recoff;
+	int64_t tile_prefix = 0, tile_total = 0, tile_u_lo = 0, tile_ord_base = 0;
+	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0;
+	int64_t k1_enq = 0;                                // chunks enqueued by the running job
+	// K2 scratch (kept across tiles)
+	DevBuf<int32_t> d_start; DevBuf<uint32_t> d_cnt; DevBuf<int64_t> d_next, d_base; DevBuf<uint32_t> d_bad; DevBuf<uint8_t> d_scan_tmp;
+	// depth state
+	DepthSet ds[N_DEPTH_SETS]; int cur_ds = 0;
 	ngsqc_timings tm{};
 	// one BAM sharded over several handles: this handle owns the records that START inside members
 	// [0, shard_own_members) of its (rebased) member table; the members behind them are only there to complete the last record
@@ -77,7 +122,8 @@ struct ngsqc_handle
 	int64_t shard_limit = -1;              // rebased inflated offset of the first byte that is NOT owned
 	int64_t shard_u_base = 0;              // inflated offset (whole file) of the handle's first member
 	int64_t shard_first_abs = -1, shard_exit_abs = -1; int shard_last_tile = -1;
-	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last ngsqc_scan_reads
+	bool verify_crc = true;
+	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last raw-read QC pass
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
 	Partial* partial = nullptr;
 };
@@ -85,7 +131,7 @@ struct ngsqc_handle
 namespace {
 
 // ---- BGZF member table (host): SAM spec §4.1 ----
-void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, int64_t& total)
+void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total)
 {
 	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
 	size_t off = 0; uint64_t upos = 0;
@@ -101,7 +147,7 @@ void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, in
 		if (!found || bsize < xend + 8 || off + bsize > n) throw FormatError("invalid BGZF block size");
 		uint32_t isize = rd32(p + bsize - 4);
 		if (isize > 65536) throw FormatError("BGZF block inflates to more than 64 KiB");
-		if (isize) blocks.push_back(BlockDesc{(uint64_t)(off + xend), upos, (uint32_t)(bsize - xend - 8), isize});
+		if (isize) { blocks.push_back(BlockDesc{(uint64_t)(off + xend), upos, (uint32_t)(bsize - xend - 8), isize}); crc.push_back(rd32(p + bsize - 8)); }
 		upos += isize; off += bsize;
 	}
 	total = (int64_t)upos;
@@ -115,94 +161,47 @@ void init_device(ngsqc_handle* h, int device)
 	h->device = device;
 	HIPCHK(hipSetDevice(device));
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&h->s_p1[0], hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&h->s_p1[1], hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&h->s_p2, hipStreamNonBlocking));
 	int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cu = cu;
+	if (const char* e = getenv("NGSQC_VERIFY_CRC")) h->verify_crc = atoi(e) != 0;
 }
 
-void check_status(ngsqc_handle* h, int64_t n_blocks)
+std::string inflate_error(const ngsqc_handle* h, int64_t member, uint32_t code)
 {
-	for (int64_t i = 0; i < n_blocks; ++i)
-		if (h->h_status[(size_t)i].error) throw FormatError("BGZF inflate failed in block " + std::to_string(i) + " (code " + std::to_string(h->h_status[(size_t)i].error) + ")");
+	// what the reference reports when htslib fails on a block (BamReader.h:389-392)
+	if (code == K1_ERR_CRC) return "Could not read next alignment in BAM/CRAM file " + h->path + " (BGZF CRC32 mismatch in block " + std::to_string(member) + ")";
+	return "Could not read next alignment in BAM/CRAM file " + h->path + " (BGZF inflate failed in block " + std::to_string(member) + ", code " + std::to_string(code) + ")";
 }
 
-// K1 dispatcher. Default: two-phase (lane-per-member Huffman -> tokens, wave-per-member LZ77 resolve). A member whose
-// token stream overflows its budget (clen + 64 tokens) makes the whole range fall back to the group kernel.
-bool inflate_members(ngsqc_handle* h, int64_t first, int64_t n, const BlockDesc* d_desc, uint8_t* d_out_base)
+// Synchronous K1 of a few members on the main stream with private scratch (header read, second chance of a member whose token
+// stream overflowed its budget). idx: member indices into h->blocks; desc/out: where each one goes. tok_cap_full: size the
+// token scratch for the worst case (every output byte a literal) instead of clen + 64.
+void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out, bool tok_cap_full)
 {
-	BlockStatus* d_st = h->d_status.p;   // status of the n members of this call
-	const char* ev = getenv("NGSQC_INFLATE_VARIANT"); const int variant = ev ? atoi(ev) : 20;
-	if (n <= 0) return true;
-	if (variant >= 20)
+	const int64_t n = (int64_t)idx.size();
+	if (n == 0) return;
+	std::vector<uint64_t> off((size_t)n + 1, 0); std::vector<uint32_t> crc((size_t)n);
+	for (int64_t i = 0; i < n; ++i)
 	{
-		bool order_dirty = false;
-		if (h->tok_first != first || h->tok_n != n)
-		{
-			order_dirty = true;
-			std::vector<uint64_t> off((size_t)n + 1, 0);
-			for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] = off[(size_t)i] + (((uint64_t)h->blocks[(size_t)(first + i)].clen + 64 + 3) & ~3ull);
-			h->d_tok_off.upload(off, h->stream);
-			if (h->d_tok.n < (size_t)off[(size_t)n] + 16) h->d_tok.alloc((size_t)off[(size_t)n] + 16);
-			if (h->d_tok_cnt.n < (size_t)n + 8) h->d_tok_cnt.alloc((size_t)n + 8);
-			h->tok_first = first; h->tok_n = n;
-		}
-		// Phase 1 decodes one member per LANE, so a launch lasts as long as its slowest lane: members are cut into chunks of at
-		// most one "round" (every decoder lane gets one member) and phase 2 of chunk c runs on a second stream while phase 1
-		// of chunk c+1 decodes: a ragged last round no longer idles the chip (both kernels are VALU-bound, so the overlap itself
-		// gains little). 6 phase-1 waves per CU leave LDS for the phase-2 workgroups.
-		const char* pe = getenv("NGSQC_K1_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;
-		const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
-		const int64_t lanes = (int64_t)h->n_cu * (pipelined ? 6 : 7) * 64;
-		const int64_t nch0 = pipelined ? std::max<int64_t>(1, (n + lanes - 1) / lanes) : 1;
-		const int64_t chunk = (((n + nch0 - 1) / nch0) + 63) & ~63ll;   // equal chunks, whole waves
-		const int64_t nch = (n + chunk - 1) / chunk;
-		while ((int64_t)h->k1_events.size() < 4 * nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->k1_events.push_back(e); }
-		if (h->k1_order_chunk != chunk || h->d_k1_order.n < (size_t)n || order_dirty)
-		{
-			// queue order inside every chunk: largest compressed size first (chunk-local indices)
-			std::vector<uint32_t> ord((size_t)n);
-			for (int64_t c0 = 0; c0 < n; c0 += chunk)
-			{
-				const int64_t cn = std::min<int64_t>(chunk, n - c0);
-				for (int64_t i = 0; i < cn; ++i) ord[(size_t)(c0 + i)] = (uint32_t)i;
-				std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(first + c0 + a)].clen > h->blocks[(size_t)(first + c0 + b)].clen; });
-			}
-			h->d_k1_order.upload(ord, h->stream); h->k1_order_chunk = chunk;
-		}
-		h->d_k1_work.ensure((size_t)nch);
-		HIPCHK(hipMemsetAsync(h->d_k1_work.p, 0, (size_t)nch * sizeof(unsigned long long), h->stream));
-		for (int64_t c = 0; c < nch; ++c)
-		{
-			const int64_t c0 = c * chunk, cn = std::min<int64_t>(chunk, n - c0);
-			hipEvent_t* e4 = &h->k1_events[(size_t)(4 * c)];
-			HIPCHK(hipEventRecord(e4[0], h->stream));
-			launch_huff_tokens(h->d_comp.p, d_desc + c0, cn, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_k1_work.p + c, sorted_queue ? h->d_k1_order.p + c0 : nullptr, h->n_cu * (pipelined ? 6 : 7), h->stream);
-			HIPCHK(hipEventRecord(e4[1], h->stream));
-			hipStream_t s2 = pipelined ? h->stream2 : h->stream;
-			if (pipelined) HIPCHK(hipStreamWaitEvent(s2, e4[1], 0));
-			HIPCHK(hipEventRecord(e4[2], s2));
-			launch_lz77_resolve(d_desc + c0, cn, d_out_base, d_st + c0, h->d_tok_off.p + c0, h->d_tok.p, h->d_tok_cnt.p + c0, s2);
-			HIPCHK(hipEventRecord(e4[3], s2));
-		}
-		if (pipelined) HIPCHK(hipStreamWaitEvent(h->stream, h->k1_events[(size_t)(4 * (nch - 1) + 3)], 0));
-		if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
-		HIPCHK(hipMemcpyAsync(h->h_status.data(), d_st, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		for (int64_t c = 0; c < nch; ++c)
-		{
-			float ms = 0; hipEvent_t* e4 = &h->k1_events[(size_t)(4 * c)];
-			HIPCHK(hipEventElapsedTime(&ms, e4[0], e4[1])); h->tm.inflate_huff_ms += ms;
-			HIPCHK(hipEventElapsedTime(&ms, e4[2], e4[3])); h->tm.inflate_lz77_ms += ms;
-		}
-		h->tm.inflate_huff_launches += nch;
-		bool overflow = false; for (int64_t i = 0; i < n; ++i) if (h->h_status[(size_t)i].error == 100) overflow = true;
-		if (!overflow) { check_status(h, n); return true; }
+		const uint64_t cap = tok_cap_full ? (uint64_t)desc[(size_t)i].usize + 64 : (uint64_t)desc[(size_t)i].clen + 64;
+		off[(size_t)i + 1] = off[(size_t)i] + ((cap + 3) & ~3ull);
+		crc[(size_t)i] = h->crc[(size_t)idx[(size_t)i]];
 	}
-	launch_inflate(h->d_comp.p, d_desc, n, d_out_base, d_st, h->stream);
-	if (h->h_status.size() < (size_t)n) h->h_status.resize((size_t)n);
-	HIPCHK(hipMemcpyAsync(h->h_status.data(), d_st, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+	DevBuf<BlockDesc> d_desc; d_desc.upload(desc, h->stream);
+	DevBuf<uint64_t> d_off; d_off.upload(off, h->stream);
+	DevBuf<uint32_t> d_tok, d_cnt, d_crc; d_tok.alloc((size_t)off[(size_t)n] + 16); d_cnt.alloc((size_t)n + 8); d_crc.upload(crc, h->stream);
+	DevBuf<BlockStatus> d_st; d_st.alloc((size_t)n);
+	DevBuf<unsigned long long> d_work; d_work.alloc(1);
+	HIPCHK(hipMemsetAsync(d_work.p, 0, sizeof(unsigned long long), h->stream));
+	launch_huff_tokens(h->d_comp.p, d_desc.p, n, d_st.p, d_off.p, d_tok.p, d_cnt.p, d_work.p, nullptr, h->n_cu * 6, h->stream);
+	launch_lz77_resolve(d_desc.p, n, d_out, d_st.p, d_off.p, d_tok.p, d_cnt.p, h->stream);
+	if (h->verify_crc) launch_crc32(d_desc.p, n, d_out, d_crc.p, d_st.p, h->stream);
+	std::vector<BlockStatus> st((size_t)n);
+	HIPCHK(hipMemcpyAsync(st.data(), d_st.p, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	check_status(h, n);
-	return true;
+	for (int64_t i = 0; i < n; ++i) if (st[(size_t)i].error) throw FormatError(inflate_error(h, idx[(size_t)i], st[(size_t)i].error));
 }
 
 // inflate the first members until the BAM header (magic, text, reference table) is complete; parse it
@@ -216,8 +215,9 @@ bool read_header(ngsqc_handle* h, int64_t avail)
 	{
 		int64_t bytes = k ? (int64_t)(h->blocks[k - 1].upos + h->blocks[k - 1].usize) : 0;
 		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
-		h->d_status.ensure((size_t)std::max<int64_t>(k, 1));
-		inflate_members(h, 0, k, h->d_blocks.p, tmp.p);
+		std::vector<int64_t> idx((size_t)k); std::vector<BlockDesc> desc((size_t)k);
+		for (int64_t i = 0; i < k; ++i) { idx[(size_t)i] = i; desc[(size_t)i] = h->blocks[(size_t)i]; }
+		inflate_sync(h, idx, desc, tmp.p, true);
 		std::vector<uint8_t> hb((size_t)bytes);
 		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
 		bool complete = false;
@@ -261,14 +261,13 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 {
 	if (n_shards < 1 || shard < 0 || shard >= n_shards) throw ArgError("invalid shard index");
 	h->csize = n;
-	scan_bgzf(bytes, n, h->blocks, h->total);
+	scan_bgzf(bytes, n, h->blocks, h->crc, h->total);
 	init_device(h, device);
 	Timer t(h->stream); t.start();
 	h->shard = shard; h->n_shards = n_shards;
 	if (n_shards == 1)
 	{
 		upload_compressed(h, bytes, 0, n);
-		h->d_blocks.upload(h->blocks, h->stream);
 		h->tm.h2d_ms = t.stop();
 		h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
 		read_header(h, (int64_t)h->blocks.size());
@@ -280,12 +279,9 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 	{
 		const size_t end = k ? (size_t)(h->blocks[(size_t)k - 1].cpos + h->blocks[(size_t)k - 1].clen) : 0;
 		upload_compressed(h, bytes, 0, end);
-		std::vector<BlockDesc> head(h->blocks.begin(), h->blocks.begin() + k);
-		h->d_blocks.upload(head, h->stream);
 		if (read_header(h, k)) break;
 		if (k >= nb) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
 	}
-	h->tok_first = -1; h->tok_n = -1;
 	// ---- member range of this shard: equal compressed bytes, cut at member starts ----
 	auto first_member_at = [&](int s) -> int64_t {
 		if (s <= 0) return 0;
@@ -298,7 +294,7 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 	const int64_t m0 = first_member_at(shard), m1 = first_member_at(shard + 1);
 	int64_t tail = SHARD_TAIL_MEMBERS; if (const char* e = getenv("NGSQC_SHARD_TAIL_MEMBERS")) tail = std::max<int64_t>(0, atoll(e));
 	const int64_t m_end = std::min<int64_t>(nb, m1 + (m1 > m0 ? tail : 0));
-	std::vector<BlockDesc> own;
+	std::vector<BlockDesc> own; std::vector<uint32_t> own_crc;
 	size_t cbeg = 0, cend = 0; int64_t u0 = 0, u_own = 0, u_all = 0;
 	if (m1 > m0)
 	{
@@ -307,114 +303,216 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 		u0 = (int64_t)h->blocks[(size_t)m0].upos;
 		u_own = (m1 < nb ? (int64_t)h->blocks[(size_t)m1].upos : h->total) - u0;
 		u_all = (m_end < nb ? (int64_t)h->blocks[(size_t)m_end].upos : h->total) - u0;
-		for (int64_t i = m0; i < m_end; ++i) { BlockDesc d = h->blocks[(size_t)i]; d.cpos -= cbeg; d.upos -= (uint64_t)u0; own.push_back(d); }
+		for (int64_t i = m0; i < m_end; ++i) { BlockDesc d = h->blocks[(size_t)i]; d.cpos -= cbeg; d.upos -= (uint64_t)u0; own.push_back(d); own_crc.push_back(h->crc[(size_t)i]); }
 	}
 	const int64_t first_rec_abs = h->first_rec;
-	h->blocks.swap(own);
+	h->blocks.swap(own); h->crc.swap(own_crc);
 	h->shard_own_members = m1 - m0; h->shard_limit = u_own; h->shard_u_base = u0; h->total = u_all;
 	h->first_rec = first_rec_abs >= u0 ? first_rec_abs - u0 : -1;   // shards behind the header: unknown, guessed by K2 and verified across shards
-	if (m1 > m0 && first_rec_abs >= u0 + u_own) { h->blocks.clear(); h->shard_own_members = 0; h->shard_limit = 0; h->total = 0; cbeg = cend = 0; }   // header only: owns no record
+	if (m1 > m0 && first_rec_abs >= u0 + u_own) { h->blocks.clear(); h->crc.clear(); h->shard_own_members = 0; h->shard_limit = 0; h->total = 0; cbeg = cend = 0; }   // header only: owns no record
 	upload_compressed(h, bytes, cbeg, cend);
 	h->csize = cend - cbeg;
-	h->d_blocks.upload(h->blocks, h->stream);
 	h->tm.h2d_ms = t.stop();
 	h->tm.compressed_bytes = (int64_t)(cend - cbeg); h->tm.inflated_bytes = u_own;
 }
 
-// Member ranges ("tiles") whose inflated bytes + token scratch + record index fit the device. NGSQC_TILE_MEMBERS overrides
-// (tests use tiny tiles to exercise the carry logic).
-void plan_tiles(ngsqc_handle* h)
+// ---- layout of the tile stream: K1 chunks, tiles (whole chunks), token ring, static device tables -------------------------
+// NGSQC_TILE_MEMBERS=k (tests): chunks and tiles of k members. NGSQC_TILE_CHUNKS: chunks per tile (default 2).
+// NGSQC_K1_CHUNK_DIV: chunk = one decoder round / div. NGSQC_CARRY_MAX: bytes reserved in front of a tile for a straddling record.
+void plan_layout(ngsqc_handle* h)
 {
-	if (!h->tiles.empty() || h->blocks.empty()) return;
+	if (h->planned) return;
 	const int64_t nb = (int64_t)h->blocks.size();
-	int64_t per_tile = nb;
-	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) per_tile = std::max<int64_t>(1, atoll(e));
+	h->planned = true;
+	if (nb == 0) return;
+	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
+	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * 6 * 64 / div);
+	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
+	bool forced = false;
+	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) { h->chunk = std::max<int64_t>(1, atoll(e)); cpt = 1; forced = true; }
 	else
+	{
+		const int64_t nch0 = std::max<int64_t>(1, (nb + lanes - 1) / lanes);
+		h->chunk = (((nb + nch0 - 1) / nch0) + 63) & ~63ll;   // equal chunks, whole waves
+	}
+	h->nch = (nb + h->chunk - 1) / h->chunk;
+	// token budget of a chunk slot
+	std::vector<uint64_t> tok_off((size_t)(nb + h->nch), 0); std::vector<uint32_t> ord((size_t)nb);
+	int64_t slot = 0; std::vector<int64_t> chunk_bytes((size_t)h->nch, 0);
+	for (int64_t c = 0; c < h->nch; ++c)
+	{
+		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
+		uint64_t acc = 0;
+		for (int64_t i = 0; i < cn; ++i)
+		{
+			tok_off[(size_t)(c0 + c + i)] = acc; acc += ((uint64_t)h->blocks[(size_t)(c0 + i)].clen + 64 + 3) & ~3ull;
+			ord[(size_t)(c0 + i)] = (uint32_t)i; chunk_bytes[(size_t)c] += h->blocks[(size_t)(c0 + i)].usize;
+		}
+		tok_off[(size_t)(c0 + c + cn)] = acc;
+		slot = std::max<int64_t>(slot, (int64_t)acc);
+		// queue order inside the chunk: largest compressed size first (the 64 lanes of a wave finish together)
+		std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(c0 + a)].clen > h->blocks[(size_t)(c0 + b)].clen; });
+	}
+	h->slot_tokens = slot + 16;
+	const int64_t n_slots = std::min<int64_t>(K1_SLOTS, h->nch);
+	for (int64_t c = 0; c < h->nch; ++c)   // slot base of the chunk
+	{
+		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0); const uint64_t base = (uint64_t)((c % K1_SLOTS) * h->slot_tokens);
+		for (int64_t i = 0; i <= cn; ++i) tok_off[(size_t)(c0 + c + i)] += base;
+	}
+	// tiles: as many chunks as fit two tile buffers next to the ring (at most cpt)
+	int64_t carry_max = 64ll << 20; if (const char* e = getenv("NGSQC_CARRY_MAX")) carry_max = std::max<int64_t>(0, atoll(e));
+	if (!forced && h->nch > 1)
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 		{
-			const double per_member = 65536.0 + 4.0 * (65536.0 / 3.0 + 64.0) + 2.0 * 8.0 * 400.0;   // inflated + tokens + record index / long list
-			int64_t fit = (int64_t)((double)free_b * 0.80 / per_member);
-			per_tile = std::max<int64_t>(4096, std::min<int64_t>(nb, fit));
+			const double fixed = (double)n_slots * (double)h->slot_tokens * 4.0 + (double)nb * 64.0 + 2.0 * (double)carry_max;
+			int64_t max_chunk = 0; for (int64_t b : chunk_bytes) max_chunk = std::max(max_chunk, b);
+			const double avail = (double)free_b * 0.85 - fixed;
+			int64_t fit = (int64_t)(avail / (2.15 * (double)std::max<int64_t>(max_chunk, 1)));   // two buffers + record index / long list
+			if (fit < 1) throw std::runtime_error("not enough device memory for one K1 chunk (" + std::to_string(max_chunk) + " inflated bytes)");
+			cpt = std::min(cpt, fit);
 		}
 	}
-	for (int64_t f = 0; f < nb; f += per_tile) h->tiles.emplace_back(f, std::min<int64_t>(per_tile, nb - f));
+	if (h->nch <= cpt) cpt = h->nch;
+	h->tiles.clear(); h->tile_first_chunk.clear();
+	for (int64_t c = 0; c < h->nch; c += cpt)
+	{
+		const int64_t m0 = c * h->chunk, m1 = std::min(nb, (c + cpt) * h->chunk);
+		h->tiles.emplace_back(m0, m1 - m0); h->tile_first_chunk.push_back(c);
+	}
+	h->tile_first_chunk.push_back(h->nch);
+	const int nt = (int)h->tiles.size();
+	h->pfx = nt > 1 ? ((carry_max + 255) & ~255ll) : 0;
+	// static K1 descriptors: upos relative to the tile's first member
+	std::vector<BlockDesc> kd((size_t)nb); h->max_tile_bytes = 0;
+	for (int t = 0; t < nt; ++t)
+	{
+		const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second; const uint64_t u_lo = h->blocks[(size_t)f].upos;
+		for (int64_t i = f; i < f + m; ++i) { kd[(size_t)i] = h->blocks[(size_t)i]; kd[(size_t)i].upos -= u_lo; }
+		h->max_tile_bytes = std::max<int64_t>(h->max_tile_bytes, (int64_t)(h->blocks[(size_t)(f + m - 1)].upos + h->blocks[(size_t)(f + m - 1)].usize - u_lo));
+	}
+	h->d_kdesc.upload(kd, h->stream); h->d_tok_off.upload(tok_off, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
+	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch);
+	h->d_tok.ensure((size_t)(n_slots * h->slot_tokens) + 16);
+	h->buf[0].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
+	if (nt > 1) h->buf[1].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
+	h->p_status.ensure((size_t)nb);
+	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
+	while ((int)h->ev_tile.size() < 2 * nt) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_tile.push_back(e); }
+	h->p_small.ensure(64);
+	HIPCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
+	h->tm.n_tiles = nt;
 }
 
-// K1 + K2 for tile t. Tiles must be decoded in order (t == 0 or t == cur_tile + 1): a record that starts in one tile and
-// ends in the next is carried as a prefix in front of the next tile's members.
-void decode_tile(ngsqc_handle* h, int t)
+// Enqueue K1 of tile t: its chunks continue the file-wide chunk stream (nothing here waits on the host).
+void enqueue_k1_tile(ngsqc_handle* h, int t)
 {
-	HIPCHK(hipSetDevice(h->device));
-	plan_tiles(h);
+	const int64_t nb = (int64_t)h->blocks.size();
+	uint8_t* out_base = h->buf[t & 1].p + h->pfx;
+	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
+	for (int64_t c = h->tile_first_chunk[(size_t)t]; c < h->tile_first_chunk[(size_t)t + 1]; ++c)
+	{
+		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
+		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
+		hipStream_t s1 = h->s_p1[c & 1];
+		if (c >= K1_SLOTS) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - K1_SLOTS) + 3)], 0));   // the ring slot is free again
+		HIPCHK(hipEventRecord(e4[0], s1));
+		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_work.p + c,
+		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->n_cu * 6, s1);
+		HIPCHK(hipEventRecord(e4[1], s1));
+		HIPCHK(hipStreamWaitEvent(h->s_p2, e4[1], 0));
+		if (c == h->tile_first_chunk[(size_t)t] && t >= 2) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - 2) + 1)], 0));   // the buffer's previous tile is consumed
+		HIPCHK(hipEventRecord(e4[2], h->s_p2));
+		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->s_p2);
+		HIPCHK(hipEventRecord(e4[3], h->s_p2));
+		if (h->verify_crc) launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, h->s_p2);   // htslib checks every member's CRC32 (bgzf.c); a mismatch fails the read
+	}
+	const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second;
+	HIPCHK(hipMemcpyAsync(h->p_status.p + f, h->d_status.p + f, (size_t)m * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->s_p2));
+	HIPCHK(hipEventRecord(h->ev_tile[(size_t)(2 * t)], h->s_p2));
+	h->tm.inflate_launches++;
+	h->k1_enq = h->tile_first_chunk[(size_t)t + 1];
+}
+
+// Wait for K1 of tile t, check every member; members whose token stream overflowed the clen + 64 budget (e.g. Huffman-only
+// streams of low-entropy data) get a second chance with a worst-case budget.
+void finish_k1_tile(ngsqc_handle* h, int t)
+{
+	HIPCHK(hipEventSynchronize(h->ev_tile[(size_t)(2 * t)]));
+	const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second;
+	std::vector<int64_t> redo;
+	for (int64_t i = f; i < f + m; ++i)
+	{
+		const uint32_t e = h->p_status.p[i].error;
+		if (e == K1_ERR_TOKEN_OVERFLOW) redo.push_back(i);
+		else if (e) throw FormatError(inflate_error(h, i, e));
+	}
+	h->tm.members_inflated += m;
+	if (redo.empty()) return;
+	std::vector<BlockDesc> desc; const uint64_t u_lo = h->blocks[(size_t)f].upos;
+	for (int64_t i : redo) { BlockDesc d = h->blocks[(size_t)i]; d.upos -= u_lo; desc.push_back(d); }
+	inflate_sync(h, redo, desc, h->buf[t & 1].p + h->pfx, true);
+}
+
+// K2 for tile t (its members are in buf[t & 1] behind the prefix area; carry_len bytes of the previous tile's straddling
+// record have been copied right in front of them). Tile-local coordinates: byte 0 = first carried byte.
+void index_tile(ngsqc_handle* h, int t)
+{
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
-	if (t == h->cur_tile && h->decoded) return;
-	if (t != 0 && t != h->cur_tile + 1) throw std::runtime_error("internal: tiles must be decoded in order");
-	const bool last = t == (int)h->tiles.size() - 1;
+	const int nt = (int)h->tiles.size();
+	const bool last = t == nt - 1;
 	const int64_t first = h->tiles[(size_t)t].first, nm = h->tiles[(size_t)t].second;
 	if (t == 0) { h->carry_len = 0; h->next_ord_base = 0; h->expected_abs = h->first_rec; }
 	const int64_t u_lo = (int64_t)h->blocks[(size_t)first].upos;
 	const int64_t u_hi = (int64_t)h->blocks[(size_t)(first + nm - 1)].upos + h->blocks[(size_t)(first + nm - 1)].usize;
 	const int64_t prefix = h->carry_len;
 	const int64_t total = prefix + (u_hi - u_lo);
-	Timer tmr(h->stream);
-	// ---- buffers ----
-	h->d_infl.ensure((size_t)total + 64);   // (the carried prefix was staged in d_carry_tmp by finish_tile)
-	if (prefix) HIPCHK(hipMemcpyAsync(h->d_infl.p, h->d_carry_tmp.p, (size_t)prefix, hipMemcpyDeviceToDevice, h->stream));
-	// tile-local member descriptors: [0] = pseudo member covering the carried prefix (not inflated), then the members
-	std::vector<BlockDesc> loc((size_t)nm + 1);
-	loc[0] = BlockDesc{0, 0, 0, (uint32_t)prefix};
-	for (int64_t i = 0; i < nm; ++i) { BlockDesc d = h->blocks[(size_t)(first + i)]; d.upos = (uint64_t)(prefix + ((int64_t)d.upos - u_lo)); loc[(size_t)i + 1] = d; }
-	h->d_tile_blocks.ensure((size_t)nm + 1);
-	HIPCHK(hipMemcpyAsync(h->d_tile_blocks.p, loc.data(), loc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, h->stream));
-	h->d_status.ensure((size_t)nm + 1);
-	// ---- K1 ----
-	tmr.start();
-	inflate_members(h, first, nm, h->d_tile_blocks.p + 1, h->d_infl.p);
-	h->tm.inflate_ms += tmr.stop(); h->tm.inflate_launches++;
-	// ---- K2 (tile-local coordinates; entry 0 is the prefix pseudo member) ----
-	tmr.start();
-	const int64_t ne = nm + 1;
-	std::vector<int32_t>& start = h->h_start; if (start.size() < (size_t)ne) start.resize((size_t)ne);
-	std::vector<int64_t>& next = h->h_next; if (next.size() < (size_t)ne) next.resize((size_t)ne);
+	const uint8_t* base = h->buf[t & 1].p + h->pfx - prefix;
+	const BlockDesc* d_desc = h->d_kdesc.p + first;
+	const int64_t ne = nm + 1;   // entry 0 = the carried prefix
+	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };
+	auto e_sz = [&](int64_t e) -> int64_t { return e == 0 ? prefix : (int64_t)h->blocks[(size_t)(first + e - 1)].usize; };
+	Timer tmr(h->stream); tmr.start();
+	h->p_start.ensure((size_t)ne); h->p_next.ensure((size_t)ne);
+	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	for (int64_t b = 0; b < ne; ++b)
 	{
-		const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
-		start[(size_t)b] = anchor_by_guess ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
+		const int64_t lo = e_lo(b), hi = lo + e_sz(b);
+		start[b] = anchor_by_guess ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
 	}
-	DevBuf<int32_t> d_start; d_start.alloc((size_t)ne); HIPCHK(hipMemcpyAsync(d_start.p, start.data(), (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-	DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)ne + 1);
-	DevBuf<int64_t> d_next; d_next.alloc((size_t)ne + 1);
-	DevBuf<uint32_t> d_bad; d_bad.alloc(1);
-	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess;
+	h->d_start.ensure((size_t)ne); h->d_cnt.ensure((size_t)ne + 1); h->d_next.ensure((size_t)ne + 1); h->d_base.ensure((size_t)ne + 1); h->d_bad.ensure(1);
+	h->d_scan_tmp.ensure(scan_tmp_bytes(ne) + 64);
+	HIPCHK(hipMemcpyAsync(h->d_start.p, start, (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
 	while (true)
 	{
-		HIPCHK(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), h->stream));
-		launch_index_count(h->d_infl.p, total, h->d_tile_blocks.p + from, ne - from, d_start.p + from, d_cnt.p + from, d_next.p + from, d_bad.p, (int32_t)h->ref_names.size(), h->stream);
-		HIPCHK(hipMemcpyAsync(start.data() + from, d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(next.data() + from, d_next.p + from, (size_t)(ne - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
+		launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+		HIPCHK(hipMemcpyAsync(start + from, h->d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(next + from, h->d_next.p + from, (size_t)(ne - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		// exact verification of the chain: every member's exit must land on the next member's start
 		int64_t expected = exp0; int64_t mismatch = -1; straddle = -1; bool anchored = !anchor_by_guess;
 		for (int64_t b = 0; b < ne; ++b)
 		{
-			const int64_t lo = (int64_t)loc[(size_t)b].upos, hi = lo + loc[(size_t)b].usize;
+			const int64_t lo = e_lo(b), hi = lo + e_sz(b);
 			if (!anchored)
 			{
-				if (start[(size_t)b] < 0) continue;          // no plausible record start inside this member
-				anchored = true; expected = lo + start[(size_t)b]; exp0 = expected;
+				if (start[b] < 0) continue;          // no plausible record start inside this member
+				anchored = true; expected = lo + start[b]; exp0 = expected;
 			}
 			const int32_t want = expected >= hi ? -1 : (int32_t)(expected - lo);
-			if (start[(size_t)b] != want) { mismatch = b; start[(size_t)b] = want; break; }
+			if (start[b] != want) { mismatch = b; start[b] = want; break; }
 			if (want >= 0)
 			{
-				const int64_t nx = next[(size_t)b];
+				const int64_t nx = next[b];
 				if (nx == -2) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
 				if (nx <= -10) { straddle = -(nx + 10); expected = INT64_MAX / 2; }   // the rest of the tile belongs to this record
 				else expected = nx;
@@ -424,23 +522,24 @@ void decode_tile(ngsqc_handle* h, int t)
 		{
 			found_start = anchored;
 			if (!anchored) { expected = total; exp0 = total; }   // no record starts in this tile at all
-			if (straddle < 0 && expected != total && !(expected == INT64_MAX / 2)) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (record chain does not end at a member boundary)");
+			// without a straddling record the chain leaves the tile exactly at its end - or behind it, when the first record of the file
+			// starts in a later tile (a BAM header longer than the first tile)
+			if (straddle < 0 && expected < total) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (record chain does not end at a member boundary)");
+			chain_exit = straddle < 0 ? expected : total;
 			if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 			break;
 		}
 		if (dbg) fprintf(stderr, "[ngsqc] tile %d: chain mismatch at entry %lld (round %d)\n", t, (long long)mismatch, rounds);
 		if (++rounds > 100000) throw FormatError("could not resolve the BAM record chain");
-		HIPCHK(hipMemcpyAsync(d_start.p + mismatch, &start[(size_t)mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->d_start.p + mismatch, &start[mismatch], sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 		from = mismatch;
 	}
-	DevBuf<int64_t> d_base; d_base.alloc((size_t)ne + 1);
-	DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(ne) + 64);
-	launch_scan_counts(d_cnt.p, ne, d_base.p, d_tmp.p, h->stream);
+	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	int64_t n_rec = 0;
-	HIPCHK(hipMemcpyAsync(&n_rec, d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(&n_rec, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec, 1));
-	launch_index_write(h->d_infl.p, total, h->d_tile_blocks.p, ne, d_start.p, d_base.p, h->d_recoff.p, h->stream);
+	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec + n_rec / 8, 1));
+	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_base.p, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
 	{
@@ -474,38 +573,87 @@ void decode_tile(ngsqc_handle* h, int t)
 	h->cur_tile = t; h->tile_prefix = prefix; h->tile_total = total; h->tile_u_lo = u_lo; h->tile_ord_base = h->next_ord_base;
 	h->n_rec = n_rec; h->tm.n_records += n_rec;
 	h->carry_src = straddle; h->carry_len = straddle >= 0 ? total - straddle : 0;
-	h->expected_abs = u_hi;   // only meaningful when nothing is carried (the next record starts at the next tile's first byte)
+	if (h->carry_len > h->pfx && !last) throw FormatError("a record that straddles two tiles is larger than the carry area (" + std::to_string(h->carry_len) + " > " + std::to_string(h->pfx) + " bytes; raise NGSQC_CARRY_MAX)");
+	h->expected_abs = u_lo + (chain_exit - prefix);   // only meaningful when nothing is carried: where the next record starts (normally the next tile's first byte)
+	h->next_ord_base = h->tile_ord_base + n_rec;
 	h->decoded = true;
 }
 
-// Called after a tile has been consumed and before the next one is decoded: stage the bytes of the straddling record.
-void finish_tile(ngsqc_handle* h)
+TileCtx resident_ctx(ngsqc_handle* h)
 {
-	if (h->carry_len > 0)
+	const int nt = (int)h->tiles.size(); const int t = h->cur_tile;
+	return TileCtx{h->buf[t & 1].p + h->pfx - h->tile_prefix, h->tile_total, h->d_recoff.p, h->n_rec, h->tile_ord_base, t, t == nt - 1};
+}
+
+void reset_decode_timings(ngsqc_handle* h)
+{
+	h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0;
+	h->tm.inflate_huff_launches = 0; h->tm.members_inflated = 0;
+}
+
+void sync_all(ngsqc_handle* h)
+{
+	(void)hipStreamSynchronize(h->s_p1[0]); (void)hipStreamSynchronize(h->s_p1[1]); (void)hipStreamSynchronize(h->s_p2); (void)hipStreamSynchronize(h->stream);
+}
+
+// Visit every tile in file order with the tile resident in HBM (K1 + K2 done) while K1 of the next tile is already running.
+// A single-tile file that is already decoded is visited without redoing K1 / K2 (the reference re-reads the file for every
+// pass; a resident tile is kept). f returns false to stop early.
+template <class F> void stream_tiles(ngsqc_handle* h, F f)
+{
+	plan_layout(h);
+	const int nt = (int)h->tiles.size();
+	if (nt == 0) { h->decoded = true; h->n_rec = 0; return; }
+	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(resident_ctx(h)); return; }
+	reset_decode_timings(h);
+	h->decoded = false; h->cur_tile = -1; h->k1_enq = 0;
+	const char* pe = getenv("NGSQC_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;   // 0: K1 of a tile starts only when the previous tile is consumed (stage attribution)
+	HIPCHK(hipMemsetAsync(h->d_work.p, 0, (size_t)h->nch * sizeof(unsigned long long), h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	try
 	{
-		h->d_carry_tmp.ensure((size_t)h->carry_len + 64);
-		HIPCHK(hipMemcpyAsync(h->d_carry_tmp.p, h->d_infl.p + h->carry_src, (size_t)h->carry_len, hipMemcpyDeviceToDevice, h->stream));
+		enqueue_k1_tile(h, 0);
+		for (int t = 0; t < nt; ++t)
+		{
+			if (pipelined && t + 1 < nt) enqueue_k1_tile(h, t + 1);
+			finish_k1_tile(h, t);
+			index_tile(h, t);
+			const bool go_on = f(resident_ctx(h));
+			const bool stop = !go_on || t == h->shard_last_tile;   // (a shard stops at the tile that holds the first record of the next shard)
+			if (!stop && t + 1 < nt && h->carry_len > 0)
+				HIPCHK(hipMemcpyAsync(h->buf[(t + 1) & 1].p + h->pfx - h->carry_len, h->buf[t & 1].p + h->pfx - h->tile_prefix + h->carry_src, (size_t)h->carry_len, hipMemcpyDeviceToDevice, h->stream));
+			HIPCHK(hipEventRecord(h->ev_tile[(size_t)(2 * t + 1)], h->stream));
+			if (stop) { if (t + 1 < nt) { sync_all(h); h->decoded = nt == 1; } break; }
+			if (!pipelined && t + 1 < nt) { HIPCHK(hipStreamSynchronize(h->stream)); enqueue_k1_tile(h, t + 1); }
+		}
 	}
-	h->next_ord_base = h->tile_ord_base + h->n_rec;
+	catch (...) { sync_all(h); h->decoded = false; h->cur_tile = -1; throw; }
+	// K1 timings: wall time from the first phase-1 start to the last phase-2 end, and the per-kernel sums
+	if (h->k1_enq > 0)
+	{
+		const int64_t c_end = h->k1_enq;
+		HIPCHK(hipEventSynchronize(h->ev_chunk[(size_t)(4 * (c_end - 1) + 3)]));
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, h->ev_chunk[0], h->ev_chunk[(size_t)(4 * (c_end - 1) + 3)])); h->tm.inflate_ms = ms;
+		for (int64_t c = 0; c < c_end; ++c)
+		{
+			hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
+			HIPCHK(hipEventElapsedTime(&ms, e4[0], e4[1])); h->tm.inflate_huff_ms += ms;
+			HIPCHK(hipEventElapsedTime(&ms, e4[2], e4[3])); h->tm.inflate_lz77_ms += ms;
+		}
+		h->tm.inflate_huff_launches = c_end;
+	}
+	if (nt > 1) { h->decoded = false; }   // (only a single-tile file stays resident)
 }
 
-void reset_decode_timings(ngsqc_handle* h) { h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0; h->tm.inflate_huff_launches = 0; }
-
-// whole-file convenience used by the single-tile fast path and the test hooks
-void do_decode(ngsqc_handle* h)
-{
-	plan_tiles(h);
-	if (h->tiles.empty()) { h->decoded = true; h->n_rec = 0; return; }
-	if (h->tiles.size() == 1) { if (!(h->decoded && h->cur_tile == 0)) { reset_decode_timings(h); decode_tile(h, 0); } return; }
-	throw std::runtime_error("internal: do_decode on a multi-tile file");
-}
+template <class F> void for_each_tile(ngsqc_handle* h, F f) { stream_tiles(h, [&](const TileCtx&) { return f(h->cur_tile); }); }
 
 // regions -> device tables. Regions must be sorted by start within a tid, non-overlapping, and each tid contiguous.
-void setup_regions(ngsqc_handle* h, const ngsqc_region* regions, int64_t n)
+void setup_regions(ngsqc_handle* h, DepthSet& D, const ngsqc_region* regions, int64_t n)
 {
 	const int n_ref = (int)h->ref_names.size();
-	h->regions.assign(regions, regions + (n > 0 ? n : 0));
-	h->doff.assign((size_t)n + 1, 0); h->rlen.assign((size_t)n, 0);
+	D.regions.assign(regions, regions + (n > 0 ? n : 0));
+	D.doff.assign((size_t)n + 1, 0); D.rlen.assign((size_t)n, 0);
 	std::vector<int32_t> rs((size_t)n), re((size_t)n), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
 	std::vector<uint8_t> seen((size_t)std::max(n_ref, 1), 0);
 	int64_t slots = 0, bases = 0;
@@ -517,115 +665,246 @@ void setup_regions(ngsqc_handle* h, const ngsqc_region* regions, int64_t n)
 		if (i > 0 && regions[i - 1].tid == r.tid) { if (regions[i - 1].end >= r.start) throw ArgError("Merged and sorted BED file required for coverage details statistics!"); }
 		else { if (seen[r.tid]) throw ArgError("Merged and sorted BED file required for coverage details statistics!"); seen[r.tid] = 1; tf[r.tid] = (int32_t)i; }
 		tl[r.tid] = (int32_t)i + 1;
-		rs[i] = r.start; re[i] = r.end; h->rlen[i] = r.end - r.start + 1; h->doff[i] = slots;
-		slots += (int64_t)h->rlen[i] + 1; bases += h->rlen[i];
+		rs[i] = r.start; re[i] = r.end; D.rlen[i] = r.end - r.start + 1; D.doff[i] = slots;
+		slots += (int64_t)D.rlen[i] + 1; bases += D.rlen[i];
 	}
-	h->doff[n] = slots; h->n_slots = slots; h->roi_bases = bases;
-	h->d_reg_start.upload(rs, h->stream); h->d_reg_end.upload(re, h->stream); h->d_reg_len.upload(h->rlen, h->stream);
-	h->d_tid_first.upload(tf, h->stream); h->d_tid_last.upload(tl, h->stream);
-	std::vector<int64_t> doff(h->doff.begin(), h->doff.begin() + n);
-	h->d_doff.upload(doff, h->stream);
-	h->d_depth.ensure((size_t)slots + 1);
-	HIPCHK(hipMemsetAsync(h->d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
-	h->depth_ready = false;
+	D.doff[n] = slots; D.n_slots = slots; D.roi_bases = bases;
+	D.d_reg_start.upload(rs, h->stream); D.d_reg_end.upload(re, h->stream); D.d_reg_len.upload(D.rlen, h->stream);
+	D.d_tid_first.upload(tf, h->stream); D.d_tid_last.upload(tl, h->stream);
+	std::vector<int64_t> doff(D.doff.begin(), D.doff.begin() + n);
+	D.d_doff.upload(doff, h->stream);
+	D.d_depth.ensure((size_t)slots + 1);
+	D.d_tmp.ensure(scan_tmp_bytes(slots) + 64);
+	HIPCHK(hipMemsetAsync(D.d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
+	D.depth_ready = false;
 }
 
-void finalize_depth(ngsqc_handle* h)
+void finalize_depth(ngsqc_handle* h, DepthSet& D)
 {
-	if (h->n_slots > 0)
+	if (D.n_slots > 0)
 	{
-		DevBuf<uint8_t> tmp; tmp.alloc(scan_tmp_bytes(h->n_slots) + 64);
-		launch_depth_prefix(h->d_depth.p, h->n_slots, tmp.p, h->stream);
-		launch_depth_mark_spare(h->d_depth.p, h->d_doff.p, h->d_reg_len.p, (int64_t)h->regions.size(), h->stream);
+		launch_depth_prefix(D.d_depth.p, D.n_slots, D.d_tmp.p, h->stream);
+		launch_depth_mark_spare(D.d_depth.p, D.d_doff.p, D.d_reg_len.p, (int64_t)D.regions.size(), h->stream);
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
-	h->depth_ready = true;
+	D.depth_ready = true;
 }
 
 struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 
-// Visit every tile in file order with the tile resident in HBM (K1+K2 done). A single-tile file that is already decoded
-// is visited without redoing K1/K2 (the reference re-reads the file for every pass; we keep it).
-template <class F> void for_each_tile(ngsqc_handle* h, F f)
+// ---- consumers of a tile -----------------------------------------------------------------------------------------------------
+
+// K3-K5 on every tile with the order-dependent carries of the reference loop resolved while the tile is resident:
+//   bases_trimmed = sum over counted records of (running maximum read length - length)   (Statistics.cpp:428-429,565-568)
+//   bases_usable_no_overlap (ROI-less modes) only counts once a paired read has been seen (:879,:1115)
+// The scan reduces (longest read, first ordinal reaching it) and (first paired ordinal) per tile; a tile whose longest read does
+// not exceed the running maximum carried in contributes n_counted x maximum, otherwise the running maximum is walked over the
+// tile's records in front of that read (prefix_fix_kernel) - normally a handful of records of the first tile.
+struct ScanState
 {
-	plan_tiles(h);
-	const int nt = (int)h->tiles.size();
-	if (nt == 0) return;
-	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(0); return; }
-	reset_decode_timings(h);
-	for (int t = 0; t < nt; ++t)
+	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<int64_t> d_long;
+	std::vector<unsigned long long> dev;   // device accumulators after the last tile
+	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
+	// running state of the in-pass fix
+	long long run_max = 0; bool paired_seen = false; long long sum_runmax = 0, fix_len = 0; unsigned long long prev_total = 0, prev_usable = 0;
+	// summary for the shard protocol
+	unsigned long long best_key = 0, first_paired = ~0ull;
+	double kernel_ms = 0, stage_ms = 0; int64_t launches = 0;
+
+	void begin(ngsqc_handle* h)
 	{
-		decode_tile(h, t);
-		const bool go_on = f(t);
-		if (!go_on || t == h->shard_last_tile) break;   // (a shard stops at the tile that holds the first record of the next shard)
-		if (t + 1 < nt) finish_tile(h);
-	}
-}
-
-// Order-dependent carries (running maximum of the read length, "a paired read has been seen") on the record prefix
-// [0, f) / [0, pidx) of this handle; floor_max = running maximum carried in from earlier shards of the same BAM.
-void run_prefix_fix(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev, int64_t f, int64_t pidx, int gmax, int floor_max)
-{
-	if (f <= 0 && pidx <= 0) return;
-	Timer t(h->stream); t.start();
-	const unsigned long long carry0 = (unsigned long long)std::max(floor_max, 0);
-	HIPCHK(hipMemcpyAsync(h->d_counters.p + A_FIX_CARRY, &carry0, sizeof(carry0), hipMemcpyHostToDevice, h->stream));
-	const int64_t upto = std::max(f, pidx);
-	// visit the tiles that hold records [0, upto) again (normally only tile 0, usually still resident)
-	for_each_tile(h, [&](int) {
-		h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
-		sp.infl = h->d_infl.p; sp.total = h->tile_total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec; sp.ord_base = h->tile_ord_base;
-		sp.long_list = h->d_long.p; sp.long_cap = h->n_rec;
-		const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - h->tile_ord_base, 0), h->n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - h->tile_ord_base, 0), h->n_rec);
-		launch_prefix_fix(sp, lf, lp, gmax, h->stream);
+		d_counters.ensure(A_DEV_TOTAL);
+		std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
+		HIPCHK(hipMemcpyAsync(d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		return h->tile_ord_base + h->n_rec < upto;
-	});
-	HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	h->tm.scan_ms += t.stop();
-}
-
-void run_scan(ngsqc_handle* h, ScanParams& sp, std::vector<unsigned long long>& dev, bool do_fix = true)
-{
-	h->d_counters.ensure(A_DEV_TOTAL);
-	std::vector<unsigned long long> init(A_DEV_TOTAL, 0ull); init[A_FIRST_PAIRED] = ~0ull;
-	HIPCHK(hipMemcpyAsync(h->d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-	sp.counters = h->d_counters.p; sp.diff = h->d_depth.p; sp.n_ref = (int32_t)h->ref_names.size();
-	h->tm.scan_kernel_ms = 0; h->tm.scan_launches = 0; h->tm.scan_ms = 0;
-	auto bind_tile = [&]() {
-		h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
-		sp.infl = h->d_infl.p; sp.total = h->tile_total; sp.recoff = h->d_recoff.p; sp.n_rec = h->n_rec; sp.ord_base = h->tile_ord_base;
-		sp.long_list = h->d_long.p; sp.long_cap = h->n_rec;
-	};
-	for_each_tile(h, [&](int) {
-		bind_tile();
+		sp.counters = d_counters.p; sp.n_ref = (int32_t)h->ref_names.size();
+		run_max = 0; paired_seen = false; sum_runmax = 0; fix_len = 0; prev_total = 0; prev_usable = 0; best_key = 0; first_paired = ~0ull;
+		kernel_ms = 0; stage_ms = 0; launches = 0;
+	}
+	void tile(ngsqc_handle* h, const TileCtx& c)
+	{
+		d_long.ensure((size_t)std::max<int64_t>(c.n_rec, 1));
+		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
+		sp.long_list = d_long.p; sp.long_cap = c.n_rec;
 		Timer t(h->stream); t.start();
-		HIPCHK(hipMemsetAsync(h->d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
+		// per-tile slots: long-record count, (longest read, first ordinal) key
+		HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_counters.p + A_FIRST_MAX_KEY, 0, sizeof(unsigned long long), h->stream));
 		Timer tk(h->stream); tk.start();
 		launch_scan(sp, h->stream);
-		h->tm.scan_kernel_ms += tk.stop();
-		unsigned long long n_long = 0;
-		HIPCHK(hipMemcpyAsync(&n_long, h->d_counters.p + A_LONG_COUNT, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		h->tm.scan_launches++;
-		if (n_long) { tk.start(); launch_scan_long(sp, (int64_t)n_long, h->stream); h->tm.scan_kernel_ms += tk.stop(); h->tm.scan_launches++; }
-		h->tm.scan_ms += t.stop();
-		return true;
-	});
-	dev.assign(A_DEV_TOTAL, 0ull);
-	HIPCHK(hipMemcpyAsync(dev.data(), h->d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	if (sp.mode != MODE_DEPTH && do_fix)
-	{
-		const unsigned long long key = dev[A_FIRST_MAX_KEY];
-		const int gmax = (int)(key >> 40);
-		const int64_t f = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : 0;
-		const int64_t pidx = (sp.mode != NGSQC_MODE_ROI && dev[A_FIRST_PAIRED] != ~0ull) ? (int64_t)dev[A_FIRST_PAIRED] : 0;
-		run_prefix_fix(h, sp, dev, f, pidx, gmax, 0);
+		kernel_ms += tk.stop(); launches++;
+		unsigned long long* s = h->p_small.p;
+		auto readback = [&]() {
+			HIPCHK(hipMemcpyAsync(s + 0, d_counters.p + A_LONG_COUNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 1, d_counters.p + A_FIRST_MAX_KEY, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 2, d_counters.p + A_FIRST_PAIRED, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 3, d_counters.p + A_TOTAL, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 4, d_counters.p + A_USABLE, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+		};
+		readback();
+		if (s[0]) { tk.start(); launch_scan_long(sp, (int64_t)s[0], h->stream); kernel_ms += tk.stop(); launches++; readback(); }
+		const unsigned long long key = s[1], fp = s[2], total = s[3], usable = s[4];
+		if (key > best_key) best_key = key;   // keys order by (length, earlier ordinal): the maximum over tiles is the BAM's first longest read
+		if (fp < first_paired) first_paired = fp;
+		if (in_pass_fix && sp.mode != MODE_DEPTH)
+		{
+			const long long tile_max = (long long)(key >> 40);
+			const long long f_local = key ? (long long)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) - c.ord_base : 0;
+			const long long n_counted = (long long)(total - prev_total);
+			const bool need_trim = tile_max > run_max;
+			const bool need_paired = sp.mode != NGSQC_MODE_ROI && !paired_seen && fp != ~0ull;
+			const long long lf = need_trim ? f_local : 0, lp = need_paired ? (long long)fp - c.ord_base : 0;
+			unsigned long long fix[3] = {0, 0, 0};
+			if (lf > 0 || lp > 0)
+			{
+				s[12] = 0; s[13] = 0; s[14] = (unsigned long long)run_max; s[15] = 0;   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
+				HIPCHK(hipMemcpyAsync(d_counters.p + A_FIX_TRIM, s + 12, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+				launch_prefix_fix(sp, lf, lp, h->stream);
+				HIPCHK(hipMemcpyAsync(s + 8, d_counters.p + A_FIX_TRIM, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipMemcpyAsync(s + 9, d_counters.p + A_FIX_LEN, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipMemcpyAsync(s + 10, d_counters.p + A_FIX_CNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipStreamSynchronize(h->stream));
+				fix[0] = s[8]; fix[1] = s[9]; fix[2] = s[10];
+			}
+			if (need_trim) { sum_runmax += (long long)fix[0] + (n_counted - (long long)fix[2]) * tile_max; run_max = tile_max; }
+			else sum_runmax += n_counted * run_max;
+			if (sp.mode != NGSQC_MODE_ROI && !paired_seen)
+			{
+				if (fp != ~0ull) { fix_len += (long long)fix[1]; paired_seen = true; }
+				else fix_len += (long long)(usable - prev_usable);   // no paired read yet: every passing record of the tile precedes the first one
+			}
+			prev_total = total; prev_usable = usable;
+		}
+		stage_ms += t.stop();
 	}
-	h->tm.scan_algorithmic_bytes = (int64_t)dev[A_ALG_BYTES];
+	void end(ngsqc_handle* h)
+	{
+		dev.assign(A_DEV_TOTAL, 0ull);
+		HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+};
+
+void bind_regions(ScanParams& sp, DepthSet& D)
+{
+	sp.reg_start = D.d_reg_start.p; sp.reg_end = D.d_reg_end.p; sp.reg_doff = D.d_doff.p;
+	sp.tid_reg_first = D.d_tid_first.p; sp.tid_reg_last = D.d_tid_last.p; sp.n_regions = (int64_t)D.regions.size();
+	sp.diff = D.d_depth.p;
 }
+
+// site pileup of a table of known sites (BamReader::getPileup per site in the reference)
+struct PileupState
+{
+	DevBuf<int32_t> d_pos, d_tf, d_tl, d_bucket; DevBuf<int64_t> d_tb0; DevBuf<uint32_t> d_cnt; DevBuf<unsigned long long> d_nlong; DevBuf<int64_t> d_long;
+	int64_t n_sites = 0; int n_ref = 0; int min_mapq = 0, min_baseq = 0, include_npp = 0; double stage_ms = 0;
+	void begin(ngsqc_handle* h, const ngsqc_region* sites, int64_t n, int32_t mq, int32_t bq, int32_t npp)
+	{
+		n_sites = n; min_mapq = mq; min_baseq = bq; include_npp = npp ? 1 : 0; stage_ms = 0;
+		n_ref = (int)h->ref_names.size();
+		std::vector<int32_t> pos((size_t)n_sites), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
+		std::vector<uint8_t> seen((size_t)std::max(n_ref, 1), 0);
+		for (int64_t i = 0; i < n_sites; ++i)
+		{
+			const ngsqc_region& r = sites[i];
+			if (r.tid < 0 || r.tid >= n_ref) throw ArgError("site with invalid reference id");
+			if (r.start < 1 || r.end != r.start) throw ArgError("a site is a single 1-based position (start == end)");
+			if (i > 0 && sites[i - 1].tid == r.tid) { if (sites[i - 1].start > r.start) throw ArgError("sites must be sorted by position within a reference"); }
+			else { if (seen[(size_t)r.tid]) throw ArgError("sites of one reference must be contiguous"); seen[(size_t)r.tid] = 1; tf[(size_t)r.tid] = (int32_t)i; }
+			tl[(size_t)r.tid] = (int32_t)i + 1; pos[(size_t)i] = r.start;
+		}
+		// 64 kb position buckets per reference (only references that have sites get buckets)
+		std::vector<int64_t> tb0((size_t)n_ref + 1, 0); std::vector<int32_t> bucket;
+		for (int t = 0; t < n_ref; ++t)
+		{
+			tb0[(size_t)t] = (int64_t)bucket.size();
+			if (tf[(size_t)t] >= tl[(size_t)t]) continue;
+			const int64_t nb = (std::max<int64_t>(h->ref_lens[(size_t)t], pos[(size_t)tl[(size_t)t] - 1]) >> PILEUP_BUCKET_SHIFT) + 2;
+			int32_t i = tf[(size_t)t];
+			for (int64_t b = 0; b < nb; ++b) { const int64_t lo = b << PILEUP_BUCKET_SHIFT; while (i < tl[(size_t)t] && pos[(size_t)i] < lo) ++i; bucket.push_back(i); }
+		}
+		tb0[(size_t)n_ref] = (int64_t)bucket.size();
+		if (bucket.empty()) bucket.push_back(0);
+		d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream); d_bucket.upload(bucket, h->stream); d_tb0.upload(tb0, h->stream);
+		d_cnt.ensure((size_t)n_sites * 8); d_nlong.ensure(1);
+		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_sites * 8 * sizeof(uint32_t), h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	void tile(ngsqc_handle* h, const TileCtx& c)
+	{
+		if (n_sites == 0) return;
+		Timer t(h->stream); t.start();
+		d_long.ensure((size_t)std::max<int64_t>(c.n_rec, 1));
+		HIPCHK(hipMemsetAsync(d_nlong.p, 0, sizeof(unsigned long long), h->stream));
+		launch_pileup(c.infl, c.recoff, c.n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_npp, d_cnt.p, d_long.p, d_nlong.p, h->stream);
+		unsigned long long* s = h->p_small.p + 16;
+		HIPCHK(hipMemcpyAsync(s, d_nlong.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (*s) launch_pileup_long(c.infl, c.recoff, d_long.p, (int64_t)*s, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream);
+		stage_ms += t.stop();
+	}
+	void end(ngsqc_handle* h, int64_t* counts)
+	{
+		if (n_sites == 0) return;
+		std::vector<uint32_t> out((size_t)n_sites * 8);
+		HIPCHK(hipMemcpyAsync(out.data(), d_cnt.p, out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		for (size_t i = 0; i < out.size(); ++i) counts[i] = (int64_t)out[i];
+	}
+};
+
+// raw-read QC (StatisticsReads::update). The read-length histogram grows with the longest read seen so far.
+struct ReadsState
+{
+	DevBuf<unsigned long long> d_max, d_acc, d_len, d_cyc; int64_t len_cap = -1; int single_end = 0; double stage_ms = 0;
+	void begin(ngsqc_handle* h, int se)
+	{
+		single_end = se ? 1 : 0; len_cap = -1; stage_ms = 0;
+		d_max.ensure(1); d_acc.ensure(RA_TOTAL); d_cyc.ensure((size_t)RQ_CYC * 7);
+		HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_acc.p, 0, RA_TOTAL * sizeof(unsigned long long), h->stream));
+		HIPCHK(hipMemsetAsync(d_cyc.p, 0, (size_t)RQ_CYC * 7 * sizeof(unsigned long long), h->stream));
+	}
+	void tile(ngsqc_handle* h, const TileCtx& c)
+	{
+		Timer t(h->stream); t.start();
+		launch_reads_max(c.infl, c.recoff, c.n_rec, d_max.p, h->stream);
+		unsigned long long* s = h->p_small.p + 24;
+		HIPCHK(hipMemcpyAsync(s, d_max.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		const int64_t need = (int64_t)*s;
+		if (need > len_cap)
+		{
+			// grow the histogram (keeps the counts of the shorter reads seen so far)
+			const int64_t cap2 = std::max<int64_t>(need, len_cap < 0 ? need : len_cap * 2);
+			DevBuf<unsigned long long> nw; nw.alloc((size_t)cap2 + 1);
+			HIPCHK(hipMemsetAsync(nw.p, 0, ((size_t)cap2 + 1) * sizeof(unsigned long long), h->stream));
+			if (len_cap >= 0) HIPCHK(hipMemcpyAsync(nw.p, d_len.p, ((size_t)len_cap + 1) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+			std::swap(nw.p, d_len.p); std::swap(nw.n, d_len.n); len_cap = cap2;
+		}
+		launch_reads(c.infl, c.recoff, c.n_rec, single_end, d_acc.p, d_len.p, len_cap, d_cyc.p, h->stream);
+		stage_ms += t.stop();
+	}
+	void end(ngsqc_handle* h, ngsqc_read_stats* st)
+	{
+		unsigned long long mx = 0;
+		HIPCHK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+		std::vector<unsigned long long> acc(RA_TOTAL), len((size_t)mx + 1, 0ull), cyc((size_t)RQ_CYC * 7);
+		HIPCHK(hipMemcpyAsync(acc.data(), d_acc.p, acc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		if (len_cap >= 0) HIPCHK(hipMemcpyAsync(len.data(), d_len.p, len.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(cyc.data(), d_cyc.p, cyc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		memset(st, 0, sizeof(*st));
+		st->c_forward = (int64_t)acc[RA_FWD]; st->c_reverse = (int64_t)acc[RA_REV]; st->bases_sequenced = (int64_t)acc[RA_BASES];
+		for (int i = 0; i < 5; ++i) st->bases[i] = (int64_t)acc[RA_A + i];
+		for (int i = 0; i < 100; ++i) { st->base_qualities[i] = (int64_t)acc[RA_BQ0 + i]; st->read_qualities[i] = (int64_t)acc[RA_RQ0 + i]; }
+		for (int i = 0; i < 60; ++i) { st->qscore_dist_r1[i] = (int64_t)acc[RA_QD0 + i]; st->qscore_dist_r2[i] = (int64_t)acc[RA_QD0 + 60 + i]; }
+		st->max_cycles = (int64_t)mx; st->n_unknown_base = (int64_t)acc[RA_BAD_BASE]; st->n_quality_out_of_range = (int64_t)acc[RA_BAD_QUAL];
+		h->rq_len_hist.assign(len.begin(), len.end()); h->rq_cyc.assign(cyc.begin(), cyc.end());
+	}
+};
 
 template <typename F> int guarded(ngsqc_handle* h, F f)
 {
@@ -681,8 +960,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 
 struct ngsqc_handle::Partial
 {
-	int mode = 0; bool yx = false; ScanParams sp{}; DevBuf<uint8_t> d_ns; GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
-	std::vector<unsigned long long> dev;
+	int mode = 0; bool yx = false; ScanState scan; DevBuf<uint8_t> d_ns; GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
 };
 
 namespace {
@@ -693,8 +971,9 @@ void mapping_setup(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_handle:
 	if (p->mode == NGSQC_MODE_ROI && (!p->regions || p->n_regions <= 0)) throw ArgError("target-region mode needs regions");
 	const int n_ref = (int)h->ref_names.size();
 	const bool use_regions = p->mode != NGSQC_MODE_NOROI && p->regions && p->n_regions > 0;
-	setup_regions(h, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
-	ScanParams& sp = st.sp; sp = ScanParams{};
+	DepthSet& D = h->ds[0];
+	setup_regions(h, D, use_regions ? p->regions : nullptr, use_regions ? p->n_regions : 0);
+	ScanParams& sp = st.scan.sp; sp = ScanParams{};
 	sp.mode = p->mode; sp.min_mapq = p->min_mapq; sp.min_baseq = 0; sp.skip_mismapped = 0;
 	sp.tid_x = p->tid_x; sp.tid_y = p->tid_y;
 	st.mode = p->mode; const bool yx = st.yx = p->tid_x >= 0 && p->tid_x < n_ref && p->tid_y >= 0 && p->tid_y < n_ref;
@@ -703,8 +982,7 @@ void mapping_setup(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_handle:
 	std::vector<uint8_t> ns((size_t)std::max(n_ref, 1), 0);
 	if (p->tid_nonspecial) for (int i = 0; i < n_ref; ++i) ns[i] = p->tid_nonspecial[i];
 	st.d_ns.upload(ns, h->stream); sp.tid_nonspecial = st.d_ns.p;
-	sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
-	sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
+	bind_regions(sp, D);
 	// GC chunks
 	GcTables& gc = st.gc; DevBuf<unsigned long long>& d_gctab = st.d_gctab; DevBuf<double>& d_gcover = st.d_gcover;
 	const bool use_gc = use_regions && p->gc_chunks && p->gc_bin && p->n_gc_chunks > 0;
@@ -724,22 +1002,24 @@ void mapping_setup(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_handle:
 			s[i] = r.start; e[i] = r.end; b[i] = p->gc_bin[i] > 100 ? -1 : p->gc_bin[i];
 		}
 		gc.start.upload(s, h->stream); gc.end.upload(e, h->stream); gc.bin.upload(b, h->stream); gc.tf.upload(tf, h->stream); gc.tl.upload(tl, h->stream);
+		HIPCHK(hipStreamSynchronize(h->stream));
 		sp.gc_start = gc.start.p; sp.gc_end = gc.end.p; sp.gc_bin = gc.bin.p; sp.tid_gc_first = gc.tf.p; sp.tid_gc_last = gc.tl.p; sp.n_gc = n;
 	}
+	HIPCHK(hipStreamSynchronize(h->stream));
 	sp.gc_tab = d_gctab.p; sp.gc_over = d_gcover.p;
 }
 
-// device accumulators -> the reference's counters. gmax / paired_end: of the whole BAM (== this handle's unless it is a shard)
-void mapping_counters(ngsqc_handle* h, ngsqc_handle::Partial& st, int gmax, bool paired_end, int64_t* counters, double* gc_reads)
+// device accumulators -> the reference's counters. gmax / paired_end: of the whole BAM (== this handle's unless it is a shard);
+// sum_runmax: sum over counted records of the running maximum read length; fix_len: passing bases in front of the first paired read
+void mapping_counters(ngsqc_handle* h, ngsqc_handle::Partial& st, int gmax, bool paired_end, long long sum_runmax, long long fix_len, int64_t* counters, double* gc_reads)
 {
-	const std::vector<unsigned long long>& dev = st.dev; const bool yx = st.yx;
-		// ---- device accumulators -> the reference's counters ----
+	const std::vector<unsigned long long>& dev = st.scan.dev; const bool yx = st.yx;
 	auto S = [&](int i) { return (int64_t)dev[i]; };
 	for (int i = 0; i < NGSQC_NCOUNTERS; ++i) counters[i] = 0;
 	counters[NGSQC_C_AL_TOTAL] = S(A_TOTAL); counters[NGSQC_C_AL_MAPPED] = S(A_MAPPED); counters[NGSQC_C_AL_ONTARGET] = S(A_ONTARGET);
 	counters[NGSQC_C_AL_NEARTARGET] = S(A_NEAR); counters[NGSQC_C_AL_DUP] = S(A_DUP); counters[NGSQC_C_AL_PROPER_PAIRED] = S(A_PP);
 	counters[NGSQC_C_INSERT_SIZE_READ_COUNT] = S(A_INS_CNT);
-	counters[NGSQC_C_BASES_TRIMMED] = S(A_TOTAL) * gmax - S(A_SUM_LEN) - S(A_FIX_TRIM);
+	counters[NGSQC_C_BASES_TRIMMED] = sum_runmax - S(A_SUM_LEN);
 	counters[NGSQC_C_BASES_MAPPED] = S(A_BASES_MAPPED); counters[NGSQC_C_BASES_CLIPPED] = S(A_CLIPPED); counters[NGSQC_C_INSERT_SIZE_SUM] = S(A_INS_SUM);
 	if (st.mode == NGSQC_MODE_ROI)
 	{
@@ -749,13 +1029,13 @@ void mapping_counters(ngsqc_handle* h, ngsqc_handle::Partial& st, int gmax, bool
 	else
 	{
 		counters[NGSQC_C_BASES_USABLE] = S(A_USABLE) - S(A_CLIPPED);                        // Statistics.cpp:917 / :1183
-		counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = (paired_end ? S(A_USABLE) - S(A_FIX_LEN) : 0) + S(A_NO_OVERLAP); // :879,:898-901
+		counters[NGSQC_C_BASES_USABLE_NO_OVERLAP] = (paired_end ? S(A_USABLE) - fix_len : 0) + S(A_NO_OVERLAP); // :879,:898-901
 	}
 	counters[NGSQC_C_BASES_USABLE_RAW] = S(A_USABLE_RAW); counters[NGSQC_C_BASES_USABLE_ROI] = S(A_USABLE_ROI);
 	for (int i = 0; i < 5; ++i) counters[NGSQC_C_BASES_USABLE_DP0 + i] = S(A_DP0 + i);
 	for (int i = 0; i < 4; ++i) counters[NGSQC_C_DP_DIST0 + i] = S(A_DD0 + i);
 	counters[NGSQC_C_MAX_LENGTH] = gmax; counters[NGSQC_C_PAIRED_END] = paired_end ? 1 : 0;
-	counters[NGSQC_C_ROI_BASES] = h->roi_bases;
+	counters[NGSQC_C_ROI_BASES] = h->ds[0].roi_bases;
 	counters[NGSQC_C_READS_X] = yx ? S(A_READS_X) : 0; counters[NGSQC_C_READS_Y] = yx ? S(A_READS_Y) : 0;
 	counters[NGSQC_C_YX_VALID] = (yx && S(A_READS_X) != 0) ? 1 : 0;
 	for (int i = 0; i < 1000; ++i) counters[NGSQC_C_INSERT_HIST0 + i] = S(A_HIST0 + i);
@@ -771,7 +1051,70 @@ void mapping_counters(ngsqc_handle* h, ngsqc_handle::Partial& st, int gmax, bool
 			gc_reads[b] = v;
 		}
 	}
+	h->tm.scan_algorithmic_bytes = (int64_t)dev[A_ALG_BYTES];
 }
+
+void depth_setup(ngsqc_handle* h, const ngsqc_depth_params* p, DepthSet& D, ScanState& sc)
+{
+	if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
+	setup_regions(h, D, p->regions, p->n_regions);
+	ScanParams& sp = sc.sp; sp = ScanParams{};
+	sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;
+	sp.tid_x = -2; sp.tid_y = -2;
+	bind_regions(sp, D);
+}
+
+// The fused job: every requested consumer sees every tile once.
+void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r)
+{
+	if (!j || !r) throw ArgError("null argument");
+	const bool do_map = j->mapping != nullptr, do_depth = j->depth != nullptr, do_sites = j->n_sites > 0, do_reads = j->read_qc != 0;
+	if (do_map && !r->counters) throw ArgError("mapping job without a counter buffer");
+	if (do_sites && (!j->sites || !r->site_counts)) throw ArgError("site pileup job without sites / count buffer");
+	if (do_reads && !r->read_stats) throw ArgError("raw-read QC job without a result buffer");
+	if (j->n_sites < 0) throw ArgError("invalid site count");
+	const double w0 = wall_ms();
+	Timer total(h->stream); total.start();
+	ngsqc_handle::Partial map; ScanState dscan; PileupState pile; ReadsState reads;
+	if (do_map) { mapping_setup(h, j->mapping, map); map.scan.begin(h); }
+	if (do_depth) { depth_setup(h, j->depth, h->ds[1], dscan); dscan.in_pass_fix = false; dscan.begin(h); }
+	if (do_sites) pile.begin(h, j->sites, j->n_sites, j->site_min_mapq, j->site_min_baseq, j->site_include_npp);
+	if (do_reads) reads.begin(h, j->read_qc_single_end);
+	stream_tiles(h, [&](const TileCtx& c) {
+		if (do_map) map.scan.tile(h, c);
+		if (do_depth) dscan.tile(h, c);
+		if (do_sites) pile.tile(h, c);
+		if (do_reads) reads.tile(h, c);
+		return true;
+	});
+	h->tm.scan_ms = 0; h->tm.scan_kernel_ms = 0; h->tm.scan_launches = 0; h->tm.finalize_ms = 0;
+	if (do_map)
+	{
+		map.scan.end(h);
+		Timer fin(h->stream); fin.start();
+		finalize_depth(h, h->ds[0]);
+		h->tm.finalize_ms = fin.stop();
+		mapping_counters(h, map, (int)(map.scan.best_key >> 40), map.scan.first_paired != ~0ull, map.scan.sum_runmax, map.scan.fix_len, r->counters, r->gc_reads);
+		h->tm.scan_ms = map.scan.stage_ms; h->tm.scan_kernel_ms = map.scan.kernel_ms; h->tm.scan_launches = map.scan.launches;
+	}
+	if (do_depth)
+	{
+		dscan.end(h);
+		Timer fin(h->stream); fin.start();
+		finalize_depth(h, h->ds[1]);
+		h->tm.finalize_ms += fin.stop();
+		h->tm.depth_scan_ms = dscan.stage_ms;
+		if (!do_map) { h->tm.scan_algorithmic_bytes = (int64_t)dscan.dev[A_ALG_BYTES]; h->tm.scan_kernel_ms = dscan.kernel_ms; h->tm.scan_launches = dscan.launches; h->tm.scan_ms = dscan.stage_ms; }
+	}
+	if (do_sites) { pile.end(h, r->site_counts); h->tm.pileup_ms = pile.stage_ms; }
+	if (do_reads) { reads.end(h, r->read_stats); h->tm.reads_ms = reads.stage_ms; }
+	h->cur_ds = do_map || !do_depth ? 0 : 1;
+	h->tm.total_ms = total.stop();
+	h->tm.job_wall_ms = wall_ms() - w0;
+}
+
+DepthSet& cur_depth(ngsqc_handle* h) { return h->ds[h->cur_ds]; }
+
 } // namespace
 
 extern "C" {
@@ -784,9 +1127,10 @@ int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, i
 void ngsqc_close(ngsqc_handle* h)
 {
 	if (!h) return;
-	if (h->stream) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-	if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-	for (hipEvent_t e : h->k1_events) (void)hipEventDestroy(e);
+	if (h->stream) { (void)hipSetDevice(h->device); sync_all(h); }
+	for (hipStream_t s : {h->stream, h->s_p1[0], h->s_p1[1], h->s_p2}) if (s) (void)hipStreamDestroy(s);
+	for (hipEvent_t e : h->ev_chunk) (void)hipEventDestroy(e);
+	for (hipEvent_t e : h->ev_tile) (void)hipEventDestroy(e);
 	delete h->partial;
 	delete h;
 }
@@ -801,23 +1145,23 @@ int64_t ngsqc_inflated_size(ngsqc_handle* h) { return h ? h->total : 0; }
 int64_t ngsqc_n_records(ngsqc_handle* h)
 {
 	int64_t n = 0;
-	int rc = guarded(h, [&] { for_each_tile(h, [&](int) { n += h->n_rec; return true; }); });
+	int rc = guarded(h, [&] { stream_tiles(h, [&](const TileCtx& c) { n += c.n_rec; return true; }); });
 	return rc == NGSQC_OK ? n : (int64_t)rc;
 }
 
-int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { for_each_tile(h, [&](int) { return true; }); }); }
+int ngsqc_decode(ngsqc_handle* h) { return guarded(h, [&] { stream_tiles(h, [&](const TileCtx&) { return true; }); HIPCHK(hipStreamSynchronize(h->stream)); }); }
 int ngsqc_drop_decoded(ngsqc_handle* h)
 {
 	// buffers stay allocated (re-used by the next decode); only the decoded STATE is dropped, so the next scan redoes K1+K2
-	return guarded(h, [&] { h->decoded = false; h->cur_tile = -1; h->depth_ready = false; h->n_rec = 0; });
+	return guarded(h, [&] { h->decoded = false; h->cur_tile = -1; for (DepthSet& D : h->ds) D.depth_ready = false; h->n_rec = 0; });
 }
 
 int ngsqc_copy_inflated(ngsqc_handle* h, uint8_t* out, int64_t cap)
 {
 	return guarded(h, [&] {
-		for_each_tile(h, [&](int) {
+		stream_tiles(h, [&](const TileCtx& c) {
 			const int64_t lo = h->tile_u_lo, n = std::min(cap, lo + (h->tile_total - h->tile_prefix)) - lo;   // this tile's own bytes (without the carried prefix)
-			if (n > 0) HIPCHK(hipMemcpy(out + lo, h->d_infl.p + h->tile_prefix, (size_t)n, hipMemcpyDeviceToHost));
+			if (n > 0) { HIPCHK(hipMemcpyAsync(out + lo, c.infl + h->tile_prefix, (size_t)n, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
 			return true;
 		});
 	});
@@ -826,11 +1170,11 @@ int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap)
 {
 	return guarded(h, [&] {
 		int64_t done = 0;
-		for_each_tile(h, [&](int) {
-			const int64_t n = std::min(cap - done, h->n_rec);
+		stream_tiles(h, [&](const TileCtx& c) {
+			const int64_t n = std::min(cap - done, c.n_rec);
 			if (n > 0)
 			{
-				HIPCHK(hipMemcpy(out + done, h->d_recoff.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+				HIPCHK(hipMemcpyAsync(out + done, c.recoff, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
 				for (int64_t i = 0; i < n; ++i) out[done + i] += h->tile_u_lo - h->tile_prefix;   // tile-local -> stream offset
 				done += n;
 			}
@@ -839,19 +1183,19 @@ int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap)
 	});
 }
 
+int ngsqc_run_job(ngsqc_handle* h, const ngsqc_job_desc* job, ngsqc_job_result* result) { return guarded(h, [&] { run_job(h, job, result); }); }
+
+int ngsqc_depth_select(ngsqc_handle* h, int32_t which)
+{
+	return guarded(h, [&] { if (which < 0 || which >= N_DEPTH_SETS) throw ArgError("invalid depth set"); h->cur_ds = which; });
+}
+
 int ngsqc_scan_mapping(ngsqc_handle* h, const ngsqc_mapping_params* p, int64_t* counters, double* gc_reads)
 {
 	return guarded(h, [&] {
 		if (!p || !counters) throw ArgError("null argument");
-		Timer total(h->stream); total.start();
-		ngsqc_handle::Partial st;
-		mapping_setup(h, p, st);
-		run_scan(h, st.sp, st.dev);
-		Timer fin(h->stream); fin.start();
-		finalize_depth(h);
-		h->tm.finalize_ms = fin.stop();
-		mapping_counters(h, st, (int)(st.dev[A_FIRST_MAX_KEY] >> 40), st.dev[A_FIRST_PAIRED] != ~0ull, counters, gc_reads);
-		h->tm.total_ms = total.stop();
+		ngsqc_job_desc j{}; j.mapping = p; ngsqc_job_result r{}; r.counters = counters; r.gc_reads = gc_reads;
+		run_job(h, &j, &r);
 	});
 }
 
@@ -864,14 +1208,18 @@ int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, n
 		delete h->partial; h->partial = new ngsqc_handle::Partial();
 		ngsqc_handle::Partial& st = *h->partial;
 		mapping_setup(h, p, st);
-		run_scan(h, st.sp, st.dev, false);
-		const unsigned long long key = st.dev[A_FIRST_MAX_KEY];
+		st.scan.in_pass_fix = false; st.scan.begin(h);
+		stream_tiles(h, [&](const TileCtx& c) { st.scan.tile(h, c); return true; });
+		st.scan.end(h);
+		h->cur_ds = 0;
+		const unsigned long long key = st.scan.best_key;
 		out->n_records = h->tm.n_records;
 		out->first_abs = h->shard_own_members >= 0 ? h->shard_first_abs : (h->tm.n_records ? h->first_rec : -1);
 		out->exit_abs = h->shard_own_members >= 0 ? h->shard_exit_abs : (h->tm.n_records ? h->total : -1);
 		out->max_len = (int64_t)(key >> 40);
 		out->first_max_ord = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : -1;
-		out->first_paired_ord = st.dev[A_FIRST_PAIRED] != ~0ull ? (int64_t)st.dev[A_FIRST_PAIRED] : -1;
+		out->first_paired_ord = st.scan.first_paired != ~0ull ? (int64_t)st.scan.first_paired : -1;
+		h->tm.scan_ms = st.scan.stage_ms; h->tm.scan_kernel_ms = st.scan.kernel_ms; h->tm.scan_launches = st.scan.launches;
 		h->tm.total_ms = total.stop();
 	});
 }
@@ -881,10 +1229,30 @@ int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64
 	return guarded(h, [&] {
 		if (!fix || !counters) throw ArgError("null argument");
 		if (!h->partial) throw ArgError("ngsqc_scan_mapping_finish without ngsqc_scan_mapping_partial");
-		ngsqc_handle::Partial& st = *h->partial;
+		ngsqc_handle::Partial& st = *h->partial; ScanState& sc = st.scan;
 		Timer total(h->stream); total.start();
-		run_prefix_fix(h, st.sp, st.dev, fix->trim_upto, st.mode != NGSQC_MODE_ROI ? fix->paired_upto : 0, (int)fix->gmax, (int)fix->floor_max);
-		mapping_counters(h, st, (int)fix->gmax, fix->paired_end != 0, counters, gc_reads);
+		// running maximum / "paired seen" on the record prefix the carries of the WHOLE BAM touch: [0, trim_upto) / [0, paired_upto)
+		// of this shard, with the running maximum of the earlier shards carried in. Normally empty or a handful of records; the
+		// tiles that hold them are visited again (a shard is rarely more than one tile).
+		const int64_t f = fix->trim_upto, pidx = st.mode != NGSQC_MODE_ROI ? fix->paired_upto : 0;
+		unsigned long long fx[4] = {0, 0, (unsigned long long)std::max<int64_t>(fix->floor_max, 0), 0};   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
+		if (f > 0 || pidx > 0)
+		{
+			HIPCHK(hipMemcpyAsync(sc.d_counters.p + A_FIX_TRIM, fx, sizeof(fx), hipMemcpyHostToDevice, h->stream));
+			const int64_t upto = std::max(f, pidx);
+			stream_tiles(h, [&](const TileCtx& c) {
+				sc.sp.infl = c.infl; sc.sp.total = c.total; sc.sp.recoff = c.recoff; sc.sp.n_rec = c.n_rec; sc.sp.ord_base = c.ord_base;
+				const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - c.ord_base, 0), c.n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - c.ord_base, 0), c.n_rec);
+				launch_prefix_fix(sc.sp, lf, lp, h->stream);
+				HIPCHK(hipStreamSynchronize(h->stream));
+				return c.ord_base + c.n_rec < upto;
+			});
+			HIPCHK(hipMemcpyAsync(fx, sc.d_counters.p + A_FIX_TRIM, sizeof(fx), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+		}
+		// records behind the prefix run at the BAM's maximum
+		const long long sum_runmax = (long long)fx[0] + ((long long)sc.dev[A_TOTAL] - (long long)fx[3]) * (long long)fix->gmax;
+		mapping_counters(h, st, (int)fix->gmax, fix->paired_end != 0, sum_runmax, (long long)fx[1], counters, gc_reads);
 		h->tm.total_ms += total.stop();
 	});
 }
@@ -893,35 +1261,68 @@ int ngsqc_depth_device(ngsqc_handle* h, void** dev_ptr, int64_t* n_slots)
 {
 	return guarded(h, [&] {
 		if (!dev_ptr || !n_slots) throw ArgError("null argument");
-		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		DepthSet& D = cur_depth(h);
+		if (D.depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
 		HIPCHK(hipStreamSynchronize(h->stream));
-		*dev_ptr = h->d_depth.p; *n_slots = h->n_slots;
+		*dev_ptr = D.d_depth.p; *n_slots = D.n_slots;
 	});
 }
 int ngsqc_depth_diff_copy(ngsqc_handle* h, int32_t* out, int64_t cap)
 {
 	return guarded(h, [&] {
-		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
-		if (cap < h->n_slots || (!out && h->n_slots)) throw ArgError("depth buffer too small");
-		if (h->n_slots) HIPCHK(hipMemcpyAsync(out, h->d_depth.p, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		DepthSet& D = cur_depth(h);
+		if (D.depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		if (cap < D.n_slots || (!out && D.n_slots)) throw ArgError("depth buffer too small");
+		if (D.n_slots) HIPCHK(hipMemcpyAsync(out, D.d_depth.p, (size_t)D.n_slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	});
 }
 int ngsqc_depth_diff_set(ngsqc_handle* h, const int32_t* in, int64_t n)
 {
 	return guarded(h, [&] {
-		if (h->depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
-		if (n != h->n_slots || (!in && n)) throw ArgError("depth buffer size mismatch");
-		if (n) HIPCHK(hipMemcpyAsync(h->d_depth.p, in, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+		DepthSet& D = cur_depth(h);
+		if (D.depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		if (n != D.n_slots || (!in && n)) throw ArgError("depth buffer size mismatch");
+		if (n) HIPCHK(hipMemcpyAsync(D.d_depth.p, in, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
+	});
+}
+// SUM of the un-prefixed difference arrays of several shard handles into dst's array. Handles on other devices are read
+// through peer copies (xGMI) into a staging buffer on dst's device; nothing passes through host memory.
+int ngsqc_depth_reduce(ngsqc_handle* dst, ngsqc_handle* const* srcs, int n_srcs)
+{
+	return guarded(dst, [&] {
+		if (n_srcs < 0 || (n_srcs && !srcs)) throw ArgError("null argument");
+		DepthSet& D = cur_depth(dst);
+		if (D.depth_ready) throw ArgError("the depth array is already finalized (prefix-summed)");
+		DevBuf<int32_t> stage;
+		for (int i = 0; i < n_srcs; ++i)
+		{
+			ngsqc_handle* s = srcs[i];
+			if (!s || s == dst) continue;
+			DepthSet& S = cur_depth(s);
+			if (S.depth_ready || S.n_slots != D.n_slots) throw ArgError("shard depth arrays do not match");
+			if (D.n_slots == 0) continue;
+			HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); HIPCHK(hipSetDevice(dst->device));
+			const int32_t* src = S.d_depth.p;
+			if (s->device != dst->device)
+			{
+				stage.ensure((size_t)D.n_slots);
+				HIPCHK(hipMemcpyPeerAsync(stage.p, dst->device, S.d_depth.p, s->device, (size_t)D.n_slots * sizeof(int32_t), dst->stream));
+				src = stage.p;
+			}
+			launch_depth_add(D.d_depth.p, src, D.n_slots, dst->stream);
+			HIPCHK(hipStreamSynchronize(dst->stream));
+		}
 	});
 }
 int ngsqc_depth_finalize(ngsqc_handle* h)
 {
 	return guarded(h, [&] {
-		if (h->depth_ready) return;
+		DepthSet& D = cur_depth(h);
+		if (D.depth_ready) return;
 		Timer fin(h->stream); fin.start();
-		finalize_depth(h);
+		finalize_depth(h, D);
 		h->tm.finalize_ms = fin.stop();
 	});
 }
@@ -954,49 +1355,11 @@ int ngsqc_site_pileup(ngsqc_handle* h, const ngsqc_region* sites, int64_t n_site
 	return guarded(h, [&] {
 		if (n_sites < 0 || (n_sites && (!sites || !counts))) throw ArgError("null argument");
 		if (n_sites == 0) return;
-		const int n_ref = (int)h->ref_names.size();
-		std::vector<int32_t> pos((size_t)n_sites), tf((size_t)std::max(n_ref, 1), 0), tl((size_t)std::max(n_ref, 1), 0);
-		std::vector<uint8_t> seen((size_t)std::max(n_ref, 1), 0);
-		for (int64_t i = 0; i < n_sites; ++i)
-		{
-			const ngsqc_region& r = sites[i];
-			if (r.tid < 0 || r.tid >= n_ref) throw ArgError("site with invalid reference id");
-			if (r.start < 1 || r.end != r.start) throw ArgError("a site is a single 1-based position (start == end)");
-			if (i > 0 && sites[i - 1].tid == r.tid) { if (sites[i - 1].start > r.start) throw ArgError("sites must be sorted by position within a reference"); }
-			else { if (seen[(size_t)r.tid]) throw ArgError("sites of one reference must be contiguous"); seen[(size_t)r.tid] = 1; tf[(size_t)r.tid] = (int32_t)i; }
-			tl[(size_t)r.tid] = (int32_t)i + 1; pos[(size_t)i] = r.start;
-		}
-		// 64 kb position buckets per reference (only references that have sites get buckets)
-		std::vector<int64_t> tb0((size_t)n_ref + 1, 0); std::vector<int32_t> bucket;
-		for (int t = 0; t < n_ref; ++t)
-		{
-			tb0[(size_t)t] = (int64_t)bucket.size();
-			if (tf[(size_t)t] >= tl[(size_t)t]) continue;
-			const int64_t nb = (std::max<int64_t>(h->ref_lens[(size_t)t], pos[(size_t)tl[(size_t)t] - 1]) >> PILEUP_BUCKET_SHIFT) + 2;
-			int32_t i = tf[(size_t)t];
-			for (int64_t b = 0; b < nb; ++b) { const int64_t lo = b << PILEUP_BUCKET_SHIFT; while (i < tl[(size_t)t] && pos[(size_t)i] < lo) ++i; bucket.push_back(i); }
-		}
-		tb0[(size_t)n_ref] = (int64_t)bucket.size();
-		if (bucket.empty()) bucket.push_back(0);
-		DevBuf<int32_t> d_pos, d_tf, d_tl, d_bucket; DevBuf<int64_t> d_tb0;
-		d_pos.upload(pos, h->stream); d_tf.upload(tf, h->stream); d_tl.upload(tl, h->stream); d_bucket.upload(bucket, h->stream); d_tb0.upload(tb0, h->stream);
-		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_sites * 8);
-		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_sites * 8 * sizeof(uint32_t), h->stream));
-		DevBuf<unsigned long long> d_nlong; d_nlong.alloc(1);
-		for_each_tile(h, [&](int) {
-			h->d_long.ensure((size_t)std::max<int64_t>(h->n_rec, 1));
-			HIPCHK(hipMemsetAsync(d_nlong.p, 0, sizeof(unsigned long long), h->stream));
-			launch_pileup(h->d_infl.p, h->d_recoff.p, h->n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_not_properly_paired ? 1 : 0, d_cnt.p, h->d_long.p, d_nlong.p, h->stream);
-			unsigned long long n_long = 0;
-			HIPCHK(hipMemcpyAsync(&n_long, d_nlong.p, sizeof(n_long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-			if (n_long) { launch_pileup_long(h->d_infl.p, h->d_recoff.p, h->d_long.p, (int64_t)n_long, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); }
-			return true;
-		});
-		std::vector<uint32_t> out((size_t)n_sites * 8);
-		HIPCHK(hipMemcpyAsync(out.data(), d_cnt.p, out.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		for (size_t i = 0; i < out.size(); ++i) counts[i] = (int64_t)out[i];
+		ngsqc_job_desc j{}; j.sites = sites; j.n_sites = n_sites; j.site_min_mapq = min_mapq; j.site_min_baseq = min_baseq; j.site_include_npp = include_not_properly_paired;
+		ngsqc_job_result r{}; r.site_counts = counts;
+		const int keep = h->cur_ds;
+		run_job(h, &j, &r);
+		h->cur_ds = keep;
 	});
 }
 
@@ -1004,31 +1367,10 @@ int ngsqc_scan_reads(ngsqc_handle* h, int32_t single_end, ngsqc_read_stats* st)
 {
 	return guarded(h, [&] {
 		if (!st) throw ArgError("null argument");
-		// pass 1: longest counted read (sizes the read-length histogram)
-		DevBuf<unsigned long long> d_max; d_max.alloc(1);
-		HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned long long), h->stream));
-		for_each_tile(h, [&](int) { launch_reads_max(h->d_infl.p, h->d_recoff.p, h->n_rec, d_max.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); return true; });
-		unsigned long long mx = 0;
-		HIPCHK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
-		const int64_t len_cap = (int64_t)mx;
-		DevBuf<unsigned long long> d_acc, d_len, d_cyc; d_acc.alloc(RA_TOTAL); d_len.alloc((size_t)len_cap + 1); d_cyc.alloc((size_t)RQ_CYC * 7);
-		HIPCHK(hipMemsetAsync(d_acc.p, 0, RA_TOTAL * sizeof(unsigned long long), h->stream));
-		HIPCHK(hipMemsetAsync(d_len.p, 0, ((size_t)len_cap + 1) * sizeof(unsigned long long), h->stream));
-		HIPCHK(hipMemsetAsync(d_cyc.p, 0, (size_t)RQ_CYC * 7 * sizeof(unsigned long long), h->stream));
-		// pass 2
-		for_each_tile(h, [&](int) { launch_reads(h->d_infl.p, h->d_recoff.p, h->n_rec, single_end ? 1 : 0, d_acc.p, d_len.p, len_cap, d_cyc.p, h->stream); HIPCHK(hipStreamSynchronize(h->stream)); return true; });
-		std::vector<unsigned long long> acc(RA_TOTAL), len((size_t)len_cap + 1), cyc((size_t)RQ_CYC * 7);
-		HIPCHK(hipMemcpyAsync(acc.data(), d_acc.p, acc.size() * 8, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(len.data(), d_len.p, len.size() * 8, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(cyc.data(), d_cyc.p, cyc.size() * 8, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		memset(st, 0, sizeof(*st));
-		st->c_forward = (int64_t)acc[RA_FWD]; st->c_reverse = (int64_t)acc[RA_REV]; st->bases_sequenced = (int64_t)acc[RA_BASES];
-		for (int i = 0; i < 5; ++i) st->bases[i] = (int64_t)acc[RA_A + i];
-		for (int i = 0; i < 100; ++i) { st->base_qualities[i] = (int64_t)acc[RA_BQ0 + i]; st->read_qualities[i] = (int64_t)acc[RA_RQ0 + i]; }
-		for (int i = 0; i < 60; ++i) { st->qscore_dist_r1[i] = (int64_t)acc[RA_QD0 + i]; st->qscore_dist_r2[i] = (int64_t)acc[RA_QD0 + 60 + i]; }
-		st->max_cycles = len_cap; st->n_unknown_base = (int64_t)acc[RA_BAD_BASE]; st->n_quality_out_of_range = (int64_t)acc[RA_BAD_QUAL];
-		h->rq_len_hist.assign(len.begin(), len.end()); h->rq_cyc.assign(cyc.begin(), cyc.end());
+		ngsqc_job_desc j{}; j.read_qc = 1; j.read_qc_single_end = single_end; ngsqc_job_result r{}; r.read_stats = st;
+		const int keep = h->cur_ds;
+		run_job(h, &j, &r);
+		h->cur_ds = keep;
 	});
 }
 int ngsqc_read_length_hist(ngsqc_handle* h, int64_t* out, int64_t cap)
@@ -1053,33 +1395,32 @@ int ngsqc_read_cycle_stats(ngsqc_handle* h, int64_t* out, int64_t n_cycles)
 namespace {
 void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 {
-	if (!p || !p->regions || p->n_regions <= 0) throw ArgError("depth scan needs regions");
 	Timer total(h->stream); total.start();
-	setup_regions(h, p->regions, p->n_regions);
-	ScanParams sp{};
-	sp.mode = MODE_DEPTH; sp.min_mapq = p->min_mapq; sp.min_baseq = p->min_baseq; sp.skip_mismapped = p->skip_mismapped;
-	sp.tid_x = -2; sp.tid_y = -2;
-	sp.reg_start = h->d_reg_start.p; sp.reg_end = h->d_reg_end.p; sp.reg_doff = h->d_doff.p;
-	sp.tid_reg_first = h->d_tid_first.p; sp.tid_reg_last = h->d_tid_last.p; sp.n_regions = (int64_t)h->regions.size();
-	std::vector<unsigned long long> dev;
-	run_scan(h, sp, dev);
-	if (finalize) { Timer fin(h->stream); fin.start(); finalize_depth(h); h->tm.finalize_ms = fin.stop(); }
+	ScanState sc; sc.in_pass_fix = false;
+	depth_setup(h, p, h->ds[0], sc);
+	sc.begin(h);
+	stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; });
+	sc.end(h);
+	h->cur_ds = 0;
+	h->tm.scan_ms = sc.stage_ms; h->tm.scan_kernel_ms = sc.kernel_ms; h->tm.scan_launches = sc.launches; h->tm.scan_algorithmic_bytes = (int64_t)sc.dev[A_ALG_BYTES];
+	if (finalize) { Timer fin(h->stream); fin.start(); finalize_depth(h, h->ds[0]); h->tm.finalize_ms = fin.stop(); }
 	h->tm.total_ms = total.stop();
 }
 } // namespace
 
 int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, true); }); }
-// shard variant: leaves the un-prefixed difference array (additive over shards: ngsqc_depth_device / _diff_copy / _diff_set, then ngsqc_depth_finalize)
+// shard variant: leaves the un-prefixed difference array (additive over shards: ngsqc_depth_reduce / _device / _diff_copy / _diff_set, then ngsqc_depth_finalize)
 int ngsqc_scan_depth_partial(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, false); }); }
 
 int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int64_t* hist, int64_t* covered)
 {
 	return guarded(h, [&] {
-		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
+		DepthSet& D = cur_depth(h);
+		if (!D.depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
 		if (hist_cap < 0 || hist_cap > 30000 || !hist || !covered) throw ArgError("invalid histogram request");
 		DevBuf<unsigned long long> d_hist; d_hist.alloc((size_t)hist_cap + 2);
 		HIPCHK(hipMemsetAsync(d_hist.p, 0, ((size_t)hist_cap + 2) * sizeof(unsigned long long), h->stream));
-		launch_depth_hist(h->d_depth.p, h->n_slots, hist_cap, half_depth, d_hist.p, d_hist.p + hist_cap + 1, h->stream);
+		launch_depth_hist(D.d_depth.p, D.n_slots, hist_cap, half_depth, d_hist.p, d_hist.p + hist_cap + 1, h->stream);
 		std::vector<unsigned long long> out((size_t)hist_cap + 2);
 		HIPCHK(hipMemcpyAsync(out.data(), d_hist.p, out.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -1091,22 +1432,23 @@ int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int
 int ngsqc_depth_copy(ngsqc_handle* h, int32_t* out, int64_t cap)
 {
 	return guarded(h, [&] {
-		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
-		if (cap < h->roi_bases) throw ArgError("depth buffer too small");
-		if (h->roi_bases == 0) return;
-		DevBuf<int32_t> d_out; d_out.alloc((size_t)h->roi_bases);
-		launch_depth_compact(h->d_depth.p, h->d_doff.p, h->d_reg_len.p, (int64_t)h->regions.size(), d_out.p, h->stream);
-		HIPCHK(hipMemcpyAsync(out, d_out.p, (size_t)h->roi_bases * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+		DepthSet& D = cur_depth(h);
+		if (!D.depth_ready) throw ArgError("no depth array: run ngsqc_scan_mapping / ngsqc_scan_depth first");
+		if (cap < D.roi_bases) throw ArgError("depth buffer too small");
+		if (D.roi_bases == 0) return;
+		DevBuf<int32_t> d_out; d_out.alloc((size_t)D.roi_bases);
+		launch_depth_compact(D.d_depth.p, D.d_doff.p, D.d_reg_len.p, (int64_t)D.regions.size(), d_out.p, h->stream);
+		HIPCHK(hipMemcpyAsync(out, d_out.p, (size_t)D.roi_bases * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	});
 }
 
 namespace {
 // locate each line inside the scanned (merged) regions: slot offset of its first base
-void locate_lines(ngsqc_handle* h, const ngsqc_region* lines, int64_t n, std::vector<int64_t>& slot, std::vector<int32_t>& len, std::vector<int32_t>& lstart)
+void locate_lines(ngsqc_handle* h, DepthSet& D, const ngsqc_region* lines, int64_t n, std::vector<int64_t>& slot, std::vector<int32_t>& len, std::vector<int32_t>& lstart)
 {
 	slot.resize((size_t)n); len.resize((size_t)n); lstart.resize((size_t)n);
-	const auto& R = h->regions;
+	const auto& R = D.regions;
 	std::vector<std::pair<int32_t, int32_t>> group(h->ref_names.size(), {0, 0}); // per tid: [first,last) in R
 	for (size_t k = 0; k < R.size();) { size_t e = k; while (e < R.size() && R[e].tid == R[k].tid) ++e; group[R[k].tid] = {(int32_t)k, (int32_t)e}; k = e; }
 	for (int64_t i = 0; i < n; ++i)
@@ -1117,7 +1459,7 @@ void locate_lines(ngsqc_handle* h, const ngsqc_region* lines, int64_t n, std::ve
 		int lo = group[l.tid].first, last = group[l.tid].second, hi = last;
 		while (lo < hi) { int m = (lo + hi) / 2; if (R[m].end < l.start) lo = m + 1; else hi = m; }
 		if (!(lo < last && R[lo].start <= l.start && R[lo].end >= l.end)) throw ArgError("line is not covered by the scanned regions");
-		slot[i] = h->doff[lo] + (l.start - R[lo].start); len[i] = l.end - l.start + 1; lstart[i] = l.start;
+		slot[i] = D.doff[lo] + (l.start - R[lo].start); len[i] = l.end - l.start + 1; lstart[i] = l.start;
 	}
 }
 }
@@ -1125,15 +1467,16 @@ void locate_lines(ngsqc_handle* h, const ngsqc_region* lines, int64_t n, std::ve
 int ngsqc_region_sums(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lines, int64_t* sums)
 {
 	return guarded(h, [&] {
-		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
+		DepthSet& D = cur_depth(h);
+		if (!D.depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
 		if (n_lines <= 0) return;
 		if (!lines || !sums) throw ArgError("null argument");
 		std::vector<int64_t> slot; std::vector<int32_t> len, ls;
-		locate_lines(h, lines, n_lines, slot, len, ls);
+		locate_lines(h, D, lines, n_lines, slot, len, ls);
 		DevBuf<int64_t> d_slot; d_slot.upload(slot, h->stream);
 		DevBuf<int32_t> d_len; d_len.upload(len, h->stream);
 		DevBuf<long long> d_sums; d_sums.alloc((size_t)n_lines);
-		launch_line_sums(h->d_depth.p, d_slot.p, d_len.p, n_lines, d_sums.p, h->stream);
+		launch_line_sums(D.d_depth.p, d_slot.p, d_len.p, n_lines, d_sums.p, h->stream);
 		HIPCHK(hipMemcpyAsync(sums, d_sums.p, (size_t)n_lines * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	});
@@ -1143,19 +1486,20 @@ int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lin
                        ngsqc_run* runs, int64_t cap, int64_t* n_runs)
 {
 	return guarded(h, [&] {
-		if (!h->depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
+		DepthSet& D = cur_depth(h);
+		if (!D.depth_ready) throw ArgError("no depth array: run ngsqc_scan_depth first");
 		if (!n_runs) throw ArgError("null argument");
 		*n_runs = 0;
 		if (n_lines <= 0) return;
 		std::vector<int64_t> slot; std::vector<int32_t> len, ls;
-		locate_lines(h, lines, n_lines, slot, len, ls);
+		locate_lines(h, D, lines, n_lines, slot, len, ls);
 		DevBuf<int64_t> d_slot; d_slot.upload(slot, h->stream);
 		DevBuf<int32_t> d_len; d_len.upload(len, h->stream);
 		DevBuf<int32_t> d_ls; d_ls.upload(ls, h->stream);
 		DevBuf<uint32_t> d_cnt; d_cnt.alloc((size_t)n_lines + 1);
 		DevBuf<int64_t> d_base; d_base.alloc((size_t)n_lines + 1);
 		DevBuf<uint8_t> d_tmp; d_tmp.alloc(scan_tmp_bytes(n_lines) + 64);
-		launch_line_runs(false, h->d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, nullptr, nullptr, h->stream);
+		launch_line_runs(false, D.d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, nullptr, nullptr, h->stream);
 		launch_scan_counts(d_cnt.p, n_lines, d_base.p, d_tmp.p, h->stream);
 		int64_t total = 0;
 		HIPCHK(hipMemcpyAsync(&total, d_base.p + n_lines, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -1163,7 +1507,7 @@ int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lin
 		*n_runs = total;
 		if (!runs || cap < total || total == 0) return;
 		DevBuf<ngsqc_run> d_runs; d_runs.alloc((size_t)total);
-		launch_line_runs(true, h->d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, d_base.p, d_runs.p, h->stream);
+		launch_line_runs(true, D.d_depth.p, d_slot.p, d_len.p, d_ls.p, n_lines, cutoff, is_high, saturate254, d_cnt.p, d_base.p, d_runs.p, h->stream);
 		HIPCHK(hipMemcpyAsync(runs, d_runs.p, (size_t)total * sizeof(ngsqc_run), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	});
@@ -1171,6 +1515,6 @@ int ngsqc_lowhigh_runs(ngsqc_handle* h, const ngsqc_region* lines, int64_t n_lin
 
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t) { if (!h || !t) return NGSQC_E_ARG; *t = h->tm; return NGSQC_OK; }
 
-const char* ngsqc_version(void) { return "ngsqc-hip 0.1 (gfx950; K1 bgzf_inflate, K2 bam_record_index, K3-K5 scan, K6 depth)"; }
+const char* ngsqc_version(void) { return "ngsqc-hip 0.2 (gfx950; K1 bgzf inflate + crc32, K2 bam record index, K3-K5 scan / pileup / read QC, K6 depth; tile stream)"; }
 
 } // extern "C"

@@ -18,18 +18,20 @@ struct BlockDesc { uint64_t cpos; uint64_t upos; uint32_t clen; uint32_t usize; 
 struct BlockStatus { uint32_t produced; uint32_t error; };
 
 // ---- K1 ----
-void launch_inflate(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status, hipStream_t s);
-
+enum { K1_ERR_CRC = 20, K1_ERR_TOKEN_OVERFLOW = 100 };   // BlockStatus.error values the host treats specially
 // two-phase K1 (inflate2.hip): lane-per-member Huffman -> tokens, then wave-per-member LZ77 resolve
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
                         const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order /* queue order inside the launch, or null */, int max_wgs, hipStream_t s);
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
                          const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s);
 
+// CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC
+void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);
+
 // ---- K2 ----
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s);
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
                         const int64_t* d_base, int64_t* d_recoff, hipStream_t s);
 void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
 void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
@@ -44,7 +46,7 @@ constexpr int MODE_DEPTH = 3;
 enum { A_TOTAL, A_MAPPED, A_ONTARGET, A_NEAR, A_DUP, A_PP, A_INS_CNT, A_SUM_LEN, A_BASES_MAPPED, A_CLIPPED, A_INS_SUM,
        A_USABLE, A_NO_OVERLAP, A_USABLE_RAW, A_USABLE_ROI, A_DP0, A_DP1, A_DP2, A_DP3, A_DP4, A_DD0, A_DD1, A_DD2, A_DD3,
        A_READS_X, A_READS_Y, A_ALG_BYTES, A_COUNT,
-       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
+       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
 
 struct ScanParams
 {
@@ -73,7 +75,7 @@ struct ScanParams
 
 void launch_scan(const ScanParams& p, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
-void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, int32_t gmax, hipStream_t s);
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, hipStream_t s);
 
 // site pileup (BamReader::getPileup SNP counts for a table of sites; counts = u32[n_sites][8])
 constexpr int PILEUP_BUCKET_SHIFT = 16;   // 64 kb position buckets per reference: bucket -> first site at or behind the bucket start
@@ -91,6 +93,7 @@ void launch_reads(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int
                   unsigned long long* d_cyc /* [RQ_CYC][7]: A,C,G,T,N, quality sum forward, quality sum reverse */, hipStream_t s);
 
 // ---- K6 ----
+void launch_depth_add(int32_t* d_dst, const int32_t* d_src, int64_t n, hipStream_t s);
 void launch_depth_mark_spare(int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, hipStream_t s);
 void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int64_t half, unsigned long long* d_hist, unsigned long long* d_cov, hipStream_t s);
 void launch_depth_compact(const int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, int32_t* d_out, hipStream_t s);
@@ -100,4 +103,6 @@ void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot,
 
 } // namespace ngsqc
 
+// after every kernel launch: a rejected launch (bad grid, too much LDS) must not pass as an empty result
+#define KCHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) { throw std::runtime_error(std::string("HIP kernel launch failed: ") + hipGetErrorString(_e)); } } while (0)
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); } } while (0)

@@ -92,10 +92,21 @@ __global__ __launch_bounds__(256) void line_runs_kernel(const int32_t* __restric
 	}
 }
 
+__global__ __launch_bounds__(256) void depth_add_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+void launch_depth_add(int32_t* d_dst, const int32_t* d_src, int64_t n, hipStream_t s)
+{
+	if (n <= 0) return;
+	const int64_t wgs = (n + 255) / 256;
+	hipLaunchKernelGGL(depth_add_kernel, dim3((int)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, d_dst, d_src, n); KCHECK();
+}
+
 void launch_depth_mark_spare(int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, hipStream_t s)
 {
 	if (n_regions <= 0) return;
-	hipLaunchKernelGGL(depth_mark_spare, dim3((int)((n_regions + 255) / 256)), dim3(256), 0, s, d_depth, d_doff, d_len, n_regions);
+	hipLaunchKernelGGL(depth_mark_spare, dim3((int)((n_regions + 255) / 256)), dim3(256), 0, s, d_depth, d_doff, d_len, n_regions); KCHECK();
 }
 
 void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int64_t half, unsigned long long* d_hist, unsigned long long* d_cov, hipStream_t s)
@@ -104,14 +115,14 @@ void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int
 	int64_t wgs = (n_slots + 256 * 16 - 1) / (256 * 16);
 	int grid = (int)(wgs < 1 ? 1 : (wgs < 1024 ? wgs : 1024));
 	size_t lds = (size_t)(cap + 1) * sizeof(uint32_t);
-	hipLaunchKernelGGL(depth_hist_kernel, dim3(grid), dim3(256), lds, s, d_depth, n_slots, cap, (long long)half, d_hist, d_cov);
+	hipLaunchKernelGGL(depth_hist_kernel, dim3(grid), dim3(256), lds, s, d_depth, n_slots, cap, (long long)half, d_hist, d_cov); KCHECK();
 }
 
 void launch_depth_compact(const int32_t* d_depth, const int64_t* d_doff, const int32_t* d_len, int64_t n_regions, int32_t* d_out, hipStream_t s)
 {
 	if (n_regions <= 0) return;
 	int grid = (int)(n_regions < 4096 ? n_regions : 4096);
-	hipLaunchKernelGGL(depth_compact_kernel, dim3(grid), dim3(256), 0, s, d_depth, d_doff, d_len, n_regions, d_out);
+	hipLaunchKernelGGL(depth_compact_kernel, dim3(grid), dim3(256), 0, s, d_depth, d_doff, d_len, n_regions, d_out); KCHECK();
 }
 
 void launch_line_sums(const int32_t* d_depth, const int64_t* d_slot, const int32_t* d_n, int64_t n_lines, long long* d_sums, hipStream_t s)
@@ -119,7 +130,7 @@ void launch_line_sums(const int32_t* d_depth, const int64_t* d_slot, const int32
 	if (n_lines <= 0) return;
 	int64_t wgs = (n_lines + 3) / 4;
 	int grid = (int)(wgs < 2048 ? wgs : 2048);
-	hipLaunchKernelGGL(line_sums_kernel, dim3(grid), dim3(256), 0, s, d_depth, d_slot, d_n, n_lines, d_sums);
+	hipLaunchKernelGGL(line_sums_kernel, dim3(grid), dim3(256), 0, s, d_depth, d_slot, d_n, n_lines, d_sums); KCHECK();
 }
 
 void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot, const int32_t* d_n, const int32_t* d_line_start, int64_t n_lines,
@@ -130,6 +141,7 @@ void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot,
 	int grid = (int)(wgs < 2048 ? wgs : 2048);
 	if (write) hipLaunchKernelGGL(line_runs_kernel<true>, dim3(grid), dim3(256), 0, s, d_depth, d_slot, d_n, d_line_start, n_lines, cutoff, is_high, sat, d_cnt, d_base, d_runs);
 	else hipLaunchKernelGGL(line_runs_kernel<false>, dim3(grid), dim3(256), 0, s, d_depth, d_slot, d_n, d_line_start, n_lines, cutoff, is_high, sat, d_cnt, d_base, d_runs);
+	KCHECK();
 }
 
 } // namespace ngsqc

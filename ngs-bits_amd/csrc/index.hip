@@ -14,6 +14,24 @@ namespace ngsqc {
 
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+// Entries of a tile: entry 0 is the pseudo member that covers the bytes carried over from the previous tile ([0, prefix)),
+// entry e >= 1 is member e - 1 of the tile's (static) descriptor table, whose upos is relative to the tile's first member.
+__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int64_t& lo, int64_t& hi)
+{
+	if (e == 0) { lo = 0; hi = prefix; }
+	else { const BlockDesc bd = blocks[e - 1]; lo = prefix + (int64_t)bd.upos; hi = lo + bd.usize; }
+}
+
+// what htslib's bam_read1 checks before it accepts a record (the reference then throws "Could not read next alignment",
+// src/cppNGS/BamReader.h:389-392): the variable-length fields must fit the record. Kernels behind K2 trust these fields.
+__device__ __forceinline__ bool record_fields_fit(const uint8_t* r, uint32_t bs)
+{
+	const uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16); const int32_t l_seq = (int32_t)ld32u(r + 20);
+	const uint32_t l_name = w & 0xff, n_cigar = w2 & 0xffff;
+	if (l_seq < 0 || l_name == 0) return false;
+	return 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq <= (uint64_t)bs;
+}
+
 // cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
 __device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
 {
@@ -36,16 +54,15 @@ __device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total
 // 4-byte loads reject almost every offset before the full plausibility check), so a member that lies inside one long record
 // (ONT: most members) costs 1 k steps instead of a 65 k-step scalar scan per thread. Members whose start is already known
 // (>= 0 or -1) are skipped; a member without any plausible start gets -1.
-__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t from,
                                                           int32_t* start, int32_t n_ref)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-	for (int64_t b = wave; b < n_blocks; b += n_waves)
+	for (int64_t b = from + wave; b < n_blocks; b += n_waves)
 	{
 		if (start[b] != -2) continue;
-		const BlockDesc bd = blocks[b];
-		const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
 		int32_t found = -1;
 		for (int64_t base = lo; base < hi; base += 64)
 		{
@@ -70,14 +87,13 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 }
 
 // start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
-__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                    uint32_t* __restrict__ bad, int32_t n_ref)
 {
-	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t b = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	const BlockDesc bd = blocks[b];
-	const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
 	int32_t s = start[b];
 	if (s == -2)
 	{
@@ -101,21 +117,21 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 		uint32_t bs = ld32u(infl + o);
 		if (bs < 32) { res = -2; stop = true; break; }
 		if (o + 4 + (int64_t)bs > total) { res = -(o + 10); stop = true; break; }
+		if (!record_fields_fit(infl + o, bs)) { res = -2; stop = true; break; }
 		++n; o += 4 + (int64_t)bs;
 	}
 	cnt[b] = n; next_abs[b] = stop ? res : o;
 	if (stop && res == -2) atomicAdd(bad, 1u);
 }
 
-__global__ void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+__global__ void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix,
                                    const int32_t* __restrict__ start, const int64_t* __restrict__ base, int64_t* __restrict__ recoff)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
 	int32_t s = start[b];
 	if (s < 0) return;
-	const BlockDesc bd = blocks[b];
-	const int64_t lo = (int64_t)bd.upos, hi = lo + bd.usize;
+	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
 	int64_t o = lo + s; int64_t k = base[b];
 	while (o < hi)
 	{
@@ -184,25 +200,27 @@ __global__ void scan_tile_apply(const TIn* __restrict__ in, int64_t n, const int
 
 size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE; return (size_t)(tiles + 2) * sizeof(int64_t); }
 
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, int32_t* d_start,
+// entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = member e - 1 of d_blocks); arrays are indexed by entry
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s)
 {
-	if (n_blocks <= 0) return;
+	const int64_t n = n_entries - from;
+	if (n <= 0) return;
 	{
 		// resolve the guesses wave-cooperatively first (the count kernel keeps its scalar guess loop only as a fallback)
-		const int64_t wg = (n_blocks + 3) / 4;
-		hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_blocks, d_start, n_ref);
+		const int64_t wg = (n + 3) / 4;
+		hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref); KCHECK();
 	}
-	int grid = (int)((n_blocks + 63) / 64);
-	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_cnt, d_next_abs, d_bad, n_ref);
+	int grid = (int)((n + 63) / 64);
+	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref); KCHECK();
 }
 
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_blocks, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
                         const int64_t* d_base, int64_t* d_recoff, hipStream_t s)
 {
-	if (n_blocks <= 0) return;
-	int grid = (int)((n_blocks + 63) / 64);
-	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_blocks, d_start, d_base, d_recoff);
+	if (n_entries <= 0) return;
+	int grid = (int)((n_entries + 63) / 64);
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, d_start, d_base, d_recoff); KCHECK();
 }
 
 // exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).
@@ -212,12 +230,12 @@ void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void*
 	int64_t* ts = (int64_t*)d_tmp;
 	if (tiles > 0)
 	{
-		hipLaunchKernelGGL(scan_tile_sums<uint32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts);
-		hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles);
-		hipLaunchKernelGGL((scan_tile_apply<uint32_t, int64_t, false>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts, d_base);
-		hipMemcpyAsync(d_base + n, ts + tiles, sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+		hipLaunchKernelGGL(scan_tile_sums<uint32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts); KCHECK();
+		hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles); KCHECK();
+		hipLaunchKernelGGL((scan_tile_apply<uint32_t, int64_t, false>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_cnt, n, ts, d_base); KCHECK();
+		HIPCHK(hipMemcpyAsync(d_base + n, ts + tiles, sizeof(int64_t), hipMemcpyDeviceToDevice, s));
 	}
-	else hipMemsetAsync(d_base, 0, sizeof(int64_t), s);
+	else HIPCHK(hipMemsetAsync(d_base, 0, sizeof(int64_t), s));
 }
 
 // in-place inclusive prefix sum of the int32 difference array -> per-base depth
@@ -226,9 +244,9 @@ void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStrea
 	int64_t tiles = (n_slots + SCAN_TILE - 1) / SCAN_TILE;
 	if (tiles <= 0) return;
 	int64_t* ts = (int64_t*)d_tmp;
-	hipLaunchKernelGGL(scan_tile_sums<int32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts);
-	hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles);
-	hipLaunchKernelGGL((scan_tile_apply<int32_t, int32_t, true>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts, d_diff);
+	hipLaunchKernelGGL(scan_tile_sums<int32_t>, dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts); KCHECK();
+	hipLaunchKernelGGL(scan_tile_prefix, dim3(1), dim3(SCAN_T), 0, s, ts, tiles); KCHECK();
+	hipLaunchKernelGGL((scan_tile_apply<int32_t, int32_t, true>), dim3((int)tiles), dim3(SCAN_T), 0, s, d_diff, n_slots, ts, d_diff); KCHECK();
 }
 
 } // namespace ngsqc

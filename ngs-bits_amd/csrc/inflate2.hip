@@ -13,7 +13,7 @@
 //            token its output range, then the batch is resolved front to back in 64-byte chunks: every OUTPUT BYTE gets a
 //            lane (owner token by popcount over a token-end bitmap), its source in periodic form (i mod dist) is
 //            gathered from HBM (before the batch), read from the LDS staging bytes (earlier chunk) or taken from the
-//            source lane (same chunk). lz77_resolve_kernel / lz77_pipe_kernel are earlier variants kept for the tests.
+//            source lane (same chunk).
 //   The host side (api.hip:inflate_members) cuts the members into chunks of one decoder "round" and overlaps phase 2 of a
 //   chunk with phase 1 of the next one on a second stream.
 //
@@ -30,7 +30,7 @@ constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W;   // 89 words per lane (22.8 KB 
 constexpr int P1_SERVICE = 4;    // symbols between service blocks
 
 enum { S_NEXT = 0, S_HDR = 1, S_P1 = 2, S_P2 = 3, S_SYM = 4, S_STORED = 5, S_FINISH = 6, S_DONE = 7 };
-enum { TOK_ERR_OVERFLOW = 100 };
+enum { TOK_ERR_OVERFLOW = K1_ERR_TOKEN_OVERFLOW };
 
 struct P1Lds
 {
@@ -162,7 +162,10 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
                                                           BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)
 {
-	__shared__ uint32_t lds[P1_LANE_W * 64];
+	// 23 KB per one-wave workgroup: exactly six fit a CU's 160 KB and a seventh does not, so the workgroups of the NEXT chunk's
+	// launch (queued on a second stream) take over the slots of this launch's finished waves without ever squeezing the LDS that
+	// the phase-2 / CRC / scan workgroups need beside them
+	__shared__ uint32_t lds[P1_LANE_W * 64 + 192];
 	const int lane = threadIdx.x;
 	P1Lds L{lds, lane};
 	const uint4* const comp_q = (const uint4*)comp;
@@ -191,7 +194,6 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	for (int i = 0; i < 7; ++i) limC[i] = 0;
 	uint32_t h_i = 0, h_n = 0, h_nlit = 0, h_prev = 0, hdr_bits = 0; uint32_t stored_left = 0;
 
-	auto exhausted = [&]() -> bool { return rd == wr && next_q >= n_q && !pf_valid; };
 	auto refill = [&]() {   // top the bit buffer up from the ring (branch-free); past the end of the member zero bits are appended
 		const bool t = bitcnt <= 32, a = rd != wr, ex = next_q >= n_q && !pf_valid;
 		uint32_t w = L.ring(rd);
@@ -481,10 +483,8 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 // ---------------------------------------------------------------------------------------------------------------- phase 2
 constexpr int P2_BMAX = 1024;   // max output bytes resolved per batch (LDS staging)
 
-struct P2Lds { unsigned long long endmask[P2_BMAX / 64]; uint16_t src[P2_BMAX + 64]; uint8_t val[P2_BMAX + 64]; };
-
-// Default phase 2. Same batching as lz77_resolve_kernel (kept below as NGSQC_P2_VARIANT=0), but the batch is resolved
-// front to back in 64-byte chunks so that no separate dependency passes are needed: a byte whose source lies
+// Phase 2. Tokens are taken in batches of at most 64 tokens / P2_BMAX output bytes; a batch is resolved front to back in
+// 64-byte chunks so that no separate dependency passes are needed: a byte whose source lies
 //   * before the batch            -> gathered from HBM (earlier batches of the same wave; stores drained by vmcnt(0)),
 //   * in an earlier chunk         -> read from the LDS staging bytes (already final),
 //   * in the same chunk           -> taken from the source LANE (ds_bpermute), iterating only while some lane's source is
@@ -616,222 +616,6 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 	}
 }
 
-// Phase 2 with the HBM gathers of a whole batch in flight at once (NGSQC_P2_VARIANT=3). Pass A walks the chunks, finds every
-// byte's owner token and source and ISSUES the gathers for sources that precede the batch (one register per chunk keeps
-// either the final byte, the gathered byte, or the in-batch source index); pass B then resolves chunk by chunk as
-// lz77_chunk_kernel does. The gather latency is paid once per batch instead of once per 64-byte chunk.
-constexpr int P2_NCH = P2_BMAX / 64;
-
-__global__ __launch_bounds__(256) void lz77_pipe_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
-                                                        const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
-{
-	__shared__ P2bLds lds[4];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	P2bLds& S = lds[wv];
-	constexpr int WAIT_VM0 = 0x0F70;
-	const uint64_t lane_lt = (1ull << lane) - 1ull;
-	const int64_t n_waves = (int64_t)gridDim.x * 4;
-	for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_blocks; b += n_waves)
-	{
-		if (status[b].error) continue;
-		const uint32_t n = tok_count[b];
-		const uint32_t* T = tok + tok_off[b];
-		uint8_t* out = out_base + blocks[b].upos;
-		const uint32_t usize = blocks[b].usize;
-		uint32_t P = 0;   // bytes written so far
-		uint32_t tk_next = (uint32_t)lane < n ? T[lane] : 0u;
-		for (uint32_t t0 = 0; t0 < n;)
-		{
-			const uint32_t i = t0 + (uint32_t)lane;
-			const uint32_t tk = tk_next;
-			const bool is_m = tk >> 31;
-			const uint32_t len = i < n ? (is_m ? ((tk >> 23) & 255u) + 3u : 1u) : 0u;
-			const uint32_t end = wave_scan_incl(len);
-			// take the longest token prefix whose output fits the staging buffer
-			const uint64_t fit = __builtin_amdgcn_ballot_w64(i < n && end <= (uint32_t)P2_BMAX);
-			uint32_t ntake = (uint32_t)__popcll(fit); if (ntake == 0) ntake = 1;
-			const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)ntake - 1);
-			const uint32_t start = end - len;
-			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
-			// the next batch's tokens are requested now; they arrive while this batch is resolved
-			{ const uint32_t i2 = t0 + ntake + (uint32_t)lane; tk_next = i2 < n ? T[i2] : 0u; }
-			// what a byte needs from its owner token: match flag, the token's start inside the batch, dist-1 or the literal
-			const uint32_t pk = (tk & 0x80000000u) | ((start & 0x7ffu) << 20) | (is_m ? (tk & 0x7fffu) : (tk & 255u));
-			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
-			if (lane < P2_NCH) S.endmask[lane] = 0ull;
-			__builtin_amdgcn_wave_barrier();
-			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
-			__builtin_amdgcn_wave_barrier();
-			// stores of earlier batches must be complete before this batch gathers from the window
-			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
-			uint32_t x[P2_NCH];
-			uint32_t ta = 0;   // tokens that end at or before the current chunk start
-			// ---- pass A: owners, sources, gathers ----
-			#pragma unroll
-			for (int c = 0; c < P2_NCH; ++c)
-			{
-				const uint32_t j0 = 64u * (uint32_t)c;
-				x[c] = 0;
-				if (j0 < B)   // (no early exit: a constant trip count keeps x[] in registers with static indices)
-				{
-				const uint32_t j = j0 + (uint32_t)lane;
-				const uint64_t m = S.endmask[c];
-				const uint32_t o = ta + (uint32_t)__popcll(m & lane_lt);
-				ta += (uint32_t)__popcll(m);
-				const uint32_t pko = (uint32_t)__shfl((int)pk, (int)(o & 63u));
-				uint32_t v = pko & 255u;
-				if (j < B && (pko >> 31))
-				{
-					const uint32_t sto = (pko >> 20) & 0x7ffu, d = (pko & 0x7fffu) + 1u, off = j - sto;
-					uint32_t r = off;
-					if (off >= d)
-					{
-						uint32_t q = (uint32_t)((float)off * __builtin_amdgcn_rcpf((float)d)); int rr = (int)off - (int)(q * d);   // q is off by at most 1
-						if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
-						r = (uint32_t)rr;
-					}
-					const int src = (int)sto - (int)d + (int)r;   // relative to P
-					if (src < 0) v = out[(int64_t)P + src];
-					else v = 0x80000000u | (uint32_t)src;
-				}
-				x[c] = v;
-				}
-			}
-			// ---- pass B: resolve front to back, store ----
-			#pragma unroll
-			for (int c = 0; c < P2_NCH; ++c)
-			{
-				const uint32_t j0 = 64u * (uint32_t)c;
-				if (j0 >= B) break;
-				const uint32_t j = j0 + (uint32_t)lane;
-				uint32_t vv = x[c], rel = (uint32_t)lane;
-				if (vv >> 31)
-				{
-					const uint32_t src = vv & 0x7ffu;
-					if (src < j0) vv = S.val[src];
-					else { vv = 0x100u; rel = src - j0; }
-				}
-				uint64_t pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
-				while (pend)
-				{
-					const uint32_t sv = (uint32_t)__shfl((int)vv, (int)rel);
-					if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
-					pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
-				}
-				if (j < B) { S.val[j] = (uint8_t)vv; out[P + j] = (uint8_t)vv; }
-				__builtin_amdgcn_wave_barrier();
-			}
-			P += B; t0 += ntake;
-		}
-		if (lane == 0 && status[b].error == 0 && P != usize) status[b].error = 17;
-		if (lane == 0) status[b].produced = P;
-	}
-}
-
-// First phase-2 design (NGSQC_P2_VARIANT=0): all bytes staged, then whole-batch dependency passes in LDS.
-__global__ __launch_bounds__(256) void lz77_resolve_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
-                                                           const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
-{
-	__shared__ P2Lds lds[4];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	P2Lds& S = lds[wv];
-	constexpr int WAIT_VM0 = 0x0F70;
-	const int64_t n_waves = (int64_t)gridDim.x * 4;
-	for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_blocks; b += n_waves)
-	{
-		if (status[b].error) continue;
-		const uint32_t n = tok_count[b];
-		const uint32_t* T = tok + tok_off[b];
-		uint8_t* out = out_base + blocks[b].upos;
-		const uint32_t usize = blocks[b].usize;
-		uint32_t P = 0;   // bytes written so far
-		for (uint32_t t0 = 0; t0 < n;)
-		{
-			const uint32_t i = t0 + (uint32_t)lane;
-			const uint32_t tk = i < n ? T[i] : 0u;
-			const bool is_m = tk >> 31;
-			const uint32_t len = i < n ? (is_m ? ((tk >> 23) & 255u) + 3u : 1u) : 0u;
-			const uint32_t dist = (tk & 0x7fffu) + 1u;
-			uint32_t end = len;
-			#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(end, o); if (lane >= o) end += t; }
-			// take the longest token prefix whose output fits the staging buffer
-			const uint64_t fit = __builtin_amdgcn_ballot_w64(i < n && end <= (uint32_t)P2_BMAX);
-			uint32_t ntake = (uint32_t)__popcll(fit); if (ntake == 0) ntake = 1;
-			const uint32_t B = (uint32_t)__shfl((int)end, (int)ntake - 1);
-			const uint32_t start = end - len;
-			if (P + B > usize) { if (lane == 0) status[b].error = 16; break; }
-			// stores of earlier batches must be complete before this batch gathers from the window
-			__builtin_amdgcn_s_waitcnt(WAIT_VM0);
-			bool any_unres = false;
-			// token-end bitmap of the batch: bit (e-1) set when a token ends at byte e (ends are strictly increasing)
-			if (lane < P2_BMAX / 64) S.endmask[lane] = 0ull;
-			__builtin_amdgcn_wave_barrier();
-			if ((uint32_t)lane < ntake && len != 0) atomicOr(&S.endmask[(end - 1) >> 6], 1ull << ((end - 1) & 63u));
-			__builtin_amdgcn_wave_barrier();
-			uint32_t ta = 0;   // tokens that end at or before the current chunk start
-			for (uint32_t j0 = 0; j0 < B; j0 += 64)
-			{
-				const uint32_t j = j0 + (uint32_t)lane;
-				// owner token of byte j = ta + #tokens ending inside the chunk at or before j. The token ends inside the chunk
-				// are strictly increasing, so they form a 64-bit mask (bit p <-> some token ends at j0 + p + 1), read from the
-				// batch's end bitmap; a popcount of the bits below (j - j0) ranks the byte.
-				const uint64_t m = S.endmask[j0 >> 6];
-				const uint32_t pj = (uint32_t)lane;   // j - j0
-				const uint32_t o = ta + (uint32_t)__popcll(m & ((1ull << pj) - 1ull));
-				ta += (uint32_t)__popcll(m);
-				const uint32_t tko = (uint32_t)__shfl((int)tk, (int)(o & 63u));
-				const uint32_t sto = (uint32_t)__shfl((int)start, (int)(o & 63u));
-				uint32_t sidx = 0xffffu;
-				if (j < B)
-				{
-					uint32_t v = tko & 255u;
-					if (tko >> 31)
-					{
-						const uint32_t d = (tko & 0x7fffu) + 1u, off = j - sto;
-						uint32_t r = off;
-						if (off >= d)
-						{
-							uint32_t q = (uint32_t)((float)off * __frcp_rn((float)d)); int rr = (int)off - (int)(q * d);
-							if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
-							r = (uint32_t)rr;
-						}
-						const int src = (int)sto - (int)d + (int)r;   // relative to P
-						if (src < 0) v = out[(int64_t)P + src];
-						else { sidx = (uint32_t)src; any_unres = true; }
-					}
-					S.val[j] = (uint8_t)v; S.src[j] = (uint16_t)sidx;
-				}
-			}
-			// in-batch dependencies: a byte copies an EARLIER byte of the same batch; iterate until all are resolved
-			uint64_t pending = __builtin_amdgcn_ballot_w64(any_unres);
-			while (pending)
-			{
-				bool still = false;
-				for (uint32_t j0 = 0; j0 < B; j0 += 64)
-				{
-					const uint32_t j = j0 + (uint32_t)lane;
-					if (j < B)
-					{
-						const uint32_t s = S.src[j];
-						if (s != 0xffffu)
-						{
-							if (S.src[s] == 0xffffu) { S.val[j] = S.val[s]; S.src[j] = 0xffffu; }
-							else still = true;
-						}
-					}
-					__builtin_amdgcn_wave_barrier();
-				}
-				pending = __builtin_amdgcn_ballot_w64(still);
-			}
-			for (uint32_t j0 = 0; j0 < B; j0 += 64) { const uint32_t j = j0 + (uint32_t)lane; if (j < B) out[P + j] = S.val[j]; }
-			P += B; t0 += ntake;
-		}
-		if (lane == 0 && status[b].error == 0 && P != usize) status[b].error = 17;
-		if (lane == 0) status[b].produced = P;
-	}
-}
-
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
                         const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s)
 {
@@ -840,7 +624,7 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
 	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
-	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
+	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi); KCHECK();
 }
 
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
@@ -849,11 +633,7 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
 	int grid2 = (int)(wg2 < 256 * 8 ? wg2 : 256 * 8);
-	const char* ve = getenv("NGSQC_P2_VARIANT"); const int variant = ve ? atoi(ve) : 2;
-	if (variant == 0) hipLaunchKernelGGL(lz77_resolve_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
-	else if (variant == 3) hipLaunchKernelGGL(lz77_pipe_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
-	else if (variant == 2) hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
-	else hipLaunchKernelGGL(lz77_chunk_kernel<true>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status);
+	hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }
 
 } // namespace ngsqc

@@ -138,7 +138,7 @@ void launch_reads_max(const uint8_t* infl, const int64_t* recoff, int64_t n_rec,
 {
 	if (n_rec <= 0) return;
 	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 16);
-	hipLaunchKernelGGL(reads_max_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, d_max);
+	hipLaunchKernelGGL(reads_max_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, d_max); KCHECK();
 }
 
 void launch_reads(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int single_end, unsigned long long* d_acc, unsigned long long* d_len_hist, int64_t len_cap,
@@ -147,7 +147,7 @@ void launch_reads(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int
 	if (n_rec <= 0) return;
 	// 2048 workgroups: the 32-bit LDS bins of a workgroup see n_bases / 2048 increments at most (< 2^32 for any tile that fits HBM)
 	const int64_t wgs = std::min<int64_t>((n_rec + 3) / 4, 256 * 8);
-	hipLaunchKernelGGL(reads_kernel, dim3((int)wgs), dim3(256), 0, s, infl, recoff, (long long)n_rec, single_end, d_acc, d_len_hist, (long long)len_cap, d_cyc);
+	hipLaunchKernelGGL(reads_kernel, dim3((int)wgs), dim3(256), 0, s, infl, recoff, (long long)n_rec, single_end, d_acc, d_len_hist, (long long)len_cap, d_cyc); KCHECK();
 }
 
 } // namespace ngsqc

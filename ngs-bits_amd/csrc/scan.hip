@@ -127,7 +127,7 @@ __device__ static void baseq_decrements(const ScanParams& p, const RecView& r, i
 		uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
 		if (op == 0)
 		{
-			for (uint32_t j = 0; j < len; ++j)
+			for (uint32_t j = 0; j < len && ai + j < (uint32_t)r.l_seq; ++j)   // (a CIGAR longer than SEQ: htslib would read past the qualities)
 			{
 				if (q[ai + j] < p.min_baseq)
 				{
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
 			else if (op == 4 || op == 5) clip += len;
 			if (op == 3) spliced = true;
 		}
-		classify<MODE>(p, r, ord, ref_len, clip, spliced, a, lds_hist);
+		classify<MODE>(p, r, ord, ref_len, clip, spliced && !(r.flag & 0x4u), a, lds_hist);
 	}
 	flush(p, a, lds_hist);
 }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 						long long ai = ai_base + sa - da, gi = gi_base + sg - dg;
 						if (op == 0)
 						{
-							for (uint32_t j = 0; j < len; ++j)
+							for (uint32_t j = 0; j < len && ai + (long long)j < (long long)r.l_seq; ++j)
 							{
 								if (q[ai + j] < p.min_baseq)
 								{
@@ -432,22 +432,23 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 		}
 		if (lane == 0)
 		{
-			classify<MODE>(p, r, ord, ref_len, clip, spl != 0, a, lds_hist);
+			classify<MODE>(p, r, ord, ref_len, clip, spl != 0 && !(r.flag & 0x4u), a, lds_hist);
 		}
 	}
 	flush(p, a, lds_hist);
 }
 
 // ---- order-dependent fix-ups on a record prefix ----
-// out2[0] += sum over counted records with ordinal < upto_max of (gmax - running_max_i)     [single workgroup, sequential chunks]
-// out2[1] += sum over "passing" records with ordinal < upto_paired of length                [same loop]
-__global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired, int gmax)
+// A_FIX_TRIM += sum over counted records with (tile-local) ordinal < upto_max of running_max_i, A_FIX_CNT += their number
+// A_FIX_LEN  += sum over "passing" records with ordinal < upto_paired of length               [single workgroup, sequential chunks]
+// The running maximum starts at A_FIX_CARRY (records before this prefix) and is left there for the next call.
+__global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired)
 {
 	__shared__ int sh[256]; __shared__ int carry;
 	if (threadIdx.x == 0) carry = (int)p.counters[A_FIX_CARRY];   // running maximum carried in from earlier tiles
 	__syncthreads();
 	long long upto = upto_max > upto_paired ? upto_max : upto_paired;   // tile-local limits
-	long long s_trim = 0, s_len = 0;
+	long long s_trim = 0, s_len = 0, s_cnt = 0;
 	for (long long base = 0; base < upto; base += 256)
 	{
 		long long ord = base + threadIdx.x;
@@ -467,15 +468,20 @@ __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, lon
 		sh[threadIdx.x] = counted ? len : 0; __syncthreads();
 		for (int d = 1; d < 256; d <<= 1) { int t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] = max(sh[threadIdx.x], t); __syncthreads(); }
 		int run = max(carry, sh[threadIdx.x]);
-		if (counted && ord < upto_max) s_trim += gmax - run;
+		if (counted && ord < upto_max) { s_trim += run; ++s_cnt; }
 		if (passing && ord < upto_paired) s_len += len;
 		__syncthreads();
 		if (threadIdx.x == 255) carry = run;
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) p.counters[A_FIX_CARRY] = (unsigned long long)carry;
-	s_trim = wave_sum(s_trim); s_len = wave_sum(s_len);
-	if ((threadIdx.x & 63) == 0) { if (s_trim) atomicAdd(&p.counters[A_FIX_TRIM], (unsigned long long)s_trim); if (s_len) atomicAdd(&p.counters[A_FIX_LEN], (unsigned long long)s_len); }
+	s_trim = wave_sum(s_trim); s_len = wave_sum(s_len); s_cnt = wave_sum(s_cnt);
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (s_trim) atomicAdd(&p.counters[A_FIX_TRIM], (unsigned long long)s_trim);
+		if (s_len) atomicAdd(&p.counters[A_FIX_LEN], (unsigned long long)s_len);
+		if (s_cnt) atomicAdd(&p.counters[A_FIX_CNT], (unsigned long long)s_cnt);
+	}
 }
 
 static int scan_grid(long long n, int per_wg)
@@ -496,6 +502,7 @@ void launch_scan(const ScanParams& p, hipStream_t s)
 		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p); break;
 		default: hipLaunchKernelGGL(scan_kernel<3>, dim3(grid), dim3(256), 0, s, p); break;
 	}
+	KCHECK();
 }
 
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
@@ -509,12 +516,13 @@ void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
 		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 		default: hipLaunchKernelGGL(scan_long_kernel<3>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 	}
+	KCHECK();
 }
 
-void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, int32_t gmax, hipStream_t s)
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, hipStream_t s)
 {
 	if (upto_max <= 0 && upto_paired <= 0) return;
-	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, gmax);
+	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired); KCHECK();
 }
 
 // ---- site pileup: BamReader::getPileup (src/cppNGS/BamReader.cpp:809-885, SNP counts) for a table of known sites ----
@@ -546,11 +554,15 @@ __device__ static int pileup_base(const RecView& r, int pos, int& qual_out)   //
 			else if (genome_pos >= pos)
 			{
 				const int ap = read_pos - (genome_pos + 1 - pos);
-				const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
-				const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15;
-				q = rec_qual(r)[ap];
-				res = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
-				done = true;
+				if (ap < 0 || ap >= r.l_seq) { res = -2; done = true; }   // CIGAR longer than SEQ
+				else
+				{
+					const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
+					const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15;
+					q = rec_qual(r)[ap];
+					res = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
+					done = true;
+				}
 			}
 		}
 	}
@@ -632,6 +644,11 @@ __global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restr
 				if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; }
 			}
 		}
+		{
+			uint32_t other = 0;
+			for (uint32_t k = lane; k < r.n_cigar_raw; k += 64) { const uint32_t op = ld32(r.core + 32 + r.l_name + 4ull * k) & 15u; other |= (op != 1u && op != 4u) ? 1u : 0u; }
+			if (__builtin_amdgcn_ballot_w64(other != 0) == 0) continue;   // insertion / soft-clip only: the reference skips the read (BamReader.cpp:845)
+		}
 		const uint32_t per = (r.n_cigar + 63) / 64, k0 = min((uint32_t)lane * per, r.n_cigar), k1 = min(k0 + per, r.n_cigar);
 		long long s_ref = 0, s_read = 0;
 		for (uint32_t k = k0; k < k1; ++k)
@@ -675,6 +692,7 @@ __global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restr
 				else if (hit_op != 3)
 				{
 					const long long ap = hit_rp - (hit_g + 1 - pos);
+					if (ap < 0 || ap >= r.l_seq) { atomicAdd(&counts[8ull * i + 7], 1u); continue; }   // CIGAR longer than SEQ
 					const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
 					const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15, q = rec_qual(r)[ap];
 					const int base = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
@@ -691,14 +709,14 @@ void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, in
 {
 	if (n_rec <= 0) return;
 	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 32);
-	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts, long_list, long_count);
+	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts, long_list, long_count); KCHECK();
 }
 void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, int64_t n_long, const int32_t* site_pos, const int32_t* tid_last,
                         const int32_t* bucket, const int64_t* tid_bucket0, int min_baseq, uint32_t* counts, hipStream_t s)
 {
 	if (n_long <= 0) return;
 	const int grid = (int)std::min<int64_t>((n_long + 3) / 4, 256 * 16);
-	hipLaunchKernelGGL(pileup_long_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, long_list, (long long)n_long, site_pos, tid_last, bucket, tid_bucket0, min_baseq, counts);
+	hipLaunchKernelGGL(pileup_long_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, long_list, (long long)n_long, site_pos, tid_last, bucket, tid_bucket0, min_baseq, counts); KCHECK();
 }
 
 } // namespace ngsqc

@@ -229,15 +229,26 @@ int orc_reads_qc(void* bam, int single_end, int64_t* out, int64_t* len_hist, int
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
 }
 
-// All-cores form of the bench baseline (throughput only, see stream.hpp). out_stats: {n_records, inflated, compressed}. Returns seconds.
-double orc_baseline_wgs_stream_mt(const uint8_t* image, int64_t n, const char* bed, int min_mapq, int threads, int64_t* out_stats, char* err, int errlen)
+// All-cores form of the bench baseline (see stream.hpp). out_stats: {n_records, inflated, compressed}. Returns seconds.
+// out_counters (optional, int64[ORC_NCOUNTERS]): the threads' counters SUMMED - exact for the additive counters of an aligned BAM,
+// meaningless for the order-dependent / maximum-like ones (bases_trimmed, bases_usable_no_overlap, max_length, paired_end, roi_bases,
+// half_depth, bases_covered_half, yx_valid). out_hist (optional, int64[hist_cap + 1]): per-base depth histogram of the ROI (depths above
+// the cap in the last bin) - the bench's parity check of the depth scatter at full size.
+double orc_baseline_wgs_stream_mt(const uint8_t* image, int64_t n, const char* bed, int min_mapq, int threads, int64_t* out_stats, int64_t* out_counters, int64_t* out_hist, int hist_cap, char* err, int errlen)
 {
 	try
 	{
 		BedFile roi; bool have = bed && *bed; if (have) roi.load(bed);
-		StreamStats st;
-		double secs = mapping_wgs_stream_mt(image, (size_t)n, have ? &roi : nullptr, min_mapq, threads, st);
+		StreamStats st; std::vector<MappingResult> per; std::vector<int32_t> depth;
+		double secs = mapping_wgs_stream_mt(image, (size_t)n, have ? &roi : nullptr, min_mapq, threads, st, out_counters ? &per : nullptr, out_hist ? &depth : nullptr);
 		if (out_stats) { out_stats[0] = st.n_records; out_stats[1] = st.inflated; out_stats[2] = st.compressed; }
+		if (out_counters)
+		{
+			std::vector<int64_t> tmp(ORC_NCOUNTERS);
+			for (int i = 0; i < ORC_NCOUNTERS; ++i) out_counters[i] = 0;
+			for (auto& m : per) { Result r; r.m = m; orc_result_counters(&r, tmp.data()); for (int i = 0; i < ORC_NCOUNTERS; ++i) out_counters[i] += tmp[(size_t)i]; }
+		}
+		if (out_hist) { for (int i = 0; i <= hist_cap; ++i) out_hist[i] = 0; for (int32_t d : depth) out_hist[d < hist_cap ? (d < 0 ? 0 : d) : hist_cap]++; }
 		return secs;
 	}
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }

@@ -166,7 +166,10 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 // All-cores form of the baseline: T threads, each over a contiguous range of BGZF members (equal compressed bytes), one
 // shared depth array. Throughput only: the two order-dependent counters (bases_trimmed, bases_usable_no_overlap) are summed
 // without the cross-range carries, so the counters of this form are NOT used for parity.
-inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int threads, StreamStats& total)
+// per_thread (optional): the threads' results, for the ADDITIVE counters (everything except bases_trimmed, bases_usable_no_overlap,
+// max_length, paired_end and the half-depth pair); depth_out (optional): the shared per-base depth array.
+inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int threads, StreamStats& total,
+                                    std::vector<MappingResult>* per_thread = nullptr, std::vector<int32_t>* depth_out = nullptr)
 {
 	std::vector<size_t> member_off;
 	for (size_t off = 0; off + 18 <= n;)
@@ -181,6 +184,7 @@ inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile
 	size_t slots = 0; for (size_t i = 0; i < roi.count(); ++i) slots += roi.lines[i].length();
 	std::vector<int32_t> depth(slots, 0);
 	std::vector<StreamStats> st((size_t)threads); std::vector<std::string> errs((size_t)threads);
+	if (per_thread) per_thread->assign((size_t)threads, MappingResult());
 	std::vector<std::thread> th;
 	auto t0 = std::chrono::steady_clock::now();
 	for (int t = 0; t < threads; ++t)
@@ -189,7 +193,8 @@ inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile
 			{
 				const size_t a = member_off[member_off.size() * (size_t)t / (size_t)threads];
 				const size_t b = t + 1 == threads ? n : member_off[member_off.size() * (size_t)(t + 1) / (size_t)threads];
-				mapping_wgs_stream(file, n, roi_in ? &roi : nullptr, min_mapq, -1, st[(size_t)t], a, b, roi_in ? depth.data() : nullptr);
+				MappingResult r = mapping_wgs_stream(file, n, roi_in ? &roi : nullptr, min_mapq, -1, st[(size_t)t], a, b, roi_in ? depth.data() : nullptr);
+				if (per_thread) (*per_thread)[(size_t)t] = std::move(r);
 			}
 			catch (std::exception& e) { errs[(size_t)t] = e.what(); }
 		});
@@ -197,6 +202,7 @@ inline double mapping_wgs_stream_mt(const uint8_t* file, size_t n, const BedFile
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	for (int t = 0; t < threads; ++t) { if (!errs[(size_t)t].empty()) throw Error(errs[(size_t)t]); total.n_records += st[(size_t)t].n_records; total.inflated += st[(size_t)t].inflated; total.compressed += st[(size_t)t].compressed; }
 	total.seconds = secs;
+	if (depth_out) depth_out->swap(depth);
 	return secs;
 }
 

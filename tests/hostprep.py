@@ -56,3 +56,24 @@ def bed_regions(bed_path, refs, merge_mode):
 def xy_tids(refs):
     tm = tid_map(refs)
     return tm.get(1001, -1), tm.get(1002, -1)
+
+
+def known_sites(refs, build="hg38"):
+    """The known common SNVs of Statistics::contamination (NGSHelper::getKnownVariants filters: SNVs with 0.2 <= AF <= 0.8) as an
+    int32 [n, 3] array of (tid, pos, pos) rows sorted by tid then position - the C layout of ngsqc_region."""
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ngs-bits_amd", "resources", f"{build}_snps.tsv")
+    tm = tid_map(refs)
+    sites = []
+    for ln in open(path):
+        c, p_, r_, a_, af = ln.rstrip("\n").split("\t")
+        try:
+            f_ = float(af)
+        except ValueError:
+            f_ = 0.0
+        a0 = a_.split(",")[0]
+        if 0.2 <= f_ <= 0.8 and len(r_) == 1 and len(a0) == 1 and chr_num(c) in tm:
+            sites.append((tm[chr_num(c)], int(p_)))
+    sites.sort()
+    return np.array([(t, p, p) for t, p in sites], dtype=np.int32).reshape(-1, 3)

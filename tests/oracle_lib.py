@@ -251,15 +251,23 @@ def reads_qc(bam, single_end=False, len_cap=None, n_cycles=320):
                 qscore_dist_r1=out[208:268].copy(), qscore_dist_r2=out[268:328].copy(), bases=out[328:333].copy(), read_lengths=lens, cycles=cyc[:n_cycles])
 
 
-def baseline_wgs_stream_mt(image, bed=None, min_mapq=1, threads=0):
-    """All-cores form of the bench baseline (throughput only). Returns (stats dict, seconds)."""
+ORDER_DEPENDENT = (7, 12, 24, 25, 26, 27, 28, 31)   # counters the all-cores baseline cannot sum (see oracle/capi.cpp)
+
+
+def baseline_wgs_stream_mt(image, bed=None, min_mapq=1, threads=0, want_counters=False, hist_cap=599):
+    """All-cores form of the bench baseline. Returns (stats dict, seconds) or, with want_counters, (stats, seconds, summed counters,
+    depth histogram): the additive counters (every index not in ORDER_DEPENDENT) and the histogram are exact for an aligned BAM."""
     import os as _os
     L = lib()
     L.orc_baseline_wgs_stream_mt.restype = C.c_double
-    L.orc_baseline_wgs_stream_mt.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    L.orc_baseline_wgs_stream_mt.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     buf = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8))
     st = np.zeros(3, dtype=np.int64); err = C.create_string_buffer(1024)
-    secs = L.orc_baseline_wgs_stream_mt(buf.ctypes.data, buf.size, _b(bed), min_mapq, threads or (_os.cpu_count() or 1), st.ctypes.data, err, 1024)
+    counters = np.zeros(NCOUNTERS, dtype=np.int64) if want_counters else None
+    hist = np.zeros(hist_cap + 1, dtype=np.int64) if want_counters else None
+    secs = L.orc_baseline_wgs_stream_mt(buf.ctypes.data, buf.size, _b(bed), min_mapq, threads or (_os.cpu_count() or 1), st.ctypes.data,
+                                         counters.ctypes.data if want_counters else None, hist.ctypes.data if want_counters else None, hist_cap, err, 1024)
     if secs < 0:
         raise OracleError(err.value.decode())
-    return dict(n_records=int(st[0]), inflated=int(st[1]), compressed=int(st[2])), secs
+    stats = dict(n_records=int(st[0]), inflated=int(st[1]), compressed=int(st[2]))
+    return (stats, secs, counters, hist) if want_counters else (stats, secs)

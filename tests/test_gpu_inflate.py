@@ -1,8 +1,9 @@
 """K1 (BGZF inflate on the GPU) against zlib on every DEFLATE shape a BAM writer can emit: stored members (samtools -u /
 level 0), fixed-Huffman blocks, dynamic blocks at levels 1/6/9, Z_RLE (overlapping matches, distance 1), Z_HUFFMAN_ONLY
 (literal-only), tiny and ragged members, several deflate blocks per member, empty members in the middle of the file,
-and corrupted payloads (must fail with an error, never hang or crash). Bit-exact on the inflated stream; every K1
-variant (two-phase default, pipelined / staged / first-design phase 2, no-parking phase 1, group-kernel fallback) is run on the same inputs."""
+and corrupted payloads (must fail with an error, never hang or crash). Bit-exact on the inflated stream; the K1 switches
+(no-parking phase 1, tiny tiles, CRC check off) run on the same inputs. The CRC32 of every member is verified on the GPU
+(htslib does: a payload that is damaged but still inflates to the right length must raise the reference's read error)."""
 import gzip
 import struct
 import zlib
@@ -68,14 +69,16 @@ SHAPES = {
     "huffman_only": dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY, sizes=[30000]),
     "multi_block": dict(level=6, sizes=[65280], flush_every=3000),
     "multi_block_fixed_mix": dict(level=1, strategy=zlib.Z_FIXED, sizes=[20000], flush_every=777),
+    "max_member": dict(level=6, sizes=[65536]),
+    "crc_lengths": dict(level=1, sizes=[4096, 4095, 4097, 63, 64, 65, 8192, 12345, 3, 61441]),
 }
 
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
-@pytest.mark.parametrize("variant", ["default", "p2_pipelined", "p2_chunk_staged", "p2_first", "no_park", "group_kernel"])
+@pytest.mark.parametrize("variant", ["default", "no_park", "tiles_of_2", "no_crc"])
 def test_inflate_shapes(raw_bam, shape, variant, monkeypatch):
-    env = {"default": {}, "p2_pipelined": {"NGSQC_P2_VARIANT": "3"}, "p2_chunk_staged": {"NGSQC_P2_VARIANT": "1"},
-           "p2_first": {"NGSQC_P2_VARIANT": "0"}, "no_park": {"NGSQC_P1_PARK": "0"}, "group_kernel": {"NGSQC_INFLATE_VARIANT": "0"}}[variant]
+    # (huffman_only overflows the clen + 64 token budget of a member: it takes the second-chance path with a worst-case budget)
+    env = {"default": {}, "no_park": {"NGSQC_P1_PARK": "0"}, "tiles_of_2": {"NGSQC_TILE_MEMBERS": "2"}, "no_crc": {"NGSQC_VERIFY_CRC": "0"}}[variant]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     kw = dict(SHAPES[shape]); sizes = kw.pop("sizes")
@@ -97,6 +100,46 @@ def test_runs_and_periodic_matches():
     raw = hdr + struct.pack("<i", len(rec)) + rec
     for kw in (dict(level=6), dict(level=9), dict(level=6, strategy=zlib.Z_RLE), dict(level=1)):
         assert _roundtrip(raw, rebgzf(raw, [65280, 30000, 65000], **kw)) == 1
+
+
+def _flip_payload_byte(image: bytes, member_index: int, at: int) -> bytes:
+    """flip one bit of the DEFLATE payload of one member (stored members: the byte is a literal of the inflated stream)"""
+    img = bytearray(image); pos, k = 0, 0
+    while pos < len(img):
+        bs = struct.unpack_from("<H", img, pos + 16)[0] + 1
+        if k == member_index:
+            img[pos + 18 + 5 + at] ^= 0x10   # 5 = stored-block header (1 + 2 + 2 bytes)
+            return bytes(img)
+        pos += bs; k += 1
+    raise AssertionError("member not found")
+
+
+def test_crc32_mismatch_is_the_reference_read_error(raw_bam, monkeypatch):
+    # stored members: a flipped payload byte leaves a valid stream of the right length; only the CRC32 can tell
+    good = rebgzf(raw_bam, [60000], level=0)
+    # pick a byte inside the SEQ field of a record that lies in member 3 (so that the record chain stays intact)
+    o = 4; o += 4 + struct.unpack_from("<i", raw_bam, o)[0]; n_ref = struct.unpack_from("<i", raw_bam, o)[0]; o += 4
+    for _ in range(n_ref):
+        o += 4 + struct.unpack_from("<i", raw_bam, o)[0] + 4
+    M = 40   # (behind the members that ngsqc_open inflates for the BAM header)
+    while o < M * 60000 + 1000:
+        o += 4 + struct.unpack_from("<i", raw_bam, o)[0]
+    l_name, n_cig = raw_bam[o + 12], struct.unpack_from("<H", raw_bam, o + 16)[0]
+    target = o + 36 + l_name + 4 * n_cig + 5
+    assert M * 60000 <= target < (M + 1) * 60000
+    bad = _flip_payload_byte(good, M, target - M * 60000)
+    assert _roundtrip(raw_bam, good) == 30000
+    h = ngsqc.Handle(data=np.frombuffer(bad, dtype=np.uint8))
+    with pytest.raises(ngsqc.NgsqcError) as ei:
+        h.decode()
+    assert "Could not read next alignment" in str(ei.value) and f"CRC32 mismatch in block {M}" in str(ei.value) and ei.value.code == -2
+    h.close()
+    # switched off, the damaged byte goes through (what round 1 did)
+    monkeypatch.setenv("NGSQC_VERIFY_CRC", "0")
+    h = ngsqc.Handle(data=np.frombuffer(bad, dtype=np.uint8))
+    got = h.inflated()
+    assert got.size == len(raw_bam) and int((got != np.frombuffer(raw_bam, dtype=np.uint8)).sum()) == 1
+    h.close()
 
 
 def test_empty_members_inside_file(raw_bam):
@@ -129,8 +172,7 @@ def test_corrupt_payload_is_an_error_not_a_hang(raw_bam, seed):
         h = ngsqc.Handle(data=np.frombuffer(bytes(image), dtype=np.uint8))
         h.decode()
         got = h.inflated()
-        # a damaged stream may still be a valid DEFLATE stream of the right length (the CRC is not checked on the GPU);
-        # then the size is intact and only content differs
+        # (only reachable when the damage cancels out in the CRC32 as well)
         assert got.size == len(raw_bam)
     except ngsqc.NgsqcError as e:
         assert "inflate" in str(e).lower() or "record" in str(e).lower() or "bam" in str(e).lower(), str(e)

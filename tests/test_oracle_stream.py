@@ -30,7 +30,12 @@ def test_all_cores_baseline_visits_every_record_once():
     import bamgen_lib as G
     img = G.generate(150_000, seed=8, start_pos=15_900_000)
     bed = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
-    _, st1, _ = O.baseline_wgs_stream(img, bed, 1, -1)
+    c1, st1, _ = O.baseline_wgs_stream(img, bed, 1, -1)
+    additive = np.ones(c1.size, dtype=bool); additive[list(O.ORDER_DEPENDENT)] = False
     for threads in (1, 3, 8):
         st, secs = O.baseline_wgs_stream_mt(img, bed, 1, threads)
         assert st["n_records"] == st1["n_records"] == 150_000 and st["inflated"] == st1["inflated"] and secs > 0, (threads, st, st1)
+        # the additive counters of the per-thread member ranges sum to the sequential loop's (what bench.py checks the GPU against at full size)
+        st, secs, cs, hist = O.baseline_wgs_stream_mt(img, bed, 1, threads, want_counters=True)
+        assert np.array_equal(cs[additive], c1[additive]), threads
+        assert int(hist.sum()) == int(c1[26]) and int((hist * np.arange(hist.size)).sum()) > 0

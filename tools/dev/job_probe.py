@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Dev probe: the fused MappingQC -wgs job (mapping_wgs + OMIM ROI + site pileup) on a synthetic shard under a few switches.
+usage: job_probe.py [reads=48000000] [steps=5] [variants=default,nopipe,nocrc,...]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+ngsqc = importlib.import_module("ngs-bits_amd")
+import bamgen_lib as G  # noqa: E402
+import hostprep as H  # noqa: E402
+
+VARIANTS = {
+    "default": {},
+    "nopipe": {"NGSQC_PIPELINE": "0"},
+    "nocrc": {"NGSQC_VERIFY_CRC": "0"},
+    "div2": {"NGSQC_K1_CHUNK_DIV": "2"},
+    "div4": {"NGSQC_K1_CHUNK_DIV": "4"},
+    "tile1": {"NGSQC_TILE_CHUNKS": "1"},
+    "tile4": {"NGSQC_TILE_CHUNKS": "4"},
+    "unsorted": {"NGSQC_K1_SORTED": "0"},
+}
+
+
+def main():
+    reads = int(sys.argv[1]) if len(sys.argv) > 1 else 48_000_000
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    names = sys.argv[3].split(",") if len(sys.argv) > 3 else ["default", "nopipe", "nocrc"]
+    t0 = time.time()
+    image = G.generate(reads, threads=os.cpu_count() or 8)
+    print(f"[probe] generated {reads} reads, {image.size} bytes in {time.time() - t0:.1f} s on {os.cpu_count()} cpus", flush=True)
+    omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
+    ref = None
+    for name in names:
+        for k in list(os.environ):
+            if k.startswith("NGSQC_") and k not in ("NGSQC_DEBUG",):
+                del os.environ[k]
+        os.environ.update(VARIANTS[name])
+        t0 = time.time()
+        h = ngsqc.Handle(data=image, device=0)
+        t_open = time.time() - t0
+        refs = h.refs
+        regs, _ = H.bed_regions(omim, refs, 3)
+        tx, ty = H.xy_tids(refs)
+        sites = H.known_sites(refs) if hasattr(H, "known_sites") else None
+        mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs))
+        walls = []
+        for i in range(steps + 1):
+            h.drop_decoded()
+            t1 = time.perf_counter()
+            out = h.run_job(mapping=mp, sites=sites)
+            walls.append(1e3 * (time.perf_counter() - t1))
+        tm = h.timings()
+        c = out["counters"]
+        if ref is None:
+            ref = c.copy()
+        same = bool(np.array_equal(ref, c))
+        w = float(np.mean(walls[1:]))
+        print(f"[probe] {name:9s} open {t_open:.2f}s wall {w:8.2f} ms  ({tm['n_records'] / w / 1e3:7.1f} Mreads/s)  K1 {tm['inflate_ms']:.2f} (huff {tm['inflate_huff_ms']:.1f} lz {tm['inflate_lz77_ms']:.1f} x{tm['inflate_huff_launches']}) "
+              f"index {tm['index_ms']:.2f} scan {tm['scan_ms']:.2f} (kernels {tm['scan_kernel_ms']:.2f}) pile {tm['pileup_ms']:.2f} fin {tm['finalize_ms']:.2f} tiles {tm['n_tiles']} members {tm['members_inflated']}/{h.n_blocks} "
+              f"records {tm['n_records']} same_counters {same}", flush=True)
+        h.close()
+
+
+if __name__ == "__main__":
+    main()
