@@ -20,6 +20,7 @@
 // Same output as inflate.hip (bit-exact; tests/test_gpu_parity.py, tests/test_gpu_inflate.py). Integer work, no MFMA.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace ngsqc {
 
@@ -632,7 +633,8 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 {
 	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
-	int grid2 = (int)(wg2 < 256 * 8 ? wg2 : 256 * 8);
+	static const int64_t cap2 = [] { const char* e = getenv("NGSQC_P2_WGS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)256 * 4; }();   // 16 waves per CU: as fast as 32 (measured) and leaves wave slots for K2 / the consumers of the previous tile
+	int grid2 = (int)(wg2 < cap2 ? wg2 : cap2);
 	hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }
 

@@ -40,15 +40,17 @@ public:
 		int parameters_set = (roi_file != "" ? 1 : 0) + wgs + rna;
 		if (parameters_set != 1) NB_THROW(CommandLineParsingException, "You have to use exactly one of the parameters 'roi', 'wgs', or 'rna' !");
 		if (cfdna && roi_file == "") NB_THROW(CommandLineParsingException, "The flag 'cfdna' can only be used with parameter 'roi'!");
-		// raw read QC (main.cpp:80-98)
+		// The reference reads the BAM once per pass (read QC main.cpp:80-98, mapping :100-141, contamination :143-151, somatic sub-panel
+		// :153-165). Here the passes behind the mapping pass are announced first, so that the mapping call runs ONE fused GPU job over
+		// the BAM and the others take their counts from it (Statistics::planFused); the outputs are the same.
 		std::string read_qc = trimmed(getOutfile("read_qc"));
-		if (!read_qc.empty())
-		{
-			StatisticsReads stats(getFlag("single_end"));
-			BamReader reader(in, ref_file);
-			stats.update(reader);
-			stats.getResult().storeToQCML(read_qc, {in}, "", "MappingQC", version());
-		}
+		std::string somatic_custom_roi_file = getInfile("somatic_custom_bed");
+		const bool do_cont = !getFlag("no_cont") && getEnum("build") != "non_human";
+		FusedPlan plan;
+		plan.contamination = do_cont; plan.build = getEnum("build"); plan.roi_file = roi_file; plan.include_not_properly_paired = getFlag("single_end");
+		plan.read_qc = !read_qc.empty(); plan.single_end = getFlag("single_end");
+		if (somatic_custom_roi_file != "") { plan.somatic = true; plan.somatic_bed.load(somatic_custom_roi_file); plan.somatic_bed.merge(); plan.somatic_min_mapq = min_mapq; }
+		Statistics::planFused(in, plan);
 
 		std::vector<std::string> parameters; QCCollection metrics;
 		if (wgs)
@@ -66,17 +68,23 @@ public:
 			parameters.push_back("-roi"); parameters.push_back(fileName(roi_file));
 			if (cfdna) parameters.push_back("-cfdna");
 		}
+		// raw read QC (main.cpp:80-98)
+		if (!read_qc.empty())
+		{
+			StatisticsReads stats(getFlag("single_end"));
+			if (!stats.takeFused(in)) { BamReader reader(in, ref_file); stats.update(reader); }
+			stats.getResult().storeToQCML(read_qc, {in}, "", "MappingQC", version());
+		}
 		// sample contamination (main.cpp:143-151)
 		QCCollection metrics_cont;
-		if (!getFlag("no_cont") && getEnum("build") != "non_human") metrics_cont = Statistics::contamination(getEnum("build"), in, ref_file, roi_file, getFlag("debug"), 20, 50, getFlag("single_end"));
+		if (do_cont) metrics_cont = Statistics::contamination(getEnum("build"), in, ref_file, roi_file, getFlag("debug"), 20, 50, getFlag("single_end"));
 		// somatic sub-panel depth (main.cpp:153-165)
-		std::string somatic_custom_roi_file = getInfile("somatic_custom_bed");
 		if (somatic_custom_roi_file != "")
 		{
-			BedFile custom_bed; custom_bed.load(somatic_custom_roi_file); custom_bed.merge();
-			metrics.insert(Statistics::somaticCustomDepth(custom_bed, in, ref_file, min_mapq));
+			metrics.insert(Statistics::somaticCustomDepth(plan.somatic_bed, in, ref_file, min_mapq));
 			parameters.push_back("-somatic_custom_bed " + somatic_custom_roi_file);
 		}
+		Statistics::clearFused();
 		if (getFlag("single_end")) parameters.push_back("-single_end");
 		std::string out = getOutfile("out");
 		if (getFlag("txt"))

@@ -157,11 +157,141 @@ std::vector<ngsqc_region> toRegions(const BedFile& bed, const BamReader& reader,
 	return r;
 }
 
+struct KnownSnp { Chromosome chr; int pos; char ref, alt; };
+struct SnpSites { std::vector<KnownSnp> snps; std::vector<ngsqc_region> sites; std::vector<size_t> slot; };   // slot[i]: row of snps[i] in the (tid, pos)-sorted site table
+
+std::vector<KnownSnp> loadKnownSnps(const std::string& build, const std::string& roi_file)
+{
+	// target region: variants whose [pos, pos + len(ref) - 1] overlaps a line are kept (VcfFile::setRegion / VcfFile.cpp:131-136)
+	std::map<int, std::vector<std::pair<int, int>>> roi_by_chr; std::map<int, std::vector<int>> roi_pmax;
+	if (roi_file != "")
+	{
+		BedFile roi; roi.load(roi_file); roi.sort();
+		for (long long i = 0; i < roi.count(); ++i) roi_by_chr[roi[i].chr().num()].push_back({roi[i].start(), roi[i].end()});
+		for (auto& kv : roi_by_chr) { std::vector<int>& pm = roi_pmax[kv.first]; int m = 0; for (auto& se : kv.second) { m = std::max(m, se.second); pm.push_back(m); } }
+	}
+	auto in_roi = [&](const Chromosome& chr, int s, int e) {
+		auto it = roi_by_chr.find(chr.num()); if (it == roi_by_chr.end()) return false;
+		const auto& v = it->second; const auto& pm = roi_pmax[chr.num()];
+		size_t hi = (size_t)(std::upper_bound(v.begin(), v.end(), std::make_pair(e, std::numeric_limits<int>::max())) - v.begin());   // lines with start <= e
+		return hi > 0 && pm[hi - 1] >= s;
+	};
+	// known variants: SNVs with 0.2 <= AF <= 0.8 (getKnownVariants(build, true, [roi,] 0.2, 0.8))
+	std::string res = resourceDir() + "/" + build + "_snps.tsv";
+	std::ifstream f(res);
+	if (!f) NB_THROW(ProgrammingException, "Unsupported genome build '" + build + "'!");   // NGSHelper.cpp copyFromResource
+	std::vector<KnownSnp> snps; std::string line;
+	while (std::getline(f, line))
+	{
+		std::vector<std::string> c = split(line, '\t');
+		if (c.size() < 5) continue;
+		const int pos = atoi(c[1].c_str());
+		Chromosome chr(c[0]);
+		if (roi_file != "" && !in_roi(chr, pos, pos + (int)c[2].size() - 1)) continue;
+		char* end = nullptr; double af = c[4].empty() ? 0.0 : strtod(c[4].c_str(), &end); if (c[4].empty() || *end) af = 0.0;   // QByteArray::toDouble
+		if (!(af >= 0.2 && af <= 0.8)) continue;
+		std::string alt0 = c[3].substr(0, c[3].find(','));
+		for (auto& ch : alt0) ch = (char)toupper(ch);
+		if (!(alt0.size() == 1 && c[2].size() == 1 && alt0 != "-" && c[2] != "-")) continue;                                    // VcfLine::isSNV
+		snps.push_back(KnownSnp{chr, pos, c[2][0], alt0[0]});
+	}
+	return snps;
+}
+
+// site table for the GPU: (tid, pos), grouped by tid in position order
+SnpSites snpSites(const BamReader& reader, std::vector<KnownSnp> snps)
+{
+	SnpSites t; t.snps.swap(snps);
+	if (!t.snps.empty()) reader.requireIndex();                                                                                // getPileup -> setRegion (BamReader.cpp:740-746)
+	std::vector<int> tids(t.snps.size()); std::vector<size_t> order;
+	for (size_t i = 0; i < t.snps.size(); ++i)
+	{
+		tids[i] = reader.chromosomeID(t.snps[i].chr);
+		if (tids[i] < 0) NB_THROW(FileAccessException, "Could not find chromosome '" + t.snps[i].chr.str() + "' in BAM/CRAM file " + reader.fileName());   // BamReader.cpp:750-754
+		order.push_back(i);
+	}
+	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tids[a] != tids[b] ? tids[a] < tids[b] : t.snps[a].pos < t.snps[b].pos; });
+	for (size_t k : order) t.sites.push_back(ngsqc_region{tids[k], t.snps[k].pos, t.snps[k].pos});
+	t.slot.resize(t.snps.size()); for (size_t j = 0; j < order.size(); ++j) t.slot[order[j]] = j;
+	return t;
+}
+
+QCCollection contaminationFromCounts(const SnpSites& t, const std::vector<int64_t>& counts, bool debug, int min_cov, int min_snps)
+{
+	const std::vector<KnownSnp>& snps = t.snps;
+	Histogram hist(0, 1, 0.05);
+	int passed = 0; double passed_depth_sum = 0.0;
+	for (size_t i = 0; i < snps.size(); ++i)                                                                                   // file order, as the reference
+	{
+		const int64_t* c = &counts[t.slot[i] * 8];
+		if (c[6]) NB_THROW(ArgumentException, "Unknown base in pileup!");                                                      // Pileup.cpp:31
+		if (c[7]) NB_THROW(Exception, "Could not find position " + std::to_string(snps[i].pos) + " in read!");                 // BamReader.cpp:366
+		const long long depth = c[0] + c[1] + c[2] + c[3];
+		if (depth < min_cov) continue;
+		auto cnt = [&](char b) -> double { b = (char)toupper(b); return b == 'A' ? (double)c[0] : b == 'C' ? (double)c[1] : b == 'G' ? (double)c[2] : b == 'T' ? (double)c[3] : b == 'N' ? (double)c[4] : -1.0; };
+		const double w = cnt(snps[i].ref), m = cnt(snps[i].alt);
+		if (w < 0) NB_THROW(ArgumentException, std::string("Unknown wild-type base '") + snps[i].ref + "' in frequency calculation!");
+		if (m < 0) NB_THROW(ArgumentException, std::string("Unknown mutant base '") + snps[i].alt + "' in frequency calculation!");
+		if (w + m == 0) continue;
+		++passed; passed_depth_sum += (double)depth;
+		hist.inc(m / (w + m), false);
+	}
+	if (debug)
+	{
+		printf("Contamination debug output:\n%d of %zu SNPs passed quality filters\nAverage depth of passed SNPs: %s\n", passed, snps.size(), number(passed_depth_sum / passed, 2).c_str());
+	}
+	double off = 0.0;
+	for (int i = 1; i <= 5; ++i) off += hist.binValue(i, true);
+	for (int i = 14; i <= 18; ++i) off += hist.binValue(i, true);
+	QCCollection output;
+	Statistics::addQcValue(output, "QC:2000051", "SNV allele frequency deviation", passed < min_snps ? std::string("n/a") : number(off, 2));
+	return output;
+}
+
+// somatic sub-panel numbers from the depth array selected on the reader's handle (Statistics.cpp:1574-1710)
+struct SomaticDepth { long long bases_usable = 0; int hist_max = 599, hist_step = 5; std::vector<int64_t> hist; long long in_bam = 0; bool scanned = false; };
+SomaticDepth somaticFromDepth(BamReader& reader, const std::vector<ngsqc_region>& regions, long long roi_bases)
+{
+	SomaticDepth d;
+	if (!regions.empty())
+	{
+		std::vector<int64_t> sums(regions.size(), 0);
+		reader.check(ngsqc_region_sums(reader.handle(), regions.data(), (int64_t)regions.size(), sums.data()));
+		for (int64_t v : sums) d.bases_usable += v;
+	}
+	const double avg_depth = (double)d.bases_usable / roi_bases;
+	if (avg_depth > 200) { d.hist_max += 400; d.hist_step += 5; }                                         // :1657-1670
+	if (avg_depth > 500) d.hist_max += 500;
+	if (avg_depth > 1000) d.hist_max += 1000;
+	if (!regions.empty())
+	{
+		d.hist.assign((size_t)d.hist_max + 1, 0); int64_t cov = 0;
+		reader.check(ngsqc_depth_stats(reader.handle(), d.hist_max, 0, d.hist.data(), &cov));
+		for (auto& r : regions) d.in_bam += r.end - r.start + 1;
+		d.scanned = true;
+	}
+	return d;
+}
+
+// state of the fused job announced by Statistics::planFused
+struct FusedState
+{
+	bool active = false, ran = false; std::string bam; FusedPlan plan;
+	SnpSites snp; std::vector<int64_t> site_counts; bool have_sites = false;
+	ngsqc_read_stats rs{}; std::vector<int64_t> read_lengths, cycles; bool have_reads = false;
+	SomaticDepth som; bool have_somatic = false;
+	ngsqc_timings tm{}; int64_t n_blocks = 0;
+};
+FusedState g_fused;
+
 struct Scan
 {
 	std::vector<int64_t> c = std::vector<int64_t>(NGSQC_NCOUNTERS, 0); std::vector<double> gc_reads = std::vector<double>(101, 0.0);
 	int64_t operator[](int i) const { return c[(size_t)i]; }
 };
+
+bool fusedWanted(const BamReader& reader);
+void runFused(BamReader& reader, const ngsqc_mapping_params& p, Scan& s);
 
 Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_region>& regions, const GcPrep* gc, const BedFile* gc_bed)
 {
@@ -177,7 +307,13 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 		p.gc_chunks = chunks.data(); p.gc_bin = bins.data(); p.n_gc_chunks = (int64_t)chunks.size();
 	}
 	const std::vector<ngsqc_handle*>& sh = reader.shards();
-	if (sh.size() == 1) { reader.check(ngsqc_scan_mapping(reader.handle(), &p, s.c.data(), s.gc_reads.data())); return s; }
+	if (sh.size() == 1 && fusedWanted(reader)) { runFused(reader, p, s); return s; }
+	if (sh.size() == 1)
+	{
+		reader.check(ngsqc_scan_mapping(reader.handle(), &p, s.c.data(), s.gc_reads.data()));
+		if (getenv("NGSQC_TIMING")) { ngsqc_timings tm{}; ngsqc_get_timings(reader.handle(), &tm); fprintf(stderr, "[ngsqc] mapping pass: %lld BGZF members inflated\n", (long long)tm.members_inflated); }
+		return s;
+	}
 
 	// ---- one BAM sharded over several handles / GPUs (include/ngsqc.h, "sharded" section): local scans run concurrently ----
 	const int n = (int)sh.size();
@@ -227,7 +363,12 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 void runDepthScan(BamReader& reader, const ngsqc_depth_params& p)
 {
 	const std::vector<ngsqc_handle*>& sh = reader.shards();
-	if (sh.size() == 1) { reader.check(ngsqc_scan_depth(reader.handle(), &p)); return; }
+	if (sh.size() == 1)
+	{
+		reader.check(ngsqc_scan_depth(reader.handle(), &p));
+		if (getenv("NGSQC_TIMING")) { ngsqc_timings tm{}; ngsqc_get_timings(reader.handle(), &tm); fprintf(stderr, "[ngsqc] depth pass: %lld BGZF members inflated\n", (long long)tm.members_inflated); }
+		return;
+	}
 	const int n = (int)sh.size(); std::vector<int> rcs((size_t)n, NGSQC_OK);
 	{
 		std::vector<std::thread> th;
@@ -492,31 +633,23 @@ QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::
 {
 	if (!bed_file.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for depth details statistics!");   // :1577-1580
 	long long roi_bases = bed_file.baseCount();
-	BamReader reader(bam_file, ref_file, true);
-	long long bases_usable = 0;
-	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
-	if (!regions.empty())
+	SomaticDepth d;
+	if (g_fused.ran && g_fused.have_somatic && g_fused.bam == bam_file && g_fused.plan.somatic_min_mapq == min_mapq) d = g_fused.som;   // the fused job scanned the sub-panel beside the mapping scan
+	else
 	{
-		ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
-		runDepthScan(reader, p);
-		std::vector<int64_t> sums(regions.size(), 0);
-		reader.check(ngsqc_region_sums(reader.handle(), regions.data(), (int64_t)regions.size(), sums.data()));
-		for (int64_t v : sums) bases_usable += v;
+		BamReader reader(bam_file, ref_file, true);
+		std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);
+		if (!regions.empty())
+		{
+			ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
+			runDepthScan(reader, p);
+		}
+		d = somaticFromDepth(reader, regions, roi_bases);
 	}
-	double avg_depth = (double)bases_usable / roi_bases;
-	int hist_max = 599, hist_step = 5;                                                                  // :1657-1670
-	if (avg_depth > 200) { hist_max += 400; hist_step += 5; }
-	if (avg_depth > 500) hist_max += 500;
-	if (avg_depth > 1000) hist_max += 1000;
-	Histogram depth_dist(0, hist_max, hist_step);
-	long long in_bam = 0;
-	if (!regions.empty())
-	{
-		long long covered = 0;
-		depth_dist = depthHistogram(reader, hist_max, hist_step, 0, covered);
-		for (auto& r : regions) in_bam += r.end - r.start + 1;
-	}
-	if (roi_bases > in_bam) depth_dist.inc(0, true, (double)(roi_bases - in_bam));   // positions on chromosomes the BAM does not know stay at depth 0
+	double avg_depth = (double)d.bases_usable / roi_bases;
+	Histogram depth_dist(0, d.hist_max, d.hist_step);
+	if (d.scanned) for (int k = 0; k <= d.hist_max; ++k) if (d.hist[(size_t)k]) depth_dist.inc(k, true, (double)d.hist[(size_t)k]);
+	if (roi_bases > d.in_bam) depth_dist.inc(0, true, (double)(roi_bases - d.in_bam));   // positions on chromosomes the BAM does not know stay at depth 0
 	QCCollection output;
 	addQcValue(output, "QC:2000097", "somatic custom target region read depth", avg_depth);
 	const int depths[8] = {10, 20, 30, 50, 60, 100, 200, 500};
@@ -534,6 +667,7 @@ QCCollection Statistics::somaticCustomDepth(const BedFile& bed_file, const std::
 void StatisticsReads::update(BamReader& reader)
 {
 	reader.check(ngsqc_scan_reads(reader.handle(), single_end_ ? 1 : 0, &st_));
+	if (getenv("NGSQC_TIMING")) { ngsqc_timings tm{}; ngsqc_get_timings(reader.handle(), &tm); fprintf(stderr, "[ngsqc] read QC pass: %lld BGZF members inflated\n", (long long)tm.members_inflated); }
 	if (st_.n_unknown_base) NB_THROW(ProgrammingException, "Unknown base in StatisticsReads::update!");                                    // :131
 	if (st_.n_quality_out_of_range) NB_THROW(ArgumentException, "Base quality > 100. This should not happen!");                            // :141
 	read_lengths_.assign((size_t)st_.max_cycles + 1, 0);
@@ -542,6 +676,16 @@ void StatisticsReads::update(BamReader& reader)
 	cycles_.assign((size_t)n_cyc * 7, 0);
 	if (n_cyc) reader.check(ngsqc_read_cycle_stats(reader.handle(), cycles_.data(), n_cyc));
 	have_ = true;
+}
+
+bool StatisticsReads::takeFused(const std::string& bam_file)
+{
+	if (!(g_fused.ran && g_fused.have_reads && g_fused.bam == bam_file && g_fused.plan.single_end == single_end_)) return false;
+	st_ = g_fused.rs; read_lengths_ = g_fused.read_lengths; cycles_ = g_fused.cycles;
+	if (st_.n_unknown_base) NB_THROW(ProgrammingException, "Unknown base in StatisticsReads::update!");                                    // :131
+	if (st_.n_quality_out_of_range) NB_THROW(ArgumentException, "Base quality > 100. This should not happen!");                            // :141
+	have_ = true;
+	return true;
 }
 
 QCCollection StatisticsReads::getResult()
@@ -643,86 +787,81 @@ QCCollection StatisticsReads::getResult()
 }
 
 // Statistics.cpp:2333-2386 + NGSHelper::getKnownVariants (NGSHelper.cpp:22-94) + BamReader::getPileup (BamReader.cpp:809-885).
-// The reference runs one indexed pileup query per known SNP; here all sites go to the GPU in one table (ngsqc_site_pileup).
+// The reference runs one indexed pileup query per known SNP; here all sites go to the GPU in one table (ngsqc_site_pileup, or the
+// site-pileup consumer of the fused job).
+namespace {
+bool fusedWanted(const BamReader& reader) { return g_fused.active && !g_fused.ran && g_fused.bam == reader.fileName(); }
+
+// ONE pass over the BAM for the mapping scan and every announced follow-up pass (ngsqc_run_job)
+void runFused(BamReader& reader, const ngsqc_mapping_params& p, Scan& s)
+{
+	FusedState& F = g_fused; const FusedPlan& plan = F.plan;
+	ngsqc_job_desc job{}; ngsqc_job_result res{};
+	job.mapping = &p; res.counters = s.c.data(); res.gc_reads = s.gc_reads.data();
+	if (plan.contamination)
+	{
+		F.snp = snpSites(reader, loadKnownSnps(plan.build, plan.roi_file));
+		F.site_counts.assign(F.snp.sites.size() * 8, 0);
+		job.sites = F.snp.sites.data(); job.n_sites = (int64_t)F.snp.sites.size();
+		job.site_min_mapq = 1; job.site_min_baseq = 13; job.site_include_npp = plan.include_not_properly_paired ? 1 : 0;
+		res.site_counts = F.site_counts.data();
+	}
+	if (plan.read_qc) { job.read_qc = 1; job.read_qc_single_end = plan.single_end ? 1 : 0; res.read_stats = &F.rs; }
+	std::vector<ngsqc_region> som_regions; ngsqc_depth_params dp{};
+	if (plan.somatic)
+	{
+		if (!plan.somatic_bed.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for depth details statistics!");   // Statistics.cpp:1577-1580
+		som_regions = toRegions(plan.somatic_bed, reader, false);
+		if (!som_regions.empty()) { dp.min_mapq = plan.somatic_min_mapq; dp.regions = som_regions.data(); dp.n_regions = (int64_t)som_regions.size(); job.depth = &dp; }
+	}
+	reader.check(ngsqc_run_job(reader.handle(), &job, &res));
+	ngsqc_get_timings(reader.handle(), &F.tm); F.n_blocks = ngsqc_n_bgzf_blocks(reader.handle());
+	F.have_sites = plan.contamination;
+	if (plan.read_qc)
+	{
+		F.read_lengths.assign((size_t)F.rs.max_cycles + 1, 0);
+		reader.check(ngsqc_read_length_hist(reader.handle(), F.read_lengths.data(), (int64_t)F.read_lengths.size()));
+		const int64_t n_cyc = std::min<int64_t>(F.rs.max_cycles, 320);
+		F.cycles.assign((size_t)n_cyc * 7, 0);
+		if (n_cyc) reader.check(ngsqc_read_cycle_stats(reader.handle(), F.cycles.data(), n_cyc));
+		F.have_reads = true;
+	}
+	if (plan.somatic)
+	{
+		if (job.depth) reader.check(ngsqc_depth_select(reader.handle(), 1));
+		F.som = somaticFromDepth(reader, som_regions, plan.somatic_bed.baseCount());
+		reader.check(ngsqc_depth_select(reader.handle(), 0));
+		F.have_somatic = true;
+	}
+	F.ran = true;
+}
+} // namespace
+
+void Statistics::planFused(const std::string& bam_file, const FusedPlan& plan)
+{
+	g_fused = FusedState();
+	const char* e = getenv("NGSQC_FUSED");
+	if (e && atoi(e) == 0) return;
+	g_fused.active = true; g_fused.bam = bam_file; g_fused.plan = plan;
+}
+void Statistics::clearFused()
+{
+	if (g_fused.ran && getenv("NGSQC_TIMING"))
+		fprintf(stderr, "[ngsqc] fused job: %.2f ms wall, K1 %.2f ms, %lld tiles, %lld of %lld BGZF members inflated, %lld records\n", g_fused.tm.job_wall_ms, g_fused.tm.inflate_ms,
+		        (long long)g_fused.tm.n_tiles, (long long)g_fused.tm.members_inflated, (long long)g_fused.n_blocks, (long long)g_fused.tm.n_records);
+	g_fused = FusedState();
+}
+
 QCCollection Statistics::contamination(const std::string& build, const std::string& bam, const std::string& ref_file, const std::string& roi_file, bool debug, int min_cov, int min_snps, bool include_not_properly_paired)
 {
+	if (g_fused.ran && g_fused.have_sites && g_fused.bam == bam && g_fused.plan.build == build && g_fused.plan.roi_file == roi_file && g_fused.plan.include_not_properly_paired == include_not_properly_paired)
+		return contaminationFromCounts(g_fused.snp, g_fused.site_counts, debug, min_cov, min_snps);
 	BamReader reader(bam, ref_file);
-	// target region: variants whose [pos, pos + len(ref) - 1] overlaps a line are kept (VcfFile::setRegion / VcfFile.cpp:131-136)
-	std::map<int, std::vector<std::pair<int, int>>> roi_by_chr; std::map<int, std::vector<int>> roi_pmax;
-	if (roi_file != "")
-	{
-		BedFile roi; roi.load(roi_file); roi.sort();
-		for (long long i = 0; i < roi.count(); ++i) roi_by_chr[roi[i].chr().num()].push_back({roi[i].start(), roi[i].end()});
-		for (auto& kv : roi_by_chr) { std::vector<int>& pm = roi_pmax[kv.first]; int m = 0; for (auto& se : kv.second) { m = std::max(m, se.second); pm.push_back(m); } }
-	}
-	auto in_roi = [&](const Chromosome& chr, int s, int e) {
-		auto it = roi_by_chr.find(chr.num()); if (it == roi_by_chr.end()) return false;
-		const auto& v = it->second; const auto& pm = roi_pmax[chr.num()];
-		size_t hi = (size_t)(std::upper_bound(v.begin(), v.end(), std::make_pair(e, std::numeric_limits<int>::max())) - v.begin());   // lines with start <= e
-		return hi > 0 && pm[hi - 1] >= s;
-	};
-	// known variants: SNVs with 0.2 <= AF <= 0.8 (getKnownVariants(build, true, [roi,] 0.2, 0.8))
-	std::string res = resourceDir() + "/" + build + "_snps.tsv";
-	std::ifstream f(res);
-	if (!f) NB_THROW(ProgrammingException, "Unsupported genome build '" + build + "'!");   // NGSHelper.cpp copyFromResource
-	struct Snp { Chromosome chr; int pos; char ref, alt; };
-	std::vector<Snp> snps; std::string line;
-	while (std::getline(f, line))
-	{
-		std::vector<std::string> c = split(line, '\t');
-		if (c.size() < 5) continue;
-		const int pos = atoi(c[1].c_str());
-		Chromosome chr(c[0]);
-		if (roi_file != "" && !in_roi(chr, pos, pos + (int)c[2].size() - 1)) continue;
-		char* end = nullptr; double af = c[4].empty() ? 0.0 : strtod(c[4].c_str(), &end); if (c[4].empty() || *end) af = 0.0;   // QByteArray::toDouble
-		if (!(af >= 0.2 && af <= 0.8)) continue;
-		std::string alt0 = c[3].substr(0, c[3].find(','));
-		for (auto& ch : alt0) ch = (char)toupper(ch);
-		if (!(alt0.size() == 1 && c[2].size() == 1 && alt0 != "-" && c[2] != "-")) continue;                                    // VcfLine::isSNV
-		snps.push_back(Snp{chr, pos, c[2][0], alt0[0]});
-	}
-	// site table for the GPU: (tid, pos), grouped by tid in position order
-	std::vector<ngsqc_region> sites; std::vector<size_t> order;
-	if (!snps.empty()) reader.requireIndex();                                                                                  // getPileup -> setRegion (BamReader.cpp:740-746)
-	std::vector<int> tids(snps.size());
-	for (size_t i = 0; i < snps.size(); ++i)
-	{
-		tids[i] = reader.chromosomeID(snps[i].chr);
-		if (tids[i] < 0) NB_THROW(FileAccessException, "Could not find chromosome '" + snps[i].chr.str() + "' in BAM/CRAM file " + bam);   // BamReader.cpp:750-754
-		order.push_back(i);
-	}
-	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tids[a] != tids[b] ? tids[a] < tids[b] : snps[a].pos < snps[b].pos; });
-	for (size_t k : order) sites.push_back(ngsqc_region{tids[k], snps[k].pos, snps[k].pos});
-	std::vector<int64_t> counts(sites.size() * 8, 0);
-	if (!sites.empty()) reader.check(ngsqc_site_pileup(reader.handle(), sites.data(), (int64_t)sites.size(), 1, 13, include_not_properly_paired ? 1 : 0, counts.data()));
-	Histogram hist(0, 1, 0.05);
-	int passed = 0; double passed_depth_sum = 0.0;
-	std::vector<size_t> slot(snps.size()); for (size_t j = 0; j < order.size(); ++j) slot[order[j]] = j;
-	for (size_t i = 0; i < snps.size(); ++i)                                                                                   // file order, as the reference
-	{
-		const int64_t* c = &counts[slot[i] * 8];
-		if (c[6]) NB_THROW(ArgumentException, "Unknown base in pileup!");                                                      // Pileup.cpp:31
-		if (c[7]) NB_THROW(Exception, "Could not find position " + std::to_string(snps[i].pos) + " in read!");                 // BamReader.cpp:366
-		const long long depth = c[0] + c[1] + c[2] + c[3];
-		if (depth < min_cov) continue;
-		auto cnt = [&](char b) -> double { b = (char)toupper(b); return b == 'A' ? (double)c[0] : b == 'C' ? (double)c[1] : b == 'G' ? (double)c[2] : b == 'T' ? (double)c[3] : b == 'N' ? (double)c[4] : -1.0; };
-		const double w = cnt(snps[i].ref), m = cnt(snps[i].alt);
-		if (w < 0) NB_THROW(ArgumentException, std::string("Unknown wild-type base '") + snps[i].ref + "' in frequency calculation!");
-		if (m < 0) NB_THROW(ArgumentException, std::string("Unknown mutant base '") + snps[i].alt + "' in frequency calculation!");
-		if (w + m == 0) continue;
-		++passed; passed_depth_sum += (double)depth;
-		hist.inc(m / (w + m), false);
-	}
-	if (debug)
-	{
-		printf("Contamination debug output:\n%d of %zu SNPs passed quality filters\nAverage depth of passed SNPs: %s\n", passed, snps.size(), number(passed_depth_sum / passed, 2).c_str());
-	}
-	double off = 0.0;
-	for (int i = 1; i <= 5; ++i) off += hist.binValue(i, true);
-	for (int i = 14; i <= 18; ++i) off += hist.binValue(i, true);
-	QCCollection output;
-	addQcValue(output, "QC:2000051", "SNV allele frequency deviation", passed < min_snps ? std::string("n/a") : number(off, 2));
-	return output;
+	SnpSites t = snpSites(reader, loadKnownSnps(build, roi_file));
+	std::vector<int64_t> counts(t.sites.size() * 8, 0);
+	if (!t.sites.empty()) reader.check(ngsqc_site_pileup(reader.handle(), t.sites.data(), (int64_t)t.sites.size(), 1, 13, include_not_properly_paired ? 1 : 0, counts.data()));
+	if (getenv("NGSQC_TIMING")) { ngsqc_timings tm{}; ngsqc_get_timings(reader.handle(), &tm); fprintf(stderr, "[ngsqc] contamination pass: %lld BGZF members inflated\n", (long long)tm.members_inflated); }
+	return contaminationFromCounts(t, counts, debug, min_cov, min_snps);
 }
 
 void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)

@@ -29,9 +29,22 @@ private:
 	std::string bam_file_; ngsqc_handle* h_ = nullptr; std::vector<ngsqc_handle*> shards_; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
 };
 
+// MappingQC reads the BAM up to four times in the reference (src/MappingQC/main.cpp:83-165: read QC, mapping, contamination, somatic
+// sub-panel). A FusedPlan announces the passes that follow the mapping pass: the next Statistics::mapping*() call on that BAM then runs
+// ONE GPU job (ngsqc_run_job: every BGZF member is inflated once, all consumers see each tile) and the announced functions take their
+// counts from it instead of reading the BAM again. Without a plan (or with NGSQC_FUSED=0, or a sharded reader) each function runs its own pass.
+struct FusedPlan
+{
+	bool contamination = false; std::string build, roi_file; bool include_not_properly_paired = false;
+	bool read_qc = false, single_end = false;
+	bool somatic = false; BedFile somatic_bed; int somatic_min_mapq = 1;
+};
+
 class Statistics
 {
 public:
+	static void planFused(const std::string& bam_file, const FusedPlan& plan);
+	static void clearFused();
 	// Statistics.cpp:343  — target-region mode (MappingQC -roi)
 	static QCCollection mapping(const BedFile& bed_file, const std::string& bam_file, const std::string& ref_file, int min_mapq = 1, bool is_cfdna = false);
 	// Statistics.cpp:805  — -rna / -wgs -build non_human
@@ -62,6 +75,7 @@ class StatisticsReads
 public:
 	explicit StatisticsReads(bool single_end = false) : single_end_(single_end) {}
 	void update(BamReader& reader);
+	bool takeFused(const std::string& bam_file);   // the counts of the fused job announced with Statistics::planFused (false: none, run update())
 	QCCollection getResult();
 private:
 	bool single_end_; ngsqc_read_stats st_{}; std::vector<int64_t> read_lengths_, cycles_; bool have_ = false;

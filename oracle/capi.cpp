@@ -95,10 +95,10 @@ int64_t orc_result_depth(void* res, int32_t* out, int64_t cap)
 	if (out) memcpy(out, d.data(), (size_t)n*4);
 	return (int64_t)d.size();
 }
-int orc_result_gc(void* res, double* gc_roi100, double* gc_reads100)
+int orc_result_gc(void* res, double* gc_roi101, double* gc_reads101)   // bins 0..100 (bin 100: chunks of pure G/C)
 {
 	const MappingResult& m = ((Result*)res)->m;
-	for (int i=0;i<100;++i) { gc_roi100[i] = (size_t)i<m.gc_roi.size() ? m.gc_roi[i] : 0; gc_reads100[i] = (size_t)i<m.gc_reads.size() ? m.gc_reads[i] : 0; }
+	for (int i=0;i<101;++i) { gc_roi101[i] = (size_t)i<m.gc_roi.size() ? m.gc_roi[i] : 0; gc_reads101[i] = (size_t)i<m.gc_reads.size() ? m.gc_reads[i] : 0; }
 	return m.have_gc ? 1 : 0;
 }
 double orc_result_seconds(void* res) { return ((Result*)res)->seconds_compute; }
@@ -166,13 +166,29 @@ double orc_baseline_wgs_stream(const uint8_t* image, int64_t n, const char* bed,
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }
 }
 
+// GC bin of every roi.chunk(100) line (Statistics.cpp:363-387): what the host layer hands to the C ABI as gc_bin. merge_mode as in
+// orc_bed_roundtrip (1 = merge(), 3 = sort + merge). Returns the number of chunks; bins[i] = floor(100 * gc) or -1 (no A/C/G/T in the chunk).
+int64_t orc_gc_bins(const char* fasta, const char* bed, int merge_mode, int32_t* bins, int64_t cap, char* err, int errlen)
+{
+	try
+	{
+		Fasta fa(fasta);
+		BedFile f; f.load(bed);
+		if (merge_mode==1) f.merge(); else if (merge_mode==3) { f.sort(); f.merge(); }
+		GcBins g(f, &fa);
+		if (bins) for (int64_t i=0; i<std::min<int64_t>(cap, (int64_t)g.bin.size()); ++i) bins[i] = g.bin[(size_t)i];
+		return (int64_t)g.bin.size();
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1; }
+}
+
 // BED helpers for host-logic tests: load -> (merge) -> text
 int64_t orc_bed_roundtrip(const char* bed, int merge_mode, char* out, int64_t cap, char* err, int errlen)
 {
 	try
 	{
 		BedFile f; f.load(bed);
-		if (merge_mode==1) f.merge(); else if (merge_mode==2) f.merge(true, true); else if (merge_mode==3) { f.sort(); f.merge(); } else if (merge_mode==4) { f.merge(); f.chunk(100); }
+		if (merge_mode==1) f.merge(); else if (merge_mode==2) f.merge(true, true); else if (merge_mode==3) { f.sort(); f.merge(); } else if (merge_mode==4) { f.merge(); f.chunk(100); } else if (merge_mode==5) { f.sort(); f.merge(); f.chunk(100); }
 		std::string t = f.toText(false);
 		if (out && cap>0) { size_t n = std::min<size_t>((size_t)cap-1, t.size()); memcpy(out, t.data(), n); out[n] = 0; }
 		return (int64_t)t.size();

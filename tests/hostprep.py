@@ -42,7 +42,7 @@ def nonspecial(refs):
 
 
 def bed_regions(bed_path, refs, merge_mode):
-    """merge_mode: 0 none, 1 merge(), 2 merge(true,true), 3 sort+merge, 4 merge+chunk(100). Returns [(tid,start,end)], annotations."""
+    """merge_mode: 0 none, 1 merge(), 2 merge(true,true), 3 sort+merge, 4 merge+chunk(100), 5 sort+merge+chunk(100). Returns [(tid,start,end)], annotations."""
     text = O.bed_roundtrip(bed_path, merge_mode)
     tm = tid_map(refs)
     regs, annos = [], []
@@ -77,3 +77,31 @@ def known_sites(refs, build="hg38"):
             sites.append((tm[chr_num(c)], int(p_)))
     sites.sort()
     return np.array([(t, p, p) for t, p in sites], dtype=np.int32).reshape(-1, 3)
+
+
+def gc_inputs(bed_path, refs, fasta, merge_mode):
+    """(gc_chunks, gc_bin) for the C ABI: roi.chunk(100) lines with the GC bin of each (Statistics.cpp:363-387), chunks on chromosomes the
+    BAM does not know dropped - what the C++ host layer passes in ngsqc_mapping_params. merge_mode: 1 (merge) or 3 (sort + merge)."""
+    chunks, _ = bed_regions(bed_path, refs, 4 if merge_mode == 1 else 5)
+    bins = O.gc_bins(fasta, bed_path, merge_mode)
+    assert len(bins) == len(chunks)
+    keep = [i for i, c in enumerate(chunks) if c[0] >= 0]
+    return [chunks[i] for i in keep], [int(bins[i]) for i in keep]
+
+
+def sparse_fasta_for(bed_path, refs, path, seed=7):
+    """synthetic genome (tools/fastagen.py) with bases under every line of the BED; contigs = the BAM's references"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fastagen
+    names = {n for n, _ in refs}
+    wins = []
+    for ln in open(bed_path):
+        if ln.startswith(("#", "track", "browser")) or not ln.strip():
+            continue
+        c, s, e = ln.rstrip("\n").split("\t")[:3]
+        c2 = c if c in names else ("chr" + c if "chr" + c in names else (c[3:] if c.startswith("chr") and c[3:] in names else None))
+        if c2 is not None:
+            wins.append((c2, int(s) + 1, int(e)))
+    return fastagen.write_sparse_fasta(path, refs, wins, seed)

@@ -117,7 +117,7 @@ class MappingResult:
         self.depth = np.zeros(n, dtype=np.int32)
         if n:
             L.orc_result_depth(h, self.depth.ctypes.data, n)
-        self.gc_roi = np.zeros(100); self.gc_reads = np.zeros(100)
+        self.gc_roi = np.zeros(101); self.gc_reads = np.zeros(101)
         self.have_gc = bool(L.orc_result_gc(h, self.gc_roi.ctypes.data, self.gc_reads.ctypes.data))
         self.seconds = L.orc_result_seconds(h)
         L.orc_result_free(h)
@@ -192,6 +192,20 @@ def bed_roundtrip(bed, merge_mode=0):
     buf = C.create_string_buffer(n + 1)
     lib().orc_bed_roundtrip(_b(bed), merge_mode, buf, n + 1, err, 1024)
     return buf.value.decode()
+
+
+def gc_bins(fasta, bed, merge_mode=1):
+    """GC bin (0..100, or -1) of every chunk of roi.chunk(100), in chunk order (Statistics.cpp:363-387)."""
+    L = lib()
+    L.orc_gc_bins.restype = C.c_int64
+    L.orc_gc_bins.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(1024)
+    n = L.orc_gc_bins(_b(fasta), _b(bed), merge_mode, None, 0, err, 1024)
+    if n < 0:
+        raise OracleError(err.value.decode())
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    L.orc_gc_bins(_b(fasta), _b(bed), merge_mode, out.ctypes.data, n, err, 1024)
+    return out[:n]
 
 
 def baseline_wgs_stream(image, bed=None, min_mapq=1, max_records=-1):

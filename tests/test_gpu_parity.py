@@ -35,18 +35,38 @@ def test_inflate_and_record_index(bam):
     h.close()
 
 
-def _compare_mapping(bam, mode, bed, merge_mode, cfdna=False, min_mapq=1):
+_FASTA = {}
+
+
+def _fasta(bed, refs, tmp_root):
+    """one synthetic genome per (BED, reference set): bases under every BED line (tools/fastagen.py), contigs = the BAM's references"""
+    key = (bed, tuple(refs))
+    if key not in _FASTA:
+        path = os.path.join(tmp_root, f"genome_{len(_FASTA)}.fa")
+        _FASTA[key] = H.sparse_fasta_for(bed, refs, path, seed=11 + len(_FASTA))
+    return _FASTA[key]
+
+
+def _compare_mapping(bam, mode, bed, merge_mode, cfdna=False, min_mapq=1, tmp_root=None):
     ob = O.Bam(p(bam))
     h = ngsqc.Handle(path=p(bam))
     refs = h.refs
-    regs = gc = None
+    regs = gc = bins = fasta = None
     if bed:
         regs, _ = H.bed_regions(bed, refs, merge_mode)
-        gc, _ = H.bed_regions(bed, refs, 4 if merge_mode == 1 else 4)
+        # real GC bins of roi.chunk(100) from a synthetic genome: the (bin, n) hit table, the n >= 64 path and the host-side reconstruction
+        # of gc_reads all take part (Statistics.cpp:363-387, 533-541, 1164-1171)
+        fasta = _fasta(bed, refs, tmp_root)
+        gc, bins = H.gc_inputs(bed, refs, fasta, merge_mode)
+        assert any(b >= 0 for b in bins)
     tx, ty = H.xy_tids(refs)
-    counters, _ = h.scan_mapping(mode, regions=regs, min_mapq=min_mapq, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs),
-                                 gc_chunks=gc, gc_bin=[-1] * len(gc) if gc else None)
-    exp = O.mapping(ob, mode, bed, merge_bed=(merge_mode == 1), min_mapq=min_mapq, cfdna=cfdna)
+    counters, gc_reads = h.scan_mapping(mode, regions=regs, min_mapq=min_mapq, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs),
+                                        gc_chunks=gc, gc_bin=bins)
+    exp = O.mapping(ob, mode, bed, merge_bed=(merge_mode == 1), fasta=fasta, min_mapq=min_mapq, cfdna=cfdna)
+    if bed:
+        want = np.zeros(101); want[:exp.gc_reads.size] = exp.gc_reads
+        assert exp.have_gc and np.allclose(gc_reads, want, rtol=1e-12, atol=0.0), (bam, float(np.abs(gc_reads - want).max()))
+        assert want.sum() > 0 or counters[O.COUNTER_NAMES.index("al_ontarget")] == 0
     for i, name in enumerate(O.COUNTER_NAMES):
         if name in SKIP_COUNTERS:
             continue
@@ -68,8 +88,8 @@ def _compare_mapping(bam, mode, bed, merge_mode, cfdna=False, min_mapq=1):
     ("MappingQC_in1.bam", "MappingQC_in2.bed", False), ("MappingQC_in4.bam", "MappingQC_in3.bed", True),
     ("MappingQC_in3.bam", "MappingQC_in2.bed", False), ("Statistics_longread.bam", "panel.bed", False),
 ])
-def test_mapping_roi(bam, bed, cfdna):
-    _compare_mapping(bam, ngsqc.MODE_ROI, p(bed), 1, cfdna)
+def test_mapping_roi(bam, bed, cfdna, tmp_path_factory):
+    _compare_mapping(bam, ngsqc.MODE_ROI, p(bed), 1, cfdna, tmp_root=str(tmp_path_factory.getbasetemp()))
 
 
 @pytest.mark.parametrize("bam", ["close_exons.bam", "MappingQC_in3.bam", "MappingQC_in1.bam", "Statistics_longread.bam", "BamReader_lr.bam"])
@@ -83,8 +103,8 @@ def test_mapping_noroi(bam):
     ("MappingQC_in2.bam", os.path.join(RESOURCES, "hg19_439_omim_genes.bed")),
     ("Statistics_longread.bam", os.path.join(RESOURCES, "hg38_440_omim_genes.bed")),
 ])
-def test_mapping_wgs(bam, bed):
-    _compare_mapping(bam, ngsqc.MODE_WGS, bed, 3 if bed else 0)
+def test_mapping_wgs(bam, bed, tmp_path_factory):
+    _compare_mapping(bam, ngsqc.MODE_WGS, bed, 3 if bed else 0, tmp_root=str(tmp_path_factory.getbasetemp()))
 
 
 @pytest.mark.parametrize("bam,bed,mapq,baseq", [

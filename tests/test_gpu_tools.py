@@ -93,3 +93,24 @@ def test_tool_errors():
     assert p.returncode != 0 and "exactly one of the parameters 'roi', 'wgs', or 'rna'" in p.stderr
     p = subprocess.run([os.path.join(BIN, "BedLowCoverage"), "-bam", os.path.join(GI, "close_exons.bam"), "-in", os.path.join(GI, "close_exons.bed"), "-cutoff", "300"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "Cutoff cannot be bigger than 255!" in p.stderr
+
+
+def test_mappingqc_inflates_every_member_once_for_all_passes(tmp_path):
+    """MappingQC with contamination, -read_qc and -somatic_custom_bed is four BAM passes in the reference (src/MappingQC/main.cpp:83-165).
+    The tool runs them as ONE fused GPU job: on a file cut into several tiles K1 must visit every BGZF member exactly once, and the
+    outputs must be byte-identical to the pass-per-function mode (NGSQC_FUSED=0), which inflates the file once per pass."""
+    bam, roi, sub = (os.path.join(GI, x) for x in ("MappingQC_in2.bam", "MappingQC_in2.bed", "MappingQC_in2_custom_subpanel.bed"))
+    args = ["-in", bam, "-roi", roi, "-somatic_custom_bed", sub, "-build", "hg19", "-no_ref"]
+    outs = {}
+    for name, env in (("fused", {}), ("separate", {"NGSQC_FUSED": "0"})):
+        out, rq = str(tmp_path / f"{name}.qcML"), str(tmp_path / f"{name}_reads.qcML")
+        p = run("MappingQC", *args, "-out", out, "-read_qc", rq, env=dict(env, NGSQC_TIMING="1", NGSQC_TILE_MEMBERS="3"))
+        outs[name] = (_lines(out), _lines(rq), p.stderr)
+    assert outs["fused"][0] == outs["separate"][0] and outs["fused"][1] == outs["separate"][1]
+    assert outs["fused"][0] == _lines(os.path.join(GO, "MappingQC_test09_out.qcML"))
+    m = re.search(r"fused job: .* (\d+) tiles, (\d+) of (\d+) BGZF members inflated", outs["fused"][2])
+    assert m and int(m.group(1)) >= 3 and m.group(2) == m.group(3), outs["fused"][2]
+    # pass-per-function: mapping, read QC and the sub-panel depth scan each inflate the whole file (the contamination pass finds none of the
+    # known SNVs inside this small target region and does not read the BAM)
+    per_pass = [int(x) for x in re.findall(r"pass: (\d+) BGZF members inflated", outs["separate"][2])]
+    assert sum(per_pass) >= 3 * int(m.group(3)), outs["separate"][2]

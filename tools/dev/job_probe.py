@@ -24,6 +24,10 @@ VARIANTS = {
     "tile1": {"NGSQC_TILE_CHUNKS": "1"},
     "tile4": {"NGSQC_TILE_CHUNKS": "4"},
     "unsorted": {"NGSQC_K1_SORTED": "0"},
+    "park8": {"NGSQC_P1_PARK": "8"}, "park24": {"NGSQC_P1_PARK": "24"}, "park32": {"NGSQC_P1_PARK": "32"},
+    "debug": {"NGSQC_DEBUG": "1"},
+    "p2wg1024": {"NGSQC_P2_WGS": "1024"}, "p2wg4096": {"NGSQC_P2_WGS": "4096"},
+    "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
 
 
@@ -38,7 +42,7 @@ def main():
     ref = None
     for name in names:
         for k in list(os.environ):
-            if k.startswith("NGSQC_") and k not in ("NGSQC_DEBUG",):
+            if k.startswith("NGSQC_"):
                 del os.environ[k]
         os.environ.update(VARIANTS[name])
         t0 = time.time()
