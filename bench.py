@@ -126,7 +126,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=2))   # (rank 0 generates the BAM for minutes while the others wait)
         assert dist.get_world_size() == world
     if args.gpus != world and world > 1 and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks: using {world}", file=sys.stderr)
@@ -165,23 +166,35 @@ def main():
     image = None
     depth = 40.0 if args.ont else 30.0
     gen_kw = dict(seed=args.seed, mode=mode, depth=depth, first_contig=0, start_pos=0, level=6, aligned=True)
-    share = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_{os.environ.get('MASTER_PORT', '0')}_{args.seed}_{reads}.bam")
+    share_name = f"ngsqc_bench_{os.environ.get('MASTER_PORT', '0')}_{args.seed}_{reads}.bam"
+    share = None
     if world > 1:
-        ok = torch.zeros(1, dtype=torch.int64, device=dev)
+        ok = torch.zeros(1, dtype=torch.int64, device=dev)   # 1 + index of the directory that took the file, 0 = none
         if rank == 0:
             try:
-                image = G.generate(reads, threads=max(1, os.cpu_count() or 8), **gen_kw)
-                image.tofile(share); ok += 1
-            except (OSError, MemoryError):
-                pass
-        dist.all_reduce(ok)
-        if int(ok.item()) == 1 and rank != 0:
-            try:
-                image = np.memmap(share, dtype=np.uint8, mode="r")
-            except OSError:
+                image = G.generate(reads, threads=0, **gen_kw)
+            except MemoryError:
                 image = None
+            for k, d in enumerate(("/dev/shm", os.environ.get("TMPDIR", "/tmp"))):
+                if image is None or not os.path.isdir(d):
+                    continue
+                try:
+                    image.tofile(os.path.join(d, share_name)); ok += k + 1; break
+                except OSError:
+                    try:
+                        os.remove(os.path.join(d, share_name))
+                    except OSError:
+                        pass
+        dist.all_reduce(ok)
+        if int(ok.item()) >= 1:
+            share = os.path.join(("/dev/shm", os.environ.get("TMPDIR", "/tmp"))[int(ok.item()) - 1], share_name)
+            if rank != 0:
+                try:
+                    image = np.memmap(share, dtype=np.uint8, mode="r")
+                except OSError:
+                    image = None
     if image is None:
-        threads = max(1, (os.cpu_count() or 8) // max(world, 1))
+        threads = max(1, 2 * G.effective_cpus() // max(world, 1))
         image = G.generate(reads, threads=threads, **dict(gen_kw, seed=args.seed + (0 if args.single_bam else rank)))
     gen_s = time.time() - t0
     # H2D of the compressed image (of this rank's member range with --single-bam): not in the timed region, reported as end_to_end
@@ -191,7 +204,7 @@ def main():
     h2d_ms = h.timings()["h2d_ms"]
     if world > 1:
         dist.barrier()
-        if rank == 0:
+        if rank == 0 and share:
             try:
                 os.remove(share)
             except OSError:
@@ -332,7 +345,7 @@ def main():
             "end_to_end": {"h2d_ms": round(h2d_ms, 2), "h2d_GBps": round(c_bytes / max(h2d_ms, 1e-9) / 1e6, 2), "open_s": round(open_s, 2),
                            "value_incl_h2d": round(n_rec / (ms_per_step + h2d_ms) / 1e3, 3), "unit": "Mreads/s",
                            "note": "open = BGZF header walk on the host + H2D of the compressed image (pageable host memory) + BAM header; one H2D per file, then one step"},
-            "host": {"cores": os.cpu_count(), "generate_s": round(gen_s, 2)},
+            "host": {"cores_reported": os.cpu_count(), "cores_usable": G.effective_cpus(), "generate_s": round(gen_s, 2)},
         }
         if serial is not None:
             t_scan = serial["index_ms"] + serial["scan_ms"] + serial["finalize_ms"]   # K2-K6
@@ -371,11 +384,13 @@ def main():
             # the same loop on ALL host cores over the whole file: contiguous BGZF-member ranges per thread. Its additive counters and
             # the depth histogram are exact for an aligned BAM: the parity check of the bench input at full size
             try:
-                st_mt, secs_mt, c_mt, hist_mt = O.baseline_wgs_stream_mt(image, omim, 1, os.cpu_count() or 1, want_counters=True)
+                ncpu = G.effective_cpus()
+                st_mt, secs_mt, c_mt, hist_mt = O.baseline_wgs_stream_mt(image, omim, 1, 2 * ncpu, want_counters=True)
                 additive = np.ones(c_mt.size, dtype=bool); additive[list(O.ORDER_DEPENDENT)] = False
                 ok = bool(np.array_equal(c_mt[additive], np.asarray(result)[additive])) and bool(np.array_equal(hist_mt, hist)) and st_mt["n_records"] == n_rec
-                out["cpu_baseline_all_cores"] = {"value": round(st_mt["n_records"] / secs_mt / 1e6, 3), "unit": "Mreads/s", "cores": os.cpu_count() or 1, "kind": "port",
-                                                 "sample": f"the whole BAM ({st_mt['n_records']} records), one thread per contiguous BGZF-member range, shared depth array, {secs_mt:.2f} s"}
+                out["cpu_baseline_all_cores"] = {"value": round(st_mt["n_records"] / secs_mt / 1e6, 3), "unit": "Mreads/s", "cores": ncpu, "kind": "port",
+                                                 "sample": f"the whole BAM ({st_mt['n_records']} records), {2 * ncpu} threads on {ncpu} usable CPUs (cgroup quota; the host reports "
+                                                           f"{os.cpu_count()}), one contiguous BGZF-member range per thread, shared depth array, {secs_mt:.2f} s"}
                 out["cpu_baseline"]["counters_match_gpu"] = ok
                 out["cpu_baseline"]["counters_match_note"] = ("all-cores oracle over the WHOLE bench input vs the GPU's last timed step: every additive counter (1024 of 1032, incl. the "
                                                               "insert-size histogram) and the 600-bin per-base depth histogram of the OMIM ROI, bit-exact; the order-dependent counters are "

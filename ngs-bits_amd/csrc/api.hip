@@ -488,26 +488,46 @@ void index_tile(ngsqc_handle* h, int t)
 	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };
 	auto e_sz = [&](int64_t e) -> int64_t { return e == 0 ? prefix : (int64_t)h->blocks[(size_t)(first + e - 1)].usize; };
 	Timer tmr(h->stream); tmr.start();
-	h->p_start.ensure((size_t)ne); h->p_next.ensure((size_t)ne);
-	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
-	for (int64_t b = 0; b < ne; ++b)
-	{
-		const int64_t lo = e_lo(b), hi = lo + e_sz(b);
-		start[b] = anchor_by_guess ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
-	}
-	h->d_start.ensure((size_t)ne); h->d_cnt.ensure((size_t)ne + 1); h->d_next.ensure((size_t)ne + 1); h->d_base.ensure((size_t)ne + 1); h->d_bad.ensure(1);
+	h->d_start.ensure((size_t)ne); h->d_cnt.ensure((size_t)ne + 1); h->d_next.ensure((size_t)ne + 1); h->d_base.ensure((size_t)ne + 1); h->d_bad.ensure(2);
 	h->d_scan_tmp.ensure(scan_tmp_bytes(ne) + 64);
-	HIPCHK(hipMemcpyAsync(h->d_start.p, start, (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
 	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
+	// ---- fast path: htslib-style members (a record starts at every member's first byte, none straddles). One round trip: guess + walk every
+	// member's chain, check the pattern on the device, scan the counts; the host reads back {violations, corrupt records, n_rec} only ----
+	launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
+	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
+	launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+	launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
+	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
+	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = n_rec
+	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(sm + 1, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	const uint32_t n_corrupt = ((const uint32_t*)sm)[0], n_viol = ((const uint32_t*)sm)[1];
+	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
+	if (aligned)
+	{
+		if (n_corrupt) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
+		chain_exit = std::max(total, exp0);   // (exp0 > total: the first record of the file starts in a later tile)
+	}
+	else
+	{
+	// ---- general path: records cut by member borders, carried records, shards that guess their first record ----
+	h->p_start.ensure((size_t)ne); h->p_next.ensure((size_t)ne);
+	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
+	bool first_round = true;
 	while (true)
 	{
-		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
-		launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+		if (!first_round)
+		{
+			HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
+			launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+		}
+		first_round = false;
 		HIPCHK(hipMemcpyAsync(start + from, h->d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipMemcpyAsync(next + from, h->d_next.p + from, (size_t)(ne - from) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -538,8 +558,8 @@ void index_tile(ngsqc_handle* h, int t)
 			// without a straddling record the chain leaves the tile exactly at its end - or behind it, when the first record of the file
 			// starts in a later tile (a BAM header longer than the first tile)
 			if (straddle < 0 && expected < total) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (record chain does not end at a member boundary)");
-			chain_exit = straddle < 0 ? expected : total;
 			if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
+			chain_exit = straddle < 0 ? expected : total;
 			break;
 		}
 		if (dbg) fprintf(stderr, "[ngsqc] tile %d: chain mismatch at entry %lld (round %d)\n", t, (long long)mismatch, rounds);
@@ -548,9 +568,10 @@ void index_tile(ngsqc_handle* h, int t)
 		from = mismatch;
 	}
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
-	int64_t n_rec = 0;
-	HIPCHK(hipMemcpyAsync(&n_rec, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(sm + 1, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	int64_t n_rec = (int64_t)sm[1];
 	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec + n_rec / 8, 1));
 	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_base.p, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;

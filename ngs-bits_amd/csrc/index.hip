@@ -124,6 +124,34 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 	if (stop && res == -2) atomicAdd(bad, 1u);
 }
 
+// start[] of every entry from what the host knows before K2: the tile-local offset exp0 of the first record (start = -2: guess)
+__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t exp0, int guess_all, int32_t* __restrict__ start)
+{
+	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+	start[b] = guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
+}
+
+// The common case of an htslib-written BAM: a record starts at the first byte of every member and no record straddles members. Then
+// every member's chain must start at 0 (at exp0 inside the member that holds it, nowhere in front of it) and leave the member exactly at
+// its end - which makes the chain consistent by construction, and the host can skip its sequential verification of the exits.
+// viol counts the entries that do not fit the pattern (any non-zero count sends the tile to the general path).
+__global__ void index_aligned_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t exp0,
+                                     const int32_t* __restrict__ start, const int64_t* __restrict__ next_abs, uint32_t* __restrict__ viol)
+{
+	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool bad = false;
+	if (b < n_blocks)
+	{
+		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+		const int32_t want = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : 0);
+		bad = start[b] != want || (want >= 0 && next_abs[b] != hi);
+	}
+	const unsigned long long m = __ballot(bad);
+	if ((threadIdx.x & 63) == 0 && m) atomicAdd(viol, (uint32_t)__popcll(m));
+}
+
 __global__ void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix,
                                    const int32_t* __restrict__ start, const int64_t* __restrict__ base, int64_t* __restrict__ recoff)
 {
@@ -213,6 +241,17 @@ void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 	}
 	int grid = (int)((n + 63) / 64);
 	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref); KCHECK();
+}
+
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)
+{
+	if (n_entries <= 0) return;
+	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, exp0, guess_all ? 1 : 0, d_start); KCHECK();
+}
+void launch_index_aligned(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, hipStream_t s)
+{
+	if (n_entries <= 0) return;
+	hipLaunchKernelGGL(index_aligned_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, exp0, d_start, d_next, d_viol); KCHECK();
 }
 
 void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,

@@ -27,7 +27,8 @@ namespace ngsqc {
 // ---------------------------------------------------------------------------------------------------------------- phase 1
 constexpr int P1_SYM_W = 81;     // lit_sym : 288 x 9 bit as a byte plane (72 words) + a bit plane (9 words)
 constexpr int P1_RING_W = 8;     // compressed input ring (32 B)
-constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W;   // 89 words per lane (22.8 KB per wave -> 7 waves per CU); tokens wait in registers
+constexpr int P1_DSYM_W = 5;     // distance symbols sorted by (len, sym): 30 x 5 bit, six per word
+constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W + P1_DSYM_W;   // 94 words per lane (24 KB per wave: exactly six waves per CU next to four phase-2 workgroups); tokens wait in registers
 constexpr int P1_SERVICE = 4;    // symbols between service blocks
 
 enum { S_NEXT = 0, S_HDR = 1, S_P1 = 2, S_P2 = 3, S_SYM = 4, S_STORED = 5, S_FINISH = 6, S_DONE = 7 };
@@ -48,6 +49,13 @@ struct P1Lds
 		uint32_t& hi = at(72 + (int)(i >> 5)); hi = (hi & ~(1u << (i & 31))) | ((s >> 8) << (i & 31));
 	}
 	__device__ __forceinline__ uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
+	// distance symbols (i < 30): one LDS read + shift instead of a mask-select over register words
+	__device__ __forceinline__ uint32_t dsym(uint32_t i) const { const uint32_t w = (i * 43u) >> 8; return (at(P1_SYM_W + P1_RING_W + (int)w) >> (5u * (i - 6u * w))) & 31u; }
+	__device__ __forceinline__ void set_dsym(uint32_t i, uint32_t s) const
+	{
+		const uint32_t w = (i * 43u) >> 8, sh = 5u * (i - 6u * w);
+		uint32_t& x = at(P1_SYM_W + P1_RING_W + (int)w); x = (x & ~(31u << sh)) | (s << sh);
+	}
 };
 
 // packed per-length counters: FW bits per field, 32/FW fields per register (FW = 10 for lit/len, 5+1 for dist/CL -> use 6)
@@ -101,24 +109,6 @@ __device__ __forceinline__ int canon_decode(uint32_t bits, const CNT& c, uint32_
 //   limit_l = (first_code_l + count_l) << (15 - l)   (upper bound, left-aligned to 15 bits; non-decreasing in l)
 //   delta_l = offset_l - first_code_l                (index of the length's first symbol in the sorted array minus its first code)
 // With v = the next 15 stream bits MSB-first: length = 1 + #{l : v >= limit_l}, index = (v >> (15 - length)) + delta_length.
-struct DistSyms
-{
-	uint64_t q[3];
-	__device__ __forceinline__ void clear() { q[0] = q[1] = q[2] = 0; }
-	__device__ __forceinline__ uint32_t get(uint32_t i) const
-	{
-		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u);   // i / 12 for i < 36
-		uint64_t v = (q[0] & (0ull - (uint64_t)(reg == 0))) | (q[1] & (0ull - (uint64_t)(reg == 1))) | (q[2] & (0ull - (uint64_t)(reg == 2)));
-		return (uint32_t)(v >> sh) & 31u;
-	}
-	__device__ __forceinline__ void set(uint32_t i, uint32_t s)
-	{
-		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u); uint64_t m = 31ull << sh, val = (uint64_t)s << sh;
-		#pragma unroll
-		for (int k = 0; k < 3; ++k) q[k] = reg == (uint32_t)k ? ((q[k] & ~m) | val) : q[k];
-	}
-};
-
 struct LimTab
 {
 	uint32_t w[15];   // (limit_l << 16) | (delta_l & 0xffff) for l = 1..15
@@ -163,10 +153,10 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
                                                           BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)
 {
-	// 23 KB per one-wave workgroup: exactly six fit a CU's 160 KB and a seventh does not, so the workgroups of the NEXT chunk's
+	// 23.5 KB per one-wave workgroup: exactly six fit a CU's 160 KB and a seventh does not, so the workgroups of the NEXT chunk's
 	// launch (queued on a second stream) take over the slots of this launch's finished waves without ever squeezing the LDS that
 	// the phase-2 / CRC / scan workgroups need beside them
-	__shared__ uint32_t lds[P1_LANE_W * 64 + 192];
+	__shared__ uint32_t lds[P1_LANE_W * 64];
 	const int lane = threadIdx.x;
 	P1Lds L{lds, lane};
 	const uint4* const comp_q = (const uint4*)comp;
@@ -185,7 +175,6 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	uint32_t tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, tq6 = 0;   // unflushed tokens, newest first (a shift register: at most 3 left over + 4 new between services)
 	uint32_t out_n = 0, err = 0; int bfinal = 0;
 	LimTab limL, limD;                                       // decode tables of the current deflate block (registers)
-	DistSyms dsym; dsym.clear();                             // distance symbols sorted by (len, sym)
 	#pragma unroll
 	for (int i = 0; i < 15; ++i) { limL.w[i] = 0; limD.w[i] = 0; }
 	LitCnt cl; DistCnt cd; cl.clear(); cd.clear();          // code-length counts
@@ -281,7 +270,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 				uint32_t dl;
 				const int di = limD.decode((uint32_t)bitbuf, dl);
 				if ((uint32_t)di >= 30u) e = 11;
-				const uint32_t ds = dsym.get((uint32_t)di < 30u ? (uint32_t)di : 29u);
+				const uint32_t ds = L.dsym((uint32_t)di < 30u ? (uint32_t)di : 29u);
 				bitbuf >>= dl; bitcnt -= dl; bits_used += dl;
 				if (ds >= 30) e = 12;
 				const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
@@ -346,7 +335,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 							{
 								uint32_t i = h_i + k;
 								if (i < h_nlit) { uint32_t o = ol.get(val - 1); ol.add(val - 1, 1); L.set_litsym(o, i); }
-								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); dsym.set(o, i - h_nlit); }
+								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); L.set_dsym(o < 30u ? o : 29u, i - h_nlit); }
 							}
 						}
 						h_i += rep; if (sym < 16) h_prev = (uint32_t)sym; else if (sym != 16) h_prev = 0;
@@ -395,7 +384,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 					for (uint32_t s = 0; s < 144; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 280; s < 288; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 144; s < 256; ++s) L.set_litsym(k++, s);
-					for (uint32_t s = 0; s < 30; ++s) dsym.set(s, s);
+					for (uint32_t s = 0; s < 30; ++s) L.set_dsym(s, s);
 					limL.build(cl); limD.build(cd);
 					state = S_SYM;
 				}

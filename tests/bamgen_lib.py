@@ -25,6 +25,24 @@ def lib():
     return _lib
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup CPU quota when there is one (a 256-thread host behind a 16-CPU quota runs 16), else
+    the affinity mask / os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 class _Mapping:
     """Owner of the generator's anonymous mapping: the numpy view keeps it alive through its base chain."""
 
@@ -41,6 +59,8 @@ class _Mapping:
 def generate(n_reads, seed=20260821, mode=0, depth=30.0, first_contig=0, start_pos=0, level=6, aligned=True, threads=0):
     """Returns the BAM file image as a numpy uint8 array (a zero-copy view of the generator's buffer).
     mode 0 = short-read WGS, 1 = ONT-like long reads."""
+    if threads <= 0:
+        threads = 2 * effective_cpus()   # (oversubscribing a CPU quota costs: 256 threads on a 16-CPU quota were 1.5x slower than 32)
     n, cap = C.c_size_t(0), C.c_size_t(0)
     p = lib().bamgen_generate_map(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, C.byref(n), C.byref(cap))
     if not p:

@@ -56,14 +56,16 @@ def _compare_mapping(bam, mode, bed, merge_mode, cfdna=False, min_mapq=1, tmp_ro
         regs, _ = H.bed_regions(bed, refs, merge_mode)
         # real GC bins of roi.chunk(100) from a synthetic genome: the (bin, n) hit table, the n >= 64 path and the host-side reconstruction
         # of gc_reads all take part (Statistics.cpp:363-387, 533-541, 1164-1171)
-        fasta = _fasta(bed, refs, tmp_root)
-        gc, bins = H.gc_inputs(bed, refs, fasta, merge_mode)
-        assert any(b >= 0 for b in bins)
+        # (the OMIM regions are 416 k chunks: the oracle's FASTA leg takes ~40 s there, so only one OMIM case runs with a genome)
+        if sum(1 for _ in open(bed)) < 5000 or bam == "MappingQC_in5.bam":
+            fasta = _fasta(bed, refs, tmp_root)
+            gc, bins = H.gc_inputs(bed, refs, fasta, merge_mode)
+            assert any(b >= 0 for b in bins)
     tx, ty = H.xy_tids(refs)
     counters, gc_reads = h.scan_mapping(mode, regions=regs, min_mapq=min_mapq, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs),
                                         gc_chunks=gc, gc_bin=bins)
     exp = O.mapping(ob, mode, bed, merge_bed=(merge_mode == 1), fasta=fasta, min_mapq=min_mapq, cfdna=cfdna)
-    if bed:
+    if fasta:
         want = np.zeros(101); want[:exp.gc_reads.size] = exp.gc_reads
         assert exp.have_gc and np.allclose(gc_reads, want, rtol=1e-12, atol=0.0), (bam, float(np.abs(gc_reads - want).max()))
         assert want.sum() > 0 or counters[O.COUNTER_NAMES.index("al_ontarget")] == 0

@@ -21,9 +21,9 @@ OMIM = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
 SKIP = {O.COUNTER_NAMES.index("half_depth"), O.COUNTER_NAMES.index("bases_covered_half")}
 
 
-def _sharded_vs_oracle(path, bed, qc_mode, merge_mode, n_shards, by_path=False):
+def _sharded_vs_oracle(path, bed, qc_mode, merge_mode, n_shards, by_path=False, fasta=None):
     ob = O.Bam(path)
-    exp = O.mapping(ob, qc_mode, bed, merge_bed=(merge_mode == 1))
+    exp = O.mapping(ob, qc_mode, bed, merge_bed=(merge_mode == 1), fasta=fasta)
     data = None if by_path else np.fromfile(path, dtype=np.uint8)
     hs = [ngsqc.Handle(path=path, shard=(i, n_shards)) if by_path else ngsqc.Handle(data=data, shard=(i, n_shards)) for i in range(n_shards)]
     try:
@@ -31,8 +31,15 @@ def _sharded_vs_oracle(path, bed, qc_mode, merge_mode, n_shards, by_path=False):
         if bed:
             regs, _ = H.bed_regions(bed, hs[0].refs, merge_mode)
         tx, ty = H.xy_tids(hs[0].refs)
-        counters, gc, summaries = ngsqc.scan_mapping_sharded_local(hs, qc_mode, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(hs[0].refs))
+        gck = {}
+        if fasta:   # GC bins of roi.chunk(100): the shards' gc_reads are additive
+            chunks, bins = H.gc_inputs(bed, hs[0].refs, fasta, merge_mode)
+            gck = dict(gc_chunks=chunks, gc_bin=bins)
+        counters, gc, summaries = ngsqc.scan_mapping_sharded_local(hs, qc_mode, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(hs[0].refs), **gck)
         assert int(summaries[:, 0].sum()) == ob.count, summaries
+        if fasta:
+            want = np.zeros(101); want[:exp.gc_reads.size] = exp.gc_reads
+            assert want.sum() > 0 and np.allclose(gc, want, rtol=1e-12, atol=0.0), float(np.abs(gc - want).max())
         for i in range(len(counters)):
             if i not in SKIP:
                 assert int(counters[i]) == int(exp.counters[i]), (O.COUNTER_NAMES[i] if i < 32 else f"insert_hist[{i - 32}]", int(counters[i]), int(exp.counters[i]), summaries)
@@ -71,8 +78,31 @@ def test_long_reads_longer_than_members(tmp_path):
     G.write(path, n_reads=1200, seed=23, mode=1, depth=40.0, start_pos=15_900_000)
     bed = tmp_path / "chr1.bed"
     bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
-    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4)
-    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3)
+    fasta = H.sparse_fasta_for(str(bed), [("chr1", 248956422)], str(tmp_path / "chr1.fa"), seed=first_full + 1)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4, fasta=fasta)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3, fasta=fasta)
+
+
+@pytest.mark.parametrize("first_full,first_paired", [(0, 0), (3100, 4200), (5900, 2), (2500, 6000)])
+@pytest.mark.parametrize("tile_members", [1, 2, 5])
+def test_carries_cross_tiles(tmp_path, monkeypatch, first_full, first_paired, tile_members):
+    """Unsharded handle, file cut into small tiles: the running maximum read length and "a paired read has been seen" are resolved while each
+    tile is resident (no second visit): the first full-length / first paired read sits in a later tile than the records it affects."""
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    path = str(tmp_path / "crafted.bam")
+    _crafted_bam(path, 6000, first_full, first_paired, [20_000, 33_333, 7_000])
+    bed = tmp_path / "chr1.bed"
+    bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
+    ob = O.Bam(path)
+    h = ngsqc.Handle(path=path)
+    for mode, b, mm in ((ngsqc.MODE_NOROI, None, 0), (ngsqc.MODE_WGS, str(bed), 3), (ngsqc.MODE_ROI, str(bed), 1)):
+        regs = H.bed_regions(b, h.refs, mm)[0] if b else None
+        counters, _ = h.scan_mapping(mode, regions=regs, nonspecial=H.nonspecial(h.refs))
+        exp = O.mapping(ob, mode, b, merge_bed=(mm == 1))
+        bad = [(O.COUNTER_NAMES[i] if i < 32 else i, int(counters[i]), int(exp.counters[i])) for i in range(len(counters)) if i not in SKIP and int(counters[i]) != int(exp.counters[i])]
+        assert not bad, (mode, bad[:5])
+    assert h.timings()["n_tiles"] >= 3
+    h.close()
 
 
 def test_multi_tile_shards(tmp_path, monkeypatch):
@@ -127,8 +157,31 @@ def test_carries_cross_shards(tmp_path, first_full, first_paired):
             assert s[0, 3] < 150                               # shard 0 never sees a full-length read: the carry really crosses shards
     bed = tmp_path / "chr1.bed"
     bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
-    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4)
-    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3)
+    fasta = H.sparse_fasta_for(str(bed), [("chr1", 248956422)], str(tmp_path / "chr1.fa"), seed=first_full + 1)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_WGS, 3, 4, fasta=fasta)
+    _sharded_vs_oracle(path, str(bed), ngsqc.MODE_ROI, 1, 3, fasta=fasta)
+
+
+@pytest.mark.parametrize("first_full,first_paired", [(0, 0), (3100, 4200), (5900, 2), (2500, 6000)])
+@pytest.mark.parametrize("tile_members", [1, 2, 5])
+def test_carries_cross_tiles(tmp_path, monkeypatch, first_full, first_paired, tile_members):
+    """Unsharded handle, file cut into small tiles: the running maximum read length and "a paired read has been seen" are resolved while each
+    tile is resident (no second visit): the first full-length / first paired read sits in a later tile than the records it affects."""
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    path = str(tmp_path / "crafted.bam")
+    _crafted_bam(path, 6000, first_full, first_paired, [20_000, 33_333, 7_000])
+    bed = tmp_path / "chr1.bed"
+    bed.write_text("chr1\t16000100\t16003000\tA\nchr1\t16010000\t16030000\tB\nchr1\t16050000\t16050400\tC\n")
+    ob = O.Bam(path)
+    h = ngsqc.Handle(path=path)
+    for mode, b, mm in ((ngsqc.MODE_NOROI, None, 0), (ngsqc.MODE_WGS, str(bed), 3), (ngsqc.MODE_ROI, str(bed), 1)):
+        regs = H.bed_regions(b, h.refs, mm)[0] if b else None
+        counters, _ = h.scan_mapping(mode, regions=regs, nonspecial=H.nonspecial(h.refs))
+        exp = O.mapping(ob, mode, b, merge_bed=(mm == 1))
+        bad = [(O.COUNTER_NAMES[i] if i < 32 else i, int(counters[i]), int(exp.counters[i])) for i in range(len(counters)) if i not in SKIP and int(counters[i]) != int(exp.counters[i])]
+        assert not bad, (mode, bad[:5])
+    assert h.timings()["n_tiles"] >= 3
+    h.close()
 
 
 _ALIAS = r"""

@@ -114,3 +114,30 @@ def test_mappingqc_inflates_every_member_once_for_all_passes(tmp_path):
     # known SNVs inside this small target region and does not read the BAM)
     per_pass = [int(x) for x in re.findall(r"pass: (\d+) BGZF members inflated", outs["separate"][2])]
     assert sum(per_pass) >= 3 * int(m.group(3)), outs["separate"][2]
+
+
+@pytest.mark.parametrize("case", ["roi", "wgs"])
+def test_mappingqc_dropout_lines_with_a_reference_genome(tmp_path, case):
+    """`AT dropout` / `GC dropout` need a genome (Statistics.cpp:363-387, 576-604): with a synthetic one (tools/fastagen.py) the tool's whole TXT output -
+    dropout lines included, nothing stripped - must equal the oracle's values, in target-region mode and in -wgs mode (OMIM ROI, N-base correction)."""
+    import hostprep as H
+    if case == "roi":
+        bam, bed = os.path.join(GI, "close_exons.bam"), os.path.join(GI, "close_exons.bed")
+        args, env, mode, merge = ["-roi", bed], {}, 0, True
+    else:
+        # -wgs takes the OMIM ROI from the resource directory: point it at a copy whose ROI lies where this small BAM has reads
+        bam = os.path.join(GI, "Statistics_mapqc_wgs.bam"); src = os.path.join(GI, "Statistics_mapqc_wgs.bed")
+        res = tmp_path / "resources"; res.mkdir()
+        for f in os.listdir(os.path.join(ROOT, "ngs-bits_amd", "resources")):
+            if not f.endswith("omim_genes.bed"):
+                os.symlink(os.path.join(ROOT, "ngs-bits_amd", "resources", f), res / f)
+        bed = str(res / "hg38_440_omim_genes.bed"); open(bed, "w").write(open(src).read())
+        args, env, mode, merge = ["-wgs"], {"NGSQC_RESOURCES": str(res)}, 2, False
+    ob = O.Bam(bam)
+    fasta = H.sparse_fasta_for(bed, ob.refs, str(tmp_path / "genome.fa"), seed=19)
+    out = str(tmp_path / "out.txt")
+    run("MappingQC", "-in", bam, *args, "-ref", fasta, "-build", "hg38", "-no_cont", "-txt", "-out", out, env=env)
+    got = dict(ln.split(": ", 1) for ln in open(out).read().splitlines() if ": " in ln)
+    exp = O.mapping(ob, mode, bed, merge_bed=merge, fasta=fasta).values()
+    assert exp["AT dropout"] != "n/a" and float(exp["AT dropout"]) + float(exp["GC dropout"]) > 0
+    assert got == {k: v for k, v in exp.items()}, (sorted(set(got.items()) ^ set(exp.items())))

@@ -26,6 +26,7 @@ VARIANTS = {
     "unsorted": {"NGSQC_K1_SORTED": "0"},
     "park8": {"NGSQC_P1_PARK": "8"}, "park24": {"NGSQC_P1_PARK": "24"}, "park32": {"NGSQC_P1_PARK": "32"},
     "debug": {"NGSQC_DEBUG": "1"},
+    "p2wg768": {"NGSQC_P2_WGS": "768"}, "p2wg2048": {"NGSQC_P2_WGS": "2048"}, "p2wg512": {"NGSQC_P2_WGS": "512"},
     "p2wg1024": {"NGSQC_P2_WGS": "1024"}, "p2wg4096": {"NGSQC_P2_WGS": "4096"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
@@ -36,7 +37,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     names = sys.argv[3].split(",") if len(sys.argv) > 3 else ["default", "nopipe", "nocrc"]
     t0 = time.time()
-    image = G.generate(reads, threads=os.cpu_count() or 8)
+    image = G.generate(reads)
     print(f"[probe] generated {reads} reads, {image.size} bytes in {time.time() - t0:.1f} s on {os.cpu_count()} cpus", flush=True)
     omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
     ref = None
