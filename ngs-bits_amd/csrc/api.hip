@@ -419,12 +419,13 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
 	// CRC of a chunk in line behind its phase 2 (default). On its own stream (NGSQC_CRC_STREAM=1) it runs beside phase 2 of the next chunk and
 	// takes the LDS that phase 2's workgroups need next to the six phase-1 waves of a CU: measured 84 ms instead of 74 ms per 48 M reads.
+	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;   // 1: the next chunk's phase 1 starts when the whole previous launch is done
 	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (ce && atoi(ce) != 0) ? h->s_crc : h->s_p2;
 	for (int64_t c = h->tile_first_chunk[(size_t)t]; c < h->tile_first_chunk[(size_t)t + 1]; ++c)
 	{
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
-		hipStream_t s1 = h->s_p1[c & 1];
+		hipStream_t s1 = h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= K1_SLOTS) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - K1_SLOTS) + 3)], 0));   // the ring slot is free again
 		HIPCHK(hipEventRecord(e4[0], s1));
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_work.p + c,

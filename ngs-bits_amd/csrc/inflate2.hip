@@ -27,8 +27,8 @@ namespace ngsqc {
 // ---------------------------------------------------------------------------------------------------------------- phase 1
 constexpr int P1_SYM_W = 81;     // lit_sym : 288 x 9 bit as a byte plane (72 words) + a bit plane (9 words)
 constexpr int P1_RING_W = 8;     // compressed input ring (32 B)
-constexpr int P1_DSYM_W = 5;     // distance symbols sorted by (len, sym): 30 x 5 bit, six per word
-constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W + P1_DSYM_W;   // 94 words per lane (24 KB per wave: exactly six waves per CU next to four phase-2 workgroups); tokens wait in registers
+constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W;   // 89 words per lane (22.8 KB per wave); tokens and the distance symbols wait in registers
+constexpr int P1_PAD_W = 192;    // + 768 B: 23 KB per one-wave workgroup (see the kernel)
 constexpr int P1_SERVICE = 4;    // symbols between service blocks
 
 enum { S_NEXT = 0, S_HDR = 1, S_P1 = 2, S_P2 = 3, S_SYM = 4, S_STORED = 5, S_FINISH = 6, S_DONE = 7 };
@@ -49,13 +49,6 @@ struct P1Lds
 		uint32_t& hi = at(72 + (int)(i >> 5)); hi = (hi & ~(1u << (i & 31))) | ((s >> 8) << (i & 31));
 	}
 	__device__ __forceinline__ uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
-	// distance symbols (i < 30): one LDS read + shift instead of a mask-select over register words
-	__device__ __forceinline__ uint32_t dsym(uint32_t i) const { const uint32_t w = (i * 43u) >> 8; return (at(P1_SYM_W + P1_RING_W + (int)w) >> (5u * (i - 6u * w))) & 31u; }
-	__device__ __forceinline__ void set_dsym(uint32_t i, uint32_t s) const
-	{
-		const uint32_t w = (i * 43u) >> 8, sh = 5u * (i - 6u * w);
-		uint32_t& x = at(P1_SYM_W + P1_RING_W + (int)w); x = (x & ~(31u << sh)) | (s << sh);
-	}
 };
 
 // packed per-length counters: FW bits per field, 32/FW fields per register (FW = 10 for lit/len, 5+1 for dist/CL -> use 6)
@@ -109,6 +102,27 @@ __device__ __forceinline__ int canon_decode(uint32_t bits, const CNT& c, uint32_
 //   limit_l = (first_code_l + count_l) << (15 - l)   (upper bound, left-aligned to 15 bits; non-decreasing in l)
 //   delta_l = offset_l - first_code_l                (index of the length's first symbol in the sorted array minus its first code)
 // With v = the next 15 stream bits MSB-first: length = 1 + #{l : v >= limit_l}, index = (v >> (15 - length)) + delta_length.
+// Distance symbols sorted by (len, sym), 30 x 5 bit in three 64-bit registers (mask-select, no indexed access). Keeping them in LDS
+// instead (5 more words per lane) was measured: phase 1 did not get faster, and the 512 B it costs per wave push the CU from four to
+// three resident phase-2 workgroups (lz77 53 -> 71 ms per 48 M reads).
+struct DistSyms
+{
+	uint64_t q[3];
+	__device__ __forceinline__ void clear() { q[0] = q[1] = q[2] = 0; }
+	__device__ __forceinline__ uint32_t get(uint32_t i) const
+	{
+		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u);   // i / 12 for i < 36
+		uint64_t v = (q[0] & (0ull - (uint64_t)(reg == 0))) | (q[1] & (0ull - (uint64_t)(reg == 1))) | (q[2] & (0ull - (uint64_t)(reg == 2)));
+		return (uint32_t)(v >> sh) & 31u;
+	}
+	__device__ __forceinline__ void set(uint32_t i, uint32_t s)
+	{
+		uint32_t reg = (i * 43u) >> 9, sh = 5u * (i - reg * 12u); uint64_t m = 31ull << sh, val = (uint64_t)s << sh;
+		#pragma unroll
+		for (int k = 0; k < 3; ++k) q[k] = reg == (uint32_t)k ? ((q[k] & ~m) | val) : q[k];
+	}
+};
+
 struct LimTab
 {
 	uint32_t w[15];   // (limit_l << 16) | (delta_l & 0xffff) for l = 1..15
@@ -149,14 +163,15 @@ struct LimTab
 	}
 };
 
+template <int PAD_W>
 __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                                           const uint64_t* __restrict__ tok_off, uint32_t* __restrict__ tok, uint32_t* __restrict__ tok_count,
                                                           BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)
 {
-	// 23.5 KB per one-wave workgroup: exactly six fit a CU's 160 KB and a seventh does not, so the workgroups of the NEXT chunk's
+	// 23 KB per one-wave workgroup: exactly six fit a CU's 160 KB and a seventh does not, so the workgroups of the NEXT chunk's
 	// launch (queued on a second stream) take over the slots of this launch's finished waves without ever squeezing the LDS that
 	// the phase-2 / CRC / scan workgroups need beside them
-	__shared__ uint32_t lds[P1_LANE_W * 64];
+	__shared__ uint32_t lds[P1_LANE_W * 64 + PAD_W];
 	const int lane = threadIdx.x;
 	P1Lds L{lds, lane};
 	const uint4* const comp_q = (const uint4*)comp;
@@ -174,6 +189,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	uint32_t* tok_ptr = nullptr; uint32_t tok_cap = 0, tok_n = 0, tok_flushed = 0;
 	uint32_t tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, tq6 = 0;   // unflushed tokens, newest first (a shift register: at most 3 left over + 4 new between services)
 	uint32_t out_n = 0, err = 0; int bfinal = 0;
+	DistSyms dsym; dsym.clear();                             // distance symbols sorted by (len, sym)
 	LimTab limL, limD;                                       // decode tables of the current deflate block (registers)
 	#pragma unroll
 	for (int i = 0; i < 15; ++i) { limL.w[i] = 0; limD.w[i] = 0; }
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 				uint32_t dl;
 				const int di = limD.decode((uint32_t)bitbuf, dl);
 				if ((uint32_t)di >= 30u) e = 11;
-				const uint32_t ds = L.dsym((uint32_t)di < 30u ? (uint32_t)di : 29u);
+				const uint32_t ds = dsym.get((uint32_t)di < 30u ? (uint32_t)di : 29u);
 				bitbuf >>= dl; bitcnt -= dl; bits_used += dl;
 				if (ds >= 30) e = 12;
 				const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 							{
 								uint32_t i = h_i + k;
 								if (i < h_nlit) { uint32_t o = ol.get(val - 1); ol.add(val - 1, 1); L.set_litsym(o, i); }
-								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); L.set_dsym(o < 30u ? o : 29u, i - h_nlit); }
+								else { uint32_t o = od.get(val - 1); od.add(val - 1, 1); dsym.set(o, i - h_nlit); }
 							}
 						}
 						h_i += rep; if (sym < 16) h_prev = (uint32_t)sym; else if (sym != 16) h_prev = 0;
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 					for (uint32_t s = 0; s < 144; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 280; s < 288; ++s) L.set_litsym(k++, s);
 					for (uint32_t s = 144; s < 256; ++s) L.set_litsym(k++, s);
-					for (uint32_t s = 0; s < 30; ++s) L.set_dsym(s, s);
+					for (uint32_t s = 0; s < 30; ++s) dsym.set(s, s);
 					limL.build(cl); limD.build(cd);
 					state = S_SYM;
 				}
@@ -614,7 +630,10 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
 	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
-	hipLaunchKernelGGL(huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi); KCHECK();
+	const char* epad = getenv("NGSQC_P1_PAD"); const bool pad = !epad || atoi(epad) != 0;   // 0: 22.8 KB workgroups (a seventh may squeeze in beside the phase-2 workgroups)
+	if (pad) hipLaunchKernelGGL(huff_tokens_kernel<P1_PAD_W>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
+	else hipLaunchKernelGGL(huff_tokens_kernel<0>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
+	KCHECK();
 }
 
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
@@ -622,7 +641,7 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 {
 	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
-	static const int64_t cap2 = [] { const char* e = getenv("NGSQC_P2_WGS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)256 * 4; }();   // 16 waves per CU: as fast as 32 (measured) and leaves wave slots for K2 / the consumers of the previous tile
+	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)256 * 4;   // 16 waves per CU: as fast as 32 (measured) and leaves wave slots for K2 / the consumers of the previous tile
 	int grid2 = (int)(wg2 < cap2 ? wg2 : cap2);
 	hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }

@@ -160,13 +160,15 @@ std::vector<ngsqc_region> toRegions(const BedFile& bed, const BamReader& reader,
 struct KnownSnp { Chromosome chr; int pos; char ref, alt; };
 struct SnpSites { std::vector<KnownSnp> snps; std::vector<ngsqc_region> sites; std::vector<size_t> slot; };   // slot[i]: row of snps[i] in the (tid, pos)-sorted site table
 
-std::vector<KnownSnp> loadKnownSnps(const std::string& build, const std::string& roi_file)
+std::vector<KnownSnp> loadKnownSnps(const std::string& build, const std::string& roi_file, const BedFile* roi_in = nullptr)
 {
 	// target region: variants whose [pos, pos + len(ref) - 1] overlaps a line are kept (VcfFile::setRegion / VcfFile.cpp:131-136)
 	std::map<int, std::vector<std::pair<int, int>>> roi_by_chr; std::map<int, std::vector<int>> roi_pmax;
-	if (roi_file != "")
+	const bool have_roi = roi_file != "" || roi_in != nullptr;
+	if (have_roi)
 	{
-		BedFile roi; roi.load(roi_file); roi.sort();
+		BedFile roi; if (roi_in) roi.add(*roi_in); else roi.load(roi_file);
+		roi.sort();
 		for (long long i = 0; i < roi.count(); ++i) roi_by_chr[roi[i].chr().num()].push_back({roi[i].start(), roi[i].end()});
 		for (auto& kv : roi_by_chr) { std::vector<int>& pm = roi_pmax[kv.first]; int m = 0; for (auto& se : kv.second) { m = std::max(m, se.second); pm.push_back(m); } }
 	}
@@ -187,7 +189,7 @@ std::vector<KnownSnp> loadKnownSnps(const std::string& build, const std::string&
 		if (c.size() < 5) continue;
 		const int pos = atoi(c[1].c_str());
 		Chromosome chr(c[0]);
-		if (roi_file != "" && !in_roi(chr, pos, pos + (int)c[2].size() - 1)) continue;
+		if (have_roi && !in_roi(chr, pos, pos + (int)c[2].size() - 1)) continue;
 		char* end = nullptr; double af = c[4].empty() ? 0.0 : strtod(c[4].c_str(), &end); if (c[4].empty() || *end) af = 0.0;   // QByteArray::toDouble
 		if (!(af >= 0.2 && af <= 0.8)) continue;
 		std::string alt0 = c[3].substr(0, c[3].find(','));
@@ -331,7 +333,6 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 		for (auto& t : th) t.join();
 	}
 	for (int i = 0; i < n; ++i) checkShard(sh[(size_t)i], rcs[(size_t)i]);
-	std::vector<int32_t> diff_sum, diff;
 	for (int i = 0; i < n; ++i)
 	{
 		ngsqc_shard_fix fix{};
@@ -344,17 +345,10 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 			s.c[(size_t)k] = max_like ? std::max(s.c[(size_t)k], c[(size_t)k]) : s.c[(size_t)k] + c[(size_t)k];
 		}
 		for (int k = 0; k < 101; ++k) s.gc_reads[(size_t)k] += g[(size_t)k];
-		// difference arrays are additive: summed on the host here (a multi-process deployment all-reduces them over RCCL instead)
-		void* dptr = nullptr; int64_t slots = 0;
-		checkShard(sh[(size_t)i], ngsqc_depth_device(sh[(size_t)i], &dptr, &slots));
-		if (slots > 0)
-		{
-			diff.resize((size_t)slots);
-			checkShard(sh[(size_t)i], ngsqc_depth_diff_copy(sh[(size_t)i], diff.data(), slots));
-			if (diff_sum.empty()) diff_sum = diff; else for (int64_t k = 0; k < slots; ++k) diff_sum[(size_t)k] += diff[(size_t)k];
-		}
 	}
-	if (!diff_sum.empty()) checkShard(sh[0], ngsqc_depth_diff_set(sh[0], diff_sum.data(), (int64_t)diff_sum.size()));
+	// difference arrays are additive: summed on shard 0's GPU; shards on other GPUs are pulled with peer copies over xGMI, nothing passes
+	// through host memory (a multi-process deployment all-reduces them over RCCL instead: ngs-bits_amd/dist.py)
+	checkShard(sh[0], ngsqc_depth_reduce(sh[0], sh.data() + 1, n - 1));
 	checkShard(sh[0], ngsqc_depth_finalize(sh[0]));
 	return s;
 }
@@ -376,17 +370,8 @@ void runDepthScan(BamReader& reader, const ngsqc_depth_params& p)
 		for (auto& t : th) t.join();
 	}
 	auto chk = [&](ngsqc_handle* h, int rc) { if (rc == NGSQC_OK) return; std::string msg = ngsqc_last_error(h); if (rc == NGSQC_E_ARG) NB_THROW(ArgumentException, msg); if (rc == NGSQC_E_FORMAT) NB_THROW(FileAccessException, msg); NB_THROW(Exception, msg); };
-	std::vector<int32_t> sum, diff;
-	for (int i = 0; i < n; ++i)
-	{
-		chk(sh[(size_t)i], rcs[(size_t)i]);
-		void* dptr = nullptr; int64_t slots = 0;
-		chk(sh[(size_t)i], ngsqc_depth_device(sh[(size_t)i], &dptr, &slots));
-		diff.resize((size_t)slots);
-		if (slots) chk(sh[(size_t)i], ngsqc_depth_diff_copy(sh[(size_t)i], diff.data(), slots));
-		if (sum.empty()) sum = diff; else for (int64_t k = 0; k < slots; ++k) sum[(size_t)k] += diff[(size_t)k];
-	}
-	if (!sum.empty()) chk(sh[0], ngsqc_depth_diff_set(sh[0], sum.data(), (int64_t)sum.size()));
+	for (int i = 0; i < n; ++i) chk(sh[(size_t)i], rcs[(size_t)i]);
+	chk(sh[0], ngsqc_depth_reduce(sh[0], sh.data() + 1, n - 1));   // device-side sum (peer copies between GPUs)
 	chk(sh[0], ngsqc_depth_finalize(sh[0]));
 }
 
@@ -862,6 +847,86 @@ QCCollection Statistics::contamination(const std::string& build, const std::stri
 	if (!t.sites.empty()) reader.check(ngsqc_site_pileup(reader.handle(), t.sites.data(), (int64_t)t.sites.size(), 1, 13, include_not_properly_paired ? 1 : 0, counts.data()));
 	if (getenv("NGSQC_TIMING")) { ngsqc_timings tm{}; ngsqc_get_timings(reader.handle(), &tm); fprintf(stderr, "[ngsqc] contamination pass: %lld BGZF members inflated\n", (long long)tm.members_inflated); }
 	return contaminationFromCounts(t, counts, debug, min_cov, min_snps);
+}
+
+// ---------------------------------------------------------------- SampleGender (Statistics.cpp:2811-2902)
+GenderEstimate Statistics::genderXY(const std::string& bam_file, double max_female, double min_male, const std::string& ref_file)
+{
+	BamReader reader(bam_file, ref_file);
+	// Statistics::yxRatio (:2659-2691): two indexed passes over chrY and chrX in the reference, two counters of one scan here
+	double count_x = 0.0, count_y = 0.0, ratio_yx = std::numeric_limits<double>::quiet_NaN();
+	if (reader.chromosomeID(Chromosome("chrX")) >= 0 && reader.chromosomeID(Chromosome("chrY")) >= 0)
+	{
+		reader.requireIndex();   // setRegion (BamReader.cpp:740-746)
+		Scan s = runScan(reader, NGSQC_MODE_NOROI, 1, {}, nullptr, nullptr);
+		count_x = (double)s[NGSQC_C_READS_X]; count_y = (double)s[NGSQC_C_READS_Y];
+		if (count_x != 0) ratio_yx = count_y / count_x;
+	}
+	GenderEstimate output;
+	output.add_info.push_back({"reads_chry", number(count_y, 0)});
+	output.add_info.push_back({"reads_chrx", number(count_x, 0)});
+	output.add_info.push_back({"ratio_chry_chrx", std::isnan(ratio_yx) ? std::string("nan") : number(ratio_yx, 4)});
+	if (ratio_yx <= max_female) output.gender = "female";
+	else if (ratio_yx >= min_male) output.gender = "male";
+	else output.gender = "unknown (ratio in gray area)";
+	return output;
+}
+
+GenderEstimate Statistics::genderHetX(const std::string& build, const std::string& bam_file, double max_male, double min_female, const std::string& ref_file, bool include_not_properly_paired)
+{
+	BamReader reader(bam_file, ref_file);
+	// common SNPs on chrX outside the pseudo-autosomal regions (NGSHelper::pseudoAutosomalRegion, NGSHelper.cpp:415-434)
+	Chromosome chrx("chrX");
+	const int chrx_end_pos = reader.chromosomeSize(chrx);
+	const bool hg38 = build == "hg38";
+	const int par[2][2] = {{hg38 ? 10001 : 60001, hg38 ? 2781479 : 2699520}, {hg38 ? 155701383 : 154931044, hg38 ? 156030895 : 155260560}};
+	BedFile roi_chrx;   // chrX:[1, end] minus the two PAR lines (BedFile::subtract)
+	int s0 = 1;
+	for (int k = 0; k < 2; ++k) { if (par[k][0] > s0) roi_chrx.append(BedLine(chrx, s0, std::min(par[k][0] - 1, chrx_end_pos))); s0 = std::max(s0, par[k][1] + 1); }
+	if (s0 <= chrx_end_pos) roi_chrx.append(BedLine(chrx, s0, chrx_end_pos));
+	SnpSites t = snpSites(reader, loadKnownSnps(build, "", &roi_chrx));
+	std::vector<int64_t> counts(t.sites.size() * 8, 0);
+	if (!t.sites.empty()) reader.check(ngsqc_site_pileup(reader.handle(), t.sites.data(), (int64_t)t.sites.size(), 20, 20, include_not_properly_paired ? 1 : 0, counts.data()));
+	int c_all = 0, c_het = 0;
+	for (size_t i = 0; i < t.snps.size(); ++i)
+	{
+		const int64_t* c = &counts[t.slot[i] * 8];
+		if (c[6]) NB_THROW(ArgumentException, "Unknown base in pileup!");
+		if (c[7]) NB_THROW(Exception, "Could not find position " + std::to_string(t.snps[i].pos) + " in read!");
+		const long long depth = c[0] + c[1] + c[2] + c[3];
+		if (depth < 20) continue;
+		auto cnt = [&](char b) -> double { b = (char)toupper(b); return b == 'A' ? (double)c[0] : b == 'C' ? (double)c[1] : b == 'G' ? (double)c[2] : b == 'T' ? (double)c[3] : b == 'N' ? (double)c[4] : -1.0; };
+		const double w = cnt(t.snps[i].ref), m = cnt(t.snps[i].alt);
+		if (w < 0) NB_THROW(ArgumentException, std::string("Unknown wild-type base '") + t.snps[i].ref + "' in frequency calculation!");
+		if (m < 0) NB_THROW(ArgumentException, std::string("Unknown mutant base '") + t.snps[i].alt + "' in frequency calculation!");
+		if (w + m == 0) continue;   // frequency() is NaN
+		const double af = m / (w + m);
+		++c_all;
+		if (af > 0.1 && af < 0.9) ++c_het;
+	}
+	const double het_frac = (double)c_het / c_all;
+	GenderEstimate output;
+	output.add_info.push_back({"snps_usable", std::to_string(c_all) + " of " + std::to_string(t.snps.size())});
+	output.add_info.push_back({"hom_count", std::to_string(c_all - c_het)});
+	output.add_info.push_back({"het_count", std::to_string(c_het)});
+	output.add_info.push_back({"het_fraction", std::isnan(het_frac) ? std::string("nan") : number(het_frac, 4)});
+	if (c_all < 20) output.gender = "unknown (too few SNPs)";
+	else if (het_frac <= max_male) output.gender = "male";
+	else if (het_frac >= min_female) output.gender = "female";
+	else output.gender = "unknown (fraction in gray area)";
+	return output;
+}
+
+GenderEstimate Statistics::genderSRY(const std::string& build, const std::string& bam_file, double min_cov, const std::string& ref_file)
+{
+	const bool hg38 = build == "hg38";
+	BedFile roi; roi.append(BedLine(Chromosome("chrY"), hg38 ? 2786989 : 2655031, hg38 ? 2787603 : 2655641));
+	Statistics::avgCoverage(roi, bam_file, 1, 1, 2, ref_file);
+	const double cov = atof(roi[0].annotations()[0].c_str());
+	GenderEstimate output;
+	output.add_info.push_back({"coverage_sry", number(cov, 2)});
+	output.gender = cov >= min_cov ? "male" : "female";
+	return output;
 }
 
 void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)

@@ -40,9 +40,17 @@ struct FusedPlan
 	bool somatic = false; BedFile somatic_bed; int somatic_min_mapq = 1;
 };
 
+// Statistics.h: result of the gender estimates (SampleGender)
+struct GenderEstimate { std::string gender; std::vector<std::pair<std::string, std::string>> add_info; };
+
 class Statistics
 {
 public:
+	// Statistics.cpp:2811 / 2836 / 2885 — SampleGender -method xy | hetx | sry on the same GPU passes (chrX / chrY read counts of the
+	// mapping scan, site pileup of the known chrX SNVs outside the pseudo-autosomal regions, depth of the SRY gene)
+	static GenderEstimate genderXY(const std::string& bam_file, double max_female = 0.06, double min_male = 0.09, const std::string& ref_file = "");
+	static GenderEstimate genderHetX(const std::string& build, const std::string& bam_file, double max_male = 0.05, double min_female = 0.25, const std::string& ref_file = "", bool include_not_properly_paired = false);
+	static GenderEstimate genderSRY(const std::string& build, const std::string& bam_file, double min_cov = 20.0, const std::string& ref_file = "");
 	static void planFused(const std::string& bam_file, const FusedPlan& plan);
 	static void clearFused();
 	// Statistics.cpp:343  — target-region mode (MappingQC -roi)

@@ -125,9 +125,15 @@ void ToolBase::parse()
 		if (p.type == "flag") { p.set = true; continue; }
 		std::vector<std::string> vals;
 		while (i + 1 < args_.size() && !(args_[i + 1].size() >= 2 && args_[i + 1][0] == '-' && !isdigit((unsigned char)args_[i + 1][1]))) vals.push_back(args_[++i]);
-		if (p.type == "infilelist") { if (vals.empty()) NB_THROW(CommandLineParsingException, "Parameter '" + name + "' given without value."); p.list = vals; p.set = true; continue; }
+		if (p.type == "infilelist")
+		{
+			if (vals.empty()) NB_THROW(CommandLineParsingException, "Parameter '" + name + "' given without value.");
+			for (auto& v : vals) if (!fileExists(v)) NB_THROW(CommandLineParsingException, "Input file '" + v + "' given for parameter '" + name + "' does not exist.");
+			p.list = vals; p.set = true; continue;
+		}
 		if (vals.size() != 1) NB_THROW(CommandLineParsingException, vals.empty() ? "Parameter '" + name + "' given without value." : "Parameter '" + name + "' given with more than one value.");
 		if (p.type == "int") { char* e; strtol(vals[0].c_str(), &e, 10); if (vals[0].empty() || *e) NB_THROW(CommandLineParsingException, "Value '" + vals[0] + "' given for parameter '" + name + "' cannot be converted to integer."); }
+		if (p.type == "float") { char* e; strtod(vals[0].c_str(), &e); if (vals[0].empty() || *e) NB_THROW(CommandLineParsingException, "Value '" + vals[0] + "' given for parameter '" + name + "' cannot be converted to float."); }
 		if (p.type == "enum" && std::find(p.values.begin(), p.values.end(), vals[0]) == p.values.end()) NB_THROW(CommandLineParsingException, "Value '" + vals[0] + "' given for parameter '" + name + "' is not valid. Valid are: '" + join(p.values, ",") + "'.");
 		if ((p.type == "infile" || p.type == "infilelist") && !vals[0].empty() && !fileExists(vals[0])) NB_THROW(CommandLineParsingException, "Input file '" + vals[0] + "' given for parameter '" + name + "' does not exist.");
 		p.value = vals[0]; p.set = true;

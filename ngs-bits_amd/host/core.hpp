@@ -376,6 +376,7 @@ protected:
 	void addInfileList(const std::string& n, const std::string& d, bool optional) { add(n, "infilelist", d, optional, ""); }
 	void addOutfile(const std::string& n, const std::string& d, bool optional) { add(n, "outfile", d, optional, ""); }
 	void addInt(const std::string& n, const std::string& d, bool optional, int def = 0) { add(n, "int", d, optional, std::to_string(def)); }
+	void addFloat(const std::string& n, const std::string& d, bool optional, double def = 0.0) { add(n, "float", d, optional, number(def, 6)); }
 	void addFlag(const std::string& n, const std::string& d) { add(n, "flag", d, true, ""); }
 	void addEnum(const std::string& n, const std::string& d, bool optional, const std::vector<std::string>& values, const std::string& def) { add(n, "enum", d, optional, def); params_.back().values = values; }
 	void changeLog(int, int, int, const std::string&) {}
@@ -383,6 +384,7 @@ protected:
 	std::vector<std::string> getInfileList(const std::string& n) const { return get(n).list; }
 	std::string getOutfile(const std::string& n) const { return get(n).value; }
 	int getInt(const std::string& n) const { return atoi(get(n).value.c_str()); }
+	double getFloat(const std::string& n) const { return atof(get(n).value.c_str()); }
 	bool getFlag(const std::string& n) const { return get(n).set; }
 	std::string getEnum(const std::string& n) const { return get(n).value; }
 	std::string appName() const { return fileName(args_.empty() ? "" : args_[0]); }

@@ -141,3 +141,34 @@ def test_mappingqc_dropout_lines_with_a_reference_genome(tmp_path, case):
     exp = O.mapping(ob, mode, bed, merge_bed=merge, fasta=fasta).values()
     assert exp["AT dropout"] != "n/a" and float(exp["AT dropout"]) + float(exp["GC dropout"]) > 0
     assert got == {k: v for k, v in exp.items()}, (sorted(set(got.items()) ^ set(exp.items())))
+
+
+@pytest.mark.parametrize("args,expected", [
+    (["-in", "SampleGender_in_lr1.bam", "-method", "xy", "-long_read"], "SampleGender_test04_out.tsv"),
+    (["-in", "SampleGender_in_lr2.bam", "-method", "xy", "-long_read"], "SampleGender_test05_out.tsv"),
+    (["-in", "SampleGender_in_lr1.bam", "-method", "hetx", "-long_read"], "SampleGender_test06_out.tsv"),
+    (["-in", "SampleGender_in_lr2.bam", "-method", "hetx", "-long_read"], "SampleGender_test07_out.tsv"),
+    (["-in", "SampleGender_in_lr1.bam", "SampleGender_in_lr2.bam", "-method", "sry", "-long_read"], "SampleGender_test08_out.tsv"),
+])
+def test_samplegender_matches_reference_expected_output(tmp_path, args, expected):
+    """src/tools-TEST/SampleGender_Test.cpp method_xy_longread1/2, method_hetx_longread1/2, method_sry_batch_longread: whole files, byte for byte
+    (test01-03 need panel.bam, a missing blob; the sry.bam line of test03 is checked below)."""
+    a = [os.path.join(GI, x) if x.endswith(".bam") else x for x in args]
+    out = str(tmp_path / expected)
+    run("SampleGender", *a, "-out", out)
+    assert open(out).read() == open(os.path.join(GO, expected)).read()
+
+
+def test_samplegender_sry_and_xy_on_short_reads(tmp_path):
+    out = str(tmp_path / "sry.tsv")
+    run("SampleGender", "-in", os.path.join(GI, "sry.bam"), "-method", "sry", "-build", "hg19", "-out", out)
+    exp = [ln for ln in open(os.path.join(GO, "SampleGender_test03_out.tsv")).read().splitlines() if not ln.startswith("panel.bam")]
+    assert open(out).read().splitlines() == exp                                   # "sry.bam  male  67.27" (SampleGender_Test.cpp method_sry_batch)
+    # xy on a short-read fixture vs the oracle's chrX / chrY counters (Statistics::yxRatio)
+    bam = os.path.join(GI, "MappingQC_in5.bam")
+    run("SampleGender", "-in", bam, "-method", "xy", "-out", out)
+    c = O.mapping(O.Bam(bam), 1, None).counters
+    rx, ry = int(c[O.COUNTER_NAMES.index("reads_x")]), int(c[O.COUNTER_NAMES.index("reads_y")])
+    ratio = "nan" if rx == 0 else f"{ry / rx:.4f}"
+    gender = "female" if rx and ry / rx <= 0.06 else ("male" if rx and ry / rx >= 0.09 else "unknown (ratio in gray area)")
+    assert open(out).read() == f"#file\tgender\treads_chry\treads_chrx\tratio_chry_chrx\nMappingQC_in5.bam\t{gender}\t{ry}\t{rx}\t{ratio}\n"

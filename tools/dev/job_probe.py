@@ -28,6 +28,8 @@ VARIANTS = {
     "debug": {"NGSQC_DEBUG": "1"},
     "p2wg768": {"NGSQC_P2_WGS": "768"}, "p2wg2048": {"NGSQC_P2_WGS": "2048"}, "p2wg512": {"NGSQC_P2_WGS": "512"},
     "p2wg1024": {"NGSQC_P2_WGS": "1024"}, "p2wg4096": {"NGSQC_P2_WGS": "4096"},
+    "nopad": {"NGSQC_P1_PAD": "0"}, "nopad_1s": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1"}, "p1_1s": {"NGSQC_P1_STREAMS": "1"},
+    "nopad_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P2_WGS": "2048"}, "nopad_1s_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1", "NGSQC_P2_WGS": "2048"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
 
