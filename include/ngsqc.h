@@ -114,6 +114,10 @@ typedef struct ngsqc_depth_params {
 } ngsqc_depth_params;
 int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p);
 
+/* ---- BedReadCount (src/BedReadCount/main.cpp:33-71): number of reads overlapping each line of a merged + sorted BED. A read counts when it is
+ * mapped, not secondary / supplementary and has MAPQ >= min_mapq (duplicates count); overlap is [start, bam_endpos] against the closed line. */
+int ngsqc_region_read_counts(ngsqc_handle* h, const ngsqc_region* regions, int64_t n_regions, int32_t min_mapq, int64_t* counts);
+
 /* ---- consumers of the per-base depth left in HBM by the last ngsqc_scan_mapping / ngsqc_scan_depth ---- */
 /* hist[d] for d in 0..hist_cap (depths > cap are clamped into hist[cap]); covered = #bases with depth >= half_depth */
 int ngsqc_depth_stats(ngsqc_handle* h, int32_t hist_cap, int64_t half_depth, int64_t* hist, int64_t* covered);

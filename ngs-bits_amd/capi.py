@@ -142,6 +142,7 @@ def lib():
         L.ngsqc_depth_diff_copy.restype = i32; L.ngsqc_depth_diff_copy.argtypes = [vp, vp, i64]
         L.ngsqc_depth_diff_set.restype = i32; L.ngsqc_depth_diff_set.argtypes = [vp, vp, i64]
         L.ngsqc_depth_finalize.restype = i32; L.ngsqc_depth_finalize.argtypes = [vp]
+        L.ngsqc_region_read_counts.restype = i32; L.ngsqc_region_read_counts.argtypes = [vp, vp, i64, C.c_int32, vp]
         L.ngsqc_run_job.restype = i32; L.ngsqc_run_job.argtypes = [vp, C.POINTER(JobDesc), C.POINTER(JobResult)]
         L.ngsqc_depth_select.restype = i32; L.ngsqc_depth_select.argtypes = [vp, C.c_int32]
         L.ngsqc_depth_reduce.restype = i32; L.ngsqc_depth_reduce.argtypes = [vp, C.POINTER(vp), i32]
@@ -156,7 +157,7 @@ EXPORTS = [
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
-    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce",
+    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts",
 ]
 
 
@@ -379,6 +380,13 @@ class Handle:
         p.min_mapq, p.min_baseq, p.skip_mismapped = min_mapq, min_baseq, int(skip_mismapped)
         p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions)
         self._chk((lib().ngsqc_scan_depth_partial if partial else lib().ngsqc_scan_depth)(self.h, C.byref(p)))
+
+    def region_read_counts(self, regions, min_mapq=1):
+        """BedReadCount: reads overlapping each (merged + sorted) region."""
+        ra = _regions_array(regions)
+        out = np.zeros(max(len(regions), 1), dtype=np.int64)
+        self._chk(lib().ngsqc_region_read_counts(self.h, C.cast(ra, C.c_void_p), len(regions), int(min_mapq), out.ctypes.data))
+        return out[:len(regions)]
 
     def depth_stats(self, hist_cap, half_depth):
         hist = np.zeros(hist_cap + 1, dtype=np.int64)

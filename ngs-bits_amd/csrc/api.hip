@@ -112,7 +112,7 @@ struct ngsqc_handle
 	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0;
 	int64_t k1_enq = 0;                                // chunks enqueued by the running job
 	// K2 scratch (kept across tiles)
-	DevBuf<int32_t> d_start; DevBuf<uint32_t> d_cnt; DevBuf<int64_t> d_next, d_base; DevBuf<uint32_t> d_bad; DevBuf<uint8_t> d_scan_tmp;
+	DevBuf<int32_t> d_start; DevBuf<uint32_t> d_cnt; DevBuf<int64_t> d_next, d_base; DevBuf<uint32_t> d_bad; DevBuf<uint8_t> d_scan_tmp; DevBuf<uint16_t> d_rel;
 	// depth state
 	DepthSet ds[N_DEPTH_SETS]; int cur_ds = 0;
 	ngsqc_timings tm{};
@@ -494,14 +494,14 @@ void index_tile(ngsqc_handle* h, int t)
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	h->d_start.ensure((size_t)ne); h->d_cnt.ensure((size_t)ne + 1); h->d_next.ensure((size_t)ne + 1); h->d_base.ensure((size_t)ne + 1); h->d_bad.ensure(2);
-	h->d_scan_tmp.ensure(scan_tmp_bytes(ne) + 64);
+	h->d_scan_tmp.ensure(scan_tmp_bytes(ne) + 64); h->d_rel.ensure((size_t)ne * K2_REL_STRIDE);
 	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
 	// ---- fast path: htslib-style members (a record starts at every member's first byte, none straddles). One round trip: guess + walk every
 	// member's chain, check the pattern on the device, scan the counts; the host reads back {violations, corrupt records, n_rec} only ----
 	launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-	launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+	launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 	launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = n_rec
@@ -526,7 +526,7 @@ void index_tile(ngsqc_handle* h, int t)
 		if (!first_round)
 		{
 			HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
-			launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->stream);
+			launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 		}
 		first_round = false;
 		HIPCHK(hipMemcpyAsync(start + from, h->d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -574,7 +574,7 @@ void index_tile(ngsqc_handle* h, int t)
 	}
 	int64_t n_rec = (int64_t)sm[1];
 	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec + n_rec / 8, 1));
-	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_base.p, h->d_recoff.p, h->stream);
+	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
 	{
@@ -789,7 +789,7 @@ struct ScanState
 		const unsigned long long key = s[1], fp = s[2], total = s[3], usable = s[4];
 		if (key > best_key) best_key = key;   // keys order by (length, earlier ordinal): the maximum over tiles is the BAM's first longest read
 		if (fp < first_paired) first_paired = fp;
-		if (in_pass_fix && sp.mode != MODE_DEPTH)
+		if (in_pass_fix && sp.mode != MODE_DEPTH && sp.mode != MODE_COUNT)
 		{
 			const long long tile_max = (long long)(key >> 40);
 			const long long f_local = key ? (long long)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) - c.ord_base : 0;
@@ -1453,6 +1453,30 @@ void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 } // namespace
 
 int ngsqc_scan_depth(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, true); }); }
+
+// BedReadCount: reads (mapped, not secondary / supplementary, MAPQ >= min_mapq) overlapping each line of a merged + sorted BED
+int ngsqc_region_read_counts(ngsqc_handle* h, const ngsqc_region* regions, int64_t n_regions, int32_t min_mapq, int64_t* counts)
+{
+	return guarded(h, [&] {
+		if (!regions || n_regions <= 0 || !counts) throw ArgError("read counting needs regions and a result buffer");
+		const int keep = h->cur_ds;
+		DepthSet& D = h->ds[1];   // (region tables only: the depth array of set 1 is not touched)
+		try { setup_regions(h, D, regions, n_regions); }
+		catch (ArgError&) { throw ArgError("Merged and sorted BED file required for coverage calculation!"); }   // src/BedReadCount/main.cpp:36-39
+		ScanState sc; sc.in_pass_fix = false;
+		ScanParams& sp = sc.sp; sp = ScanParams{};
+		sp.mode = MODE_COUNT; sp.min_mapq = min_mapq; sp.tid_x = -2; sp.tid_y = -2;
+		bind_regions(sp, D);
+		DevBuf<unsigned long long> d_cnt; d_cnt.alloc((size_t)n_regions);
+		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_regions * sizeof(unsigned long long), h->stream));
+		sp.region_reads = d_cnt.p;
+		sc.begin(h);
+		stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; });
+		HIPCHK(hipMemcpyAsync(counts, d_cnt.p, (size_t)n_regions * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		h->cur_ds = keep;
+	});
+}
 // shard variant: leaves the un-prefixed difference array (additive over shards: ngsqc_depth_reduce / _device / _diff_copy / _diff_set, then ngsqc_depth_finalize)
 int ngsqc_scan_depth_partial(ngsqc_handle* h, const ngsqc_depth_params* p) { return guarded(h, [&] { depth_scan(h, p, false); }); }
 

@@ -29,12 +29,13 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);
 
 // ---- K2 ----
+constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the member) the count pass keeps per member for the write pass
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
-                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s);
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s);
 void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s);
 void launch_index_aligned(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, hipStream_t s);
 void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
-                        const int64_t* d_base, int64_t* d_recoff, hipStream_t s);
+                        const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s);
 void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
 void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
 size_t scan_tmp_bytes(int64_t n);
@@ -43,6 +44,7 @@ size_t scan_tmp_bytes(int64_t n);
 constexpr int GC_NMAX = 64;      // (bin, n) integer hit table for reads overlapping n < GC_NMAX GC chunks
 constexpr int LONG_CIGAR = 64;   // records with more CIGAR ops go to the wave-per-record kernel
 constexpr int MODE_DEPTH = 3;
+constexpr int MODE_COUNT = 4;   // BedReadCount: reads per target region (src/BedReadCount/main.cpp:33-71)
 
 // device accumulator slots (scan.hip); the host side of the library maps them onto NGSQC_C_*
 enum { A_TOTAL, A_MAPPED, A_ONTARGET, A_NEAR, A_DUP, A_PP, A_INS_CNT, A_SUM_LEN, A_BASES_MAPPED, A_CLIPPED, A_INS_SUM,
@@ -70,6 +72,7 @@ struct ScanParams
 	// outputs
 	unsigned long long* counters;  // [A_DEV_TOTAL]
 	int32_t* diff;                 // difference array -> depth
+	unsigned long long* region_reads;   // MODE_COUNT: reads overlapping each region
 	unsigned long long* gc_tab;    // [101][GC_NMAX]
 	double* gc_over;               // [101]
 	int64_t* long_list; int64_t long_cap;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 // start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
 __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
-                                   uint32_t* __restrict__ bad, int32_t n_ref)
+                                   uint32_t* __restrict__ bad, int32_t n_ref, uint16_t* __restrict__ rel)
 {
 	int64_t b = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
@@ -118,6 +118,7 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 		if (bs < 32) { res = -2; stop = true; break; }
 		if (o + 4 + (int64_t)bs > total) { res = -(o + 10); stop = true; break; }
 		if (!record_fields_fit(infl + o, bs)) { res = -2; stop = true; break; }
+		if (n < (uint32_t)K2_REL_STRIDE) rel[b * K2_REL_STRIDE + n] = (uint16_t)(o - lo);   // (entry 0, the carried prefix, may exceed 16 bits: it is always walked again)
 		++n; o += 4 + (int64_t)bs;
 	}
 	cnt[b] = n; next_abs[b] = stop ? res : o;
@@ -152,15 +153,28 @@ __global__ void index_aligned_kernel(const BlockDesc* __restrict__ blocks, int64
 	if ((threadIdx.x & 63) == 0 && m) atomicAdd(viol, (uint32_t)__popcll(m));
 }
 
-__global__ void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix,
-                                   const int32_t* __restrict__ start, const int64_t* __restrict__ base, int64_t* __restrict__ recoff)
+// Record offsets of every entry, ONE WAVE PER ENTRY: the member-relative offsets that the count pass stored are expanded with coalesced loads
+// and stores (the chain is not walked a second time: that would read a third of the inflated tile again). Entry 0 (the carried prefix, offsets
+// may exceed 16 bits) and members with more than K2_REL_STRIDE records walk their chain on lane 0.
+__global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix,
+                                                          const int32_t* __restrict__ start, const uint32_t* __restrict__ cnt, const int64_t* __restrict__ base,
+                                                          const uint16_t* __restrict__ rel, int64_t* __restrict__ recoff)
 {
-	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	if (b >= n_blocks) return;
-	int32_t s = start[b];
+	const int32_t s = start[b];
 	if (s < 0) return;
+	const uint32_t n = cnt[b];
 	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
-	int64_t o = lo + s; int64_t k = base[b];
+	const int64_t k0 = base[b];
+	if (b != 0 && n <= (uint32_t)K2_REL_STRIDE)
+	{
+		for (uint32_t k = lane; k < n; k += 64) recoff[k0 + k] = lo + rel[b * K2_REL_STRIDE + k];
+		return;
+	}
+	if (lane != 0) return;
+	int64_t o = lo + s; int64_t k = k0;
 	while (o < hi)
 	{
 		if (o + 4 > total) break;
@@ -230,7 +244,7 @@ size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TI
 
 // entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = member e - 1 of d_blocks); arrays are indexed by entry
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
-                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, hipStream_t s)
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
@@ -240,7 +254,7 @@ void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 		hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref); KCHECK();
 	}
 	int grid = (int)((n + 63) / 64);
-	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref); KCHECK();
+	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
 }
 
 void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)
@@ -255,11 +269,11 @@ void launch_index_aligned(const BlockDesc* d_blocks, int64_t n_entries, int64_t 
 }
 
 void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
-                        const int64_t* d_base, int64_t* d_recoff, hipStream_t s)
+                        const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	int grid = (int)((n_entries + 63) / 64);
-	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, d_start, d_base, d_recoff); KCHECK();
+	int grid = (int)((n_entries + 3) / 4);   // one wave per entry
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, d_start, d_cnt, d_base, d_rel, d_recoff); KCHECK();
 }
 
 // exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).

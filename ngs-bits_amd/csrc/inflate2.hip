@@ -641,7 +641,9 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 {
 	if (n_blocks <= 0) return;
 	int64_t wg2 = (n_blocks + 3) / 4;
-	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)256 * 4;   // 16 waves per CU: as fast as 32 (measured) and leaves wave slots for K2 / the consumers of the previous tile
+	// one member per wave, handed out by the dispatcher: measured 72 ms per 48 M reads at 16 k workgroups, 75 ms at 2 k - 4 k (every wave strides
+	// over ~10 members), 92 ms at 1 k (all workgroups resident from the start: the launch ends with a long ragged tail)
+	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)32768;
 	int grid2 = (int)(wg2 < cap2 ? wg2 : cap2);
 	hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }

@@ -155,6 +155,15 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 	const bool tid_ok = r.tid >= 0 && r.tid < p.n_ref;
 	a.v[A_ALG_BYTES] += 4 + (long long)r.bs;
 
+	if (MODE == MODE_COUNT)
+	{
+		// BedReadCount (src/BedReadCount/main.cpp:55-66): mapped, not secondary / supplementary, MAPQ >= min_mapq; +1 for every overlapped line
+		if (unmapped || secondary || supp || (int)r.mapq < p.min_mapq || !tid_ok) return;
+		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+		if (first >= last) return;
+		for (int i = lower_region(p.reg_end, first, last, start1); i < last && p.reg_start[i] <= end1; ++i) atomicAdd(&p.region_reads[i], 1ull);
+		return;
+	}
 	if (MODE == 3)
 	{
 		// coverage-tool filter: WorkerAverageCoverage.cpp:41-45 / WorkerLowOrHighCoverage.cpp:47-49
@@ -500,6 +509,7 @@ void launch_scan(const ScanParams& p, hipStream_t s)
 		case NGSQC_MODE_ROI: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(256), 0, s, p); break;
 		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(256), 0, s, p); break;
 		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p); break;
+		case MODE_COUNT: hipLaunchKernelGGL(scan_kernel<MODE_COUNT>, dim3(grid), dim3(256), 0, s, p); break;
 		default: hipLaunchKernelGGL(scan_kernel<3>, dim3(grid), dim3(256), 0, s, p); break;
 	}
 	KCHECK();
@@ -514,6 +524,7 @@ void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
 		case NGSQC_MODE_ROI: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 		case NGSQC_MODE_WGS: hipLaunchKernelGGL(scan_long_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
+		case MODE_COUNT: hipLaunchKernelGGL(scan_long_kernel<MODE_COUNT>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 		default: hipLaunchKernelGGL(scan_long_kernel<3>, dim3(grid), dim3(256), 0, s, p, (long long)n_long); break;
 	}
 	KCHECK();

@@ -122,6 +122,21 @@ void* orc_avg_coverage(void* bam, const char* bed, int merge_bed, int min_mapq, 
 	}
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
 }
+// BedReadCount core: load -> merge(false) (the tool's main) -> read counts; result: cov = counts, bed_text = the annotated BED
+void* orc_read_counts(void* bam, const char* bed, int min_mapq, char* err, int errlen)
+{
+	try
+	{
+		auto* r = new Result();
+		BedFile f; f.load(bed); f.merge(false);
+		double t0 = now();
+		r->cov = read_counts(f, *(BamFile*)bam, min_mapq);
+		r->seconds_compute = now() - t0;
+		r->bed_text = f.toText(false);
+		return r;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return nullptr; }
+}
 int64_t orc_result_cov(void* res, int64_t* out, int64_t cap)
 {
 	auto* r = (Result*)res; int64_t n = std::min<int64_t>(cap, (int64_t)r->cov.size());

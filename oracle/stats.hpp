@@ -497,6 +497,27 @@ static inline MappingResult mapping_wgs(const BamFile& bam, const BedFile* roi_i
 
 // ---------------------------------------------------------------- avgCoverage  Statistics.cpp:2698-2804 + WorkerAverageCoverage.cpp
 // Returns the per-line coverage sums (long) and appends the formatted annotation to each line like the reference.
+// BedReadCount: src/BedReadCount/main.cpp:33-71 (readCount). The BED must be merged + sorted; every read that is mapped, not
+// secondary / supplementary and has MAPQ >= min_mapq counts once for every line its [start, end] overlaps. Appends the count as annotation.
+static inline std::vector<int64_t> read_counts(BedFile& bed, const BamFile& bam, int min_mapq)
+{
+	if (!bed.isMergedAndSorted()) throw Error("Merged and sorted BED file required for coverage calculation!");
+	std::vector<int64_t> n(bed.count(), 0);
+	ChrIndex index(bed);
+	std::vector<int> num; for (auto& nm : bam.ref_names) num.push_back(chr_num(nm));
+	for (size_t k=0; k<bam.count(); ++k)
+	{
+		const Rec al = bam.rec(k);
+		if (al.isUnmapped()) continue;
+		if (al.isSecondary() || al.isSupplementary()) continue;
+		if (al.mapq < min_mapq) continue;
+		if (al.tid<0 || (size_t)al.tid>=num.size()) continue;
+		index.forMatches(num[al.tid], al.start(), al.end(), [&](int i){ n[i] += 1; });
+	}
+	for (size_t i=0;i<bed.count();++i) bed.lines[i].annos.push_back(std::to_string(n[i]));
+	return n;
+}
+
 static inline std::vector<int64_t> avg_coverage(BedFile& bed, const BamFile& bam, int min_mapq, int decimals, bool random_access, bool skip_mismapped)
 {
 	if (!random_access && !bed.isSorted()) throw Error("Input BED file has to be sorted for sweep algorithm!");

@@ -164,6 +164,22 @@ def avg_coverage(bam, bed, merge_bed=False, min_mapq=1, decimals=2, random_acces
     return cov, text, secs
 
 
+def read_counts(bam, bed, min_mapq=1):
+    """BedReadCount: (counts per line of the merged BED, BED text with the count as annotation)."""
+    err = C.create_string_buffer(1024)
+    L = lib()
+    L.orc_read_counts.restype = C.c_void_p; L.orc_read_counts.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    h = L.orc_read_counts(bam.h, _b(bed), min_mapq, err, 1024)
+    if not h:
+        raise OracleError(err.value.decode())
+    n = L.orc_result_cov(h, None, 0)
+    cov = np.zeros(max(n, 1), dtype=np.int64)
+    L.orc_result_cov(h, cov.ctypes.data, n)
+    text = L.orc_result_bed(h).decode()
+    L.orc_result_free(h)
+    return cov[:n], text
+
+
 def low_high_coverage(bam, bed, cutoff, min_mapq=1, min_baseq=0, is_high=False, random_access=False, tool_merge=1):
     """tool_merge: 1 = merge(true,true) like the tools, 2 = plain merge() like the unit tests, 0 = none."""
     err = C.create_string_buffer(1024)

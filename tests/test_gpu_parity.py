@@ -152,3 +152,19 @@ def test_depth_tools(bam, bed, mapq, baseq):
         lines, _ = H.bed_regions(p(bed), h.refs, 0)
         assert np.array_equal(h.region_sums(lines), cov)
     h.close()
+
+
+@pytest.mark.parametrize("bam,bed,mapq", [("close_exons.bam", "close_exons.bed", 1), ("MappingQC_in4.bam", "MappingQC_in3.bed", 30), ("Statistics_longread.bam", "panel.bed", 0)])
+def test_region_read_counts(bam, bed, mapq):
+    """BedReadCount core through the C ABI vs the oracle (src/BedReadCount/main.cpp:33-71)."""
+    h = ngsqc.Handle(path=p(bam))
+    regs, _ = H.bed_regions(p(bed), h.refs, 2 if False else 0)
+    exp, text = O.read_counts(O.Bam(p(bam)), p(bed), mapq)
+    # the oracle merged the BED (merge(false)): take its lines as the regions
+    tm = H.tid_map(h.refs)
+    regs = [(tm.get(H.chr_num(f[0]), -1), int(f[1]) + 1, int(f[2])) for f in (ln.split("\t") for ln in text.splitlines())]
+    keep = [i for i, r in enumerate(regs) if r[0] >= 0]
+    got = h.region_read_counts([regs[i] for i in keep], mapq)
+    assert np.array_equal(got, exp[keep]) and all(exp[i] == 0 for i in range(len(regs)) if i not in keep)
+    assert int(exp.sum()) > 0
+    h.close()

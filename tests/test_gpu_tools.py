@@ -172,3 +172,13 @@ def test_samplegender_sry_and_xy_on_short_reads(tmp_path):
     ratio = "nan" if rx == 0 else f"{ry / rx:.4f}"
     gender = "female" if rx and ry / rx <= 0.06 else ("male" if rx and ry / rx >= 0.09 else "unknown (ratio in gray area)")
     assert open(out).read() == f"#file\tgender\treads_chry\treads_chrx\tratio_chry_chrx\nMappingQC_in5.bam\t{gender}\t{ry}\t{rx}\t{ratio}\n"
+
+
+@pytest.mark.parametrize("bam,bed,mapq", [("close_exons.bam", "close_exons.bed", 1), ("MappingQC_in2.bam", "MappingQC_in2.bed", 0), ("Statistics_longread.bam", "panel.bed", 20)])
+def test_bedreadcount_matches_oracle(tmp_path, bam, bed, mapq):
+    """BedReadCount (src/BedReadCount/main.cpp): the reference's expected files need panel.bam (a missing blob), so the tool's whole output is compared
+    with the oracle's restatement of readCount(); the C ABI entry (ngsqc_region_read_counts) is checked in test_gpu_parity.py."""
+    out = str(tmp_path / "rc.tsv")
+    run("BedReadCount", "-bam", os.path.join(GI, bam), "-in", os.path.join(GI, bed), "-out", out, "-min_mapq", str(mapq))
+    _, text = O.read_counts(O.Bam(os.path.join(GI, bam)), os.path.join(GI, bed), mapq)
+    assert open(out).read() == f"#chr\tstart\tend\t{bam.split('.')[0]}\n" + text

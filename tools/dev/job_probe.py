@@ -27,6 +27,8 @@ VARIANTS = {
     "park8": {"NGSQC_P1_PARK": "8"}, "park24": {"NGSQC_P1_PARK": "24"}, "park32": {"NGSQC_P1_PARK": "32"},
     "debug": {"NGSQC_DEBUG": "1"},
     "p2wg768": {"NGSQC_P2_WGS": "768"}, "p2wg2048": {"NGSQC_P2_WGS": "2048"}, "p2wg512": {"NGSQC_P2_WGS": "512"},
+    "p2wg3072": {"NGSQC_P2_WGS": "3072"}, "p2wg8192": {"NGSQC_P2_WGS": "8192"}, "p2wg16384": {"NGSQC_P2_WGS": "16384"}, "p2wg1536": {"NGSQC_P2_WGS": "1536"},
+    "p2wg4096_nopad": {"NGSQC_P2_WGS": "4096", "NGSQC_P1_PAD": "0"},
     "p2wg1024": {"NGSQC_P2_WGS": "1024"}, "p2wg4096": {"NGSQC_P2_WGS": "4096"},
     "nopad": {"NGSQC_P1_PAD": "0"}, "nopad_1s": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1"}, "p1_1s": {"NGSQC_P1_STREAMS": "1"},
     "nopad_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P2_WGS": "2048"}, "nopad_1s_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1", "NGSQC_P2_WGS": "2048"},
