@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--single-bam", action="store_true", help="strong scaling: ONE BAM sharded over the ranks by BGZF member range "
                     "(all-gather of shard summaries, SUM all-reduce of counters and of the int32 difference array) instead of one BAM per rank")
+    ap.add_argument("--image-cache", default="", help="keep / reuse the generated BAM image at this path (profiling passes on one box)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="debug: map every rank to cuda:0")
     return ap.parse_args()
 
@@ -110,6 +111,19 @@ def synthetic_exome_bed(path, refs, seed, n_intervals=200_000, overlapping=False
         for c, a, b in lines:
             f.write(f"{c}\t{a}\t{b}\n")
     return len(lines)
+
+
+def prefix_image(image, target_bytes):
+    """The BGZF members of the image's first ~target_bytes plus the EOF marker: a valid BAM with the first records of the batch (aligned input:
+    members end at record ends)."""
+    import struct
+    pos = 0; n = image.size
+    while pos < min(target_bytes, n - 28):
+        pos += struct.unpack_from("<H", image, pos + 16)[0] + 1
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    out = np.empty(pos + 28, dtype=np.uint8)
+    out[:pos] = image[:pos]; out[pos:] = np.frombuffer(eof, dtype=np.uint8)
+    return out
 
 
 def main():
@@ -193,9 +207,13 @@ def main():
                     image = np.memmap(share, dtype=np.uint8, mode="r")
                 except OSError:
                     image = None
+    if image is None and args.image_cache and os.path.exists(args.image_cache):
+        image = np.fromfile(args.image_cache, dtype=np.uint8)
     if image is None:
         threads = max(1, 2 * G.effective_cpus() // max(world, 1))
         image = G.generate(reads, threads=threads, **dict(gen_kw, seed=args.seed + (0 if args.single_bam else rank)))
+        if args.image_cache:
+            image.tofile(args.image_cache)
     gen_s = time.time() - t0
     # H2D of the compressed image (of this rank's member range with --single-bam): not in the timed region, reported as end_to_end
     t0 = time.time()
@@ -374,9 +392,9 @@ def main():
             out["roofline"]["traffic_pmc"] = traffic(dom[0].split(" ")[0])
         except OSError:
             pass
-        if world == 1 and not args.no_cpu_baseline and tool == "mappingqc" and not args.ont:
+        if world == 1 and not args.no_cpu_baseline and tool == "mappingqc":
             import oracle_lib as O
-            sample = min(args.cpu_sample_reads, n_rec)
+            sample = min(args.cpu_sample_reads if not args.ont else 150_000, n_rec)
             c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, sample)
             out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
                                    "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop "
@@ -398,7 +416,26 @@ def main():
             except Exception as e:   # never let the extra leg break the bench line
                 out["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
         elif world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = None   # (the coverage tools' / ONT CPU legs run from tools/dev/bench_tools_cpu.py: they need the BAM on disk)
+            # coverage tools: the oracle's restatement (1 thread) on the first records of the same BAM, and the same sample through the GPU path as parity check
+            import oracle_lib as O
+            samp = prefix_image(image, min(int(image.size), args.cpu_sample_reads // 4 * BYTES_PER_READ_COMPRESSED))
+            sp = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_sample_{args.seed}.bam")
+            samp.tofile(sp)
+            ob = O.Bam(sp); hs = ngsqc.Handle(data=samp, device=local_rank)
+            t1 = time.time()
+            if tool == "bedcoverage":
+                cov, _, _ = O.avg_coverage(ob, bed_path, merge_bed=False, min_mapq=1, random_access=False)
+                secs = time.time() - t1
+                hs.scan_depth(union, min_mapq=1); ok = bool(np.array_equal(hs.region_sums(lines), cov))
+            else:
+                exp = O.low_high_coverage(ob, bed_path, 20, 1, args.min_baseq, is_high=False, random_access=False, tool_merge=1)
+                secs = time.time() - t1
+                hs.scan_depth(union, min_mapq=1, min_baseq=args.min_baseq)
+                ok = bool(np.array_equal(np.minimum(hs.depth(exp["roi_bases"]), 254), np.minimum(exp["depth"], 254)))
+            hs.close(); os.remove(sp)
+            out["cpu_baseline"] = {"value": round(ob.count / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ob.count} records of the same BAM, oracle restatement of the tool's sweep (1 thread), {secs:.1f} s", "counters_match_gpu": ok,
+                                   "counters_match_note": "per-line depth sums (BedCoverage) / per-base depth of the whole exome BED (BedLowCoverage) of the sample, GPU vs oracle, bit-exact"}
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

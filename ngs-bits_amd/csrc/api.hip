@@ -15,7 +15,9 @@
 #include <algorithm>
 #include <cstring>
 #include <chrono>
+#include <atomic>
 #include <functional>
+#include <thread>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -252,12 +254,47 @@ bool read_header(ngsqc_handle* h, int64_t avail)
 	}
 }
 
+// H2D of the compressed image. The source is pageable memory (an mmap of the file, a caller's buffer): one hipMemcpy of it runs at ~12 GB/s
+// (staged by the runtime on one thread). Large images are therefore staged by a few host threads, each through its own pair of pinned
+// buffers and its own stream: the memcpy of a piece overlaps the DMA of the previous one and the pieces of different threads overlap each other.
 void upload_compressed(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 {
 	const size_t n = end - beg;
 	h->d_comp.alloc(n + 1024);
 	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
-	if (n) HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes + beg, n, hipMemcpyHostToDevice, h->stream));
+	if (!n) return;
+	constexpr size_t PIECE = 32u << 20;
+	int T = 8; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
+	if (n < 8 * PIECE || T == 1) { HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes + beg, n, hipMemcpyHostToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); return; }
+	const size_t n_pieces = (n + PIECE - 1) / PIECE;
+	std::atomic<size_t> next(0); std::vector<std::string> errs((size_t)T);
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; ++t)
+		th.emplace_back([&, t] {
+			uint8_t* pin[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+			try
+			{
+				HIPCHK(hipSetDevice(h->device));
+				HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+				for (int k = 0; k < 2; ++k) { HIPCHK(hipHostMalloc((void**)&pin[k], PIECE, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+				for (int k = 0;; k ^= 1)
+				{
+					const size_t i = next.fetch_add(1); if (i >= n_pieces) break;
+					const size_t off = i * PIECE, sz = std::min(PIECE, n - off);
+					HIPCHK(hipEventSynchronize(ev[k]));   // the previous DMA out of this buffer is done (an unrecorded event is complete)
+					memcpy(pin[k], bytes + beg + off, sz);
+					HIPCHK(hipMemcpyAsync(h->d_comp.p + off, pin[k], sz, hipMemcpyHostToDevice, st));
+					HIPCHK(hipEventRecord(ev[k], st));
+				}
+				HIPCHK(hipStreamSynchronize(st));
+			}
+			catch (std::exception& e) { errs[(size_t)t] = e.what(); }
+			for (int k = 0; k < 2; ++k) { if (pin[k]) (void)hipHostFree(pin[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+			if (st) (void)hipStreamDestroy(st);
+		});
+	for (auto& t : th) t.join();
+	for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+	HIPCHK(hipStreamSynchronize(h->stream));
 }
 
 constexpr int64_t SHARD_TAIL_MEMBERS = 64;   // members behind a shard that are inflated to complete its last record (NGSQC_SHARD_TAIL_MEMBERS)
@@ -419,13 +456,14 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
 	// CRC of a chunk in line behind its phase 2 (default). On its own stream (NGSQC_CRC_STREAM=1) it runs beside phase 2 of the next chunk and
 	// takes the LDS that phase 2's workgroups need next to the six phase-1 waves of a CU: measured 84 ms instead of 74 ms per 48 M reads.
-	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;   // 1: the next chunk's phase 1 starts when the whole previous launch is done
+	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;
+	const char* eks = getenv("NGSQC_K1_SERIAL"); const bool k1_serial = eks && atoi(eks) != 0;   // profiling: every K1 kernel in line on ONE stream (isolated per-kernel counters)   // 1: the next chunk's phase 1 starts when the whole previous launch is done
 	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (ce && atoi(ce) != 0) ? h->s_crc : h->s_p2;
 	for (int64_t c = h->tile_first_chunk[(size_t)t]; c < h->tile_first_chunk[(size_t)t + 1]; ++c)
 	{
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
-		hipStream_t s1 = h->s_p1[one_p1_stream ? 0 : (c & 1)];
+		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= K1_SLOTS) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - K1_SLOTS) + 3)], 0));   // the ring slot is free again
 		HIPCHK(hipEventRecord(e4[0], s1));
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_work.p + c,

@@ -145,7 +145,7 @@ void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_
 	if (n_blocks <= 0) return;
 	const uint32_t* tabs = device_tables();
 	const int64_t wgs = (n_blocks + 3) / 4;
-	hipLaunchKernelGGL(crc32_kernel, dim3((int)(wgs < 256 * 8 ? wgs : 256 * 8)), dim3(256), 0, s, d_blocks, n_blocks, d_out, d_expected, d_status, tabs); KCHECK();
+	hipLaunchKernelGGL(crc32_kernel, dim3((int)(wgs < 32768 ? wgs : 32768)), dim3(256), 0, s, d_blocks, n_blocks, d_out, d_expected, d_status, tabs); KCHECK();
 }
 
 } // namespace ngsqc

@@ -11,9 +11,11 @@ import sqlite3
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-CMD = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)"
+PFX = "r1" if tag.startswith("r01") else "r2"
+CMD = ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)" if PFX == "r1" else
+       "python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles per step, 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)")
 out = open(f"profiles/{tag}_kernel_stats.txt", "w")
-c = sqlite3.connect("gpurun_out/r1_trace/t_results.db")
+c = sqlite3.connect(f"gpurun_out/{PFX}_trace/t_results.db")
 out.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}\n")
 out.write("# name\tcalls\ttotal_ms\tavg_ms\tpercent\n")
 for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
@@ -25,21 +27,21 @@ pm.write("# per-kernel SUM over dispatches / number of dispatches = per-launch v
 pm.write("# gfx950 note (MI355X_MICROARCH.md HBM section): FETCH_SIZE counts 64 B per 128 B request for wide coalesced streams (x2 correction);\n")
 pm.write("# other access widths (the scan kernel's sparse 4-byte gathers, the inflate kernels' byte traffic) are uncalibrated.\n")
 pm.write("# kernel\tcounter\tdispatches\tsum_KiB\tper_launch\n")
-for db, ctr in (("gpurun_out/r1_fetch/f_results.db", "FETCH_SIZE"), ("gpurun_out/r1_write/w_results.db", "WRITE_SIZE")):
+for db, ctr in ((f"gpurun_out/{PFX}_fetch/f_results.db", "FETCH_SIZE"), (f"gpurun_out/{PFX}_write/w_results.db", "WRITE_SIZE")):
     if not os.path.exists(db):
         continue
     c = sqlite3.connect(db)
     for r in c.execute("select kernel_name, count(*), sum(value), max(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
         pm.write(f"{r[0][:70]}\t{ctr}\t{r[1]}\t{r[2]:.1f}\tavg_launch={r[2]/r[1]:.1f}\n")
 pm.close()
-if os.path.exists("gpurun_out/r1_sq/s_results.db"):
+if os.path.exists(f"gpurun_out/{PFX}_sq/s_results.db"):
     sq = open(f"profiles/{tag}_sq_counters.txt", "w")
     sq.write(f"# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -- {CMD}\n")
     sq.write("# SQ_INSTS_* count wave-level instructions, the *_CYCLES counters tick in quad-cycles (one wave64 VALU instruction = one tick);\n")
     sq.write("# the counters see about 3/4 of the waves of a dispatch on this part (SQ_WAVES vs the launched grid), ratios are unaffected.\n")
     sq.write("# derived: valu_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's lifetime spent issuing VALU)\n")
     sq.write("# kernel\tcounter\tdispatches\tsum_over_dispatches\n")
-    c = sqlite3.connect("gpurun_out/r1_sq/s_results.db")
+    c = sqlite3.connect(f"gpurun_out/{PFX}_sq/s_results.db")
     acc = {}
     for k, cn, n, s in c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
         sq.write(f"{k[:60]}\t{cn}\t{n}\t{s:.4e}\n")
@@ -48,6 +50,26 @@ if os.path.exists("gpurun_out/r1_sq/s_results.db"):
     for k, v in acc.items():
         if v.get("SQ_WAVE_CYCLES"):
             sq.write(f"{k}\t{v.get('SQ_ACTIVE_INST_VALU', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_ACTIVE_INST_ANY', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_INSTS_VALU', 0)/max(v.get('SQ_INSTS_SALU', 1), 1):.2f}\n")
+    sq.close()
+# r02 extras: the kernel trace of the serialized run (every kernel alone) and the second SQ pass (stall / LDS counters)
+if os.path.exists(f"gpurun_out/{PFX}_trace_serial/t_results.db"):
+    o2 = open(f"profiles/{tag}_kernel_stats_serial.txt", "w")
+    o2.write(f"# NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0 rocprofv3 --kernel-trace --stats -- {CMD}\n# name\tcalls\ttotal_ms\tavg_ms\tpercent\n")
+    for r in sqlite3.connect(f"gpurun_out/{PFX}_trace_serial/t_results.db").execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        o2.write(f"{r[0]}\t{r[1]}\t{r[2]/1e3:.3f}\t{r[3]/1e3:.4f}\t{r[4]:.2f}\n")
+    o2.close()
+if os.path.exists(f"gpurun_out/{PFX}_sq2/s_results.db"):
+    sq = open(f"profiles/{tag}_sq_stall_counters.txt", "w")
+    sq.write(f"# rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -- {CMD}\n")
+    sq.write("# WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles); LDS_BANK_CONFLICT = extra LDS cycles, LDS_IDX_ACTIVE = all LDS-array cycles\n")
+    sq.write("# kernel\tcounter\tdispatches\tsum_over_dispatches\n")
+    acc = {}
+    for k, cn, n, sm in sqlite3.connect(f"gpurun_out/{PFX}_sq2/s_results.db").execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        sq.write(f"{k[:60]}\t{cn}\t{n}\t{sm:.4e}\n"); acc.setdefault(k[:60], {})[cn] = sm
+    sq.write("# kernel\twait_any_share\twait_inst_any_share\tlds_conflict_share_of_lds_cycles\n")
+    for k, v in acc.items():
+        if v.get("SQ_WAVE_CYCLES"):
+            sq.write(f"{k}\t{v.get('SQ_WAIT_ANY', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_WAIT_INST_ANY', 0)/v['SQ_WAVE_CYCLES']:.3f}\t{v.get('SQ_LDS_BANK_CONFLICT', 0)/max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1):.3f}\n")
     sq.close()
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:1800])
 print(open(f"profiles/{tag}_hbm_traffic_pmc.txt").read()[:3000])
