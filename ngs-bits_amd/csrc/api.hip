@@ -254,9 +254,10 @@ bool read_header(ngsqc_handle* h, int64_t avail)
 	}
 }
 
-// H2D of the compressed image. The source is pageable memory (an mmap of the file, a caller's buffer): one hipMemcpy of it runs at ~12 GB/s
-// (staged by the runtime on one thread). Large images are therefore staged by a few host threads, each through its own pair of pinned
-// buffers and its own stream: the memcpy of a piece overlaps the DMA of the previous one and the pieces of different threads overlap each other.
+// H2D of the compressed image. The source is pageable memory (an mmap of the file, a caller's buffer). One hipMemcpy of it is the default: the
+// runtime pins the pages and runs the DMA at 37-56 GB/s on a 14 GB image whose pages are warm (12 GB/s on the 60 GB image right after it was
+// generated: first pinning of cold pages). NGSQC_H2D_THREADS=T stages the image through T host threads with pinned buffer pairs instead; measured
+// slower on this host (16-CPU quota: 14 / 20 / 26 GB/s at 8 / 4 / 16 threads), kept as a switch for hosts with more cores per GPU.
 void upload_compressed(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 {
 	const size_t n = end - beg;
@@ -264,7 +265,7 @@ void upload_compressed(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t
 	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
 	if (!n) return;
 	constexpr size_t PIECE = 32u << 20;
-	int T = 8; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
+	int T = 1; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
 	if (n < 8 * PIECE || T == 1) { HIPCHK(hipMemcpyAsync(h->d_comp.p, bytes + beg, n, hipMemcpyHostToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); return; }
 	const size_t n_pieces = (n + PIECE - 1) / PIECE;
 	std::atomic<size_t> next(0); std::vector<std::string> errs((size_t)T);

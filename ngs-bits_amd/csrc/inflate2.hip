@@ -174,6 +174,14 @@ __global__ __launch_bounds__(64) void huff_tokens_kernel(const uint8_t* __restri
 	__shared__ uint32_t lds[P1_LANE_W * 64 + PAD_W];
 	const int lane = threadIdx.x;
 	P1Lds L{lds, lane};
+	// Phase 1 is the long pole of K1 (alone 16.8 ms per round of members, 25 ms next to phase 2 / CRC / the previous tile's consumers) and its
+	// waves run a dependent instruction stream: every issue slot lost to a co-resident wave delays them. park_hi's upper bits carry a wave
+	// priority: the other kernels' waves then only get the slots phase 1 leaves (s_setprio, VALU arbitration is priority first, then age).
+	{
+		const int prio = park_hi >> 8;
+		if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+		park_hi &= 255;
+	}
 	const uint4* const comp_q = (const uint4*)comp;
 	constexpr int WAIT_VM0 = 0x0F70;
 
@@ -629,7 +637,9 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	// d_work: the launch's member queue head (zeroed by the caller). One-wave workgroups; 7 fit a CU (22.8 KB LDS each).
 	int64_t wgs = (n_blocks + 63) / 64;
 	int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
-	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
+	const char* pe = getenv("NGSQC_P1_PARK"); int park_hi = pe ? atoi(pe) : 16;
+	const char* pr = getenv("NGSQC_P1_PRIO"); const int prio = pr ? atoi(pr) : 0;   // (measured: no effect on the pipelined K1, 70.8 vs 70.9 ms per 48 M reads)
+	park_hi = (park_hi & 255) | (prio << 8);
 	const char* epad = getenv("NGSQC_P1_PAD"); const bool pad = !epad || atoi(epad) != 0;   // 0: 22.8 KB workgroups (a seventh may squeeze in beside the phase-2 workgroups)
 	if (pad) hipLaunchKernelGGL(huff_tokens_kernel<P1_PAD_W>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
 	else hipLaunchKernelGGL(huff_tokens_kernel<0>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);

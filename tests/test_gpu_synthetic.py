@@ -92,3 +92,54 @@ def test_tiled_processing_matches_single_tile(tmp_path, monkeypatch, tile_member
     h = ngsqc.Handle(path=path)
     assert np.array_equal(h.inflated(), O.Bam(path).inflated())
     h.close()
+
+
+@pytest.mark.parametrize("tile_members", [None, 5])
+def test_fused_job_equals_single_purpose_calls(tmp_path, monkeypatch, tile_members):
+    """ngsqc_run_job: mapping scan + extra depth scan + site pileup + raw-read QC in ONE pass over the BAM (every member inflated once) give exactly
+    what the single-purpose entry points give in four passes - on a resident single-tile file and on a file streamed through many small tiles."""
+    if tile_members:
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    path = str(tmp_path / "job.bam")
+    G.write(path, n_reads=120_000, seed=61, aligned=False, start_pos=15_900_000)
+    sub = tmp_path / "sub.bed"
+    sub.write_text("chr1\t15950000\t15960000\nchr1\t16100000\t16100500\nchr1\t16300000\t16340000\n")
+    ob = O.Bam(path)
+    h = ngsqc.Handle(path=path)
+    refs = h.refs
+    regs, _ = H.bed_regions(OMIM, refs, 3)
+    sub_regs, _ = H.bed_regions(str(sub), refs, 1)
+    tx, ty = H.xy_tids(refs)
+    sites = [(0, p_) for p_ in range(15_950_000, 16_350_000, 997)]
+    mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs))
+    out = h.run_job(mapping=mp, depth=dict(regions=sub_regs, min_mapq=1), sites=sites, site_params=(1, 13, False), read_qc=dict(single_end=False))
+    tm = h.timings()
+    assert tm["members_inflated"] == h.n_blocks and (tile_members is None or tm["n_tiles"] > 3)   # one K1 visit per member for all four consumers
+    # depth set 0 = mapping ROI, set 1 = the extra depth scan
+    roi_bases = int(out["counters"][26])
+    d0 = h.depth(roi_bases)
+    h.depth_select(1)
+    d1 = h.depth(sum(e - s + 1 for _, s, e in sub_regs)); sums1 = h.region_sums(sub_regs)
+    h.depth_select(0)
+    assert np.array_equal(h.depth(roi_bases), d0)
+    h.close()
+    # the same through four single-purpose passes on a fresh handle
+    g = ngsqc.Handle(path=path)
+    c2, gc2 = g.scan_mapping(**mp)
+    assert np.array_equal(out["counters"], c2) and np.array_equal(g.depth(roi_bases), d0)
+    assert np.array_equal(g.site_pileup(sites, 1, 13, False), out["site_counts"])
+    r2 = g.scan_reads(single_end=False)
+    for k, v in r2.items():
+        assert np.array_equal(np.asarray(out["reads"][k]), np.asarray(v)), k
+    g.scan_depth(sub_regs, min_mapq=1)
+    assert np.array_equal(g.depth(len(d1)), d1) and np.array_equal(g.region_sums(sub_regs), sums1)
+    g.close()
+    # and the oracle
+    exp = O.mapping(ob, ngsqc.MODE_WGS, OMIM, merge_bed=False)
+    for i in range(len(c2)):
+        if i not in SKIP:
+            assert int(out["counters"][i]) == int(exp.counters[i]), i
+    assert np.array_equal(d0, exp.depth)
+    assert np.array_equal(out["site_counts"][:, :6], O.site_pileup(ob, sites, 1, 13, False))
+    cov, _, _ = O.avg_coverage(ob, str(sub), merge_bed=True, min_mapq=1, random_access=True)
+    assert np.array_equal(sums1, cov) and int(d1.sum()) == int(cov.sum()) > 0

@@ -32,6 +32,8 @@ VARIANTS = {
     "p2wg1024": {"NGSQC_P2_WGS": "1024"}, "p2wg4096": {"NGSQC_P2_WGS": "4096"},
     "nopad": {"NGSQC_P1_PAD": "0"}, "nopad_1s": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1"}, "p1_1s": {"NGSQC_P1_STREAMS": "1"},
     "nopad_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P2_WGS": "2048"}, "nopad_1s_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1", "NGSQC_P2_WGS": "2048"},
+    "prio0": {"NGSQC_P1_PRIO": "0"}, "prio1": {"NGSQC_P1_PRIO": "1"}, "prio3": {"NGSQC_P1_PRIO": "3"},
+    "prio3_nopad": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PAD": "0"}, "prio0_nocrc": {"NGSQC_P1_PRIO": "0", "NGSQC_VERIFY_CRC": "0"}, "prio3_nocrc": {"NGSQC_P1_PRIO": "3", "NGSQC_VERIFY_CRC": "0"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
 
