@@ -389,7 +389,14 @@ def main():
                 wk = [v for (k, c), v in prof.items() if kname in k and c == "WRITE_SIZE"]
                 return {"fetch_bytes_raw": int(fk[0]), "write_bytes_raw": int(wk[0]), "source": "profiles/r02_hbm_traffic_pmc.txt (average per launch)",
                         "note": "raw FETCH_SIZE/WRITE_SIZE x 1024; gfx950 FETCH_SIZE counts 64 B per 128 B request for wide streams; narrow accesses uncalibrated"} if fk and wk else None
-            out["roofline"]["traffic_pmc"] = traffic(dom[0].split(" ")[0])
+            tp = traffic(dom[0].split(" ")[0])
+            out["roofline"]["traffic_pmc"] = tp
+            if tp:
+                # per launch of 83 k members (the profile's chunk; this run's chunk may hold a few more members). No correction applied: the kernel's loads are
+                # 16 B per lane from 64 different member streams, between the guide's x1 and x2 regimes (raw FETCH / known compressed bytes = 0.755)
+                out["roofline"]["traffic"] = tp["fetch_bytes_raw"] + tp["write_bytes_raw"]
+                out["roofline"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE per launch, K1 kernels serialized (NGSQC_K1_SERIAL=1); the 9.4 GB written are the 4-byte tokens "
+                                                   "that phase 2 reads back: 6.9x the compressed bytes the kernel has to read")
         except OSError:
             pass
         if world == 1 and not args.no_cpu_baseline and tool == "mappingqc":

@@ -115,6 +115,7 @@ void launch_depth_hist(const int32_t* d_depth, int64_t n_slots, int32_t cap, int
 	int64_t wgs = (n_slots + 256 * 16 - 1) / (256 * 16);
 	int grid = (int)(wgs < 1 ? 1 : (wgs < 1024 ? wgs : 1024));
 	size_t lds = (size_t)(cap + 1) * sizeof(uint32_t);
+	if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)depth_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // cfDNA: 20 000 bins = 80 KB of the CU's 160 KB
 	hipLaunchKernelGGL(depth_hist_kernel, dim3(grid), dim3(256), lds, s, d_depth, n_slots, cap, (long long)half, d_hist, d_cov); KCHECK();
 }
 

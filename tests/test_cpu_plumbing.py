@@ -67,6 +67,41 @@ def test_tool_cli_contract():
         assert p.returncode != 0 and "Mandatory parameter 'cutoff' not given." in p.stderr
 
 
+def test_sibling_tool_cli_contract_and_no_device_error():
+    bam = os.path.join(GI, "close_exons.bam")
+    p = _tool("SampleGender", "--help")
+    for flag in ("-in", "-out", "-method", "-max_female", "-min_male", "-min_female", "-max_male", "-sry_cov", "-build", "-ref", "-long_read"):
+        assert f"  {flag}" in p.stdout, flag   # src/SampleGender/main.cpp:22-36
+    p = _tool("SampleGender", "-in", bam, "-method", "zz")
+    assert p.returncode != 0 and "is not valid" in p.stderr
+    p = _tool("SampleGender", "-in", bam)
+    assert p.returncode != 0 and "Mandatory parameter 'method' not given." in p.stderr
+    p = _tool("BedReadCount", "--help")
+    for flag in ("-bam", "-min_mapq", "-in", "-out", "-ref"):
+        assert f"  {flag}" in p.stdout, flag   # src/BedReadCount/main.cpp:23-30
+    import torch
+    if not torch.cuda.is_available():   # no CPU fallback in any tool
+        for args in (("SampleGender", "-in", bam, "-method", "xy"), ("BedReadCount", "-bam", bam, "-in", os.path.join(GI, "close_exons.bed"))):
+            p = _tool(*args)
+            assert p.returncode != 0 and "no CPU fallback" in p.stderr, p.stderr
+
+
+def test_bench_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): checked with a stub that
+    replaces main() by printing the rank environment (no GPU needed)."""
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import importlib.util, os, sys\n"
+        f"spec = importlib.util.spec_from_file_location('bench', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "if 'WORLD_SIZE' in os.environ:\n"
+        "    print('rank', os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], flush=True); sys.exit(0)\n"
+        "b.__file__ = __file__\n"
+        "sys.exit(b.spawn_ranks(3))\n")
+    p = subprocess.run([sys.executable, str(stub), "--gpus", "3"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.split() == ["rank", "0", "0", "3", "127.0.0.1"]   # rank 0's stdout passes through, the other ranks are silenced
+
+
 def test_combine_counters_semantics():
     rng = np.random.default_rng(0)
     a, b = rng.integers(0, 1000, ngsqc.NCOUNTERS), rng.integers(0, 1000, ngsqc.NCOUNTERS)

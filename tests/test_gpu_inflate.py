@@ -142,6 +142,31 @@ def test_crc32_mismatch_is_the_reference_read_error(raw_bam, monkeypatch):
     h.close()
 
 
+@pytest.mark.parametrize("field", ["l_seq", "n_cigar", "l_read_name", "neg_l_seq"])
+def test_record_with_impossible_lengths_is_the_reference_read_error(raw_bam, field):
+    """htslib's bam_read1 rejects a record whose variable-length fields do not fit block_size (the reference then throws "Could not read next
+    alignment"); the kernels behind K2 trust l_read_name / n_cigar_op / l_seq, so K2 must refuse such a record instead of reading past it."""
+    raw = bytearray(raw_bam)
+    o = 4; o += 4 + struct.unpack_from("<i", raw, o)[0]; n_ref = struct.unpack_from("<i", raw, o)[0]; o += 4
+    for _ in range(n_ref):
+        o += 4 + struct.unpack_from("<i", raw, o)[0] + 4
+    for _ in range(5000):
+        o += 4 + struct.unpack_from("<i", raw, o)[0]
+    if field == "l_seq":
+        struct.pack_into("<i", raw, o + 20, 1 << 20)
+    elif field == "neg_l_seq":
+        struct.pack_into("<i", raw, o + 20, -5)
+    elif field == "n_cigar":
+        struct.pack_into("<H", raw, o + 16, 60000)
+    else:
+        raw[o + 12] = 0
+    h = ngsqc.Handle(data=np.frombuffer(rebgzf(bytes(raw), [65280]), dtype=np.uint8))
+    with pytest.raises(ngsqc.NgsqcError) as ei:
+        h.n_records
+    assert "Could not read next alignment" in str(ei.value) and ei.value.code == -2
+    h.close()
+
+
 def test_empty_members_inside_file(raw_bam):
     body = rebgzf(raw_bam, [20000])
     members = []
