@@ -177,6 +177,12 @@ def plan_shard_fix(summaries, shard):
 
 
 def _regions_array(regions):
+    if isinstance(regions, C.Array):   # prepared once by the caller (bench: 200 k lines per step)
+        return regions
+    if isinstance(regions, np.ndarray):
+        a = np.ascontiguousarray(regions, dtype=np.int32).reshape(-1, 3)
+        arr = (Region * max(a.shape[0], 1)).from_buffer_copy(a.tobytes() if a.shape[0] else bytes(C.sizeof(Region)))
+        return arr
     arr = (Region * max(len(regions), 1))()
     for i, (tid, s, e) in enumerate(regions):
         arr[i].tid, arr[i].start, arr[i].end = int(tid), int(s), int(e)
@@ -373,12 +379,12 @@ class Handle:
     def depth_finalize(self):
         self._chk(lib().ngsqc_depth_finalize(self.h))
 
-    def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False, partial=False):
+    def scan_depth(self, regions, min_mapq=1, min_baseq=0, skip_mismapped=False, partial=False, n_regions=None):
         """partial=True: shard variant that leaves the additive difference array (see depth_diff / depth_finalize)."""
         p = DepthParams()
         ra = _regions_array(regions)
         p.min_mapq, p.min_baseq, p.skip_mismapped = min_mapq, min_baseq, int(skip_mismapped)
-        p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions)
+        p.regions = C.cast(ra, C.c_void_p).value; p.n_regions = len(regions) if n_regions is None else n_regions
         self._chk((lib().ngsqc_scan_depth_partial if partial else lib().ngsqc_scan_depth)(self.h, C.byref(p)))
 
     def region_read_counts(self, regions, min_mapq=1):
@@ -399,20 +405,24 @@ class Handle:
         self._chk(lib().ngsqc_depth_copy(self.h, out.ctypes.data, roi_bases))
         return out[:roi_bases]
 
-    def region_sums(self, lines):
+    def region_sums(self, lines, n_lines=None):
         la = _regions_array(lines)
-        sums = np.zeros(max(len(lines), 1), dtype=np.int64)
-        self._chk(lib().ngsqc_region_sums(self.h, C.cast(la, C.c_void_p), len(lines), sums.ctypes.data))
-        return sums[:len(lines)]
+        n = len(lines) if n_lines is None else n_lines
+        sums = np.zeros(max(n, 1), dtype=np.int64)
+        self._chk(lib().ngsqc_region_sums(self.h, C.cast(la, C.c_void_p), n, sums.ctypes.data))
+        return sums[:n]
 
-    def lowhigh_runs(self, lines, cutoff, is_high=False, saturate254=False):
+    def lowhigh_runs(self, lines, cutoff, is_high=False, saturate254=False, n_lines=None, as_array=False):
         la = _regions_array(lines)
+        nl = len(lines) if n_lines is None else n_lines
         n = C.c_int64(0)
-        self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), len(lines), cutoff, int(is_high), int(saturate254), None, 0, C.byref(n)))
+        self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), nl, cutoff, int(is_high), int(saturate254), None, 0, C.byref(n)))
         runs = (Run * max(n.value, 1))()
         if n.value:
-            self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), len(lines), cutoff, int(is_high), int(saturate254),
+            self._chk(lib().ngsqc_lowhigh_runs(self.h, C.cast(la, C.c_void_p), nl, cutoff, int(is_high), int(saturate254),
                                                C.cast(runs, C.c_void_p), n.value, C.byref(n)))
+        if as_array:   # (bench: no per-run Python objects)
+            return runs
         return [(runs[i].line, runs[i].start, runs[i].end) for i in range(n.value)]
 
     def timings(self):
