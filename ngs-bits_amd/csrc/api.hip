@@ -369,7 +369,8 @@ void plan_layout(ngsqc_handle* h)
 	h->planned = true;
 	if (nb == 0) return;
 	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
-	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * 6 * 64 / div);
+	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
+	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * 6 * 64 * mul / div);
 	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	bool forced = false;
 	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) { h->chunk = std::max<int64_t>(1, atoll(e)); cpt = 1; forced = true; }

@@ -529,9 +529,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t member_rsrc(uint8_t* p, uint32
 	return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
-// STAGED: the batch is stored from the LDS staging bytes after the chunk loop as aligned dwords (the staging index is shifted
-// by the output address's misalignment), so no store sits between the gathers of consecutive chunks.
-template <bool STAGED>
 __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
                                                          const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
 {
@@ -576,7 +573,6 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 			// the next batch's tokens are requested now; they arrive while this batch is resolved
 			{ const uint32_t i2 = t0 + ntake + (uint32_t)lane; tk_next = i2 < n ? T[i2] : 0u; }
 			uint32_t ta = 0;   // tokens that end at or before the current chunk start
-			const uint32_t sh = STAGED ? (uint32_t)((uintptr_t)(out + P) & 3u) : 0u;
 			for (uint32_t j0 = 0; j0 < B; j0 += 64)
 			{
 				const uint32_t j = j0 + (uint32_t)lane;
@@ -599,7 +595,7 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 					}
 					const int src = (int)sto - (int)d + (int)r;   // relative to P
 					if (src < 0) vv = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)P + src, 0, 0);
-					else if ((uint32_t)src < j0) vv = S.val[sh + (uint32_t)src];
+					else if ((uint32_t)src < j0) vv = S.val[(uint32_t)src];
 					else { vv = 0x100u; rel = (uint32_t)src - j0; }
 				}
 				uint64_t pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
@@ -609,18 +605,7 @@ __global__ __launch_bounds__(256) void lz77_chunk_kernel(const uint32_t* __restr
 					if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
 					pend = __builtin_amdgcn_ballot_w64((vv & 0x100u) != 0);
 				}
-				if (j < B) { S.val[sh + j] = (uint8_t)vv; if (!STAGED) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vv, rs, (int)(P + j), 0, 0); }
-				__builtin_amdgcn_wave_barrier();
-			}
-			if (STAGED)
-			{
-				// shifted byte x of the staging buffer lives at out + P - sh + x; whole dwords where all four bytes are in [sh, sh + B)
-				uint8_t* const o4 = out + P - sh; const uint32_t hi = sh + B;
-				for (uint32_t x = 4u * (uint32_t)lane; x < hi; x += 256)
-				{
-					if (x >= sh && x + 4 <= hi) *(uint32_t*)(o4 + x) = *(const uint32_t*)&S.val[x];
-					else { for (uint32_t k = x; k < x + 4; ++k) if (k >= sh && k < hi) o4[k] = S.val[k]; }
-				}
+				if (j < B) { S.val[j] = (uint8_t)vv; __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vv, rs, (int)(P + j), 0, 0); }
 				__builtin_amdgcn_wave_barrier();
 			}
 			P += B; t0 += ntake;
@@ -655,7 +640,7 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 	// over ~10 members), 92 ms at 1 k (all workgroups resident from the start: the launch ends with a long ragged tail)
 	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)32768;
 	int grid2 = (int)(wg2 < cap2 ? wg2 : cap2);
-	hipLaunchKernelGGL(lz77_chunk_kernel<false>, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
+	hipLaunchKernelGGL(lz77_chunk_kernel, dim3(grid2), dim3(256), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }
 
 } // namespace ngsqc

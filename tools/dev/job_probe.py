@@ -34,6 +34,7 @@ VARIANTS = {
     "nopad_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P2_WGS": "2048"}, "nopad_1s_p2wg2048": {"NGSQC_P1_PAD": "0", "NGSQC_P1_STREAMS": "1", "NGSQC_P2_WGS": "2048"},
     "prio0": {"NGSQC_P1_PRIO": "0"}, "prio1": {"NGSQC_P1_PRIO": "1"}, "prio3": {"NGSQC_P1_PRIO": "3"},
     "prio3_nopad": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PAD": "0"}, "prio0_nocrc": {"NGSQC_P1_PRIO": "0", "NGSQC_VERIFY_CRC": "0"}, "prio3_nocrc": {"NGSQC_P1_PRIO": "3", "NGSQC_VERIFY_CRC": "0"},
+    "mul2": {"NGSQC_K1_CHUNK_MUL": "2", "NGSQC_TILE_CHUNKS": "1"}, "mul3": {"NGSQC_K1_CHUNK_MUL": "3", "NGSQC_TILE_CHUNKS": "1"}, "mul2_t2": {"NGSQC_K1_CHUNK_MUL": "2"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
 
@@ -43,7 +44,10 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     names = sys.argv[3].split(",") if len(sys.argv) > 3 else ["default", "nopipe", "nocrc"]
     t0 = time.time()
-    image = G.generate(reads)
+    cache = f'/tmp/ngsqc_probe_{reads}.bam'
+    image = np.fromfile(cache, dtype=np.uint8) if os.path.exists(cache) else G.generate(reads)
+    if not os.path.exists(cache):
+        image.tofile(cache)
     print(f"[probe] generated {reads} reads, {image.size} bytes in {time.time() - t0:.1f} s on {os.cpu_count()} cpus", flush=True)
     omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
     ref = None
