@@ -192,7 +192,7 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 	std::vector<uint64_t> off((size_t)n + 1, 0); std::vector<uint32_t> crc((size_t)n);
 	for (int64_t i = 0; i < n; ++i)
 	{
-		const uint64_t cap = tok_cap_full ? (uint64_t)desc[(size_t)i].usize + 64 : (uint64_t)desc[(size_t)i].clen + 64;
+		const uint64_t cap = tok_cap_full ? 4ull * desc[(size_t)i].usize + 64 : (uint64_t)desc[(size_t)i].clen + 64;
 		off[(size_t)i + 1] = off[(size_t)i] + ((cap + 3) & ~3ull);
 		crc[(size_t)i] = h->crc[(size_t)idx[(size_t)i]];
 	}

@@ -7,19 +7,12 @@
 #include <string>
 #include <vector>
 #include "../../include/ngsqc.h"
+#include "k1_types.h"
 
 namespace ngsqc {
 
-// One BGZF member as the device sees it (SAM spec §4.1). cpos = byte offset of the raw DEFLATE payload inside the
-// compressed image in HBM, clen = payload bytes, upos/usize = where its output goes in the inflated stream.
-struct BlockDesc { uint64_t cpos; uint64_t upos; uint32_t clen; uint32_t usize; };
-
-// Per-member result of K1: bytes produced (must equal usize) and an error code (0 = ok).
-struct BlockStatus { uint32_t produced; uint32_t error; };
-
 // ---- K1 ----
-enum { K1_ERR_CRC = 20, K1_ERR_TOKEN_OVERFLOW = 100 };   // BlockStatus.error values the host treats specially
-// two-phase K1 (inflate2.hip): lane-per-member Huffman -> tokens, then wave-per-member LZ77 resolve
+// two-phase K1 (k1_kernels.h / inflate3.hip): lane-per-member Huffman -> token groups, then wave-per-member LZ77 resolve
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
                         const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order /* queue order inside the launch, or null */, int max_wgs, hipStream_t s);
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,

@@ -1,0 +1,136 @@
+// Wave emulator for the K1 kernels (test infrastructure, CPU only - never part of the library).
+//
+// ngs-bits_amd/csrc/k1_kernels.h is written against the small wave vocabulary of csrc/wave.h. This header implements the same
+// vocabulary for g++: the 64 lanes of a wave are 64 fibers (ucontext) that run one after the other; every cross-lane operation
+// (ballot, readlane, shfl, scan, barrier) is a rendezvous - a lane deposits its operand, yields, and continues when all live
+// lanes of the wave have arrived. Between two rendezvous a lane runs alone, so an LDS exchange that lacks a barrier shows up as
+// a wrong result here even where the lockstep hardware would forgive it. A cross-lane operation reached from divergent control
+// flow (lanes arriving from different call sites) aborts the run. One workgroup (= one wave) runs at a time; K1_SHARED
+// variables are function-local statics.
+#pragma once
+#include <ucontext.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define K1_KERNEL(bounds)
+#define K1_SHARED static
+#define K1_DEV inline
+#ifndef __restrict__
+#define __restrict__
+#endif
+
+namespace ngsqc { namespace wv {
+
+struct u32x4 { uint32_t x, y, z, w; };
+inline u32x4 make4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return u32x4{a, b, c, d}; }
+
+struct Emu
+{
+	static constexpr int W = 64;
+	ucontext_t main_ctx, ctx[W];
+	std::vector<char> stack[W];
+	bool live[W];
+	int cur = 0;
+	int64_t block = 0, grid = 1;
+	uint64_t opno[W], xv[2][W], stamp[2][W]; const void* site[2][W];
+	uint64_t n_sync = 0;
+	std::function<void()> body;
+};
+inline Emu& emu() { static Emu e; return e; }
+
+inline void lane_entry()
+{
+	Emu& E = emu();
+	E.body();
+	E.live[E.cur] = false;
+	swapcontext(&E.ctx[E.cur], &E.main_ctx);
+}
+
+// run one workgroup of 64 threads
+inline void run_block(int64_t block, int64_t grid, std::function<void()> body)
+{
+	Emu& E = emu();
+	E.block = block; E.grid = grid; E.body = std::move(body);
+	for (int l = 0; l < Emu::W; ++l)
+	{
+		if (E.stack[l].empty()) E.stack[l].resize(512 << 10);
+		getcontext(&E.ctx[l]);
+		E.ctx[l].uc_stack.ss_sp = E.stack[l].data(); E.ctx[l].uc_stack.ss_size = E.stack[l].size(); E.ctx[l].uc_link = &E.main_ctx;
+		makecontext(&E.ctx[l], (void (*)())lane_entry, 0);
+		E.live[l] = true; E.opno[l] = 0;
+	}
+	memset(E.stamp, 0xff, sizeof(E.stamp));
+	bool any = true;
+	while (any)
+	{
+		any = false;
+		for (int l = 0; l < Emu::W; ++l)
+			if (E.live[l]) { E.cur = l; swapcontext(&E.main_ctx, &E.ctx[l]); any = any || E.live[l]; }
+	}
+}
+
+// rendezvous: returns the parity slot holding every participating lane's operand (participating: stamp == op number)
+struct Xchg { const uint64_t* v; const uint64_t* stamp; uint64_t k; bool has(int l) const { return stamp[l] == k; } };
+__attribute__((noinline)) inline Xchg rendezvous(uint64_t v, const void* site)
+{
+	Emu& E = emu(); const int l = E.cur; const uint64_t k = ++E.opno[l]; const int p = (int)(k & 1);
+	E.xv[p][l] = v; E.stamp[p][l] = k; E.site[p][l] = site; ++E.n_sync;
+	swapcontext(&E.ctx[l], &E.main_ctx);
+	for (int i = 0; i < Emu::W; ++i)
+		if (E.stamp[p][i] == k && E.site[p][i] != site)
+		{
+			fprintf(stderr, "wave_emul: cross-lane operation reached from divergent control flow (lanes %d and %d, block %lld)\n", l, i, (long long)E.block);
+			abort();
+		}
+	return Xchg{E.xv[p], E.stamp[p], k};
+}
+#define WV_SITE __builtin_return_address(0)
+
+inline int lane() { return emu().cur; }
+inline int64_t block_id() { return emu().block; }
+inline int64_t grid_size() { return emu().grid; }
+
+__attribute__((noinline)) inline uint64_t ballot(bool p)
+{
+	const Xchg x = rendezvous(p ? 1u : 0u, WV_SITE); uint64_t m = 0;
+	for (int i = 0; i < Emu::W; ++i) if (x.has(i) && x.v[i]) m |= 1ull << i;
+	return m;
+}
+__attribute__((noinline)) inline uint32_t readlane(uint32_t v, int l) { const Xchg x = rendezvous(v, WV_SITE); return x.has(l & 63) ? (uint32_t)x.v[l & 63] : 0u; }
+__attribute__((noinline)) inline uint32_t shfl(uint32_t v, int src) { const Xchg x = rendezvous(v, WV_SITE); return x.has(src & 63) ? (uint32_t)x.v[src & 63] : 0u; }
+__attribute__((noinline)) inline void barrier() { rendezvous(0, WV_SITE); }
+__attribute__((noinline)) inline uint32_t scan_incl(uint32_t v)
+{
+	const Xchg x = rendezvous(v, WV_SITE); const int me = emu().cur; uint32_t s = 0;
+	for (int i = 0; i <= me; ++i) if (x.has(i)) s += (uint32_t)x.v[i];
+	return s;
+}
+
+inline void wait_vm0() {}
+inline unsigned long long atomic_inc(unsigned long long* p) { return (*p)++; }
+inline void lds_or(unsigned long long* p, unsigned long long v) { *p |= v; }
+
+struct ByteBuf
+{
+	uint8_t* p; uint32_t bytes;
+	static ByteBuf make(uint8_t* p, uint32_t bytes) { return ByteBuf{p, bytes}; }
+	uint32_t load(uint32_t off) const { return off < bytes ? p[off] : 0u; }
+	void store(uint32_t off, uint32_t v) const { if (off < bytes) p[off] = (uint8_t)v; }
+};
+
+inline uint32_t brev(uint32_t x)
+{
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4); x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+	return (x >> 16) | (x << 16);
+}
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
+inline uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { width &= 31u; return width ? (x >> (off & 31u)) & ((1u << width) - 1u) : 0u; }
+inline uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+inline float rcp(float x) { return 1.0f / x; }
+
+} } // namespace ngsqc::wv
