@@ -37,7 +37,8 @@ template <typename T> struct DevBuf
 	T* p = nullptr; size_t n = 0;
 	void alloc(size_t count) { release(); if (count) { HIPCHK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
 	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
-	void ensure(size_t count) { if (n < count) alloc(count); }   // keep a big-enough allocation (hipMalloc/hipFree of multi-GB buffers can stall for a second)
+	void ensure(size_t count) { if (n < count) alloc(count); }
+	void ensure_slack(size_t count) { if (n < count) alloc(count + count / 4); }   // per-tile scratch: growing it means hipFree, and hipFree waits for every queued kernel of the device   // keep a big-enough allocation (hipMalloc/hipFree of multi-GB buffers can stall for a second)
 	void upload(const std::vector<T>& v, hipStream_t s) { ensure(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
 	~DevBuf() { release(); }
 	DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
@@ -67,7 +68,7 @@ double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono:
 uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-constexpr int K1_SLOTS = 3;          // token ring: chunk c uses slot c % 3 (phase 1 of c+1 and c+2 may run while phase 2 of c reads)
+constexpr int K1_SLOTS_DEFAULT = 4;  // token ring: chunk c uses slot c % slots (phase 1 of the next chunks runs while phase 2 of c reads); NGSQC_TOKEN_SLOTS
 constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
 
 // target regions + per-base depth of one scan
@@ -103,13 +104,16 @@ struct ngsqc_handle
 	int64_t pfx = 0, max_tile_bytes = 0, slot_tokens = 0;
 	DevBuf<BlockDesc> d_kdesc;                         // per member: cpos into d_comp, upos relative to its tile's first member
 	DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt, d_order, d_tok, d_crc; DevBuf<unsigned long long> d_work; DevBuf<BlockStatus> d_status;
-	DevBuf<uint8_t> buf[2];                            // tile buffers: [pfx carried bytes right-aligned][members][64]
+	static constexpr int MAX_TILE_BUFS = 4;
+	int k1_slots = K1_SLOTS_DEFAULT;
+	DevBuf<uint8_t> buf[MAX_TILE_BUFS]; int nbuf = 2;  // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
 	std::vector<hipEvent_t> ev_chunk;                  // 4 per chunk: p1 start/end, p2 start/end
 	std::vector<hipEvent_t> ev_tile;                   // 2 per tile: K1 done (status on the host), consumed
 	PinBuf<BlockStatus> p_status; PinBuf<int32_t> p_start; PinBuf<int64_t> p_next; PinBuf<unsigned long long> p_small;
 	// ---- the resident tile ----
 	bool decoded = false; int cur_tile = -1;
 	int64_t n_rec = 0; DevBuf<int64_t> d_recoff;
+	DevBuf<int64_t> d_long;                            // long-record list of the consumer that runs (scan, pileup: one after the other on the main stream); kept across tiles and jobs
 	int64_t tile_prefix = 0, tile_total = 0, tile_u_lo = 0, tile_ord_base = 0;
 	int64_t carry_len = 0, carry_src = 0, next_ord_base = 0, expected_abs = 0;
 	int64_t k1_enq = 0;                                // chunks enqueued by the running job
@@ -372,6 +376,9 @@ void plan_layout(ngsqc_handle* h)
 	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
 	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * 6 * 64 * mul / div);
 	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
+	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
+	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile). NGSQC_TILE_BUFFERS=2..4.
+	h->nbuf = 3; if (const char* e = getenv("NGSQC_TILE_BUFFERS")) h->nbuf = std::min<int>(ngsqc_handle::MAX_TILE_BUFS, std::max(2, atoi(e)));
 	bool forced = false;
 	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) { h->chunk = std::max<int64_t>(1, atoll(e)); cpt = 1; forced = true; }
 	else
@@ -398,10 +405,11 @@ void plan_layout(ngsqc_handle* h)
 		std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(c0 + a)].clen > h->blocks[(size_t)(c0 + b)].clen; });
 	}
 	h->slot_tokens = slot + 16;
-	const int64_t n_slots = std::min<int64_t>(K1_SLOTS, h->nch);
+	h->k1_slots = K1_SLOTS_DEFAULT; if (const char* e = getenv("NGSQC_TOKEN_SLOTS")) h->k1_slots = std::min(8, std::max(2, atoi(e)));
+	const int64_t n_slots = std::min<int64_t>(h->k1_slots, h->nch);
 	for (int64_t c = 0; c < h->nch; ++c)   // slot base of the chunk
 	{
-		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0); const uint64_t base = (uint64_t)((c % K1_SLOTS) * h->slot_tokens);
+		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0); const uint64_t base = (uint64_t)((c % h->k1_slots) * h->slot_tokens);
 		for (int64_t i = 0; i <= cn; ++i) tok_off[(size_t)(c0 + c + i)] += base;
 	}
 	// tiles: as many chunks as fit two tile buffers next to the ring (at most cpt)
@@ -411,10 +419,10 @@ void plan_layout(ngsqc_handle* h)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 		{
-			const double fixed = (double)n_slots * (double)h->slot_tokens * 4.0 + (double)nb * 64.0 + 2.0 * (double)carry_max;
+			const double fixed = (double)n_slots * (double)h->slot_tokens * 4.0 + (double)nb * 64.0 + (double)h->nbuf * (double)carry_max;
 			int64_t max_chunk = 0; for (int64_t b : chunk_bytes) max_chunk = std::max(max_chunk, b);
 			const double avail = (double)free_b * 0.85 - fixed;
-			int64_t fit = (int64_t)(avail / (2.15 * (double)std::max<int64_t>(max_chunk, 1)));   // two buffers + record index / long list
+			int64_t fit = (int64_t)(avail / (((double)h->nbuf + 0.15) * (double)std::max<int64_t>(max_chunk, 1)));   // the tile buffers + record index / long list
 			if (fit < 1) throw std::runtime_error("not enough device memory for one K1 chunk (" + std::to_string(max_chunk) + " inflated bytes)");
 			cpt = std::min(cpt, fit);
 		}
@@ -440,8 +448,7 @@ void plan_layout(ngsqc_handle* h)
 	h->d_kdesc.upload(kd, h->stream); h->d_tok_off.upload(tok_off, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
 	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch);
 	h->d_tok.ensure((size_t)(n_slots * h->slot_tokens) + 16);
-	h->buf[0].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
-	if (nt > 1) h->buf[1].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
+	for (int i = 0; i < std::min(nt, h->nbuf); ++i) h->buf[i].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
 	h->p_status.ensure((size_t)nb);
 	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
 	while ((int)h->ev_tile.size() < 2 * nt) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_tile.push_back(e); }
@@ -454,7 +461,7 @@ void plan_layout(ngsqc_handle* h)
 void enqueue_k1_tile(ngsqc_handle* h, int t)
 {
 	const int64_t nb = (int64_t)h->blocks.size();
-	uint8_t* out_base = h->buf[t & 1].p + h->pfx;
+	uint8_t* out_base = h->buf[t % h->nbuf].p + h->pfx;
 	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
 	// CRC of a chunk in line behind its phase 2 (default). On its own stream (NGSQC_CRC_STREAM=1) it runs beside phase 2 of the next chunk and
 	// takes the LDS that phase 2's workgroups need next to the six phase-1 waves of a CU: measured 84 ms instead of 74 ms per 48 M reads.
@@ -466,13 +473,13 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
-		if (c >= K1_SLOTS) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - K1_SLOTS) + 3)], 0));   // the ring slot is free again
+		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
 		HIPCHK(hipEventRecord(e4[0], s1));
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_work.p + c,
 		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->n_cu * 6, s1);
 		HIPCHK(hipEventRecord(e4[1], s1));
 		HIPCHK(hipStreamWaitEvent(h->s_p2, e4[1], 0));
-		if (c == h->tile_first_chunk[(size_t)t] && t >= 2) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - 2) + 1)], 0));   // the buffer's previous tile is consumed
+		if (c == h->tile_first_chunk[(size_t)t] && t >= h->nbuf) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - h->nbuf) + 1)], 0));   // the buffer's previous tile is consumed
 		HIPCHK(hipEventRecord(e4[2], h->s_p2));
 		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->s_p2);
 		HIPCHK(hipEventRecord(e4[3], h->s_p2));
@@ -507,10 +514,10 @@ void finish_k1_tile(ngsqc_handle* h, int t)
 	if (redo.empty()) return;
 	std::vector<BlockDesc> desc; const uint64_t u_lo = h->blocks[(size_t)f].upos;
 	for (int64_t i : redo) { BlockDesc d = h->blocks[(size_t)i]; d.upos -= u_lo; desc.push_back(d); }
-	inflate_sync(h, redo, desc, h->buf[t & 1].p + h->pfx, true);
+	inflate_sync(h, redo, desc, h->buf[t % h->nbuf].p + h->pfx, true);
 }
 
-// K2 for tile t (its members are in buf[t & 1] behind the prefix area; carry_len bytes of the previous tile's straddling
+// K2 for tile t (its members are in buf[t % nbuf] behind the prefix area; carry_len bytes of the previous tile's straddling
 // record have been copied right in front of them). Tile-local coordinates: byte 0 = first carried byte.
 void index_tile(ngsqc_handle* h, int t)
 {
@@ -523,7 +530,7 @@ void index_tile(ngsqc_handle* h, int t)
 	const int64_t u_hi = (int64_t)h->blocks[(size_t)(first + nm - 1)].upos + h->blocks[(size_t)(first + nm - 1)].usize;
 	const int64_t prefix = h->carry_len;
 	const int64_t total = prefix + (u_hi - u_lo);
-	const uint8_t* base = h->buf[t & 1].p + h->pfx - prefix;
+	const uint8_t* base = h->buf[t % h->nbuf].p + h->pfx - prefix;
 	const BlockDesc* d_desc = h->d_kdesc.p + first;
 	const int64_t ne = nm + 1;   // entry 0 = the carried prefix
 	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };
@@ -533,8 +540,9 @@ void index_tile(ngsqc_handle* h, int t)
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
-	h->d_start.ensure((size_t)ne); h->d_cnt.ensure((size_t)ne + 1); h->d_next.ensure((size_t)ne + 1); h->d_base.ensure((size_t)ne + 1); h->d_bad.ensure(2);
-	h->d_scan_tmp.ensure(scan_tmp_bytes(ne) + 64); h->d_rel.ensure((size_t)ne * K2_REL_STRIDE);
+	// (with slack: a later tile has one entry more - its carried prefix - and regrowing means hipFree, which waits for all queued K1 work)
+	h->d_start.ensure_slack((size_t)ne); h->d_cnt.ensure_slack((size_t)ne + 1); h->d_next.ensure_slack((size_t)ne + 1); h->d_base.ensure_slack((size_t)ne + 1); h->d_bad.ensure(2);
+	h->d_scan_tmp.ensure_slack(scan_tmp_bytes(ne) + 64); h->d_rel.ensure_slack((size_t)ne * K2_REL_STRIDE);
 	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
 	// ---- fast path: htslib-style members (a record starts at every member's first byte, none straddles). One round trip: guess + walk every
@@ -558,7 +566,7 @@ void index_tile(ngsqc_handle* h, int t)
 	else
 	{
 	// ---- general path: records cut by member borders, carried records, shards that guess their first record ----
-	h->p_start.ensure((size_t)ne); h->p_next.ensure((size_t)ne);
+	h->p_start.ensure((size_t)ne + 64); h->p_next.ensure((size_t)ne + 64);
 	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
 	bool first_round = true;
 	while (true)
@@ -613,7 +621,7 @@ void index_tile(ngsqc_handle* h, int t)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	}
 	int64_t n_rec = (int64_t)sm[1];
-	h->d_recoff.ensure((size_t)std::max<int64_t>(n_rec + n_rec / 8, 1));
+	h->d_recoff.ensure_slack((size_t)std::max<int64_t>(n_rec, 1));
 	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
@@ -657,7 +665,7 @@ void index_tile(ngsqc_handle* h, int t)
 TileCtx resident_ctx(ngsqc_handle* h)
 {
 	const int nt = (int)h->tiles.size(); const int t = h->cur_tile;
-	return TileCtx{h->buf[t & 1].p + h->pfx - h->tile_prefix, h->tile_total, h->d_recoff.p, h->n_rec, h->tile_ord_base, t, t == nt - 1};
+	return TileCtx{h->buf[t % h->nbuf].p + h->pfx - h->tile_prefix, h->tile_total, h->d_recoff.p, h->n_rec, h->tile_ord_base, t, t == nt - 1};
 }
 
 void reset_decode_timings(ngsqc_handle* h)
@@ -688,11 +696,14 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	try
 	{
-		enqueue_k1_tile(h, 0);
+		// K1 is queued nbuf - 1 tiles ahead of the tile the host works on (tile t + nbuf - 1 reuses the buffer of tile t - 1, whose consumers were
+		// queued - and their event recorded - in the previous iteration)
+		const int ahead = pipelined ? h->nbuf - 1 : 0;
+		for (int u = 0; u < std::min(nt, std::max(1, ahead)); ++u) enqueue_k1_tile(h, u);
 		for (int t = 0; t < nt; ++t)
 		{
 			const double d0 = wall_ms();
-			if (pipelined && t + 1 < nt) enqueue_k1_tile(h, t + 1);
+			if (pipelined && t + ahead < nt) enqueue_k1_tile(h, t + ahead);
 			const double d1 = wall_ms();
 			finish_k1_tile(h, t);
 			const double d2 = wall_ms();
@@ -702,7 +713,7 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 			if (dbg) fprintf(stderr, "[ngsqc] tile %d/%d: enqueue next K1 %.2f ms, wait K1 %.2f ms, K2 %.2f ms, consumers %.2f ms (%lld records)\n", t, nt, d1 - d0, d2 - d1, d3 - d2, wall_ms() - d3, (long long)h->n_rec);
 			const bool stop = !go_on || t == h->shard_last_tile;   // (a shard stops at the tile that holds the first record of the next shard)
 			if (!stop && t + 1 < nt && h->carry_len > 0)
-				HIPCHK(hipMemcpyAsync(h->buf[(t + 1) & 1].p + h->pfx - h->carry_len, h->buf[t & 1].p + h->pfx - h->tile_prefix + h->carry_src, (size_t)h->carry_len, hipMemcpyDeviceToDevice, h->stream));
+				HIPCHK(hipMemcpyAsync(h->buf[(t + 1) % h->nbuf].p + h->pfx - h->carry_len, h->buf[t % h->nbuf].p + h->pfx - h->tile_prefix + h->carry_src, (size_t)h->carry_len, hipMemcpyDeviceToDevice, h->stream));
 			HIPCHK(hipEventRecord(h->ev_tile[(size_t)(2 * t + 1)], h->stream));
 			if (stop) { if (t + 1 < nt) { sync_all(h); h->decoded = nt == 1; } break; }
 			if (!pipelined && t + 1 < nt) { HIPCHK(hipStreamSynchronize(h->stream)); enqueue_k1_tile(h, t + 1); }
@@ -784,7 +795,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 // tile's records in front of that read (prefix_fix_kernel) - normally a handful of records of the first tile.
 struct ScanState
 {
-	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<int64_t> d_long;
+	ScanParams sp{}; DevBuf<unsigned long long> d_counters;
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
 	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
 	// running state of the in-pass fix
@@ -805,9 +816,9 @@ struct ScanState
 	}
 	void tile(ngsqc_handle* h, const TileCtx& c)
 	{
-		d_long.ensure((size_t)std::max<int64_t>(c.n_rec, 1));
+		h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));
 		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
-		sp.long_list = d_long.p; sp.long_cap = c.n_rec;
+		sp.long_list = h->d_long.p; sp.long_cap = c.n_rec;
 		Timer t(h->stream); t.start();
 		// per-tile slots: long-record count, (longest read, first ordinal) key
 		HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
@@ -878,7 +889,7 @@ void bind_regions(ScanParams& sp, DepthSet& D)
 // site pileup of a table of known sites (BamReader::getPileup per site in the reference)
 struct PileupState
 {
-	DevBuf<int32_t> d_pos, d_tf, d_tl, d_bucket; DevBuf<int64_t> d_tb0; DevBuf<uint32_t> d_cnt; DevBuf<unsigned long long> d_nlong; DevBuf<int64_t> d_long;
+	DevBuf<int32_t> d_pos, d_tf, d_tl, d_bucket; DevBuf<int64_t> d_tb0; DevBuf<uint32_t> d_cnt; DevBuf<unsigned long long> d_nlong;
 	int64_t n_sites = 0; int n_ref = 0; int min_mapq = 0, min_baseq = 0, include_npp = 0; double stage_ms = 0;
 	void begin(ngsqc_handle* h, const ngsqc_region* sites, int64_t n, int32_t mq, int32_t bq, int32_t npp)
 	{
@@ -916,13 +927,13 @@ struct PileupState
 	{
 		if (n_sites == 0) return;
 		Timer t(h->stream); t.start();
-		d_long.ensure((size_t)std::max<int64_t>(c.n_rec, 1));
+		h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));
 		HIPCHK(hipMemsetAsync(d_nlong.p, 0, sizeof(unsigned long long), h->stream));
-		launch_pileup(c.infl, c.recoff, c.n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_npp, d_cnt.p, d_long.p, d_nlong.p, h->stream);
+		launch_pileup(c.infl, c.recoff, c.n_rec, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_npp, d_cnt.p, h->d_long.p, d_nlong.p, h->stream);
 		unsigned long long* s = h->p_small.p + 16;
 		HIPCHK(hipMemcpyAsync(s, d_nlong.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		if (*s) launch_pileup_long(c.infl, c.recoff, d_long.p, (int64_t)*s, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream);
+		if (*s) launch_pileup_long(c.infl, c.recoff, h->d_long.p, (int64_t)*s, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream);
 		stage_ms += t.stop();
 	}
 	void end(ngsqc_handle* h, int64_t* counts)

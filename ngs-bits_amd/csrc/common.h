@@ -12,7 +12,7 @@
 namespace ngsqc {
 
 // ---- K1 ----
-// two-phase K1 (k1_kernels.h / inflate3.hip): lane-per-member Huffman -> token groups, then wave-per-member LZ77 resolve
+// two-phase K1 (k1_kernels.h / inflate.hip): lane-per-member Huffman -> token groups, then wave-per-member LZ77 resolve
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
                         const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order /* queue order inside the launch, or null */, int max_wgs, hipStream_t s);
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,

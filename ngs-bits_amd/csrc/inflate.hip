@@ -7,23 +7,15 @@
 
 namespace ngsqc {
 
-// the previous generation of the two kernels (inflate2.hip), selectable with NGSQC_K1_V=2 for A/B measurements
-void launch_huff_tokens_v2(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
-                           const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s);
-void launch_lz77_resolve_v2(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
-                            const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s);
-
-static bool k1_v2() { const char* e = getenv("NGSQC_K1_V"); return e && atoi(e) == 2; }
-
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
                         const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	if (k1_v2()) { launch_huff_tokens_v2(d_comp, d_blocks, n_blocks, d_status, d_tok_off, d_tok, d_tok_count, d_work, d_order, max_wgs, s); return; }
 	// d_work: the launch's member queue head (zeroed by the caller). One-wave workgroups of 23 KB LDS: six per CU.
 	const int64_t wgs = (n_blocks + 63) / 64;
 	const int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
-	const char* pe = getenv("NGSQC_P1_PARK"); const int park_hi = pe ? atoi(pe) : 16;
+	const char* pe = getenv("NGSQC_P1_PARK"); int park_hi = pe ? atoi(pe) : 16;
+	const char* pr = getenv("NGSQC_P1_PRIO"); park_hi = (park_hi & 255) | ((pr ? atoi(pr) : 0) << 8);
 	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
 	KCHECK();
 }
@@ -32,7 +24,6 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
                          const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	if (k1_v2()) { launch_lz77_resolve_v2(d_blocks, n_blocks, d_out, d_status, d_tok_off, d_tok, d_tok_count, s); return; }
 	// one member per one-wave workgroup, handed out by the dispatcher (NGSQC_P2_WGS caps the grid: the waves then stride over the members)
 	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)1 << 20;
 	const int grid2 = (int)(n_blocks < cap2 ? n_blocks : cap2);

@@ -1,4 +1,4 @@
-// K1 - BGZF inflate in two phases (the kernels; inflate3.hip holds the launchers).
+// K1 - BGZF inflate in two phases (the kernels; inflate.hip holds the launchers).
 //
 //   phase 1  huff_tokens_kernel : ONE LANE PER BGZF MEMBER. Every lane Huffman-decodes its own raw-DEFLATE stream into tokens
 //            (literal byte | match{len,dist}); 64 members advance per wave instruction. Canonical Huffman decode runs out of
@@ -29,7 +29,7 @@ namespace ngsqc { namespace k1 {
 constexpr int P1_SYM_W = 81;     // lit_sym : 288 x 9 bit as a byte plane (72 words) + a bit plane (9 words)
 constexpr int P1_RING_W = 8;     // compressed input window (32 B)
 constexpr int P1_LANE_W = P1_SYM_W + P1_RING_W;   // 89 words per lane (22.8 KB per wave); tokens and the distance symbols stay in registers
-constexpr int P1_PAD_W = 192;    // + 768 B: 23 KB per one-wave workgroup (exactly six fit a CU's 160 KB, see the kernel); holds the constant tables
+constexpr int P1_PAD_W = 192;    // + 768 B: 23 KB per one-wave workgroup (exactly six fit a CU's 160 KB, see the kernel): the window's mirror slot and the constant tables
 constexpr int P1_LDS_W = P1_LANE_W * 64 + P1_PAD_W;
 constexpr int P1_SERVICE = 4;    // trips between service blocks = tokens per group
 
@@ -49,7 +49,14 @@ struct P1Lds
 		uint32_t& lo = at((int)(i >> 2)); uint32_t sh = 8 * (i & 3); lo = (lo & ~(255u << sh)) | ((s & 255u) << sh);
 		uint32_t& hi = at(72 + (int)(i >> 5)); hi = (hi & ~(1u << (i & 31))) | ((s >> 8) << (i & 31));
 	}
-	K1_DEV uint32_t& ring(uint32_t i) const { return at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
+	// input window: word k of the member's piece stream sits in slot k & 7; slot 8 (the first 64 words of the workgroup's pad area)
+	// mirrors slot 0, so that the two words under a bit cursor are always slots s and s + 1: one address, two reads
+	K1_DEV uint32_t* slot(uint32_t i) const { return &at(P1_SYM_W + (int)(i & (P1_RING_W - 1))); }
+	K1_DEV void stage(uint32_t wr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const   // a piece = four words, wr a multiple of 4
+	{
+		uint32_t* p = slot(wr & 4u); p[0] = a; p[64] = b; p[128] = c; p[192] = d;
+		if ((wr & 4u) == 0) at(P1_SYM_W + P1_RING_W) = a;
+	}
 };
 
 // packed per-length counters: FW bits per field, 32/FW fields per register
@@ -158,9 +165,10 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 	K1_SHARED uint32_t lds[P1_LDS_W];
 	const int lane = wv::lane();
 	P1Lds L{lds, lane};
+	wv::set_priority(park_hi >> 8); park_hi &= 255;   // (upper bits: wave priority, a measurement switch)
 	const wv::u32x4* const comp_q = (const wv::u32x4*)comp;
 	// base | extra-bits << 16 of the 29 length symbols (words 0..28) and the 30 distance symbols (words 32..61) of RFC 1951 §3.2.5
-	uint32_t* const tab = lds + P1_LANE_W * 64;
+	uint32_t* const tab = lds + P1_LANE_W * 64 + 64;   // (behind the window's mirror slot)
 	{
 		const uint32_t i = (uint32_t)lane;
 		if (i < 29)
@@ -203,13 +211,12 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 
 	auto exhausted = [&]() -> bool { return next_q >= n_q && !pf_valid; };   // every piece of the member is in the window (what lies behind it is never consumed by a valid stream)
 	auto ready = [&](uint32_t bits) -> bool { return (int)(wr * 32u - abit) >= (int)bits || exhausted(); };   // `bits` stream bits from the cursor on are staged (a window may also read a stale word behind them: those bits are never used)
-	auto window = [&](uint32_t ab) -> uint32_t { const uint32_t w = ab >> 5; return wv::alignbit(L.ring(w + 1), L.ring(w), ab & 31u); };   // the 32 stream bits at bit position ab
+	auto window = [&](uint32_t ab) -> uint32_t { const uint32_t* p = L.slot(ab >> 5); return wv::alignbit(p[64], p[0], ab & 31u); };   // the 32 stream bits at bit position ab
 	auto seek = [&](uint32_t target) {   // synchronous restart of the reader at bit position `target`
 		next_q = target >> 7; wr = next_q * 4; pf_valid = false;
 		wv::u32x4 c0 = next_q < n_q ? comp_q[q0 + next_q] : wv::make4(0, 0, 0, 0); ++next_q;
 		wv::u32x4 c1 = next_q < n_q ? comp_q[q0 + next_q] : wv::make4(0, 0, 0, 0); ++next_q;
-		L.ring(wr) = c0.x; L.ring(wr + 1) = c0.y; L.ring(wr + 2) = c0.z; L.ring(wr + 3) = c0.w;
-		L.ring(wr + 4) = c1.x; L.ring(wr + 5) = c1.y; L.ring(wr + 6) = c1.z; L.ring(wr + 7) = c1.w; wr += 8;
+		L.stage(wr, c0.x, c0.y, c0.z, c0.w); L.stage(wr + 4, c1.x, c1.y, c1.z, c1.w); wr += 8;
 		abit = target;
 	};
 
@@ -222,7 +229,7 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 		{
 			if (wv::ballot(state != S_DONE) == 0) break;
 			// a piece is always in flight; it enters the window as soon as four slots in front of the cursor's word are free
-			if (pf_valid && (int)(wr - (abit >> 5)) <= P1_RING_W - 4) { L.ring(wr) = pf.x; L.ring(wr + 1) = pf.y; L.ring(wr + 2) = pf.z; L.ring(wr + 3) = pf.w; wr += 4; pf_valid = false; }
+			if (pf_valid && (int)(wr - (abit >> 5)) <= P1_RING_W - 4) { L.stage(wr, pf.x, pf.y, pf.z, pf.w); wr += 4; pf_valid = false; }
 			if (state != S_DONE && state != S_NEXT)
 			{
 				if ((g0 & g1 & g2 & g3) != K1_TOK_NOOP)   // g3..g0 are exactly the four trips since the last service block
@@ -240,10 +247,9 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 		// park_hi == 0: no parking (both per trip).
 		{
 			const uint64_t slow_m = wv::ballot(state != S_SYM && state != S_STORED && state != S_DONE);
-			const uint64_t fast_m = wv::ballot(state == S_SYM || state == S_STORED);
 			if (!slow_mode)
 			{
-				if (slow_m != 0 && ((int)wv::popc64(slow_m) >= park_hi || fast_m == 0)) slow_mode = true;
+				if (slow_m != 0 && ((int)wv::popc64(slow_m) >= park_hi || wv::ballot(state == S_SYM || state == S_STORED) == 0)) slow_mode = true;
 			}
 			else if (slow_m == 0) slow_mode = false;
 		}
@@ -251,34 +257,35 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 
 		if (run_fast && state == S_SYM && ready(48))   // a trip consumes at most 20 + 28 bits
 		{
-			// few exec regions: everything is computed unconditionally (indices clamped), errors are collected in e
+			// few exec regions: everything is computed unconditionally (indices clamped); the common path only ORs one error flag
 			const uint32_t win = window(abit);
 			uint32_t len;
 			const int idx = limL.decode(win, len);
-			uint32_t e = (uint32_t)idx < 288u ? 0u : 9u;
+			bool bad = (uint32_t)idx >= 288u;
 			const uint32_t s = L.litsym((uint32_t)idx < 288u ? (uint32_t)idx : 287u);
-			uint32_t used = len, tokv = s, add = 1;
+			uint32_t used = len, tokv = s, add = 1, ls = 0, ds = 0, mdist = 0; int di = 0;
 			if (s > 256)
 			{
-				const uint32_t ls = s - 257;
-				if (ls >= 29) e = 10;
+				ls = s - 257;
 				const uint32_t lt = tab[ls < 29 ? ls : 28];
 				const uint32_t eb = lt >> 16, mlen = (lt & 0xffffu) + wv::bfe(win, len, eb);   // len <= 16, eb <= 5
 				const uint32_t win2 = window(abit + len + eb);
 				uint32_t dl;
-				const int di = limD.decode(win2, dl);
-				if ((uint32_t)di >= 30u) e = 11;
-				const uint32_t ds = dsym.get((uint32_t)di < 30u ? (uint32_t)di : 29u);
-				if (ds >= 30) e = 12;
+				di = limD.decode(win2, dl);
+				ds = dsym.get((uint32_t)di < 30u ? (uint32_t)di : 29u);
 				const uint32_t dt = tab[32 + (ds < 30 ? ds : 29u)];
-				const uint32_t deb = dt >> 16, mdist = (dt & 0xffffu) + wv::bfe(win2, dl, deb);   // dl <= 16, deb <= 13
+				const uint32_t deb = dt >> 16; mdist = (dt & 0xffffu) + wv::bfe(win2, dl, deb);   // dl <= 16, deb <= 13
 				used = len + eb + dl + deb;
-				if (mdist > out_n) e = 13;
-				tokv = 0x80000000u | (((mlen - 3) & 255u) << 23) | ((mdist - 1) & 0x7fffu); add = mlen;
+				bad = bad || ls >= 29 || (uint32_t)di >= 30u || ds >= 30 || mdist > out_n;
+				tokv = (mlen << 23) + mdist + (0x80000000u - (3u << 23) - 1u); add = mlen;   // = bit 31 | (mlen - 3) << 23 | (mdist - 1): 3 <= mlen <= 258, 1 <= mdist <= 32768 on the good path
 			}
 			abit += used;
-			if (e == 0 && s != 256 && out_n + add > usize) e = s < 256 ? 3u : 13u;
-			if (e) { err = e; state = S_FINISH; }
+			bad = bad || (s != 256 && out_n + add > usize);
+			if (bad)
+			{
+				err = (uint32_t)idx >= 288u ? 9u : s <= 256 ? 3u : ls >= 29 ? 10u : (uint32_t)di >= 30u ? 11u : ds >= 30 ? 12u : 13u;
+				state = S_FINISH;
+			}
 			else if (s == 256) state = bfinal ? S_FINISH : S_HDR;
 			else { tk = tokv; out_n += add; }
 		}

@@ -58,6 +58,9 @@ struct ByteBuf
 	K1_DEV void store(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, rs, (int)off, 0, 0); }
 };
 
+// wave priority for instruction arbitration on its SIMD (0..3)
+K1_DEV void set_priority(int p) { if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else if (p >= 3) __builtin_amdgcn_s_setprio(3); }
+
 // ---- bit arithmetic ----
 K1_DEV uint32_t brev(uint32_t x) { return __brev(x); }
 K1_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }   // ({hi,lo} >> (sh & 31)) & 0xffffffff

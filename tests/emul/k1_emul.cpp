@@ -12,7 +12,8 @@ extern "C" {
 // comp: compressed image with at least 64 readable bytes behind the last payload. blocks[i]: payload position / output position.
 // tok_mode: 0 = the library's budget (clen + 64 words per member), 1 = worst-case budget. p1_wgs / p2_wgs: grid sizes (0 = one lane /
 // one wave per member). order_mode: 1 = members handed out largest compressed size first (what the library does).
-// stats[0] = rendezvous count, stats[1] = token words written, stats[2] = no-op words among them.
+// stats[0] = rendezvous count, stats[1] = token words written, stats[2] = no-op words among them, stats[3] = rendezvous count of phase 1
+// (2.25 per decoder trip and wave: two ballots per trip, one more per service block).
 int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uint8_t* out, BlockStatus* st, int park_hi, int tok_mode,
                     int p1_wgs, int p2_wgs, int order_mode, uint64_t* stats)
 {
@@ -34,6 +35,7 @@ int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uin
 		wv::run_block(blk, g1, [&] {
 			k1::huff_tokens_kernel(comp, blocks, n, tok_off.data(), tok.data(), tok_count.data(), st, &work, order_mode ? order.data() : nullptr, park_hi);
 		});
+	const uint64_t sync1 = wv::emu().n_sync;
 	uint64_t words = 0, noops = 0;
 	for (int64_t i = 0; i < n; ++i)
 	{
@@ -46,7 +48,7 @@ int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uin
 		wv::run_block(blk, g2, [&] {
 			k1::lz77_groups_kernel(tok.data(), tok_off.data(), tok_count.data(), blocks, n, out, st);
 		});
-	if (stats) { stats[0] = wv::emu().n_sync; stats[1] = words; stats[2] = noops; }
+	if (stats) { stats[0] = wv::emu().n_sync; stats[1] = words; stats[2] = noops; stats[3] = sync1; }
 	return 0;
 }
 

@@ -111,6 +111,7 @@ __attribute__((noinline)) inline uint32_t scan_incl(uint32_t v)
 }
 
 inline void wait_vm0() {}
+inline void set_priority(int) {}
 inline unsigned long long atomic_inc(unsigned long long* p) { return (*p)++; }
 inline void lds_or(unsigned long long* p, unsigned long long v) { *p |= v; }
 

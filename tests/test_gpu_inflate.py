@@ -75,10 +75,10 @@ SHAPES = {
 
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
-@pytest.mark.parametrize("variant", ["default", "no_park", "tiles_of_2", "no_crc", "k1_v2"])
+@pytest.mark.parametrize("variant", ["default", "no_park", "tiles_of_2", "no_crc"])
 def test_inflate_shapes(raw_bam, shape, variant, monkeypatch):
     # (huffman_only overflows the clen + 64 token budget of a member: it takes the second-chance path with a worst-case budget)
-    env = {"default": {}, "no_park": {"NGSQC_P1_PARK": "0"}, "tiles_of_2": {"NGSQC_TILE_MEMBERS": "2"}, "no_crc": {"NGSQC_VERIFY_CRC": "0"}, "k1_v2": {"NGSQC_K1_V": "2"}}[variant]
+    env = {"default": {}, "no_park": {"NGSQC_P1_PARK": "0"}, "tiles_of_2": {"NGSQC_TILE_MEMBERS": "2"}, "no_crc": {"NGSQC_VERIFY_CRC": "0"}}[variant]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     kw = dict(SHAPES[shape]); sizes = kw.pop("sizes")

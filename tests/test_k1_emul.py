@@ -1,0 +1,175 @@
+"""The two K1 kernels (ngs-bits_amd/csrc/k1_kernels.h: the text libngsqc_hip.so compiles for gfx950) under the wave emulator
+of tests/emul on the CPU, against zlib: every DEFLATE block type, ragged and empty members, overlapping matches, the token
+budget of the library and the worst-case one, member queues longer than the grid, and damaged streams. No GPU needed; the
+GPU runs of the same kernels are tests/test_gpu_inflate.py / test_gpu_parity.py."""
+import ctypes as C
+import os
+import random
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import bamgen_lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL = os.path.join(HERE, "emul")
+CSRC = os.path.join(os.path.dirname(HERE), "ngs-bits_amd", "csrc")
+
+
+class BD(C.Structure):
+    _fields_ = [("cpos", C.c_uint64), ("upos", C.c_uint64), ("clen", C.c_uint32), ("usize", C.c_uint32)]
+
+
+class BS(C.Structure):
+    _fields_ = [("produced", C.c_uint32), ("error", C.c_uint32)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL, "libk1emul.so")
+    srcs = [os.path.join(EMUL, "k1_emul.cpp"), os.path.join(EMUL, "wave_emul.h"), os.path.join(CSRC, "k1_kernels.h"), os.path.join(CSRC, "k1_types.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+    L = C.CDLL(so)
+    L.k1_emul_inflate.argtypes = [C.c_char_p, C.POINTER(BD), C.c_int64, C.c_void_p, C.POINTER(BS), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    return L
+
+
+def run(L, img, mem, park=16, tok_mode=0, p1=0, p2=0, order=1):
+    """mem: [(payload offset, payload bytes, inflated bytes)] -> (inflated stream, [(produced, error)], stats)"""
+    n = len(mem); bd = (BD * n)(); up = 0
+    for i, (cp, cl, us) in enumerate(mem):
+        bd[i] = BD(cp, up, cl, us); up += us
+    out = np.zeros(up + 64, np.uint8); st = (BS * n)(); stats = (C.c_uint64 * 4)()
+    L.k1_emul_inflate(img + b"\0" * 64, bd, n, out.ctypes.data, st, park, tok_mode, p1, p2, order, stats)
+    return out[:up].tobytes(), [(s.produced, s.error) for s in st], list(stats)
+
+
+def deflate(data, level=6, mem=8, strat=zlib.Z_DEFAULT_STRATEGY, flushes=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strat); out = b""
+    if flushes:
+        step = max(1, len(data) // (flushes + 1))
+        for i in range(0, len(data), step):
+            out += c.compress(data[i:i + step]); out += c.flush(zlib.Z_FULL_FLUSH if (i // step) % 2 else zlib.Z_SYNC_FLUSH)
+    else:
+        out += c.compress(data)
+    return out + c.flush()
+
+
+def image(cases, rng):
+    """payloads at arbitrary byte alignment, as in a BGZF file"""
+    img = b""; mem = []
+    for raw, comp in cases:
+        img += bytes(rng.randrange(256) for _ in range(rng.randrange(0, 23)))
+        mem.append((len(img), len(comp), len(raw))); img += comp
+    return img, mem
+
+
+def texty(rng, n):
+    words = [bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(3, 12))) for _ in range(50)]
+    out = b""
+    while len(out) < n:
+        out += rng.choice(words) + bytes([rng.randrange(33, 74)]) * rng.randrange(1, 5)
+    return out[:n]
+
+
+def shapes(rng):
+    cs = [(b"", deflate(b"")), (b"", bytes([3, 0])), (b"A", deflate(b"A"))]   # empty members (bytes 03 00 = the BGZF EOF block)
+    for n in (1, 2, 5, 300):                                              # tiny stored / fixed / dynamic members
+        r = bytes(rng.randrange(256) for _ in range(n)); cs.append((r, deflate(r, 0)))
+        r = texty(rng, n); cs.append((r, deflate(r, 6))); cs.append((r, deflate(r, 6, 8, zlib.Z_FIXED)))
+    r = bytes(rng.randrange(256) for _ in range(20000)); cs.append((r, deflate(r)))                 # incompressible: stored blocks inside
+    r = texty(rng, 30000); cs.append((r, deflate(r))); cs.append((r, deflate(r, 9))); cs.append((r, deflate(r, 1)))
+    r = texty(rng, 20000); cs.append((r, deflate(r, 6, 8, zlib.Z_FIXED)))
+    r = texty(rng, 20000); cs.append((r, deflate(r, 6, 1)))                                         # memLevel 1: many small dynamic blocks
+    r = texty(rng, 20000); cs.append((r, deflate(r, 6, 8, zlib.Z_DEFAULT_STRATEGY, 7)))             # sync / full flushes: empty stored blocks between
+    r = b"\0" * 65280; cs.append((r, deflate(r)))                                                    # one long run: overlapping matches (dist 1, len 258)
+    r = (b"ab" * 40000)[:65535]; cs.append((r, deflate(r)))                                          # dist 2, the largest member size
+    r = (b"abcde" * 3000) + texty(rng, 2000) + (b"xyz" * 900); cs.append((r, deflate(r, 9)))
+    r = bytes(rng.choice(b"AB") for _ in range(20000)); cs.append((r, deflate(r, 6, 8, zlib.Z_HUFFMAN_ONLY)))   # more tokens than clen + 64 words
+    r = bytes(rng.randrange(64, 80) for _ in range(8000)); cs.append((r, deflate(r, 6, 8, zlib.Z_RLE)))
+    for _ in range(70):                                                                              # > 64 members: more than one wave, a second member per lane
+        r = texty(rng, rng.randrange(1, 3000)); cs.append((r, deflate(r, rng.choice([1, 6, 9]))))
+    return cs
+
+
+def check(cases, got, st, allow_overflow):
+    pos = 0
+    for i, (raw, _) in enumerate(cases):
+        if st[i][1] == 100 and allow_overflow:   # K1_ERR_TOKEN_OVERFLOW: the library inflates such a member again with the worst-case budget
+            pos += len(raw); continue
+        assert st[i] == (len(raw), 0), f"member {i}: {st[i]}"
+        assert got[pos:pos + len(raw)] == raw, f"member {i} differs"
+        pos += len(raw)
+
+
+@pytest.mark.parametrize("variant", ["library_budget", "worst_case_budget", "no_parking", "park_all", "one_decoder_wave_three_resolver_waves", "file_order"])
+def test_deflate_shapes(emul, variant):
+    rng = random.Random(11)
+    cases = shapes(rng); img, mem = image(cases, rng)
+    kw = {"library_budget": {}, "worst_case_budget": dict(tok_mode=1), "no_parking": dict(park=0), "park_all": dict(park=64),
+          "one_decoder_wave_three_resolver_waves": dict(p1=1, p2=3), "file_order": dict(order=0)}[variant]
+    got, st, stats = run(emul, img, mem, **kw)
+    check(cases, got, st, allow_overflow=kw.get("tok_mode", 0) == 0)
+    overflow = [i for i, s in enumerate(st) if s[1] == 100]
+    if kw.get("tok_mode", 0) == 0:
+        assert overflow, "the run / Huffman-only members are expected to exceed the clen + 64 budget"
+    else:
+        assert not overflow
+    assert stats[2] <= 0.02 * stats[1]   # no-op words inside the token groups stay a small share
+
+
+def test_synthetic_bam_members(emul):
+    """members of the bench generator's BAM (one dynamic block each, ~14 k tokens): the token stream carries (almost) no no-ops"""
+    import struct
+    img = np.asarray(bamgen_lib.generate(n_reads=3000, seed=5)).tobytes()
+    pos = 0; mem = []
+    while pos < len(img):
+        bs = struct.unpack_from("<H", img, pos + 16)[0] + 1
+        mem.append((pos + 18, bs - 26, struct.unpack_from("<I", img, pos + bs - 4)[0])); pos += bs
+    ref = b"".join(zlib.decompress(img[cp:cp + cl], -15) for cp, cl, _ in mem)
+    got, st, stats = run(emul, img, mem)
+    assert all(s[1] == 0 for s in st) and got == ref
+    assert stats[2] <= 0.002 * stats[1]
+
+
+def test_damaged_streams(emul):
+    """bit flips, truncation, header damage, garbage: the kernels terminate, never report success with a wrong size, and agree with
+    zlib on every stream zlib accepts (payload damage that leaves a valid stream is the CRC32 kernel's business)"""
+    rng = random.Random(7)
+    base = []
+    for _ in range(5):
+        r = texty(rng, rng.randrange(1000, 9000))
+        base.append((r, deflate(r, rng.choice([1, 6, 9]), rng.choice([1, 8]), rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED]))))
+    r = bytes(rng.randrange(256) for _ in range(2000)); base.append((r, deflate(r, 0)))
+    cases = []
+    for k in range(128):
+        raw, comp = base[k % len(base)]; c = bytearray(comp); mode = k % 4
+        if mode == 0:
+            for _ in range(rng.randrange(1, 4)):
+                c[rng.randrange(len(c))] ^= 1 << rng.randrange(8)
+        elif mode == 1:
+            c = c[:rng.randrange(1, len(c))]
+        elif mode == 2:
+            c[rng.randrange(min(40, len(c)))] ^= 1 << rng.randrange(8)
+        else:
+            c = bytearray(rng.randrange(256) for _ in range(rng.randrange(1, 400)))
+        cases.append((raw, bytes(c)))
+    img, mem = image(cases, rng)
+    got, st, _ = run(emul, img, mem)
+    pos = 0; rejected = 0
+    for i, (raw, comp) in enumerate(cases):
+        try:
+            d = zlib.decompressobj(-15); z = d.decompress(comp); zok = d.eof and len(z) == len(raw)
+        except zlib.error:
+            zok, z = False, None
+        if st[i][1] == 0:
+            assert st[i][0] == len(raw)
+            assert zok and got[pos:pos + len(raw)] == z, f"member {i}: accepted, but zlib {'differs' if zok else 'rejects it'}"
+        else:
+            rejected += 1
+            assert not zok, f"member {i}: zlib accepts what the kernels reject ({st[i]})"
+        pos += len(raw)
+    assert rejected > 60
