@@ -333,7 +333,7 @@ def main():
         if huff_ms >= lz_ms:
             dom = ("huff_tokens_kernel (K1 phase 1: Huffman decode, lane per BGZF member)", c_bytes / k1_launches, huff_ms / k1_launches)
         else:
-            dom = ("lz77_chunk_kernel (K1 phase 2: LZ77 window resolve, wave per BGZF member)", u_bytes / k1_launches, lz_ms / k1_launches)
+            dom = ("lz77_groups_kernel (K1 phase 2: LZ77 window resolve, wave per BGZF member)", u_bytes / k1_launches, lz_ms / k1_launches)
         dom_gbs = dom[1] / (dom[2] * 1e-3) / 1e9
         k1_gbs = (c_bytes + u_bytes) / (infl_ms * 1e-3) / 1e9
         scan_bytes = int(tms[-1]["scan_algorithmic_bytes"])
@@ -362,7 +362,7 @@ def main():
                          "note": "HIP events on the kernel's own stream over the timed steps; phase 2 of chunk c overlaps phase 1 of chunk c+1 and the consumers of the previous "
                                  "tile, so the kernels' summed durations exceed the step. DEFLATE decode is bit-serial per BGZF member: VALU-issue bound, not HBM bound "
                                  "(SURVEY.md §7); PMC traffic per launch is in profiles/ (separate --pmc passes)"},
-            "roofline_k1_stage": {"kernels": "huff_tokens_kernel + lz77_chunk_kernel + crc32_kernel (chunk stream on three HIP streams)", "achieved": round(k1_gbs, 2), "unit": "GB/s",
+            "roofline_k1_stage": {"kernels": "huff_tokens_kernel + lz77_groups_kernel + crc32_kernel (chunk stream on three HIP streams)", "achieved": round(k1_gbs, 2), "unit": "GB/s",
                                   "frac": round(k1_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes": c_bytes + u_bytes, "ms": round(infl_ms, 4)},
             "stage_ms": {"note": "sums of HIP-event intervals over the timed (pipelined) steps; index / scan / pileup overlap K1 of the next tile",
                          "inflate_huff": round(huff_ms, 4), "inflate_lz77": round(lz_ms, 4), "inflate_stage_wall": round(infl_ms, 4),
@@ -404,8 +404,8 @@ def main():
                 # per launch of 83 k members (the profile's chunk; this run's chunk may hold a few more members). No correction applied: the kernel's loads are
                 # 16 B per lane from 64 different member streams, between the guide's x1 and x2 regimes (raw FETCH / known compressed bytes = 0.755)
                 out["roofline"]["traffic"] = tp["fetch_bytes_raw"] + tp["write_bytes_raw"]
-                out["roofline"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE per launch, K1 kernels serialized (NGSQC_K1_SERIAL=1); the 9.4 GB written are the 4-byte tokens "
-                                                   "that phase 2 reads back: 6.9x the compressed bytes the kernel has to read")
+                out["roofline"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE per launch, K1 kernels serialized (NGSQC_K1_SERIAL=1). Phase 1 writes the 4-byte tokens that "
+                                                   f"phase 2 reads back: {tp['write_bytes_raw'] / max(dom[1], 1):.1f}x the algorithmic bytes of the launch")
         except OSError:
             pass
         if world == 1 and not args.no_cpu_baseline and tool == "mappingqc":

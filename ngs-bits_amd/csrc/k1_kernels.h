@@ -11,7 +11,7 @@
 //            Tokens: every trip shifts the lane's token (or a no-op) into a four-register group; the service block that runs
 //            every four trips stores the group with one 16-byte store when it holds a real token. No compaction, no
 //            per-lane queue: phase 2 reads the same groups, one per lane, and skips the no-ops.
-//   phase 2  lz77_groups_kernel : ONE WAVE PER MEMBER. A batch is up to 64 token groups (<= 256 tokens, <= P2_BMAX bytes): a
+//   phase 2  lz77_groups_kernel : ONE WAVE PER MEMBER. A batch is up to 56 token groups (<= 224 tokens, <= P2_BMAX bytes): a
 //            wave prefix sum places every token, every OUTPUT BYTE of the batch gets a lane (owner token by popcount over a
 //            token-end bitmap) and its source in periodic form (i mod dist). Pass 1 classifies all bytes of the batch and
 //            issues every gather that reaches behind the batch (HBM) in one go; pass 2 resolves the chunks front to back: a
@@ -211,6 +211,8 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 
 	auto exhausted = [&]() -> bool { return next_q >= n_q && !pf_valid; };   // every piece of the member is in the window (what lies behind it is never consumed by a valid stream)
 	auto ready = [&](uint32_t bits) -> bool { return (int)(wr * 32u - abit) >= (int)bits || exhausted(); };   // `bits` stream bits from the cursor on are staged (a window may also read a stale word behind them: those bits are never used)
+	// (Reading the next trip's window words at the end of a trip - taking their LDS latency out of the dependent chain - was measured: no gain,
+	// phase 1 alone 94.1 vs 91.1 ms per 96 M reads. A lone wave is bound by the issue latency of its dependent VALU chain, not by the LDS round trips.)
 	auto window = [&](uint32_t ab) -> uint32_t { const uint32_t* p = L.slot(ab >> 5); return wv::alignbit(p[64], p[0], ab & 31u); };   // the 32 stream bits at bit position ab
 	auto seek = [&](uint32_t target) {   // synchronous restart of the reader at bit position `target`
 		next_q = target >> 7; wr = next_q * 4; pf_valid = false;
@@ -480,7 +482,8 @@ K1_KERNEL(64) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const Bl
 // ---------------------------------------------------------------------------------------------------------------- phase 2
 constexpr int P2_BMAX = 1056;                  // output bytes resolved per batch: at least one whole group (4 x 258 bytes) always fits
 constexpr int P2_NCH = (P2_BMAX + 63) / 64;    // 64-byte chunks per batch
-struct P2Lds { unsigned long long endmask[P2_NCH + 1]; uint32_t pk[256]; uint8_t val[P2_NCH * 64]; };   // 2256 B per wave
+constexpr int P2_GROUPS = 56;                  // groups per batch: 224 tokens are ~1000 bytes of BAM, so the byte limit binds first anyway - and pk + val stay under 2 KB
+struct P2Lds { uint32_t pk[P2_GROUPS * 4]; alignas(8) uint8_t val[P2_NCH * 64]; };   // 1984 B per wave (eleven waves fit beside the six decoder waves of a CU); val: token-end flags during pass 1, the staged output bytes from pass 2 on
 
 K1_DEV uint32_t tok_len(uint32_t t) { return t == K1_TOK_NOOP ? 0u : ((t >> 31) ? ((t >> 23) & 255u) + 3u : 1u); }
 
@@ -489,7 +492,6 @@ K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const ui
 {
 	K1_SHARED P2Lds S;
 	const int lane = wv::lane();
-	const uint64_t lane_lt = (1ull << lane) - 1ull;
 	const wv::u32x4 noop4 = wv::make4(K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP);
 	for (int64_t b = wv::block_id(); b < n_blocks; b += wv::grid_size())
 	{
@@ -499,11 +501,11 @@ K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const ui
 		const uint32_t usize = blocks[b].usize;
 		const wv::ByteBuf out = wv::ByteBuf::make(out_base + blocks[b].upos, usize);
 		uint32_t P = 0, fail = 0;   // bytes written so far
-		wv::u32x4 nxt = (uint32_t)lane < ngroups ? T4[lane] : noop4;
+		wv::u32x4 nxt = (lane < P2_GROUPS && (uint32_t)lane < ngroups) ? T4[lane] : noop4;
 		for (uint32_t g0 = 0; g0 < ngroups;)
 		{
 			// ---- place the batch: one group per lane, a prefix sum over (bytes | real tokens << 20) ----
-			const bool valid = g0 + (uint32_t)lane < ngroups;
+			const bool valid = lane < P2_GROUPS && g0 + (uint32_t)lane < ngroups;
 			const uint32_t t0 = nxt.x, t1 = nxt.y, t2 = nxt.z, t3 = nxt.w;
 			const uint32_t l0 = valid ? tok_len(t0) : 0u, l1 = valid ? tok_len(t1) : 0u, l2 = valid ? tok_len(t2) : 0u, l3 = valid ? tok_len(t3) : 0u;
 			const uint32_t s = l0 + l1 + l2 + l3, c = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
@@ -514,8 +516,11 @@ K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const ui
 			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 258 bytes: not a token stream of phase 1
 			const uint32_t B = wv::readlane(Eb, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
-			// per real token: match flag | start inside the batch << 20 | dist-1 or the literal; token-end bitmap (bit e-1 set when a token ends at byte e)
-			if (lane < P2_NCH + 1) S.endmask[lane] = 0ull;
+			// per real token: match flag | start inside the batch << 20 | dist-1 or the literal; a flag on the token's last byte
+			{
+				unsigned long long* z = (unsigned long long*)S.val;
+				z[lane] = 0ull; z[64 + lane] = 0ull; if (lane < P2_NCH * 8 - 128) z[128 + lane] = 0ull;
+			}
 			wv::barrier();
 			if ((uint32_t)lane < ng)
 			{
@@ -526,17 +531,16 @@ K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const ui
 					if (ll[k])
 					{
 						const uint32_t t = tt[k];
-						S.pk[rk & 255u] = (t & 0x80000000u) | (st << 20) | ((t >> 31) ? (t & 0x7fffu) : (t & 255u));
-						const uint32_t e1 = st + ll[k] - 1;
-						wv::lds_or(&S.endmask[e1 >> 6], 1ull << (e1 & 63u));
-						++rk; st += ll[k];
+						S.pk[rk] = (t & 0x80000000u) | (st << 20) | ((t >> 31) ? (t & 0x7fffu) : (t & 255u));
+						st += ll[k]; ++rk;
+						S.val[st - 1] = 1;
 					}
 			}
 			wv::barrier();
 			// stores of earlier batches must be complete before this batch gathers from the window behind P
 			wv::wait_vm0();
 			// the next batch's groups are requested now; they arrive while this batch is resolved
-			{ const uint32_t i2 = g0 + ng + (uint32_t)lane; nxt = i2 < ngroups ? T4[i2] : noop4; }
+			{ const uint32_t i2 = g0 + ng + (uint32_t)lane; nxt = (lane < P2_GROUPS && i2 < ngroups) ? T4[i2] : noop4; }
 
 			// ---- pass 1: classify every byte of the batch, issue all gathers that reach behind the batch ----
 			// inf: bits 0..7 value, bits 8..9 kind (0 value known, 1 gathered from HBM, 2 staged byte of an earlier chunk, 3 a lower lane of the same chunk), bits 10.. source
@@ -549,26 +553,25 @@ K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const ui
 				if ((uint32_t)(ch * 64) < B)
 				{
 					const uint32_t j0 = (uint32_t)(ch * 64), j = j0 + (uint32_t)lane;
-					// owner token of byte j = ta + #tokens ending inside the chunk before j (popcount over the end bitmap)
-					const uint64_t m = S.endmask[ch];
-					const uint32_t o = ta + wv::popc64(m & lane_lt);
+					// owner token of byte j = ta + #tokens ending inside the chunk before j: the end flags of the chunk as a lane mask
+					const uint64_t m = wv::ballot(S.val[j] != 0);
+					const uint32_t o = ta + wv::mbcnt(m);
 					ta += wv::popc64(m);
-					const uint32_t pko = S.pk[o & 255u];
+					const uint32_t pko = S.pk[o < (uint32_t)(P2_GROUPS * 4) ? o : 0u];   // (only lanes behind the batch's last byte can run past the table)
 					uint32_t f = pko & 255u;
 					if (j < B && (pko >> 31))
 					{
-						const uint32_t sto = (pko >> 20) & 0x7ffu, d = (pko & 0x7fffu) + 1u, off = j - sto;
-						uint32_t r = off;
-						if (off >= d)
+						const uint32_t sto = (pko >> 20) & 0x7ffu, d = (pko & 0x7fffu) + 1u;
+						int src = (int)j - (int)d;   // relative to P
+						if (src >= (int)sto)         // the match reaches into its own output (distance < length): periodic form sto - d + (j - sto) mod d
 						{
+							const uint32_t off = j - sto;
 							uint32_t q = (uint32_t)((float)off * wv::rcp((float)d)); int rr = (int)off - (int)(q * d);   // q is off by at most 1
 							if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
-							r = (uint32_t)rr;
+							src = (int)sto - (int)d + rr;
 						}
-						const int src = (int)sto - (int)d + (int)r;   // relative to P
 						if (src < 0) { gth[ch] = out.load(P + (uint32_t)src); f = 0x100u; }
-						else if ((uint32_t)src < j0) f = 0x200u | ((uint32_t)src << 10);
-						else f = 0x300u | (((uint32_t)src - j0) << 10);
+						else f = ((uint32_t)src < j0 ? 0x200u : 0x300u) | ((uint32_t)src << 10);   // (same chunk: the source lane is src & 63)
 					}
 					inf[ch] = f;
 				}

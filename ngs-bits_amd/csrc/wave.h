@@ -66,6 +66,7 @@ K1_DEV uint32_t brev(uint32_t x) { return __brev(x); }
 K1_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }   // ({hi,lo} >> (sh & 31)) & 0xffffffff
 K1_DEV uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }        // (x >> off) & ((1 << width) - 1), width 0 -> 0
 K1_DEV uint32_t popc64(uint64_t x) { return (uint32_t)__popcll(x); }
+K1_DEV uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }   // bits of m below this lane
 K1_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 } } // namespace ngsqc::wv

@@ -132,6 +132,7 @@ inline uint32_t brev(uint32_t x)
 inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 inline uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { width &= 31u; return width ? (x >> (off & 31u)) & ((1u << width) - 1u) : 0u; }
 inline uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+inline uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << emu().cur) - 1ull)); }
 inline float rcp(float x) { return 1.0f / x; }
 
 } } // namespace ngsqc::wv

@@ -38,7 +38,6 @@ if os.path.exists(f"gpurun_out/{PFX}_sq/s_results.db"):
     sq = open(f"profiles/{tag}_sq_counters.txt", "w")
     sq.write(f"# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -- {CMD}\n")
     sq.write("# SQ_INSTS_* count wave-level instructions, the *_CYCLES counters tick in quad-cycles (one wave64 VALU instruction = one tick);\n")
-    sq.write("# the counters see about 3/4 of the waves of a dispatch on this part (SQ_WAVES vs the launched grid), ratios are unaffected.\n")
     sq.write("# derived: valu_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's lifetime spent issuing VALU)\n")
     sq.write("# kernel\tcounter\tdispatches\tsum_over_dispatches\n")
     c = sqlite3.connect(f"gpurun_out/{PFX}_sq/s_results.db")
