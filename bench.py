@@ -7,7 +7,7 @@ in HBM when the timed region starts (the H2D time of the image is reported separ
 A "step" is what `bin/MappingQC -wgs` does with the BAM, as ONE fused job (ngsqc_run_job): every BGZF member is inflated once (K1),
 records are indexed (K2), and the mapping_wgs scan (counters, insert-size histogram, chrX/chrY counts, OMIM-ROI depth scatter) plus the
 contamination pileup of the known common SNVs see every tile of the inflated stream while it is resident; then K6 (depth prefix sum,
-histogram, half-depth count) and the result copies. The file is larger than HBM once inflated, so it streams through two tile buffers
+histogram, half-depth count) and the result copies. The file is larger than HBM once inflated, so it streams through three tile buffers
 (K1 of tile t+1 overlaps K2 + consumers of tile t). If the host cannot hold the full image the read count is scaled down and
 `config.workload` says so.
 

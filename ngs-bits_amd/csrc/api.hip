@@ -1,10 +1,10 @@
-// Host side of libngsqc_hip.so: the C ABI of include/ngsqc.h on top of the HIP kernels (K1 inflate2.hip + crc.hip, K2
+// Host side of libngsqc_hip.so: the C ABI of include/ngsqc.h on top of the HIP kernels (K1 k1_kernels.h / inflate.hip + crc.hip, K2
 // index.hip, K3-K5 scan.hip / reads.hip, K6 depth.hip).
 //
 // A BAM is processed as a STREAM OF TILES (contiguous BGZF-member ranges sized to HBM):
 //   * K1 runs as one continuous stream of member chunks over the whole file on its own HIP streams (Huffman phase of chunk
-//     c+1 overlaps the LZ77 phase of chunk c; the token scratch is a ring of three chunk slots), writing into one of two
-//     tile buffers;
+//     c+1 overlaps the LZ77 phase of chunk c; the token scratch is a ring of four chunk slots), writing into one of three
+//     tile buffers, queued two tiles ahead of the tile the host works on;
 //   * K2 (record index) and every consumer of a tile (mapping scan, depth scan, site pileup, raw-read QC) run on the handle's
 //     main stream while K1 already decodes the next tile: each member is inflated exactly once per job, and all consumers
 //     of a job see the tile while it is resident (ngsqc_run_job; the single-purpose entry points are jobs with one consumer).
@@ -412,7 +412,7 @@ void plan_layout(ngsqc_handle* h)
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0); const uint64_t base = (uint64_t)((c % h->k1_slots) * h->slot_tokens);
 		for (int64_t i = 0; i <= cn; ++i) tok_off[(size_t)(c0 + c + i)] += base;
 	}
-	// tiles: as many chunks as fit two tile buffers next to the ring (at most cpt)
+	// tiles: as many chunks as fit the tile buffers next to the ring (at most cpt)
 	int64_t carry_max = 64ll << 20; if (const char* e = getenv("NGSQC_CARRY_MAX")) carry_max = std::max<int64_t>(0, atoll(e));
 	if (!forced && h->nch > 1)
 	{
