@@ -27,7 +27,8 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 	// one member per one-wave workgroup, handed out by the dispatcher (NGSQC_P2_WGS caps the grid: the waves then stride over the members)
 	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)1 << 20;
 	const int grid2 = (int)(n_blocks < cap2 ? n_blocks : cap2);
-	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), 0, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
+	const char* ep = getenv("NGSQC_P2_LDS_PAD"); const int pad = ep ? std::max(0, atoi(ep)) : 0;   // measurement switch: extra LDS per workgroup = fewer phase-2 waves beside the decoder waves
+	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), pad, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
 }
 
 } // namespace ngsqc

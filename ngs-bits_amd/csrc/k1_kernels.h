@@ -487,7 +487,9 @@ struct P2Lds { uint32_t pk[P2_GROUPS * 4]; alignas(8) uint8_t val[P2_NCH * 64]; 
 
 K1_DEV uint32_t tok_len(uint32_t t) { return t == K1_TOK_NOOP ? 0u : ((t >> 31) ? ((t >> 23) & 255u) + 3u : 1u); }
 
-K1_KERNEL(64) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
+// Register budget of five waves per SIMD (70 VGPRs instead of 98, no spills): next to the decoder waves (163 VGPRs each, one or two per SIMD) the
+// register file, not LDS, decides how many phase-2 waves a CU holds - 12 instead of 8.
+K1_KERNEL_OCC(64, 5) void lz77_groups_kernel(const uint32_t* __restrict__ tok, const uint64_t* __restrict__ tok_off, const uint32_t* __restrict__ tok_count,
                                       const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status)
 {
 	K1_SHARED P2Lds S;

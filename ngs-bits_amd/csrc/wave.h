@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #define K1_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define K1_KERNEL_OCC(bounds, waves_per_simd) __global__ __launch_bounds__(bounds, waves_per_simd)   // + a register budget for that many waves per SIMD
 #define K1_SHARED __shared__
 #define K1_DEV __device__ __forceinline__
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #define K1_KERNEL(bounds)
+#define K1_KERNEL_OCC(bounds, waves_per_simd)
 #define K1_SHARED static
 #define K1_DEV inline
 #ifndef __restrict__

@@ -39,6 +39,7 @@ VARIANTS = {
     "bufs2": {"NGSQC_TILE_BUFFERS": "2", "NGSQC_TOKEN_SLOTS": "3"}, "slots3": {"NGSQC_TOKEN_SLOTS": "3"}, "bufs4": {"NGSQC_TILE_BUFFERS": "4", "NGSQC_TOKEN_SLOTS": "5"},
     "tile1_b4": {"NGSQC_TILE_CHUNKS": "1", "NGSQC_TILE_BUFFERS": "4", "NGSQC_TOKEN_SLOTS": "4"}, "tile1_b3": {"NGSQC_TILE_CHUNKS": "1"}, "tile3": {"NGSQC_TILE_CHUNKS": "3", "NGSQC_TOKEN_SLOTS": "5"},
     "prio3_park32": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PARK": "32"}, "prio2": {"NGSQC_P1_PRIO": "2"},
+    "p2pad2k": {"NGSQC_P2_LDS_PAD": "2048"}, "p2pad6k": {"NGSQC_P2_LDS_PAD": "6144"}, "p2pad1k": {"NGSQC_P2_LDS_PAD": "1024"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
 }
 
