@@ -12,11 +12,11 @@
 //            every four trips stores the group with one 16-byte store when it holds a real token. No compaction, no
 //            per-lane queue: phase 2 reads the same groups, one per lane, and skips the no-ops.
 //   phase 2  lz77_groups_kernel : ONE WAVE PER MEMBER. A batch is up to 56 token groups (<= 224 tokens, <= P2_BMAX bytes): a
-//            wave prefix sum places every token, every OUTPUT BYTE of the batch gets a lane (owner token by popcount over a
-//            token-end bitmap) and its source in periodic form (i mod dist). Pass 1 classifies all bytes of the batch and
-//            issues every gather that reaches behind the batch (HBM) in one go; pass 2 resolves the chunks front to back: a
-//            source in an earlier chunk comes from the LDS staging bytes, one in the same chunk from the source LANE.
-//            One HBM round trip per batch instead of one per 64 bytes.
+//            wave prefix sum places every token and sets a flag on its last byte; per 64-byte chunk the flags become a lane
+//            mask (ballot) from which every OUTPUT BYTE gets its owner token (v_mbcnt), and its source in periodic form
+//            (i mod dist). Pass 1 classifies all bytes of the batch and issues every gather that reaches behind the batch
+//            (HBM) in one go; pass 2 resolves the chunks front to back: a source in an earlier chunk comes from the LDS
+//            staging bytes, one in the same chunk from the source LANE. One HBM round trip per batch instead of one per 64 bytes.
 //
 // Written against the wave vocabulary of wave.h only (see there). Integer work, no MFMA. RFC 1951; the reference reaches
 // zlib's inflate through htslib's bgzf.c under BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-392).
