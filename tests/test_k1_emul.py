@@ -123,16 +123,31 @@ def test_deflate_shapes(emul, variant):
 
 def test_synthetic_bam_members(emul):
     """members of the bench generator's BAM (one dynamic block each, ~14 k tokens): the token stream carries (almost) no no-ops"""
-    import struct
     img = np.asarray(bamgen_lib.generate(n_reads=3000, seed=5)).tobytes()
-    pos = 0; mem = []
-    while pos < len(img):
-        bs = struct.unpack_from("<H", img, pos + 16)[0] + 1
-        mem.append((pos + 18, bs - 26, struct.unpack_from("<I", img, pos + bs - 4)[0])); pos += bs
+    mem = _bgzf_members(img)
     ref = b"".join(zlib.decompress(img[cp:cp + cl], -15) for cp, cl, _ in mem)
     got, st, stats = run(emul, img, mem)
     assert all(s[1] == 0 for s in st) and got == ref
     assert stats[2] <= 0.002 * stats[1]
+
+
+def _bgzf_members(img):
+    import struct
+    pos = 0; mem = []
+    while pos < len(img):
+        bs = struct.unpack_from("<H", img, pos + 16)[0] + 1
+        mem.append((pos + 18, bs - 26, struct.unpack_from("<I", img, pos + bs - 4)[0])); pos += bs
+    return mem
+
+
+@pytest.mark.parametrize("name", ["sry.bam", "BamReader_sr.bam", "MappingQC_in1.bam"])
+def test_reference_fixture_bams(emul, name):
+    """the BGZF members of the reference's own fixture BAMs (htslib / samtools streams: several deflate blocks per member, an EOF block)"""
+    img = open(os.path.join(HERE, "golden", "ref_in", name), "rb").read()
+    mem = _bgzf_members(img)
+    ref = b"".join(zlib.decompress(img[cp:cp + cl], -15) for cp, cl, _ in mem)
+    got, st, _ = run(emul, img, mem, tok_mode=1)
+    assert all(s[1] == 0 for s in st) and got == ref and ref[:4] == b"BAM\x01"
 
 
 def test_damaged_streams(emul):
