@@ -68,6 +68,8 @@ double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono:
 uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
+constexpr int K1_CHUNK_WAVES_PER_CU = 6;   // a K1 chunk = this many decoder waves per CU (x 64 members); the launch itself keeps up to P1_WAVES_PER_CU resident
+constexpr int P1_WAVES_PER_CU = 12;       // decoder waves a CU holds (11 KB LDS and <= 128 VGPRs each); NGSQC_P1_WAVES
 constexpr int K1_SLOTS_DEFAULT = 4;  // token ring: chunk c uses slot c % slots (phase 1 of the next chunks runs while phase 2 of c reads); NGSQC_TOKEN_SLOTS
 constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
 
@@ -101,9 +103,11 @@ struct ngsqc_handle
 	int64_t chunk = 0, nch = 0;                        // K1 chunk size (members) and count
 	std::vector<std::pair<int64_t, int64_t>> tiles;    // (first member, count); whole chunks
 	std::vector<int64_t> tile_first_chunk;             // size nt + 1
-	int64_t pfx = 0, max_tile_bytes = 0, slot_tokens = 0;
+	int64_t pfx = 0, max_tile_bytes = 0, slot_pages = 0;   // slot_pages: token pool pages of one chunk slot
 	DevBuf<BlockDesc> d_kdesc;                         // per member: cpos into d_comp, upos relative to its tile's first member
-	DevBuf<uint64_t> d_tok_off; DevBuf<uint32_t> d_tok_cnt, d_order, d_tok, d_crc; DevBuf<unsigned long long> d_work; DevBuf<BlockStatus> d_status;
+	DevBuf<uint32_t> d_tok_first, d_tok_cnt, d_order, d_tok, d_crc, d_pool_ctr; DevBuf<unsigned long long> d_work; DevBuf<BlockStatus> d_status;   // d_tok: the token pool ring (k1_slots x slot_pages pages)
+	int p1_wgs = 0;                                    // decoder workgroups a launch may keep resident
+	DevBuf<uint32_t> d_sync_pool; DevBuf<BlockDesc> d_sync_desc; DevBuf<uint32_t> d_sync_u32; DevBuf<BlockStatus> d_sync_st; DevBuf<unsigned long long> d_sync_work;   // scratch of inflate_sync (kept: a hipFree waits for every queued kernel)
 	static constexpr int MAX_TILE_BUFS = 4;
 	int k1_slots = K1_SLOTS_DEFAULT;
 	DevBuf<uint8_t> buf[MAX_TILE_BUFS]; int nbuf = 2;  // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
@@ -176,6 +180,9 @@ void init_device(ngsqc_handle* h, int device)
 	HIPCHK(hipStreamCreateWithFlags(&h->s_p2, hipStreamNonBlocking));
 	HIPCHK(hipStreamCreateWithFlags(&h->s_crc, hipStreamNonBlocking));
 	int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cu = cu;
+	int pw = P1_WAVES_PER_CU; if (const char* e = getenv("NGSQC_P1_WAVES")) pw = std::min(32, std::max(1, atoi(e)));
+	h->p1_wgs = h->n_cu * pw;
+	k1_read_switches();
 	if (const char* e = getenv("NGSQC_VERIFY_CRC")) h->verify_crc = atoi(e) != 0;
 }
 
@@ -186,33 +193,34 @@ std::string inflate_error(const ngsqc_handle* h, int64_t member, uint32_t code)
 	return "Could not read next alignment in BAM/CRAM file " + h->path + " (BGZF inflate failed in block " + std::to_string(member) + ", code " + std::to_string(code) + ")";
 }
 
-// Synchronous K1 of a few members on the main stream with private scratch (header read, second chance of a member whose token
-// stream overflowed its budget). idx: member indices into h->blocks; desc/out: where each one goes. tok_cap_full: size the
-// token scratch for the worst case (every output byte a literal) instead of clen + 64.
-void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out, bool tok_cap_full)
+// Synchronous K1 of a few members on the main stream with private scratch (header read, second chance of members that found the token
+// pool of their launch used up). idx: member indices into h->blocks; desc/out: where each one goes. The pool is sized for the worst
+// case (two token slots per output byte), so the call is made in batches of bounded scratch; the scratch is kept across calls.
+void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out)
 {
-	const int64_t n = (int64_t)idx.size();
-	if (n == 0) return;
-	std::vector<uint64_t> off((size_t)n + 1, 0); std::vector<uint32_t> crc((size_t)n);
-	for (int64_t i = 0; i < n; ++i)
+	constexpr int64_t BATCH = 2048;   // members per batch: <= 2048 x (2 x 64 Ki slots + tables) x 4 B = 1.1 GB of pool
+	for (int64_t b0 = 0; b0 < (int64_t)idx.size(); b0 += BATCH)
 	{
-		const uint64_t cap = tok_cap_full ? 4ull * desc[(size_t)i].usize + 64 : (uint64_t)desc[(size_t)i].clen + 64;
-		off[(size_t)i + 1] = off[(size_t)i] + ((cap + 3) & ~3ull);
-		crc[(size_t)i] = h->crc[(size_t)idx[(size_t)i]];
+		const int64_t n = std::min<int64_t>(BATCH, (int64_t)idx.size() - b0);
+		std::vector<BlockDesc> dd(desc.begin() + b0, desc.begin() + b0 + n); std::vector<uint32_t> crc((size_t)n);
+		uint64_t sc = 0, su = 0;
+		for (int64_t i = 0; i < n; ++i) { crc[(size_t)i] = h->crc[(size_t)idx[(size_t)(b0 + i)]]; sc += dd[(size_t)i].clen; su += dd[(size_t)i].usize; }
+		const uint64_t pages = k1_pool_pages(sc, su, (uint64_t)n, true);
+		h->d_sync_desc.ensure_slack((size_t)n); h->d_sync_st.ensure_slack((size_t)n); h->d_sync_work.ensure(2);
+		h->d_sync_u32.ensure_slack((size_t)(3 * n + 16));   // [first | count | crc]
+		h->d_sync_pool.ensure_slack((size_t)pages * K1_PAGE_WORDS + 16);
+		uint32_t* d_first = h->d_sync_u32.p, *d_cnt = d_first + n, *d_crc = d_cnt + n;
+		HIPCHK(hipMemcpyAsync(h->d_sync_desc.p, dd.data(), (size_t)n * sizeof(BlockDesc), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(d_crc, crc.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemsetAsync(h->d_sync_work.p, 0, 2 * sizeof(unsigned long long), h->stream));   // [queue head | pool counter]
+		launch_huff_tokens(h->d_comp.p, h->d_sync_desc.p, n, h->d_sync_st.p, h->d_sync_pool.p, (uint32_t)pages, (uint32_t*)(h->d_sync_work.p + 1), d_first, d_cnt, h->d_sync_work.p, nullptr, h->p1_wgs, h->stream);
+		launch_lz77_resolve(h->d_sync_desc.p, n, d_out, h->d_sync_st.p, h->d_sync_pool.p, d_first, d_cnt, h->d_comp.p, h->stream);
+		if (h->verify_crc) launch_crc32(h->d_sync_desc.p, n, d_out, d_crc, h->d_sync_st.p, h->stream);
+		std::vector<BlockStatus> st((size_t)n);
+		HIPCHK(hipMemcpyAsync(st.data(), h->d_sync_st.p, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		for (int64_t i = 0; i < n; ++i) if (st[(size_t)i].error) throw FormatError(inflate_error(h, idx[(size_t)(b0 + i)], st[(size_t)i].error));
 	}
-	DevBuf<BlockDesc> d_desc; d_desc.upload(desc, h->stream);
-	DevBuf<uint64_t> d_off; d_off.upload(off, h->stream);
-	DevBuf<uint32_t> d_tok, d_cnt, d_crc; d_tok.alloc((size_t)off[(size_t)n] + 16); d_cnt.alloc((size_t)n + 8); d_crc.upload(crc, h->stream);
-	DevBuf<BlockStatus> d_st; d_st.alloc((size_t)n);
-	DevBuf<unsigned long long> d_work; d_work.alloc(1);
-	HIPCHK(hipMemsetAsync(d_work.p, 0, sizeof(unsigned long long), h->stream));
-	launch_huff_tokens(h->d_comp.p, d_desc.p, n, d_st.p, d_off.p, d_tok.p, d_cnt.p, d_work.p, nullptr, h->n_cu * 6, h->stream);
-	launch_lz77_resolve(d_desc.p, n, d_out, d_st.p, d_off.p, d_tok.p, d_cnt.p, h->stream);
-	if (h->verify_crc) launch_crc32(d_desc.p, n, d_out, d_crc.p, d_st.p, h->stream);
-	std::vector<BlockStatus> st((size_t)n);
-	HIPCHK(hipMemcpyAsync(st.data(), d_st.p, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	for (int64_t i = 0; i < n; ++i) if (st[(size_t)i].error) throw FormatError(inflate_error(h, idx[(size_t)i], st[(size_t)i].error));
 }
 
 // inflate the first members until the BAM header (magic, text, reference table) is complete; parse it
@@ -228,7 +236,7 @@ bool read_header(ngsqc_handle* h, int64_t avail)
 		DevBuf<uint8_t> tmp; tmp.alloc((size_t)bytes + 64);
 		std::vector<int64_t> idx((size_t)k); std::vector<BlockDesc> desc((size_t)k);
 		for (int64_t i = 0; i < k; ++i) { idx[(size_t)i] = i; desc[(size_t)i] = h->blocks[(size_t)i]; }
-		inflate_sync(h, idx, desc, tmp.p, true);
+		inflate_sync(h, idx, desc, tmp.p);
 		std::vector<uint8_t> hb((size_t)bytes);
 		if (bytes) HIPCHK(hipMemcpy(hb.data(), tmp.p, (size_t)bytes, hipMemcpyDeviceToHost));
 		bool complete = false;
@@ -374,7 +382,7 @@ void plan_layout(ngsqc_handle* h)
 	if (nb == 0) return;
 	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
 	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
-	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * 6 * 64 * mul / div);
+	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * K1_CHUNK_WAVES_PER_CU * 64 * mul / div);
 	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
 	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile). NGSQC_TILE_BUFFERS=2..4.
@@ -387,31 +395,23 @@ void plan_layout(ngsqc_handle* h)
 		h->chunk = (((nb + nch0 - 1) / nch0) + 63) & ~63ll;   // equal chunks, whole waves
 	}
 	h->nch = (nb + h->chunk - 1) / h->chunk;
-	// token budget of a chunk slot
-	std::vector<uint64_t> tok_off((size_t)(nb + h->nch), 0); std::vector<uint32_t> ord((size_t)nb);
-	int64_t slot = 0; std::vector<int64_t> chunk_bytes((size_t)h->nch, 0);
+	// token pool of a chunk slot: the pages the chunk with the largest need may take (k1_types.h), queue order inside every chunk
+	std::vector<uint32_t> ord((size_t)nb);
+	std::vector<int64_t> chunk_bytes((size_t)h->nch, 0);
+	double pool_factor = 1.0; if (const char* e = getenv("NGSQC_TOKEN_POOL_FACTOR")) pool_factor = std::max(0.01, atof(e));   // (tests: a small pool forces the second-chance path)
+	h->slot_pages = 0;
 	for (int64_t c = 0; c < h->nch; ++c)
 	{
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
-		uint64_t acc = 0;
-		for (int64_t i = 0; i < cn; ++i)
-		{
-			tok_off[(size_t)(c0 + c + i)] = acc; acc += ((uint64_t)h->blocks[(size_t)(c0 + i)].clen + 64 + 3) & ~3ull;
-			ord[(size_t)(c0 + i)] = (uint32_t)i; chunk_bytes[(size_t)c] += h->blocks[(size_t)(c0 + i)].usize;
-		}
-		tok_off[(size_t)(c0 + c + cn)] = acc;
-		slot = std::max<int64_t>(slot, (int64_t)acc);
+		uint64_t sc = 0, su = 0;
+		for (int64_t i = 0; i < cn; ++i) { sc += h->blocks[(size_t)(c0 + i)].clen; su += h->blocks[(size_t)(c0 + i)].usize; ord[(size_t)(c0 + i)] = (uint32_t)i; }
+		chunk_bytes[(size_t)c] = (int64_t)su;
+		h->slot_pages = std::max<int64_t>(h->slot_pages, (int64_t)((double)k1_pool_pages(sc, su, (uint64_t)cn, false) * pool_factor) + 1);
 		// queue order inside the chunk: largest compressed size first (the 64 lanes of a wave finish together)
 		std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(c0 + a)].clen > h->blocks[(size_t)(c0 + b)].clen; });
 	}
-	h->slot_tokens = slot + 16;
 	h->k1_slots = K1_SLOTS_DEFAULT; if (const char* e = getenv("NGSQC_TOKEN_SLOTS")) h->k1_slots = std::min(8, std::max(2, atoi(e)));
 	const int64_t n_slots = std::min<int64_t>(h->k1_slots, h->nch);
-	for (int64_t c = 0; c < h->nch; ++c)   // slot base of the chunk
-	{
-		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0); const uint64_t base = (uint64_t)((c % h->k1_slots) * h->slot_tokens);
-		for (int64_t i = 0; i <= cn; ++i) tok_off[(size_t)(c0 + c + i)] += base;
-	}
 	// tiles: as many chunks as fit the tile buffers next to the ring (at most cpt)
 	int64_t carry_max = 64ll << 20; if (const char* e = getenv("NGSQC_CARRY_MAX")) carry_max = std::max<int64_t>(0, atoll(e));
 	if (!forced && h->nch > 1)
@@ -419,7 +419,7 @@ void plan_layout(ngsqc_handle* h)
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 		{
-			const double fixed = (double)n_slots * (double)h->slot_tokens * 4.0 + (double)nb * 64.0 + (double)h->nbuf * (double)carry_max;
+			const double fixed = (double)n_slots * (double)h->slot_pages * (double)K1_PAGE_WORDS * 4.0 + (double)nb * 64.0 + (double)h->nbuf * (double)carry_max;
 			int64_t max_chunk = 0; for (int64_t b : chunk_bytes) max_chunk = std::max(max_chunk, b);
 			const double avail = (double)free_b * 0.85 - fixed;
 			int64_t fit = (int64_t)(avail / (((double)h->nbuf + 0.15) * (double)std::max<int64_t>(max_chunk, 1)));   // the tile buffers + record index / long list
@@ -445,9 +445,9 @@ void plan_layout(ngsqc_handle* h)
 		for (int64_t i = f; i < f + m; ++i) { kd[(size_t)i] = h->blocks[(size_t)i]; kd[(size_t)i].upos -= u_lo; }
 		h->max_tile_bytes = std::max<int64_t>(h->max_tile_bytes, (int64_t)(h->blocks[(size_t)(f + m - 1)].upos + h->blocks[(size_t)(f + m - 1)].usize - u_lo));
 	}
-	h->d_kdesc.upload(kd, h->stream); h->d_tok_off.upload(tok_off, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
-	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch);
-	h->d_tok.ensure((size_t)(n_slots * h->slot_tokens) + 16);
+	h->d_kdesc.upload(kd, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
+	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_tok_first.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch); h->d_pool_ctr.ensure((size_t)h->nch);
+	h->d_tok.ensure((size_t)(n_slots * h->slot_pages) * K1_PAGE_WORDS + 16);
 	for (int i = 0; i < std::min(nt, h->nbuf); ++i) h->buf[i].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
 	h->p_status.ensure((size_t)nb);
 	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
@@ -463,11 +463,12 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	const int64_t nb = (int64_t)h->blocks.size();
 	uint8_t* out_base = h->buf[t % h->nbuf].p + h->pfx;
 	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
-	// CRC of a chunk in line behind its phase 2 (default). On its own stream (NGSQC_CRC_STREAM=1) it runs beside phase 2 of the next chunk and
-	// takes the LDS that phase 2's workgroups need next to the six phase-1 waves of a CU: measured 84 ms instead of 74 ms per 48 M reads.
+	// CRC of a chunk on its own stream behind the chunk's phase 2, beside phase 2 of the next chunk (NGSQC_CRC_STREAM=0: in line on the phase-2
+	// stream). With the round-3 kernels (2.4 KB LDS and 37 VGPRs per phase-2 wave) the two no longer compete for a CU's LDS: K1 of a
+	// 96 M-read shard 100 -> 88 ms.
 	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;
 	const char* eks = getenv("NGSQC_K1_SERIAL"); const bool k1_serial = eks && atoi(eks) != 0;   // profiling: every K1 kernel in line on ONE stream (isolated per-kernel counters)   // 1: the next chunk's phase 1 starts when the whole previous launch is done
-	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (ce && atoi(ce) != 0) ? h->s_crc : h->s_p2;
+	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (!ce || atoi(ce) != 0) ? h->s_crc : h->s_p2;
 	for (int64_t c = h->tile_first_chunk[(size_t)t]; c < h->tile_first_chunk[(size_t)t + 1]; ++c)
 	{
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
@@ -475,13 +476,14 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
 		HIPCHK(hipEventRecord(e4[0], s1));
-		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->d_work.p + c,
-		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->n_cu * 6, s1);
+		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
+		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, pool, (uint32_t)h->slot_pages, h->d_pool_ctr.p + c, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_work.p + c,
+		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->p1_wgs, s1);
 		HIPCHK(hipEventRecord(e4[1], s1));
 		HIPCHK(hipStreamWaitEvent(h->s_p2, e4[1], 0));
 		if (c == h->tile_first_chunk[(size_t)t] && t >= h->nbuf) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - h->nbuf) + 1)], 0));   // the buffer's previous tile is consumed
 		HIPCHK(hipEventRecord(e4[2], h->s_p2));
-		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, h->d_tok_off.p + c0 + c, h->d_tok.p, h->d_tok_cnt.p + c0, h->s_p2);
+		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, pool, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_comp.p, h->s_p2);
 		HIPCHK(hipEventRecord(e4[3], h->s_p2));
 		if (h->verify_crc)   // htslib checks every member's CRC32 (bgzf.c); a mismatch fails the read
 		{
@@ -514,7 +516,7 @@ void finish_k1_tile(ngsqc_handle* h, int t)
 	if (redo.empty()) return;
 	std::vector<BlockDesc> desc; const uint64_t u_lo = h->blocks[(size_t)f].upos;
 	for (int64_t i : redo) { BlockDesc d = h->blocks[(size_t)i]; d.upos -= u_lo; desc.push_back(d); }
-	inflate_sync(h, redo, desc, h->buf[t % h->nbuf].p + h->pfx, true);
+	inflate_sync(h, redo, desc, h->buf[t % h->nbuf].p + h->pfx);
 }
 
 // K2 for tile t (its members are in buf[t % nbuf] behind the prefix area; carry_len bytes of the previous tile's straddling
@@ -693,6 +695,7 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
 	const char* pe = getenv("NGSQC_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;   // 0: K1 of a tile starts only when the previous tile is consumed (stage attribution)
 	HIPCHK(hipMemsetAsync(h->d_work.p, 0, (size_t)h->nch * sizeof(unsigned long long), h->stream));
+	HIPCHK(hipMemsetAsync(h->d_pool_ctr.p, 0, (size_t)h->nch * sizeof(uint32_t), h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	try
 	{

@@ -12,11 +12,14 @@
 namespace ngsqc {
 
 // ---- K1 ----
-// two-phase K1 (k1_kernels.h / inflate.hip): lane-per-member Huffman -> token groups, then wave-per-member LZ77 resolve
+// two-phase K1 (k1_kernels.h / inflate.hip): lane-per-member Huffman -> token groups in pages of a pool, then wave-per-member LZ77 resolve
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
-                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order /* queue order inside the launch, or null */, int max_wgs, hipStream_t s);
+                        uint32_t* d_pool, uint32_t pool_pages, uint32_t* d_pool_ctr /* zeroed */, uint32_t* d_tok_first, uint32_t* d_tok_count,
+                        unsigned long long* d_work /* zeroed */, const uint32_t* d_order /* queue order inside the launch, or null */, int max_wgs, hipStream_t s);
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
-                         const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s);
+                         const uint32_t* d_pool, const uint32_t* d_tok_first, const uint32_t* d_tok_count, const uint8_t* d_comp, hipStream_t s);
+
+void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC
 void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);

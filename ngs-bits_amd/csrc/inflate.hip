@@ -7,28 +7,36 @@
 
 namespace ngsqc {
 
+// measurement switches of the K1 launches, read when a handle is opened (not per launch)
+static struct { int park_hi = 32, p1_pad = 0, p2_pad = 0; int64_t p2_cap = (int64_t)1 << 20; } g_sw;
+void k1_read_switches()
+{
+	const char* e;
+	g_sw.park_hi = (e = getenv("NGSQC_P1_PARK")) ? atoi(e) : 32;                       // lanes that wait for the slow section before the wave enters it
+	g_sw.p1_pad = (e = getenv("NGSQC_P1_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per decoder workgroup = fewer decoder waves per CU
+	g_sw.p2_pad = (e = getenv("NGSQC_P2_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per phase-2 workgroup = fewer phase-2 waves beside the decoder waves
+	g_sw.p2_cap = (e = getenv("NGSQC_P2_WGS")) ? std::max<int64_t>(1, atoll(e)) : (int64_t)1 << 20;   // caps the phase-2 grid: the waves then stride over the members
+}
+
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
-                        const uint64_t* d_tok_off, uint32_t* d_tok, uint32_t* d_tok_count, unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s)
+                        uint32_t* d_pool, uint32_t pool_pages, uint32_t* d_pool_ctr, uint32_t* d_tok_first, uint32_t* d_tok_count,
+                        unsigned long long* d_work, const uint32_t* d_order, int max_wgs, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	// d_work: the launch's member queue head (zeroed by the caller). One-wave workgroups of 23 KB LDS: six per CU.
+	// d_work: the launch's member queue head, d_pool_ctr: pages taken from the launch's token pool (both zeroed by the caller). One-wave workgroups.
 	const int64_t wgs = (n_blocks + 63) / 64;
 	const int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
-	const char* pe = getenv("NGSQC_P1_PARK"); int park_hi = pe ? atoi(pe) : 32;   // (16: 731-743, 32: 756 Mreads/s on a 96 M-read shard)
-	const char* pr = getenv("NGSQC_P1_PRIO"); park_hi = (park_hi & 255) | ((pr ? atoi(pr) : 0) << 8);
-	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_tok_off, d_tok, d_tok_count, d_status, d_work, d_order, park_hi);
+	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), g_sw.p1_pad, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, g_sw.park_hi);
 	KCHECK();
 }
 
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
-                         const uint64_t* d_tok_off, const uint32_t* d_tok, const uint32_t* d_tok_count, hipStream_t s)
+                         const uint32_t* d_pool, const uint32_t* d_tok_first, const uint32_t* d_tok_count, const uint8_t* d_comp, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
 	// one member per one-wave workgroup, handed out by the dispatcher (NGSQC_P2_WGS caps the grid: the waves then stride over the members)
-	const char* e2 = getenv("NGSQC_P2_WGS"); const int64_t cap2 = e2 ? std::max<int64_t>(1, atoll(e2)) : (int64_t)1 << 20;
-	const int grid2 = (int)(n_blocks < cap2 ? n_blocks : cap2);
-	const char* ep = getenv("NGSQC_P2_LDS_PAD"); const int pad = ep ? std::max(0, atoi(ep)) : 0;   // measurement switch: extra LDS per workgroup = fewer phase-2 waves beside the decoder waves
-	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), pad, s, d_tok, d_tok_off, d_tok_count, d_blocks, n_blocks, d_out, d_status); KCHECK();
+	const int grid2 = (int)(n_blocks < g_sw.p2_cap ? n_blocks : g_sw.p2_cap);
+	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), g_sw.p2_pad, s, d_pool, d_tok_first, d_tok_count, d_blocks, n_blocks, d_out, d_status, d_comp); KCHECK();
 }
 
 } // namespace ngsqc

@@ -14,10 +14,32 @@ struct BlockStatus { uint32_t produced; uint32_t error; };
 
 enum { K1_ERR_CRC = 20, K1_ERR_TOKEN_OVERFLOW = 100 };   // BlockStatus.error values the host treats specially
 
-// Token stream between phase 1 and phase 2: groups of four 32-bit words, one group per 16-byte store of a decoder lane.
-//   literal : the byte value (bits 8..31 zero)
-//   match   : bit 31 | (length - 3) << 23 | (distance - 1)           (bits 15..22 zero)
-//   no-op   : 0xffffffff  (a trip in which the lane produced nothing; only inside a group that also holds real tokens)
-constexpr uint32_t K1_TOK_NOOP = 0xffffffffu;
+// Token stream between phase 1 and phase 2. It lives in a POOL of pages that the decoder lanes of one launch allocate from with an
+// atomic counter (a member takes what its token stream needs; nothing is sized per member in advance). A page is K1_PAGE_WORDS
+// 32-bit words = K1_PAGE_GROUPS groups of four words; a group is one 16-byte store of a decoder lane. The last group of a page is the
+// link to the member's next page. Token words:
+//   literal   : 0x000000ii  index into the literal table of the current DEFLATE block (the literals sorted by (code length, value));
+//               phase 2 translates it - the decoder lanes keep no symbol table for literals
+//   match     : bit 31 | (length - 3) << 23 | (distance - 1)                      (bits 15..22 zero)
+//   raw run   : bit 30 | (length - 1) << 16 | byte offset in the member's payload  (stored blocks: 1..256 bytes copied from the input)
+//   no-op     : 0xffffffff  (a slot in which the lane produced nothing)
+// Groups with a special first word (the other words are not tokens):
+//   table     : {K1_TOK_TABLE, pool word offset of a 256-byte literal table, 0, 0}  - the block that starts here uses that table
+//   link      : {K1_TOK_LINK, index of the member's next page, 0, 0}               - always group K1_PAGE_GROUPS - 1 of a page
+constexpr uint32_t K1_TOK_NOOP = 0xffffffffu, K1_TOK_TABLE = 0xfffffffeu, K1_TOK_LINK = 0xfffffffdu;
+constexpr uint32_t K1_TOK_SPECIAL = 0xfffffffdu;   // words >= this are no tokens (a match token never reaches it: its bits 15..22 are zero)
+constexpr uint32_t K1_PAGE_WORDS = 1024, K1_PAGE_GROUPS = K1_PAGE_WORDS / 4, K1_TABLE_WORDS = 64, K1_TABLES_PER_PAGE = K1_PAGE_WORDS / K1_TABLE_WORDS;
+
+// Pages a launch over members with these sizes may need: the expected token volume of BAM data (about one token word per
+// compressed byte, incl. the no-op slots) with a 6x margin over the compressed size, bounded by the worst case (two slots per
+// output byte), plus per member one partly used token page and one table page. A launch that runs out of pages reports
+// K1_ERR_TOKEN_OVERFLOW for the members it could not finish; the host repeats those with a worst-case pool.
+inline uint64_t k1_pool_pages(uint64_t sum_clen, uint64_t sum_usize, uint64_t n_members, bool worst_case)
+{
+	const uint64_t worst = 2 * sum_usize + 64 * n_members;   // token words
+	uint64_t words = worst_case ? worst : (6 * sum_clen) / 4 * 1;   // 6 bytes of token space per compressed byte
+	if (!worst_case && words > worst) words = worst;
+	return words / (K1_PAGE_WORDS - 4) + 3 * n_members + 64;
+}
 
 } // namespace ngsqc

@@ -10,6 +10,7 @@
 #define K1_KERNEL_OCC(bounds, waves_per_simd) __global__ __launch_bounds__(bounds, waves_per_simd)   // + a register budget for that many waves per SIMD
 #define K1_SHARED __shared__
 #define K1_DEV __device__ __forceinline__
+#define K1_STAT(i) ((void)0)   // (instrumentation hook of the wave emulator)
 
 namespace ngsqc { namespace wv {
 
@@ -41,6 +42,7 @@ K1_DEV uint32_t scan_incl(uint32_t x)
 // ---- memory ----
 K1_DEV void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): every vector-memory load has returned, every store is acknowledged
 K1_DEV unsigned long long atomic_inc(unsigned long long* p) { return atomicAdd(p, 1ull); }
+K1_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 K1_DEV void lds_or(unsigned long long* p, unsigned long long v) { atomicOr(p, v); }
 
 // A byte range in HBM behind a buffer resource: 32-bit offsets (one VALU add per address) and hardware bounds clamping
@@ -68,6 +70,7 @@ K1_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __built
 K1_DEV uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }        // (x >> off) & ((1 << width) - 1), width 0 -> 0
 K1_DEV uint32_t popc64(uint64_t x) { return (uint32_t)__popcll(x); }
 K1_DEV uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }   // bits of m below this lane
+K1_DEV uint32_t mbcnt_add(uint64_t m, uint32_t a) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, a)); }   // a + bits of m below this lane
 K1_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 } } // namespace ngsqc::wv

@@ -5,7 +5,7 @@
 // (ballot, readlane, shfl, scan, barrier) is a rendezvous - a lane deposits its operand, yields, and continues when all live
 // lanes of the wave have arrived. Between two rendezvous a lane runs alone, so an LDS exchange that lacks a barrier shows up as
 // a wrong result here even where the lockstep hardware would forgive it. A cross-lane operation reached from divergent control
-// flow (lanes arriving from different call sites) aborts the run. One workgroup (= one wave) runs at a time; K1_SHARED
+// flow (lanes arriving from different source lines) aborts the run. One workgroup (= one wave) runs at a time; K1_SHARED
 // variables are function-local statics.
 #pragma once
 #include <ucontext.h>
@@ -20,6 +20,7 @@
 #define K1_KERNEL_OCC(bounds, waves_per_simd)
 #define K1_SHARED static
 #define K1_DEV inline
+#define K1_STAT(i) (++::ngsqc::wv::emu_stats()[i])   // instrumentation of the kernels (compiled out in the library)
 #ifndef __restrict__
 #define __restrict__
 #endif
@@ -42,6 +43,7 @@ struct Emu
 	std::function<void()> body;
 };
 inline Emu& emu() { static Emu e; return e; }
+inline uint64_t* emu_stats() { static uint64_t s[8]; return s; }
 
 inline void lane_entry()
 {
@@ -89,22 +91,22 @@ __attribute__((noinline)) inline Xchg rendezvous(uint64_t v, const void* site)
 		}
 	return Xchg{E.xv[p], E.stamp[p], k};
 }
-#define WV_SITE __builtin_return_address(0)
+#define WV_SITE ((const void*)(uintptr_t)line)   // the SOURCE line of the call (the compiler may clone a call site: return addresses would differ for one operation)
 
 inline int lane() { return emu().cur; }
 inline int64_t block_id() { return emu().block; }
 inline int64_t grid_size() { return emu().grid; }
 
-__attribute__((noinline)) inline uint64_t ballot(bool p)
+__attribute__((noinline)) inline uint64_t ballot(bool p, int line = __builtin_LINE())
 {
 	const Xchg x = rendezvous(p ? 1u : 0u, WV_SITE); uint64_t m = 0;
 	for (int i = 0; i < Emu::W; ++i) if (x.has(i) && x.v[i]) m |= 1ull << i;
 	return m;
 }
-__attribute__((noinline)) inline uint32_t readlane(uint32_t v, int l) { const Xchg x = rendezvous(v, WV_SITE); return x.has(l & 63) ? (uint32_t)x.v[l & 63] : 0u; }
-__attribute__((noinline)) inline uint32_t shfl(uint32_t v, int src) { const Xchg x = rendezvous(v, WV_SITE); return x.has(src & 63) ? (uint32_t)x.v[src & 63] : 0u; }
-__attribute__((noinline)) inline void barrier() { rendezvous(0, WV_SITE); }
-__attribute__((noinline)) inline uint32_t scan_incl(uint32_t v)
+__attribute__((noinline)) inline uint32_t readlane(uint32_t v, int l, int line = __builtin_LINE()) { const Xchg x = rendezvous(v, WV_SITE); return x.has(l & 63) ? (uint32_t)x.v[l & 63] : 0u; }
+__attribute__((noinline)) inline uint32_t shfl(uint32_t v, int src, int line = __builtin_LINE()) { const Xchg x = rendezvous(v, WV_SITE); return x.has(src & 63) ? (uint32_t)x.v[src & 63] : 0u; }
+__attribute__((noinline)) inline void barrier(int line = __builtin_LINE()) { rendezvous(0, WV_SITE); }
+__attribute__((noinline)) inline uint32_t scan_incl(uint32_t v, int line = __builtin_LINE())
 {
 	const Xchg x = rendezvous(v, WV_SITE); const int me = emu().cur; uint32_t s = 0;
 	for (int i = 0; i <= me; ++i) if (x.has(i)) s += (uint32_t)x.v[i];
@@ -114,6 +116,7 @@ __attribute__((noinline)) inline uint32_t scan_incl(uint32_t v)
 inline void wait_vm0() {}
 inline void set_priority(int) {}
 inline unsigned long long atomic_inc(unsigned long long* p) { return (*p)++; }
+inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void lds_or(unsigned long long* p, unsigned long long v) { *p |= v; }
 
 struct ByteBuf
@@ -134,6 +137,7 @@ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32
 inline uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { width &= 31u; return width ? (x >> (off & 31u)) & ((1u << width) - 1u) : 0u; }
 inline uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 inline uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << emu().cur) - 1ull)); }
+inline uint32_t mbcnt_add(uint64_t m, uint32_t a) { return a + mbcnt(m); }
 inline float rcp(float x) { return 1.0f / x; }
 
 } } // namespace ngsqc::wv

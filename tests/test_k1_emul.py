@@ -42,7 +42,7 @@ def run(L, img, mem, park=16, tok_mode=0, p1=0, p2=0, order=1):
     n = len(mem); bd = (BD * n)(); up = 0
     for i, (cp, cl, us) in enumerate(mem):
         bd[i] = BD(cp, up, cl, us); up += us
-    out = np.zeros(up + 64, np.uint8); st = (BS * n)(); stats = (C.c_uint64 * 4)()
+    out = np.zeros(up + 64, np.uint8); st = (BS * n)(); stats = (C.c_uint64 * 16)()
     L.k1_emul_inflate(img + b"\0" * 64, bd, n, out.ctypes.data, st, park, tok_mode, p1, p2, order, stats)
     return out[:up].tobytes(), [(s.produced, s.error) for s in st], list(stats)
 
@@ -105,30 +105,34 @@ def check(cases, got, st, allow_overflow):
         pos += len(raw)
 
 
-@pytest.mark.parametrize("variant", ["library_budget", "worst_case_budget", "no_parking", "park_all", "one_decoder_wave_three_resolver_waves", "file_order"])
+@pytest.mark.parametrize("variant", ["library_pool", "worst_case_pool", "small_pool", "no_parking", "park_all", "one_decoder_wave_three_resolver_waves", "file_order"])
 def test_deflate_shapes(emul, variant):
     rng = random.Random(11)
     cases = shapes(rng); img, mem = image(cases, rng)
-    kw = {"library_budget": {}, "worst_case_budget": dict(tok_mode=1), "no_parking": dict(park=0), "park_all": dict(park=64),
+    kw = {"library_pool": {}, "worst_case_pool": dict(tok_mode=1), "small_pool": dict(tok_mode=150), "no_parking": dict(park=0), "park_all": dict(park=64),
           "one_decoder_wave_three_resolver_waves": dict(p1=1, p2=3), "file_order": dict(order=0)}[variant]
     got, st, stats = run(emul, img, mem, **kw)
-    check(cases, got, st, allow_overflow=kw.get("tok_mode", 0) == 0)
+    check(cases, got, st, allow_overflow=variant == "small_pool")
     overflow = [i for i, s in enumerate(st) if s[1] == 100]
-    if kw.get("tok_mode", 0) == 0:
-        assert overflow, "the run / Huffman-only members are expected to exceed the clen + 64 budget"
+    if variant == "small_pool":
+        # a pool that runs out: the members that could not get a page report K1_ERR_TOKEN_OVERFLOW (the library repeats them with a
+        # worst-case pool), every other member is complete and correct
+        assert overflow and len(overflow) < len(cases) and stats[4] >= 150
     else:
         assert not overflow
-    assert stats[2] <= 0.02 * stats[1]   # no-op words inside the token groups stay a small share
+    assert stats[2] <= 0.5 * stats[1]   # no-op slots: the second slot of a trip whose first symbol is a match, table groups
 
 
 def test_synthetic_bam_members(emul):
-    """members of the bench generator's BAM (one dynamic block each, ~14 k tokens): the token stream carries (almost) no no-ops"""
+    """members of the bench generator's BAM (one dynamic block each, ~14 k tokens): a trip yields two slots, the second one is a no-op
+    when the first symbol is a match - about a fifth of the slots"""
     img = np.asarray(bamgen_lib.generate(n_reads=3000, seed=5)).tobytes()
     mem = _bgzf_members(img)
     ref = b"".join(zlib.decompress(img[cp:cp + cl], -15) for cp, cl, _ in mem)
     got, st, stats = run(emul, img, mem)
     assert all(s[1] == 0 for s in st) and got == ref
-    assert stats[2] <= 0.002 * stats[1]
+    assert stats[2] <= 0.25 * stats[1]
+    assert stats[6] * 1.5 <= stats[1] - stats[2]   # more than 1.5 tokens per decoding lane trip
 
 
 def _bgzf_members(img):

@@ -41,6 +41,7 @@ VARIANTS = {
     "prio3_park32": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PARK": "32"}, "prio2": {"NGSQC_P1_PRIO": "2"},
     "p2pad2k": {"NGSQC_P2_LDS_PAD": "2048"}, "p2pad6k": {"NGSQC_P2_LDS_PAD": "6144"}, "p2pad1k": {"NGSQC_P2_LDS_PAD": "1024"},
     "crcserial": {"NGSQC_CRC_STREAM": "0"}, "crcstream": {"NGSQC_CRC_STREAM": "1"},
+    "park16": {"NGSQC_P1_PARK": "16"}, "park48": {"NGSQC_P1_PARK": "48"},
 }
 
 
@@ -60,7 +61,14 @@ def main():
         for k in list(os.environ):
             if k.startswith("NGSQC_"):
                 del os.environ[k]
-        os.environ.update(VARIANTS[name])
+        if name in VARIANTS:
+            os.environ.update(VARIANTS[name])
+        else:   # ad-hoc: "serial+P1_WAVES=8+K1_CHUNK_MUL=2" (names of VARIANTS and NGSQC_ switches joined by +)
+            for part in name.split("+"):
+                if part in VARIANTS:
+                    os.environ.update(VARIANTS[part])
+                else:
+                    k, v = part.split("="); os.environ["NGSQC_" + k] = v
         t0 = time.time()
         h = ngsqc.Handle(data=image, device=0)
         t_open = time.time() - t0
@@ -81,7 +89,7 @@ def main():
             ref = c.copy()
         same = bool(np.array_equal(ref, c))
         w = float(np.mean(walls[1:]))
-        print(f"[probe] {name:9s} open {t_open:.2f}s wall {w:8.2f} ms  ({tm['n_records'] / w / 1e3:7.1f} Mreads/s)  K1 {tm['inflate_ms']:.2f} (huff {tm['inflate_huff_ms']:.1f} lz {tm['inflate_lz77_ms']:.1f} x{tm['inflate_huff_launches']}) "
+        print(f"[probe] {name:28s} open {t_open:.2f}s wall {w:8.2f} ms  ({tm['n_records'] / w / 1e3:7.1f} Mreads/s)  K1 {tm['inflate_ms']:.2f} (huff {tm['inflate_huff_ms']:.1f} lz {tm['inflate_lz77_ms']:.1f} x{tm['inflate_huff_launches']}) "
               f"index {tm['index_ms']:.2f} scan {tm['scan_ms']:.2f} (kernels {tm['scan_kernel_ms']:.2f}) pile {tm['pileup_ms']:.2f} fin {tm['finalize_ms']:.2f} tiles {tm['n_tiles']} members {tm['members_inflated']}/{h.n_blocks} "
               f"records {tm['n_records']} same_counters {same}", flush=True)
         h.close()
