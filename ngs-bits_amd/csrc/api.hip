@@ -12,6 +12,7 @@
 //     (a fixed prefix area in every tile buffer, so K1 of tile t+1 does not depend on K2 of tile t).
 // There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails with NGSQC_E_DEVICE.
 #include "common.h"
+#include <memory>
 #include <algorithm>
 #include <cstring>
 #include <chrono>
@@ -61,6 +62,8 @@ struct Timer
 	~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 	void start() { HIPCHK(hipEventRecord(a, s)); }
 	double stop() { HIPCHK(hipEventRecord(b, s)); HIPCHK(hipEventSynchronize(b)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); return ms; }
+	void mark() { HIPCHK(hipEventRecord(b, s)); }   // end of the interval without waiting for it
+	double elapsed() { HIPCHK(hipEventSynchronize(b)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); return ms; }
 };
 
 double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -134,6 +137,16 @@ struct ngsqc_handle
 	int64_t shard_u_base = 0;              // inflated offset (whole file) of the handle's first member
 	int64_t shard_first_abs = -1, shard_exit_abs = -1; int shard_last_tile = -1;
 	bool verify_crc = true;
+	// the scan that rides K2's chain walk (launch_walk_scan): set by the job for its first scan consumer; fuse_ok turns false when a tile is not laid out like an
+	// htslib file (the general K2 path takes over); fused_tile = the tile whose records that scan has already seen
+	struct FusedScan   // what K2 needs of such a scan (ScanState)
+	{
+		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int64_t scan_limit) = 0;
+		virtual unsigned long long* fused_long_count() = 0;   // device address of the deferred-record count
+		virtual double fused_elapsed_ms() = 0;                // duration of the last fused_launch (waits for it)
+		virtual ~FusedScan() = default;
+	};
+	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
 	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last raw-read QC pass
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
 	Partial* partial = nullptr;
@@ -551,15 +564,36 @@ void index_tile(ngsqc_handle* h, int t)
 	// member's chain, check the pattern on the device, scan the counts; the host reads back {violations, corrupt records, n_rec} only ----
 	launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-	launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	// the job's first scan consumer rides the chain walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
+	h->fused_tile = -1;
+	const bool try_fuse = h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
+	const int64_t fuse_limit = h->shard_own_members >= 0 ? prefix + (h->shard_limit - u_lo) : INT64_MAX;   // a shard only scans the records that start in front of its limit
+	if (try_fuse)
+	{
+		h->d_long.ensure_slack((size_t)std::max<int64_t>(total / 160, 1024));   // deferred (long-CIGAR) records of the tile: an estimate, checked below
+		launch_index_guess(base, total, d_desc, ne, prefix, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
+		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, fuse_limit);
+	}
+	else launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 	launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = n_rec
 	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipMemcpyAsync(sm + 1, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	sm[2] = 0; if (try_fuse) HIPCHK(hipMemcpyAsync(sm + 2, h->fuse->fused_long_count(), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	const uint32_t n_corrupt = ((const uint32_t*)sm)[0], n_viol = ((const uint32_t*)sm)[1];
 	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
+	if (try_fuse)
+	{
+		if (aligned && n_corrupt == 0 && sm[2] <= (unsigned long long)h->d_long.n) h->fused_tile = t;
+		else if (n_corrupt == 0)
+		{
+			// not an htslib-style tile (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual
+			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, fuse_limit);
+			if (!aligned) h->fuse_ok = false; else h->d_long.ensure_slack((size_t)sm[2]);
+		}
+	}
 	if (aligned)
 	{
 		if (n_corrupt) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
@@ -653,7 +687,7 @@ void index_tile(ngsqc_handle* h, int t)
 			}
 		}
 	}
-	h->tm.index_ms += tmr.stop();
+	{ const double el = tmr.stop(); h->tm.index_ms += h->fused_tile == t ? std::max(0.0, el - h->fuse->fused_elapsed_ms()) : el; }   // (the riding scan is booked as scan time)
 	// ---- publish tile state ----
 	h->cur_tile = t; h->tile_prefix = prefix; h->tile_total = total; h->tile_u_lo = u_lo; h->tile_ord_base = h->next_ord_base;
 	h->n_rec = n_rec; h->tm.n_records += n_rec;
@@ -796,7 +830,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 // The scan reduces (longest read, first ordinal reaching it) and (first paired ordinal) per tile; a tile whose longest read does
 // not exceed the running maximum carried in contributes n_counted x maximum, otherwise the running maximum is walked over the
 // tile's records in front of that read (prefix_fix_kernel) - normally a handful of records of the first tile.
-struct ScanState
+struct ScanState : ngsqc_handle::FusedScan
 {
 	ScanParams sp{}; DevBuf<unsigned long long> d_counters;
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
@@ -817,29 +851,68 @@ struct ScanState
 		run_max = 0; paired_seen = false; sum_runmax = 0; fix_len = 0; prev_total = 0; prev_usable = 0; best_key = 0; first_paired = ~0ull;
 		kernel_ms = 0; stage_ms = 0; launches = 0;
 	}
+	// the scan of a tile inside K2's chain walk (index_tile); sgn = -1 takes the tile's contributions back
+	void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int64_t scan_limit) override
+	{
+		sp.scan_limit = scan_limit; sp.infl = infl; sp.total = total; sp.recoff = nullptr; sp.n_rec = 0; sp.ord_base = 0;
+		sp.long_list = h->d_long.p; sp.long_cap = (int64_t)h->d_long.n; sp.entry_base = nullptr; sp.sgn = sgn; sp.tile_slots = 1;
+		if (sgn > 0)
+		{
+			unsigned long long* s = h->p_small.p + 40; s[0] = 0; s[1] = ~0ull;
+			HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
+			HIPCHK(hipMemcpyAsync(d_counters.p + A_TILE_KEY, s, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));   // A_TILE_KEY, A_TILE_PAIRED
+		}
+		if (!ftk) ftk.reset(new Timer(h->stream));
+		ftk->start();
+		launch_walk_scan(sp, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
+		ftk->mark(); launches++;
+		sp.sgn = 1; sp.scan_limit = INT64_MAX;
+	}
+	unsigned long long* fused_long_count() override { return d_counters.p + A_LONG_COUNT; }
+	double fused_elapsed_ms() override { fused_ms = ftk ? ftk->elapsed() : 0; return fused_ms; }
+	std::unique_ptr<Timer> ftk; double fused_ms = 0;
+
 	void tile(ngsqc_handle* h, const TileCtx& c)
 	{
+		const bool fused = h->fuse == this && h->fused_tile == c.tile;   // K2's chain walk has scanned the tile's records already
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));
 		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
-		sp.long_list = h->d_long.p; sp.long_cap = c.n_rec;
+		sp.long_list = h->d_long.p; sp.long_cap = fused ? (int64_t)h->d_long.n : c.n_rec; sp.sgn = 1;
+		sp.entry_base = fused ? h->d_base.p : nullptr; sp.tile_slots = fused ? 1 : 0;
 		Timer t(h->stream); t.start();
-		// per-tile slots: long-record count, (longest read, first ordinal) key
-		HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
-		HIPCHK(hipMemsetAsync(d_counters.p + A_FIRST_MAX_KEY, 0, sizeof(unsigned long long), h->stream));
-		Timer tk(h->stream); tk.start();
-		launch_scan(sp, h->stream);
-		kernel_ms += tk.stop(); launches++;
+		Timer tk(h->stream);
+		if (!fused)
+		{
+			// per-tile slots: long-record count, (longest read, first ordinal) key
+			HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
+			HIPCHK(hipMemsetAsync(d_counters.p + A_FIRST_MAX_KEY, 0, sizeof(unsigned long long), h->stream));
+			tk.start();
+			launch_scan(sp, h->stream);
+			kernel_ms += tk.stop(); launches++;
+		}
+		else { kernel_ms += fused_ms; stage_ms += fused_ms; }   // (the walk + scan kernel of index_tile: booked here, not under K2)
 		unsigned long long* s = h->p_small.p;
 		auto readback = [&]() {
 			HIPCHK(hipMemcpyAsync(s + 0, d_counters.p + A_LONG_COUNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 1, d_counters.p + A_FIRST_MAX_KEY, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 2, d_counters.p + A_FIRST_PAIRED, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 1, d_counters.p + (fused ? A_TILE_KEY : A_FIRST_MAX_KEY), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(s + 2, d_counters.p + (fused ? A_TILE_PAIRED : A_FIRST_PAIRED), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipMemcpyAsync(s + 3, d_counters.p + A_TOTAL, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipMemcpyAsync(s + 4, d_counters.p + A_USABLE, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipStreamSynchronize(h->stream));
 		};
 		readback();
 		if (s[0]) { tk.start(); launch_scan_long(sp, (int64_t)s[0], h->stream); kernel_ms += tk.stop(); launches++; readback(); }
+		if (fused)
+		{
+			// (entry, k) names -> ordinals in the file: index in the tile = first record of the entry (the scanned counts) + k
+			auto ordinal = [&](unsigned long long name) -> unsigned long long {
+				int64_t b0 = 0;
+				HIPCHK(hipMemcpyAsync(&b0, h->d_base.p + (name >> 20), sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+				return (unsigned long long)(c.ord_base + b0 + (int64_t)(name & 0xfffffull));
+			};
+			if (s[1]) s[1] = (s[1] & ~0xFFFFFFFFFFull) | (0xFFFFFFFFFFull - ordinal(0xFFFFFFFFFFull - (s[1] & 0xFFFFFFFFFFull)));
+			if (s[2] != ~0ull) s[2] = ordinal(s[2]);
+		}
 		const unsigned long long key = s[1], fp = s[2], total = s[3], usable = s[4];
 		if (key > best_key) best_key = key;   // keys order by (length, earlier ordinal): the maximum over tiles is the BAM's first longest read
 		if (fp < first_paired) first_paired = fp;
@@ -880,6 +953,14 @@ struct ScanState
 		HIPCHK(hipMemcpyAsync(dev.data(), d_counters.p, dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
+};
+
+// the job's first scan consumer rides K2's chain walk while the tiles stream
+struct FuseGuard
+{
+	ngsqc_handle* h;
+	FuseGuard(ngsqc_handle* hh, ScanState* sc) : h(hh) { h->fuse = sc; h->fused_tile = -1; h->fuse_ok = true; }
+	~FuseGuard() { h->fuse = nullptr; h->fused_tile = -1; }
 };
 
 void bind_regions(ScanParams& sp, DepthSet& D)
@@ -1176,6 +1257,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r)
 	if (do_sites) pile.begin(h, j->sites, j->n_sites, j->site_min_mapq, j->site_min_baseq, j->site_include_npp);
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
 	const double w1 = wall_ms();
+	FuseGuard fg(h, do_map ? &map.scan : (do_depth ? &dscan : nullptr));
 	stream_tiles(h, [&](const TileCtx& c) {
 		if (do_map) map.scan.tile(h, c);
 		if (do_depth) dscan.tile(h, c);
@@ -1307,7 +1389,7 @@ int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, n
 		ngsqc_handle::Partial& st = *h->partial;
 		mapping_setup(h, p, st);
 		st.scan.in_pass_fix = false; st.scan.begin(h);
-		stream_tiles(h, [&](const TileCtx& c) { st.scan.tile(h, c); return true; });
+		{ FuseGuard fg(h, &st.scan); stream_tiles(h, [&](const TileCtx& c) { st.scan.tile(h, c); return true; }); }
 		st.scan.end(h);
 		h->cur_ds = 0;
 		const unsigned long long key = st.scan.best_key;
@@ -1497,7 +1579,7 @@ void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 	ScanState sc; sc.in_pass_fix = false;
 	depth_setup(h, p, h->ds[0], sc);
 	sc.begin(h);
-	stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; });
+	{ FuseGuard fg(h, &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
 	sc.end(h);
 	h->cur_ds = 0;
 	h->tm.scan_ms = sc.stage_ms; h->tm.scan_kernel_ms = sc.kernel_ms; h->tm.scan_launches = sc.launches; h->tm.scan_algorithmic_bytes = (int64_t)sc.dev[A_ALG_BYTES];
@@ -1525,7 +1607,7 @@ int ngsqc_region_read_counts(ngsqc_handle* h, const ngsqc_region* regions, int64
 		HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)n_regions * sizeof(unsigned long long), h->stream));
 		sp.region_reads = d_cnt.p;
 		sc.begin(h);
-		stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; });
+		{ FuseGuard fg(h, &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
 		HIPCHK(hipMemcpyAsync(counts, d_cnt.p, (size_t)n_regions * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		h->cur_ds = keep;

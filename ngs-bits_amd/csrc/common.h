@@ -46,7 +46,9 @@ constexpr int MODE_COUNT = 4;   // BedReadCount: reads per target region (src/Be
 enum { A_TOTAL, A_MAPPED, A_ONTARGET, A_NEAR, A_DUP, A_PP, A_INS_CNT, A_SUM_LEN, A_BASES_MAPPED, A_CLIPPED, A_INS_SUM,
        A_USABLE, A_NO_OVERLAP, A_USABLE_RAW, A_USABLE_ROI, A_DP0, A_DP1, A_DP2, A_DP3, A_DP4, A_DD0, A_DD1, A_DD2, A_DD3,
        A_READS_X, A_READS_Y, A_ALG_BYTES, A_COUNT,
-       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT, A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
+       A_MAX_LEN = A_COUNT, A_FIRST_MAX_KEY, A_FIRST_PAIRED, A_LONG_COUNT, A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT,
+       A_TILE_KEY, A_TILE_PAIRED,   // the fused walk + scan: (longest read, first record) and first paired record of the tile, in (entry, k) form
+       A_HIST0, A_DEV_TOTAL = A_HIST0 + 1000 };
 
 struct ScanParams
 {
@@ -72,9 +74,15 @@ struct ScanParams
 	unsigned long long* gc_tab;    // [101][GC_NMAX]
 	double* gc_over;               // [101]
 	int64_t* long_list; int64_t long_cap;
+	// the scan fused into K2's chain walk (launch_walk_scan): records are named (entry << 20 | k) until the counts are scanned (entry_base != null: the
+	// long list holds such names); sgn = -1 takes a tile's contributions back (a tile that turned out not to be laid out like an htslib file)
+	const int64_t* entry_base = nullptr; int32_t sgn = 1; int32_t tile_slots = 0; int64_t scan_limit = INT64_MAX;   // scan_limit: (a shard) records that start at or behind this tile-local offset are walked, not scanned
 };
 
 void launch_scan(const ScanParams& p, hipStream_t s);
+// K2's chain walk (what launch_index_count does) with the scan of every record the walk passes: one read of a record's first line instead of two
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, hipStream_t s);
 
@@ -103,6 +111,25 @@ void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot,
                       int32_t cutoff, int32_t is_high, int32_t sat, uint32_t* d_cnt, const int64_t* d_base, ngsqc_run* d_runs, hipStream_t s);
 
 } // namespace ngsqc
+
+#ifdef __HIPCC__
+namespace ngsqc {
+// Entries of a tile: entry 0 is the pseudo member that covers the bytes carried over from the previous tile ([0, prefix)),
+// entry e >= 1 is member e - 1 of the tile's (static) descriptor table, whose upos is relative to the tile's first member.
+__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int64_t& lo, int64_t& hi)
+{
+	if (e == 0) { lo = 0; hi = prefix; }
+	else { const BlockDesc bd = blocks[e - 1]; lo = prefix + (int64_t)bd.upos; hi = lo + bd.usize; }
+}
+// what htslib's bam_read1 checks before it accepts a record (the reference then throws "Could not read next alignment",
+// src/cppNGS/BamReader.h:389-392): the variable-length fields must fit the record. Kernels behind K2 trust these fields.
+__device__ __forceinline__ bool record_fields_fit(uint32_t l_name, uint32_t n_cigar, int32_t l_seq, uint32_t bs)
+{
+	if (l_seq < 0 || l_name == 0) return false;
+	return 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq <= (uint64_t)bs;
+}
+}
+#endif
 
 // after every kernel launch: a rejected launch (bad grid, too much LDS) must not pass as an empty result
 #define KCHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) { throw std::runtime_error(std::string("HIP kernel launch failed: ") + hipGetErrorString(_e)); } } while (0)

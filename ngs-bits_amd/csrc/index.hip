@@ -14,22 +14,11 @@ namespace ngsqc {
 
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-// Entries of a tile: entry 0 is the pseudo member that covers the bytes carried over from the previous tile ([0, prefix)),
-// entry e >= 1 is member e - 1 of the tile's (static) descriptor table, whose upos is relative to the tile's first member.
-__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int64_t& lo, int64_t& hi)
-{
-	if (e == 0) { lo = 0; hi = prefix; }
-	else { const BlockDesc bd = blocks[e - 1]; lo = prefix + (int64_t)bd.upos; hi = lo + bd.usize; }
-}
-
-// what htslib's bam_read1 checks before it accepts a record (the reference then throws "Could not read next alignment",
-// src/cppNGS/BamReader.h:389-392): the variable-length fields must fit the record. Kernels behind K2 trust these fields.
+// (entry_range and record_fields_fit: common.h, shared with the scan that rides the chain walk)
 __device__ __forceinline__ bool record_fields_fit(const uint8_t* r, uint32_t bs)
 {
-	const uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16); const int32_t l_seq = (int32_t)ld32u(r + 20);
-	const uint32_t l_name = w & 0xff, n_cigar = w2 & 0xffff;
-	if (l_seq < 0 || l_name == 0) return false;
-	return 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq <= (uint64_t)bs;
+	const uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16);
+	return record_fields_fit(w & 0xff, w2 & 0xffff, (int32_t)ld32u(r + 20), bs);
 }
 
 // cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
@@ -248,13 +237,18 @@ void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	{
-		// resolve the guesses wave-cooperatively first (the count kernel keeps its scalar guess loop only as a fallback)
-		const int64_t wg = (n + 3) / 4;
-		hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref); KCHECK();
-	}
+	launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref, s);   // (the count kernel keeps its scalar guess loop only as a fallback)
 	int grid = (int)((n + 63) / 64);
 	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
+}
+
+// resolve the guessed first-record offsets (start == -2) wave-cooperatively
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s)
+{
+	const int64_t n = n_entries - from;
+	if (n <= 0) return;
+	const int64_t wg = (n + 3) / 4;
+	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref); KCHECK();
 }
 
 void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)

@@ -95,7 +95,7 @@ __device__ __forceinline__ int lower_region(const int32_t* __restrict__ reg_end,
 __device__ __forceinline__ void diff_add(const ScanParams& p, int reg, int a, int b) // +1 on [a,b] of region reg
 {
 	int32_t* d = p.diff + p.reg_doff[reg] - p.reg_start[reg];
-	atomicAdd(d + a, 1); atomicAdd(d + b + 1, -1);
+	atomicAdd(d + a, p.sgn); atomicAdd(d + b + 1, -p.sgn);
 }
 
 __device__ static void gc_hit(const ScanParams& p, int tid, int s, int e)
@@ -111,8 +111,8 @@ __device__ static void gc_hit(const ScanParams& p, int tid, int s, int e)
 	{
 		int bin = p.gc_bin[i];
 		if (bin < 0) continue;
-		if (n < GC_NMAX) atomicAdd(&p.gc_tab[(size_t)bin * GC_NMAX + n], 1ull);
-		else atomicAdd(&p.gc_over[bin], 1.0 / (double)n);
+		if (n < GC_NMAX) atomicAdd(&p.gc_tab[(size_t)bin * GC_NMAX + n], (unsigned long long)(long long)p.sgn);
+		else atomicAdd(&p.gc_over[bin], (double)p.sgn / (double)n);
 	}
 }
 
@@ -132,7 +132,7 @@ __device__ static void baseq_decrements(const ScanParams& p, const RecView& r, i
 				if (q[ai + j] < p.min_baseq)
 				{
 					int pos1 = start1 + gi + (int)j;
-					for (int i = i0; i < i1; ++i) if (pos1 >= p.reg_start[i] && pos1 <= p.reg_end[i]) { int32_t* d = p.diff + p.reg_doff[i] - p.reg_start[i]; atomicAdd(d + pos1, -1); atomicAdd(d + pos1 + 1, 1); }
+					for (int i = i0; i < i1; ++i) if (pos1 >= p.reg_start[i] && pos1 <= p.reg_end[i]) { int32_t* d = p.diff + p.reg_doff[i] - p.reg_start[i]; atomicAdd(d + pos1, -p.sgn); atomicAdd(d + pos1 + 1, p.sgn); }
 				}
 			}
 			ai += len; gi += (int)len;
@@ -161,7 +161,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		if (unmapped || secondary || supp || (int)r.mapq < p.min_mapq || !tid_ok) return;
 		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
 		if (first >= last) return;
-		for (int i = lower_region(p.reg_end, first, last, start1); i < last && p.reg_start[i] <= end1; ++i) atomicAdd(&p.region_reads[i], 1ull);
+		for (int i = lower_region(p.reg_end, first, last, start1); i < last && p.reg_start[i] <= end1; ++i) atomicAdd(&p.region_reads[i], (unsigned long long)(long long)p.sgn);
 		return;
 	}
 	if (MODE == 3)
@@ -300,7 +300,7 @@ __device__ __forceinline__ long long wave_sum(long long v)
 __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 {
 	const int lane = threadIdx.x & 63;
-	for (int i = 0; i < A_COUNT; ++i) { long long s = wave_sum(a.v[i]); if (lane == 0 && s) atomicAdd(&p.counters[i], (unsigned long long)s); }
+	for (int i = 0; i < A_COUNT; ++i) { long long s = wave_sum(a.v[i]); if (lane == 0 && s) atomicAdd(&p.counters[i], (unsigned long long)(p.sgn * s)); }
 	int m = a.max_len; unsigned long long bk = a.best_key, fp = a.first_paired;
 	for (int o = 32; o > 0; o >>= 1)
 	{
@@ -308,14 +308,37 @@ __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 		unsigned long long t = __shfl_xor(bk, o); if (t > bk) bk = t;
 		t = __shfl_xor(fp, o); if (t < fp) fp = t;
 	}
-	if (lane == 0)
+	if (lane == 0 && p.sgn > 0)
 	{
 		if (m > 0) atomicMax(&p.counters[A_MAX_LEN], (unsigned long long)m);
-		if (bk) atomicMax(&p.counters[A_FIRST_MAX_KEY], bk);
-		if (fp != ~0ull) atomicMin(&p.counters[A_FIRST_PAIRED], fp);
+		if (bk) atomicMax(&p.counters[p.tile_slots ? A_TILE_KEY : A_FIRST_MAX_KEY], bk);
+		if (fp != ~0ull) atomicMin(&p.counters[p.tile_slots ? A_TILE_PAIRED : A_FIRST_PAIRED], fp);
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < 1000; i += blockDim.x) if (lds_hist[i]) atomicAdd(&p.counters[A_HIST0 + i], (unsigned long long)lds_hist[i]);
+	for (int i = threadIdx.x; i < 1000; i += blockDim.x) if (lds_hist[i]) atomicAdd(&p.counters[A_HIST0 + i], (unsigned long long)(p.sgn * (long long)lds_hist[i]));
+}
+
+// CIGAR sums of a short record + classify; false: the record goes to the wave-per-record kernel (long CIGAR, possible CG:B,I tag)
+template <int MODE>
+__device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist)
+{
+	bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
+	if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
+	{
+		uint32_t c0 = ld32(r.cigar);
+		if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq) defer = true; // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
+	}
+	if (defer) return false;
+	long long ref_len = 0, clip = 0; bool spliced = false;
+	for (uint32_t k = 0; k < r.n_cigar; ++k)
+	{
+		uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
+		if ((0x18Du >> op) & 1u) ref_len += len;            // M,D,N,=,X  (bits 0,2,3,7,8)
+		else if (op == 4 || op == 5) clip += len;
+		if (op == 3) spliced = true;
+	}
+	classify<MODE>(p, r, ord, ref_len, clip, spliced && !(r.flag & 0x4u), a, lds_hist);
+	return true;
 }
 
 template <int MODE>
@@ -330,27 +353,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
 	{
 		const long long ord = p.ord_base + li;   // ordinal in the file; li = index inside the resident tile
 		RecView r = load_rec(p.infl, p.recoff[li]);
-		bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
-		if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
-		{
-			uint32_t c0 = ld32(r.cigar);
-			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq) defer = true; // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
-		}
-		if (defer)
+		if (!scan_record<MODE>(p, r, ord, a, lds_hist))
 		{
 			unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
 			if ((long long)k < p.long_cap) p.long_list[k] = li;
-			continue;
 		}
-		long long ref_len = 0, clip = 0; bool spliced = false;
-		for (uint32_t k = 0; k < r.n_cigar; ++k)
-		{
-			uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
-			if ((0x18Du >> op) & 1u) ref_len += len;            // M,D,N,=,X  (bits 0,2,3,7,8)
-			else if (op == 4 || op == 5) clip += len;
-			if (op == 3) spliced = true;
-		}
-		classify<MODE>(p, r, ord, ref_len, clip, spliced && !(r.flag & 0x4u), a, lds_hist);
 	}
 	flush(p, a, lds_hist);
 }
@@ -368,7 +375,9 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 	const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
 	for (long long w = wave; w < n_long; w += n_waves)
 	{
-		const long long li = p.long_list[w]; const long long ord = p.ord_base + li;
+		long long li = p.long_list[w]; long long ord;
+		if (p.entry_base) { ord = li; li = p.entry_base[li >> 20] + (li & 0xfffff); }   // a tile scanned by the chain walk: records are compared by their (entry, k) names
+		else ord = p.ord_base + li;
 		RecView r = load_rec(p.infl, p.recoff[li]);
 		// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries
 		if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
@@ -445,6 +454,75 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 		}
 	}
 	flush(p, a, lds_hist);
+}
+
+// ---- the scan fused into K2's chain walk ----
+// What index_count_kernel does (one thread per entry walks the entry's record chain, validates every record like bam_read1, keeps the member-relative
+// offsets) - and every record the walk passes is scanned right there: the walk has the record's first line in its hands, the separate scan kernel would
+// fetch it a second time (a third of the inflated tile per pass). A record is named (entry << 20 | k) until the counts are scanned; the order-dependent
+// results (first longest read, first paired read) are kept per tile in that form (A_TILE_KEY / A_TILE_PAIRED), the host turns them into ordinals.
+// Only for tiles laid out like an htslib file (a record starts every member): the launch happens before that is known, sgn = -1 takes it back.
+template <int MODE>
+__global__ __launch_bounds__(64) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix,
+                                                        const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
+                                                        uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
+{
+	__shared__ uint32_t lds_hist[1000];
+	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
+	__syncthreads();
+	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < n_entries)
+	{
+		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+		const int32_t s = start[b];   // (the guess kernel ran: >= 0 or -1)
+		if (s < 0) { cnt[b] = 0; next_abs[b] = -1; }
+		else
+		{
+			// the next record's block_size is requested before this record is processed: its line arrives while the scan works
+			int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
+			uint32_t bs = o < hi && o + 4 <= p.total ? ld32(p.infl + o) : 0u;
+			while (o < hi)
+			{
+				if (o + 4 > p.total) { res = -(o + 10); stop = true; break; }
+				if (bs < 32) { res = -2; stop = true; break; }
+				if (o + 4 + (int64_t)bs > p.total) { res = -(o + 10); stop = true; break; }
+				const int64_t o_next = o + 4 + (int64_t)bs;
+				RecView r = load_rec(p.infl, o);
+				const uint32_t bs_next = o_next < hi && o_next + 4 <= p.total ? ld32(p.infl + o_next) : 0u;
+				if (!record_fields_fit(r.l_name, r.n_cigar_raw, r.l_seq, r.bs)) { res = -2; stop = true; break; }
+				if (n < (uint32_t)K2_REL_STRIDE) rel[b * K2_REL_STRIDE + n] = (uint16_t)(o - lo);
+				if (o < p.scan_limit)
+				{
+					const long long name = (long long)((b << 20) | (int64_t)n);
+					if (!scan_record<MODE>(p, r, name, a, lds_hist) && p.sgn > 0)
+					{
+						unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
+						if ((long long)k < p.long_cap) p.long_list[k] = name;
+					}
+				}
+				++n; o = o_next; bs = bs_next;
+			}
+			cnt[b] = n; next_abs[b] = stop ? res : o;
+			if (stop && res == -2) atomicAdd(bad, 1u);
+		}
+	}
+	flush(p, a, lds_hist);
+}
+
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
+{
+	if (n_entries <= 0) return;
+	const int grid = (int)((n_entries + 63) / 64);
+	switch (p.mode)
+	{
+		case NGSQC_MODE_ROI: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_WGS: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case MODE_COUNT: hipLaunchKernelGGL(walk_scan_kernel<MODE_COUNT>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		default: hipLaunchKernelGGL(walk_scan_kernel<3>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+	}
+	KCHECK();
 }
 
 // ---- order-dependent fix-ups on a record prefix ----
