@@ -44,6 +44,10 @@ int  ngsqc_open(const char* bam_path, int device, ngsqc_handle** out);
 /* Same, from a BAM image already in host memory (bytes are copied to HBM; caller keeps ownership). */
 int  ngsqc_open_memory(const void* bam_bytes, size_t n_bytes, int device, ngsqc_handle** out);
 void ngsqc_close(ngsqc_handle* h);
+/* ngsqc_open copies the compressed image to the device in the background (pieces in file order; the first job starts on the pieces that have
+ * arrived - what the reference overlaps with htslib's reader thread, BamReader.cpp:472). This call returns when the whole image is on the device;
+ * ngsqc_timings.h2d_ms is final behind it. NGSQC_ASYNC_H2D=0: ngsqc_open itself waits (ngsqc_open_memory always does: the caller owns the buffer). */
+int  ngsqc_upload_wait(ngsqc_handle* h);
 /* Message of the last failing call on h (or of the last failing ngsqc_open* when h is NULL). */
 const char* ngsqc_last_error(const ngsqc_handle* h);
 

@@ -157,7 +157,7 @@ EXPORTS = [
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
-    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts",
+    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait",
 ]
 
 
@@ -424,6 +424,11 @@ class Handle:
         if as_array:   # (bench: no per-run Python objects)
             return runs
         return [(runs[i].line, runs[i].start, runs[i].end) for i in range(n.value)]
+
+    def upload_wait(self):
+        """The compressed image is on the device (a path is copied in the background); timings()['h2d_ms'] is final behind this call."""
+        L = lib(); L.ngsqc_upload_wait.restype = C.c_int; L.ngsqc_upload_wait.argtypes = [C.c_void_p]
+        self._chk(L.ngsqc_upload_wait(self.h))
 
     def timings(self):
         t = Timings()

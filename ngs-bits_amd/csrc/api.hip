@@ -13,6 +13,8 @@
 // There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails with NGSQC_E_DEVICE.
 #include "common.h"
 #include <memory>
+#include <condition_variable>
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 #include <chrono>
@@ -137,6 +139,17 @@ struct ngsqc_handle
 	int64_t shard_u_base = 0;              // inflated offset (whole file) of the handle's first member
 	int64_t shard_first_abs = -1, shard_exit_abs = -1; int shard_last_tile = -1;
 	bool verify_crc = true;
+	// H2D of the compressed image in the background (ngsqc_open of a path): host threads copy pieces in file order, every piece has an event that
+	// the K1 chunk stream waits for; the mapping of the file lives until the last piece is on the device
+	struct Upload
+	{
+		std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+		std::vector<hipEvent_t> ev; std::vector<char> recorded; size_t piece = 0, n_pieces = 0, bytes = 0; std::atomic<size_t> next{0}; std::atomic<bool> cancel{false};
+		std::string err; void* map = nullptr; size_t map_n = 0; int fd = -1; double t0 = 0, t_done = 0; size_t done = 0;
+		size_t waited[4] = {0, 0, 0, 0};   // pieces [0, waited[k]) have been waited for by stream slot k (main, s_p1[0], s_p1[1], s_p2)
+	};
+	Upload* up = nullptr;
+	std::thread plan_thread; std::string plan_err;   // plan_layout in the background of ngsqc_open (device buffers of the tile stream: allocation overlaps the H2D)
 	// the scan that rides K2's chain walk (launch_walk_scan): set by the job for its first scan consumer; fuse_ok turns false when a tile is not laid out like an
 	// htslib file (the general K2 path takes over); fused_tile = the tile whose records that scan has already seen
 	struct FusedScan   // what K2 needs of such a scan (ScanState)
@@ -206,6 +219,8 @@ std::string inflate_error(const ngsqc_handle* h, int64_t member, uint32_t code)
 	return "Could not read next alignment in BAM/CRAM file " + h->path + " (BGZF inflate failed in block " + std::to_string(member) + ", code " + std::to_string(code) + ")";
 }
 
+void upload_wait(ngsqc_handle* h, size_t end_byte, hipStream_t st, int slot);   // (H2D in the background, below)
+
 // Synchronous K1 of a few members on the main stream with private scratch (header read, second chance of members that found the token
 // pool of their launch used up). idx: member indices into h->blocks; desc/out: where each one goes. The pool is sized for the worst
 // case (two token slots per output byte), so the call is made in batches of bounded scratch; the scratch is kept across calls.
@@ -219,6 +234,7 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 		uint64_t sc = 0, su = 0;
 		for (int64_t i = 0; i < n; ++i) { crc[(size_t)i] = h->crc[(size_t)idx[(size_t)(b0 + i)]]; sc += dd[(size_t)i].clen; su += dd[(size_t)i].usize; }
 		const uint64_t pages = k1_pool_pages(sc, su, (uint64_t)n, true);
+		{ uint64_t cend = 0; for (const BlockDesc& d : dd) cend = std::max<uint64_t>(cend, d.cpos + d.clen + 64); upload_wait(h, (size_t)cend, h->stream, 0); }
 		h->d_sync_desc.ensure_slack((size_t)n); h->d_sync_st.ensure_slack((size_t)n); h->d_sync_work.ensure(2);
 		h->d_sync_u32.ensure_slack((size_t)(3 * n + 16));   // [first | count | crc]
 		h->d_sync_pool.ensure_slack((size_t)pages * K1_PAGE_WORDS + 16);
@@ -323,20 +339,107 @@ void upload_compressed(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t
 	HIPCHK(hipStreamSynchronize(h->stream));
 }
 
+// ---- H2D in the background: pieces of the compressed image in file order, one event per piece ----
+// T host threads (NGSQC_H2D_THREADS, default 4) each copy whole pieces with hipMemcpyAsync on their own stream; the source is the mapping of the file
+// (pageable: the runtime stages it, a call returns when its piece is staged), so T pieces are in flight and the first K1 chunk starts as soon as its
+// pieces have arrived instead of behind the whole image.
+void upload_join(ngsqc_handle* h)
+{
+	ngsqc_handle::Upload* u = h->up;
+	if (!u) return;
+	u->cancel = true;
+	for (auto& t : u->th) if (t.joinable()) t.join();
+	u->th.clear();
+	for (hipEvent_t e : u->ev) if (e) (void)hipEventDestroy(e);
+	u->ev.clear();
+	if (u->map) { munmap(u->map, u->map_n); u->map = nullptr; }
+	if (u->fd >= 0) { ::close(u->fd); u->fd = -1; }
+}
+void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
+{
+	ngsqc_handle::Upload* u = h->up;
+	const size_t n = end - beg;
+	h->d_comp.alloc(n + 1024);
+	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	u->piece = 64u << 20; if (const char* e = getenv("NGSQC_H2D_PIECE_MB")) u->piece = (size_t)std::max(1, atoi(e)) << 20;
+	u->bytes = n; u->n_pieces = (n + u->piece - 1) / u->piece; u->next = 0; u->done = 0; u->cancel = false; u->t0 = wall_ms(); u->t_done = u->t0;
+	u->recorded.assign(u->n_pieces, 0); u->ev.assign(u->n_pieces, nullptr);
+	for (auto& e : u->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	int T = 4; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
+	T = (int)std::min<size_t>((size_t)T, std::max<size_t>(u->n_pieces, 1));
+	uint8_t* const dst = h->d_comp.p; const uint8_t* const src = bytes + beg; const int device = h->device;
+	for (int t = 0; t < T && u->n_pieces; ++t)
+		u->th.emplace_back([u, dst, src, device] {
+			hipStream_t st = nullptr;
+			try
+			{
+				HIPCHK(hipSetDevice(device));
+				HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+				for (;;)
+				{
+					const size_t i = u->next.fetch_add(1);
+					if (i >= u->n_pieces || u->cancel) break;
+					const size_t off = i * u->piece, sz = std::min(u->piece, u->bytes - off);
+					HIPCHK(hipMemcpyAsync(dst + off, src + off, sz, hipMemcpyHostToDevice, st));
+					HIPCHK(hipEventRecord(u->ev[i], st));
+					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
+					u->cv.notify_all();
+				}
+				HIPCHK(hipStreamSynchronize(st));
+			}
+			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); u->cv.notify_all(); }
+			if (st) (void)hipStreamDestroy(st);
+			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
+			u->cv.notify_all();
+		});
+}
+// stream st (slot: 0 main, 1 / 2 the phase-1 streams) may read the compressed bytes [0, end_byte) behind this call
+void upload_wait(ngsqc_handle* h, size_t end_byte, hipStream_t st, int slot)
+{
+	ngsqc_handle::Upload* u = h->up;
+	if (!u || !u->n_pieces) return;
+	const size_t p1 = std::min(u->n_pieces, (std::min(end_byte, u->bytes) + u->piece - 1) / u->piece);
+	for (size_t p = u->waited[slot]; p < p1; ++p)
+	{
+		{
+			std::unique_lock<std::mutex> lk(u->mu);
+			u->cv.wait(lk, [&] { return u->recorded[p] || !u->err.empty(); });
+			if (!u->err.empty()) throw std::runtime_error("H2D of the compressed image failed: " + u->err);
+		}
+		HIPCHK(hipStreamWaitEvent(st, u->ev[p], 0));
+	}
+	if (p1 > u->waited[slot]) u->waited[slot] = p1;
+}
+// the whole image is on the device (ngsqc_upload_wait / timings)
+void upload_finish(ngsqc_handle* h)
+{
+	ngsqc_handle::Upload* u = h->up;
+	if (!u) return;
+	{ std::unique_lock<std::mutex> lk(u->mu); u->cv.wait(lk, [&] { return u->done == u->th.size() || !u->err.empty(); }); if (!u->err.empty()) throw std::runtime_error("H2D of the compressed image failed: " + u->err); }
+	h->tm.h2d_ms = u->t_done - u->t0;
+}
+
 constexpr int64_t SHARD_TAIL_MEMBERS = 64;   // members behind a shard that are inflated to complete its last record (NGSQC_SHARD_TAIL_MEMBERS)
 
 void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, int shard, int n_shards)
 {
 	if (n_shards < 1 || shard < 0 || shard >= n_shards) throw ArgError("invalid shard index");
 	h->csize = n;
-	scan_bgzf(bytes, n, h->blocks, h->crc, h->total);
-	init_device(h, device);
+	if (h->up)
+	{
+		// a path: the copy starts before anything else looks at the file (the BGZF member walk below runs beside it; the header read waits for the first pieces only)
+		if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+		init_device(h, device);
+		upload_start(h, bytes, 0, n);
+		scan_bgzf(bytes, n, h->blocks, h->crc, h->total);
+	}
+	else { scan_bgzf(bytes, n, h->blocks, h->crc, h->total); init_device(h, device); }
 	Timer t(h->stream); t.start();
 	h->shard = shard; h->n_shards = n_shards;
 	if (n_shards == 1)
 	{
-		upload_compressed(h, bytes, 0, n);
-		h->tm.h2d_ms = t.stop();
+		if (!h->up) { upload_compressed(h, bytes, 0, n); h->tm.h2d_ms = t.stop(); }
 		h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
 		read_header(h, (int64_t)h->blocks.size());
 		return;
@@ -387,9 +490,10 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 // ---- layout of the tile stream: K1 chunks, tiles (whole chunks), token ring, static device tables -------------------------
 // NGSQC_TILE_MEMBERS=k (tests): chunks and tiles of k members. NGSQC_TILE_CHUNKS: chunks per tile (default 2).
 // NGSQC_K1_CHUNK_DIV: chunk = one decoder round / div. NGSQC_CARRY_MAX: bytes reserved in front of a tile for a straddling record.
-void plan_layout(ngsqc_handle* h)
+void plan_layout_now(ngsqc_handle* h)
 {
 	if (h->planned) return;
+	const double pl0 = wall_ms();
 	const int64_t nb = (int64_t)h->blocks.size();
 	h->planned = true;
 	if (nb == 0) return;
@@ -468,6 +572,17 @@ void plan_layout(ngsqc_handle* h)
 	h->p_small.ensure(64);
 	HIPCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
 	h->tm.n_tiles = nt;
+	if (getenv("NGSQC_DEBUG")) fprintf(stderr, "[ngsqc] layout: %d tiles, %lld chunks, token pool %.1f GB, tile buffers %.1f GB, %.1f ms\n", nt, (long long)h->nch, (double)n_slots * (double)h->slot_pages * K1_PAGE_WORDS * 4e-9, (double)std::min(nt, h->nbuf) * (double)(h->pfx + h->max_tile_bytes) * 1e-9, wall_ms() - pl0);
+}
+
+void plan_layout(ngsqc_handle* h)
+{
+	if (h->plan_thread.joinable())
+	{
+		h->plan_thread.join();
+		if (!h->plan_err.empty()) { const std::string e = h->plan_err; h->plan_err.clear(); throw std::runtime_error(e); }
+	}
+	plan_layout_now(h);
 }
 
 // Enqueue K1 of tile t: its chunks continue the file-wide chunk stream (nothing here waits on the host).
@@ -488,6 +603,7 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
+		if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
 		HIPCHK(hipEventRecord(e4[0], s1));
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, pool, (uint32_t)h->slot_pages, h->d_pool_ctr.p + c, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_work.p + c,
@@ -1118,13 +1234,24 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		}
 		else h->path = "<memory>";
 		if (!bytes && n) throw ArgError("null BAM buffer");
+		const char* ea = getenv("NGSQC_ASYNC_H2D");
+		if (path && n_shards == 1 && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
 		open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
+		if (h->up) { h->up->map = map; h->up->map_n = map_n; h->up->fd = fd; map = nullptr; fd = -1; }   // the mapping lives until the last piece is copied
+		const char* ep = getenv("NGSQC_ASYNC_PLAN");
+		if (h->up && (!ep || atoi(ep) != 0))
+			h->plan_thread = std::thread([h] {
+				try { HIPCHK(hipSetDevice(h->device)); plan_layout_now(h); }
+				catch (std::exception& e) { h->plan_err = e.what(); h->planned = false; }
+			});
 	}
 	catch (FormatError& e) { g_open_error = e.what(); rc = NGSQC_E_FORMAT; }
 	catch (ArgError& e) { g_open_error = e.what(); rc = NGSQC_E_ARG; }
 	catch (IoError& e) { g_open_error = e.what(); rc = NGSQC_E_IO; }
 	catch (std::domain_error& e) { g_open_error = e.what(); rc = NGSQC_E_UNSUPPORTED; }
 	catch (std::exception& e) { g_open_error = e.what(); rc = NGSQC_E_DEVICE; }
+	if (h->plan_thread.joinable() && rc != NGSQC_OK) h->plan_thread.join();
+	if (rc != NGSQC_OK && h->up) upload_join(h);   // (the copier threads read the mapping)
 	if (map) munmap(map, map_n);
 	if (fd >= 0) ::close(fd);
 	if (rc != NGSQC_OK) { ngsqc_close(h); return rc; }
@@ -1307,6 +1434,8 @@ int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, i
 void ngsqc_close(ngsqc_handle* h)
 {
 	if (!h) return;
+	if (h->plan_thread.joinable()) h->plan_thread.join();
+	if (h->up) { upload_join(h); delete h->up; h->up = nullptr; }
 	if (h->stream) { (void)hipSetDevice(h->device); sync_all(h); }
 	for (hipStream_t s : {h->stream, h->s_p1[0], h->s_p1[1], h->s_p2, h->s_crc}) if (s) (void)hipStreamDestroy(s);
 	for (hipEvent_t e : h->ev_chunk) (void)hipEventDestroy(e);
@@ -1314,6 +1443,9 @@ void ngsqc_close(ngsqc_handle* h)
 	delete h->partial;
 	delete h;
 }
+
+// the compressed image is on the device (a path is copied in the background while the first job already runs); h2d_ms of the timings is final behind this call
+int ngsqc_upload_wait(ngsqc_handle* h) { return guarded(h, [&] { upload_finish(h); }); }
 
 const char* ngsqc_last_error(const ngsqc_handle* h) { return h ? h->err.c_str() : g_open_error.c_str(); }
 int ngsqc_n_ref(const ngsqc_handle* h) { return h ? (int)h->ref_names.size() : 0; }
