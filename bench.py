@@ -234,8 +234,6 @@ def main():
                 os.remove(share)
             except OSError:
                 pass
-        if rank != 0:
-            image = None   # only rank 0 needs the host copy (CPU legs)
     refs = h.refs
     omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
     tx, ty = H.xy_tids(refs)
@@ -249,21 +247,25 @@ def main():
         regs, _ = H.bed_regions(omim, refs, 3)
         mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=nonspecial)
 
-        def step():
-            h.drop_decoded()                                  # whole job from the compressed bytes, every step
-            if args.single_bam:
-                counters, _, _ = ngsqc.scan_mapping_sharded(h, ngsqc.MODE_WGS, device=dev, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=nonspecial)
-                h.site_pileup(sites_arr, 1, 13, args.ont)    # (site counts of a shard are additive; not reduced here)
+        def job_step(hh, sharded):
+            hh.drop_decoded()                                  # whole job from the compressed bytes, every step
+            if sharded:
+                # one decode per shard for the mapping scan AND the contamination pileup (ngsqc_run_job_partial); site counts are summed over the shards
+                counters, _, _, _ = ngsqc.scan_mapping_sharded(hh, ngsqc.MODE_WGS, device=dev, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=nonspecial,
+                                                               sites=sites_arr, site_params=(1, 13, args.ont))
             else:
-                out = h.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont))
+                out = hh.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont))
                 counters = out["counters"]
             roi_bases = int(counters[26]); usable_roi = int(counters[14])
             half = int(round(0.5 * usable_roi / roi_bases)) if roi_bases else 0
-            hist, cov = h.depth_stats(599, half)             # Histogram(0,599,5) input + half-depth count (Statistics.cpp:1185-1204)
+            hist, cov = hh.depth_stats(599, half)             # Histogram(0,599,5) input + half-depth count (Statistics.cpp:1185-1204)
             counters[27] = half; counters[28] = cov
-            if world > 1 and not args.single_bam:
+            if world > 1 and not sharded:
                 counters = ngsqc.allreduce_counters(counters, device=dev)   # C1: RCCL reduce of the counter vectors over xGMI
             return counters, hist
+
+        def step():
+            return job_step(h, args.single_bam)
     else:
         bed_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_exome_{args.seed}_{rank}.bed")
         n_lines = synthetic_exome_bed(bed_path, refs, args.seed, overlapping=(tool == "bedcoverage"))
@@ -330,10 +332,18 @@ def main():
         infl_ms = avg("inflate_ms")
         huff_ms, lz_ms = avg("inflate_huff_ms"), avg("inflate_lz77_ms")
         k1_launches = max(1, int(tms[-1]["inflate_huff_launches"]))
-        if huff_ms >= lz_ms:
-            dom = ("huff_tokens_kernel (K1 phase 1: Huffman decode, lane per BGZF member)", c_bytes / k1_launches, huff_ms / k1_launches)
+        # ---- one more extra step with every K1 kernel in line on ONE stream (NGSQC_K1_SERIAL): a launch's HIP-event interval is then the kernel's own
+        # duration (in the pipelined steps two phase-1 launches and phase 2 / CRC of earlier chunks share the chip, their intervals overlap) ----
+        iso = None
+        if world == 1:
+            os.environ["NGSQC_PIPELINE"] = "0"; os.environ["NGSQC_K1_SERIAL"] = "1"
+            step(); iso = h.timings()
+            del os.environ["NGSQC_PIPELINE"]; del os.environ["NGSQC_K1_SERIAL"]
+        src = iso if iso is not None else {"inflate_huff_ms": huff_ms, "inflate_lz77_ms": lz_ms}
+        if src["inflate_huff_ms"] >= src["inflate_lz77_ms"]:
+            dom = ("huff_tokens_kernel (K1 phase 1: Huffman decode, lane per BGZF member)", c_bytes / k1_launches, src["inflate_huff_ms"] / k1_launches)
         else:
-            dom = ("lz77_groups_kernel (K1 phase 2: LZ77 window resolve, wave per BGZF member)", u_bytes / k1_launches, lz_ms / k1_launches)
+            dom = ("lz77_groups_kernel (K1 phase 2: LZ77 window resolve, wave per BGZF member)", u_bytes / k1_launches, src["inflate_lz77_ms"] / k1_launches)
         dom_gbs = dom[1] / (dom[2] * 1e-3) / 1e9
         k1_gbs = (c_bytes + u_bytes) / (infl_ms * 1e-3) / 1e9
         scan_bytes = int(tms[-1]["scan_algorithmic_bytes"])
@@ -358,10 +368,14 @@ def main():
                                       else f"{world} BAM(s), one per GPU, 1 process/GPU, RCCL all-reduce of the counter vectors"},
             "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(dom[1]),
-                         "avg_launch_ms": round(dom[2], 4), "launches_per_step": k1_launches,
-                         "note": "HIP events on the kernel's own stream over the timed steps; phase 2 of chunk c overlaps phase 1 of chunk c+1 and the consumers of the previous "
-                                 "tile, so the kernels' summed durations exceed the step. DEFLATE decode is bit-serial per BGZF member: VALU-issue bound, not HBM bound "
-                                 "(SURVEY.md §7); PMC traffic per launch is in profiles/ (separate --pmc passes)"},
+                         "avg_launch_ms": round(dom[2], 4), "launches_per_step": k1_launches, "sum_launches_ms": round(dom[2] * k1_launches, 3),
+                         "isolated": iso is not None,
+                         "pipelined_interval_ms": {"huff_tokens_kernel": round(huff_ms / k1_launches, 4), "lz77_groups_kernel": round(lz_ms / k1_launches, 4),
+                                                   "note": "HIP-event intervals of the timed (pipelined) steps: co-resident launches on several streams, not kernel durations"},
+                         "isolated_launch_ms": None if iso is None else {"huff_tokens_kernel": round(iso["inflate_huff_ms"] / k1_launches, 4), "lz77_groups_kernel": round(iso["inflate_lz77_ms"] / k1_launches, 4)},
+                         "note": "avg_launch_ms: HIP events around the launch on its own stream in one extra step with the K1 kernels in line on one stream (the kernel alone on the "
+                                 "chip), so launches x avg_launch_ms <= ms_per_step. achieved = algorithmic bytes of a launch (compressed bytes in for phase 1, inflated bytes out for "
+                                 "phase 2) / that duration. DEFLATE decode is bit-serial per BGZF member: VALU-issue bound, not HBM bound (SURVEY.md §7)"},
             "roofline_k1_stage": {"kernels": "huff_tokens_kernel + lz77_groups_kernel + crc32_kernel (chunk stream on three HIP streams)", "achieved": round(k1_gbs, 2), "unit": "GB/s",
                                   "frac": round(k1_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes": c_bytes + u_bytes, "ms": round(infl_ms, 4)},
             "stage_ms": {"note": "sums of HIP-event intervals over the timed (pipelined) steps; index / scan / pileup overlap K1 of the next tile",
@@ -371,7 +385,8 @@ def main():
                          "contamination_sites": int(sites_arr.shape[0])},
             "end_to_end": {"h2d_ms": round(h2d_ms, 2), "h2d_GBps": round(c_bytes / max(h2d_ms, 1e-9) / 1e6, 2), "open_s": round(open_s, 2),
                            "value_incl_h2d": round(n_rec / (ms_per_step + h2d_ms) / 1e3, 3), "unit": "Mreads/s",
-                           "note": "open = BGZF header walk on the host + H2D of the compressed image (pageable host memory) + BAM header; one H2D per file, then one step"},
+                           "sequential_value_incl_h2d": round(n_rec / (ms_per_step + h2d_ms) / 1e3, 3),
+                           "sequential_note": "ngsqc_open_memory (the caller owns the buffer: the H2D completes inside open), then one resident step"},
             "host": {"cores_reported": os.cpu_count(), "cores_usable": G.effective_cpus(), "generate_s": round(gen_s, 2)},
         }
         if serial is not None:
@@ -385,27 +400,31 @@ def main():
             out["stage_ms_unpipelined"] = {"inflate_stage": round(serial["inflate_ms"], 4), "inflate_huff": round(serial["inflate_huff_ms"], 4), "inflate_lz77": round(serial["inflate_lz77_ms"], 4),
                                            "index": round(serial["index_ms"], 4), "scan_stage": round(serial["scan_ms"], 4), "scan_kernels": round(serial["scan_kernel_ms"], 4),
                                            "depth_finalize": round(serial["finalize_ms"], 4), "contamination_pileup": round(serial["pileup_ms"], 4), "step_wall": round(serial["wall_ms"], 4)}
-        # HBM traffic measured with rocprofv3 PMC passes on this same command (committed under profiles/): raw counter bytes per launch
+        # HBM traffic from the rocprofv3 PMC passes committed under profiles/ (separate --pmc runs of this command on a 48 M-read shard, K1 kernels in line):
+        # raw FETCH_SIZE / WRITE_SIZE bytes per BGZF member (K1) or per record (scan stage), scaled to this run's launch
         try:
-            prof = {}
-            for ln in open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.txt")):
+            per = {}
+            for ln in open(os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.txt")):
                 f = ln.rstrip("\n").split("\t")
-                if len(f) == 5 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and "avg_launch=" in f[4]:
-                    prof[(f[0], f[1])] = float(f[4].split("=")[1]) * 1024.0
-
-            def traffic(kname):
-                fk = [v for (k, c), v in prof.items() if kname in k and c == "FETCH_SIZE"]
-                wk = [v for (k, c), v in prof.items() if kname in k and c == "WRITE_SIZE"]
-                return {"fetch_bytes_raw": int(fk[0]), "write_bytes_raw": int(wk[0]), "source": "profiles/r02_hbm_traffic_pmc.txt (average per launch)",
-                        "note": "raw FETCH_SIZE/WRITE_SIZE x 1024; gfx950 FETCH_SIZE counts 64 B per 128 B request for wide streams; narrow accesses uncalibrated"} if fk and wk else None
-            tp = traffic(dom[0].split(" ")[0])
-            out["roofline"]["traffic_pmc"] = tp
-            if tp:
-                # per launch of 83 k members (the profile's chunk; this run's chunk may hold a few more members). No correction applied: the kernel's loads are
-                # 16 B per lane from 64 different member streams, between the guide's x1 and x2 regimes (raw FETCH / known compressed bytes = 0.755)
-                out["roofline"]["traffic"] = tp["fetch_bytes_raw"] + tp["write_bytes_raw"]
-                out["roofline"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE per launch, K1 kernels serialized (NGSQC_K1_SERIAL=1). Phase 1 writes the 4-byte tokens that "
-                                                   f"phase 2 reads back: {tp['write_bytes_raw'] / max(dom[1], 1):.1f}x the algorithmic bytes of the launch")
+                if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and f[2] in ("bytes_per_member", "bytes_per_record"):
+                    per[(f[0], f[1])] = float(f[3])
+            members_per_launch = int(h.n_blocks) / k1_launches
+            kname = dom[0].split(" ")[0]
+            if (kname, "FETCH_SIZE") in per and (kname, "WRITE_SIZE") in per:
+                fb, wb = per[(kname, "FETCH_SIZE")] * members_per_launch, per[(kname, "WRITE_SIZE")] * members_per_launch
+                out["roofline"]["traffic"] = int(fb + wb)
+                out["roofline"]["traffic_pmc"] = {"fetch_bytes_raw": int(fb), "write_bytes_raw": int(wb), "members_per_launch": int(members_per_launch),
+                                                  "source": "profiles/r03_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
+                                                  "ratio_to_algorithmic": round((fb + wb) / max(dom[1], 1), 2),
+                                                  "note": "raw FETCH_SIZE / WRITE_SIZE x 1024 B (no x2: the K1 accesses are 16-byte pieces of 64 different member streams per "
+                                                          "instruction, between the guide's narrow and wide regimes)"}
+            if "roofline_scan" in out:
+                keys = [k for k in per if k[0] in ("walk_scan_kernel", "scan_kernel", "index_count_kernel", "index_write_kernel", "index_guess_kernel")]
+                if keys:
+                    tot = sum(per[k] for k in keys) * n_rec
+                    out["roofline_scan"]["traffic"] = int(tot)
+                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r03_hbm_traffic_pmc.txt) x the records of the step; the "
+                                                            "kernels gather one or two 128-byte lines per record, so the guide's x2 for wide streams does not apply")
         except OSError:
             pass
         if world == 1 and not args.no_cpu_baseline and tool == "mappingqc":
@@ -465,8 +484,96 @@ def main():
             out["cpu_baseline"] = {"value": round(ob.count / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
                                    "sample": f"first {ob.count} records of the same BAM: sequential inflate + record framing + the oracle's restatement of the tool's sweep, 1 thread, {secs:.1f} s", "counters_match_gpu": ok,
                                    "counters_match_note": "per-line depth sums (BedCoverage) / per-base depth of the whole exome BED (BedLowCoverage) of the sample, GPU vs oracle, bit-exact"}
-        print(json.dumps(out), flush=True)
+    n_members_file = int(h.n_blocks) if not args.single_bam else None
     h.close()
+    if args.single_bam and rank == 0 and tool == "mappingqc" and image is not None:
+        # parity of the sharded path: the unsharded job on this rank's GPU over the whole BAM (all 1032 counters and the depth histogram)
+        try:
+            hf = ngsqc.Handle(data=image, device=local_rank)
+            of = hf.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont)); cf = of["counters"]
+            rb, ur = int(cf[26]), int(cf[14]); half = int(round(0.5 * ur / rb)) if rb else 0
+            hist_f, cov_f = hf.depth_stats(599, half); cf[27] = half; cf[28] = cov_f
+            out["config"]["bgzf_members"] = int(hf.n_blocks)
+            out["single_bam_parity"] = {"counters_match_one_gpu_job": bool(np.array_equal(cf, np.asarray(result))) and bool(np.array_equal(hist_f, hist)),
+                                        "note": "all 1032 counters (order-dependent ones included) and the 600-bin depth histogram of the sharded step against the unsharded job over the whole BAM"}
+            hf.close()
+        except Exception as e:
+            out["single_bam_parity"] = {"error": str(e)[:300]}
+
+    # ---- the other way to use N GPUs, in the same line: ONE BAM sharded over the ranks by BGZF member range (configs[1] at N GPUs; `value` above is
+    # configs[3], one BAM per GPU). Fused shard job per rank, all-gather of the summaries, SUM all-reduce of counters / site counts / difference array. ----
+    strong = None
+    if tool == "mappingqc" and not args.ont and not args.single_bam and image is not None and os.environ.get("NGSQC_BENCH_NO_STRONG") is None:
+        try:
+            hs = ngsqc.Handle(data=image, device=local_rank, shard=(rank, world))
+            k2 = max(1, min(args.steps, 5))
+            job_step(hs, True)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            for _ in range(k2):
+                c_s, hist_s = job_step(hs, True)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); el = time.perf_counter() - ts
+            mem = torch.tensor([int(hs.timings()["members_inflated"]), int(hs.timings()["n_records"])], dtype=torch.int64, device=dev)
+            if world > 1:
+                et = torch.tensor([el], dtype=torch.float64, device=dev); dist.all_reduce(et, op=dist.ReduceOp.MAX); el = float(et.item())
+                dist.all_reduce(mem)
+            hs.close()
+            if rank == 0:
+                same = bool(np.array_equal(np.asarray(c_s), np.asarray(result))) and bool(np.array_equal(hist_s, hist))
+                strong = {"what": f"ONE 30x BAM over {world} GPU(s): shards by BGZF member range, ngsqc_run_job_partial per shard (mapping_wgs + contamination pileup in one decode), "
+                                  "all-gather of the shard summaries, SUM all-reduce of counters, site counts and the int32 difference array",
+                          "value": round(int(mem[1].item()) * k2 / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong", "steps": k2, "ms_per_step": round(el / k2 * 1e3, 3),
+                          "members_inflated_per_step": int(mem[0].item()), "bgzf_members": n_members_file,
+                          "counters_match_one_gpu_job": same,
+                          "note": "all 1032 counters (the order-dependent ones included) and the 600-bin depth histogram against the unsharded job of rank 0; members behind a shard that "
+                                  "only complete its last record are inflated by two shards (64 per cut)"}
+        except Exception as e:   # never let the extra leg break the bench line
+            if rank == 0:
+                strong = {"error": str(e)[:300]}
+    if rank == 0:
+        if strong is not None:
+            out["single_bam"] = strong
+        # ---- end to end from a file: ngsqc_open(path) copies the image in the background while the first job already runs; and the tool itself ----
+        if world == 1 and tool == "mappingqc" and not args.ont and os.environ.get("NGSQC_BENCH_NO_E2E") is None:
+            try:
+                import shutil
+                d_ = next((d for d in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")) if os.path.isdir(d) and shutil.disk_usage(d).free > image.size * 1.1), None)
+                if d_ is not None:
+                    bam_path = os.path.join(d_, f"ngsqc_bench_e2e_{args.seed}_{reads}.bam")
+                    image.tofile(bam_path); open(bam_path + ".bai", "wb").close()   # (the tools only check that an index exists: nothing is read from it)
+                    try:
+                        te = time.perf_counter()
+                        h2 = ngsqc.Handle(path=bam_path, device=local_rank)
+                        t_open = time.perf_counter() - te
+                        o2 = h2.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont))
+                        t_e2e = time.perf_counter() - te
+                        h2.upload_wait(); tm2 = h2.timings(); h2.close()
+                        out["end_to_end"].update({"open_plus_first_job_s": round(t_e2e, 3), "open_returns_after_s": round(t_open, 3), "h2d_ms": round(tm2["h2d_ms"], 2),
+                                                  "h2d_GBps": round(c_bytes / max(tm2["h2d_ms"], 1e-9) / 1e6, 2), "value_incl_h2d": round(n_rec / t_e2e / 1e6, 3),
+                                                  "counters_match": bool(np.array_equal(o2["counters"][:27], np.asarray(result)[:27])),
+                                                  "note": "ngsqc_open(path of the page-cached file) + ONE job, wall clock: the compressed image is copied in the background (pieces in file "
+                                                          "order, K1 chunks wait for their pieces), the tile-stream buffers are allocated beside it"})
+                        tool_bin = os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC")
+                        if os.path.exists(tool_bin):
+                            qc = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_e2e_{args.seed}.qcML")
+                            tt = time.perf_counter()
+                            rc = subprocess.run([tool_bin, "-in", bam_path, "-wgs", "-build", "hg38", "-out", qc, "-no_ref"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+                            out["end_to_end"]["tool_wall_s"] = round(time.perf_counter() - tt, 3) if rc.returncode == 0 else None
+                            out["end_to_end"]["tool"] = "bin/MappingQC -in <file> -wgs -build hg38 -out <qcML> -no_ref (process start to exit: open, fused job incl. contamination, qcML)"
+                            if rc.returncode != 0:
+                                out["end_to_end"]["tool_error"] = rc.stderr.decode(errors="replace")[-200:]
+                            if os.path.exists(qc):
+                                os.remove(qc)
+                    finally:
+                        for f_ in (bam_path, bam_path + ".bai"):
+                            if os.path.exists(f_):
+                                os.remove(f_)
+            except Exception as e:
+                out["end_to_end"]["e2e_error"] = str(e)[:300]
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -222,6 +222,11 @@ typedef struct ngsqc_shard_fix {
 	int32_t reserved;
 } ngsqc_shard_fix;
 int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, ngsqc_shard_summary* out);
+/* the fused job of a shard (what MappingQC runs on one BAM, src/MappingQC/main.cpp:100-151): the mapping scan in shard form (job->mapping is required;
+ * summary in *out, counters later from ngsqc_scan_mapping_finish), the extra depth scan without its prefix sum, the site pileup (result->site_counts:
+ * additive over shards). Every BGZF member of the shard is inflated once for all consumers; the shard's first records are kept in the form the
+ * cross-shard fix-ups need, so ngsqc_scan_mapping_finish does not inflate anything again. read_qc is not available on shards. */
+int ngsqc_run_job_partial(ngsqc_handle* h, const ngsqc_job_desc* job, ngsqc_job_result* result, ngsqc_shard_summary* out);
 /* coverage tools on a shard: ngsqc_scan_depth without the final prefix sum (the depth scan has no order-dependent carries) */
 int ngsqc_scan_depth_partial(ngsqc_handle* h, const ngsqc_depth_params* p);
 /* returns NGSQC_E_FORMAT (message via ngsqc_last_error(NULL)) when the shards' record chains do not join */

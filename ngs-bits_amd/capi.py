@@ -157,7 +157,7 @@ EXPORTS = [
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
-    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait",
+    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial",
 ]
 
 
@@ -274,8 +274,9 @@ class Handle:
         self._chk(lib().ngsqc_scan_mapping(self.h, C.byref(p), counters.ctypes.data, gc.ctypes.data))
         return counters, gc
 
-    def run_job(self, mapping=None, depth=None, sites=None, site_params=(1, 13, False), read_qc=None, n_cycles=320):
-        """ONE pass over the BAM for every requested consumer (ngsqc_run_job).
+    def run_job(self, mapping=None, depth=None, sites=None, site_params=(1, 13, False), read_qc=None, n_cycles=320, partial=False):
+        """ONE pass over the BAM for every requested consumer (ngsqc_run_job; partial=True: ngsqc_run_job_partial on a shard handle - the result
+        holds 'summary' (ngsqc_shard_summary as int64[6]) instead of 'counters', which come from scan_mapping_finish after the exchange).
         mapping: dict of scan_mapping keyword arguments incl. 'mode'; depth: dict(regions=, min_mapq=, min_baseq=, skip_mismapped=);
         sites: list of (tid, pos) or int32 [n, 3]; read_qc: None or dict(single_end=bool).
         Returns a dict with 'counters', 'gc_reads', 'site_counts', 'reads' for the consumers that ran."""
@@ -303,7 +304,13 @@ class Handle:
         st = None
         if read_qc is not None:
             st = ReadStats(); jd.read_qc = 1; jd.read_qc_single_end = int(bool(read_qc.get("single_end", False))); jr.read_stats = C.addressof(st)
-        self._chk(lib().ngsqc_run_job(self.h, C.byref(jd), C.byref(jr)))
+        if partial:
+            L = lib(); L.ngsqc_run_job_partial.restype = C.c_int; L.ngsqc_run_job_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            sm = ShardSummary()
+            self._chk(L.ngsqc_run_job_partial(self.h, C.byref(jd), C.byref(jr), C.byref(sm)))
+            out["summary"] = np.array([getattr(sm, f) for f in SUMMARY_FIELDS], dtype=np.int64); out.pop("counters", None); out.pop("gc_reads", None)
+        else:
+            self._chk(lib().ngsqc_run_job(self.h, C.byref(jd), C.byref(jr)))
         if sites is not None:
             out["site_counts"] = out["site_counts"][:jd.n_sites]
         if st is not None:

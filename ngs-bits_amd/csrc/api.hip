@@ -1045,7 +1045,7 @@ struct ScanState : ngsqc_handle::FusedScan
 			{
 				s[12] = 0; s[13] = 0; s[14] = (unsigned long long)run_max; s[15] = 0;   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
 				HIPCHK(hipMemcpyAsync(d_counters.p + A_FIX_TRIM, s + 12, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-				launch_prefix_fix(sp, lf, lp, h->stream);
+				launch_prefix_fix(sp, lf, lp, nullptr, h->stream);
 				HIPCHK(hipMemcpyAsync(s + 8, d_counters.p + A_FIX_TRIM, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 				HIPCHK(hipMemcpyAsync(s + 9, d_counters.p + A_FIX_LEN, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 				HIPCHK(hipMemcpyAsync(s + 10, d_counters.p + A_FIX_CNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1264,6 +1264,9 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 struct ngsqc_handle::Partial
 {
 	int mode = 0; bool yx = false; ScanState scan; DevBuf<uint8_t> d_ns; GcTables gc; DevBuf<unsigned long long> d_gctab; DevBuf<double> d_gcover;
+	// shard protocol: what the order-dependent fix-ups need of the shard's first records (l_seq, counted, passing), kept so that
+	// ngsqc_scan_mapping_finish does not inflate the shard's first tile a second time
+	static constexpr int64_t HEAD_MAX = 1 << 20; DevBuf<uint32_t> d_head; int64_t head_n = 0;
 };
 
 namespace {
@@ -1368,18 +1371,22 @@ void depth_setup(ngsqc_handle* h, const ngsqc_depth_params* p, DepthSet& D, Scan
 }
 
 // The fused job: every requested consumer sees every tile once.
-void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r)
+void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsqc_shard_summary* shard_out = nullptr)
 {
 	if (!j || !r) throw ArgError("null argument");
+	const bool part = shard_out != nullptr;   // a shard: additive results only (mapping: summary now, counters from ngsqc_scan_mapping_finish; depth: the un-prefixed difference arrays)
 	const bool do_map = j->mapping != nullptr, do_depth = j->depth != nullptr, do_sites = j->n_sites > 0, do_reads = j->read_qc != 0;
-	if (do_map && !r->counters) throw ArgError("mapping job without a counter buffer");
+	if (do_map && !part && !r->counters) throw ArgError("mapping job without a counter buffer");
+	if (part && (!do_map || do_reads)) throw ArgError("a shard job needs the mapping scan and cannot run the raw-read QC");
 	if (do_sites && (!j->sites || !r->site_counts)) throw ArgError("site pileup job without sites / count buffer");
 	if (do_reads && !r->read_stats) throw ArgError("raw-read QC job without a result buffer");
 	if (j->n_sites < 0) throw ArgError("invalid site count");
 	const double w0 = wall_ms();
 	Timer total(h->stream); total.start();
-	ngsqc_handle::Partial map; ScanState dscan; PileupState pile; ReadsState reads;
-	if (do_map) { mapping_setup(h, j->mapping, map); map.scan.begin(h); }
+	ngsqc_handle::Partial local_map; ScanState dscan; PileupState pile; ReadsState reads;
+	if (part) { delete h->partial; h->partial = new ngsqc_handle::Partial(); }
+	ngsqc_handle::Partial& map = part ? *h->partial : local_map;
+	if (do_map) { mapping_setup(h, j->mapping, map); map.scan.in_pass_fix = !part; map.scan.begin(h); }
 	if (do_depth) { depth_setup(h, j->depth, h->ds[1], dscan); dscan.in_pass_fix = false; dscan.begin(h); }
 	if (do_sites) pile.begin(h, j->sites, j->n_sites, j->site_min_mapq, j->site_min_baseq, j->site_include_npp);
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
@@ -1387,6 +1394,13 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r)
 	FuseGuard fg(h, do_map ? &map.scan : (do_depth ? &dscan : nullptr));
 	stream_tiles(h, [&](const TileCtx& c) {
 		if (do_map) map.scan.tile(h, c);
+		if (part && c.ord_base == 0 && c.n_rec > 0)
+		{
+			// the shard's first records in the form the cross-shard fix-ups need them
+			map.head_n = std::min<int64_t>(c.n_rec, ngsqc_handle::Partial::HEAD_MAX);
+			map.d_head.ensure((size_t)map.head_n);
+			launch_prefix_capture(map.scan.sp, map.head_n, map.d_head.p, h->stream);
+		}
 		if (do_depth) dscan.tile(h, c);
 		if (do_sites) pile.tile(h, c);
 		if (do_reads) reads.tile(h, c);
@@ -1397,18 +1411,29 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r)
 	if (do_map)
 	{
 		map.scan.end(h);
-		Timer fin(h->stream); fin.start();
-		finalize_depth(h, h->ds[0]);
-		h->tm.finalize_ms = fin.stop();
-		mapping_counters(h, map, (int)(map.scan.best_key >> 40), map.scan.first_paired != ~0ull, map.scan.sum_runmax, map.scan.fix_len, r->counters, r->gc_reads);
+		if (!part)
+		{
+			Timer fin(h->stream); fin.start();
+			finalize_depth(h, h->ds[0]);
+			h->tm.finalize_ms = fin.stop();
+			mapping_counters(h, map, (int)(map.scan.best_key >> 40), map.scan.first_paired != ~0ull, map.scan.sum_runmax, map.scan.fix_len, r->counters, r->gc_reads);
+		}
+		else
+		{
+			const unsigned long long key = map.scan.best_key;
+			shard_out->n_records = h->tm.n_records;
+			shard_out->first_abs = h->shard_own_members >= 0 ? h->shard_first_abs : (h->tm.n_records ? h->first_rec : -1);
+			shard_out->exit_abs = h->shard_own_members >= 0 ? h->shard_exit_abs : (h->tm.n_records ? h->total : -1);
+			shard_out->max_len = (int64_t)(key >> 40);
+			shard_out->first_max_ord = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : -1;
+			shard_out->first_paired_ord = map.scan.first_paired != ~0ull ? (int64_t)map.scan.first_paired : -1;
+		}
 		h->tm.scan_ms = map.scan.stage_ms; h->tm.scan_kernel_ms = map.scan.kernel_ms; h->tm.scan_launches = map.scan.launches;
 	}
 	if (do_depth)
 	{
 		dscan.end(h);
-		Timer fin(h->stream); fin.start();
-		finalize_depth(h, h->ds[1]);
-		h->tm.finalize_ms += fin.stop();
+		if (!part) { Timer fin(h->stream); fin.start(); finalize_depth(h, h->ds[1]); h->tm.finalize_ms += fin.stop(); }
 		h->tm.depth_scan_ms = dscan.stage_ms;
 		if (!do_map) { h->tm.scan_algorithmic_bytes = (int64_t)dscan.dev[A_ALG_BYTES]; h->tm.scan_kernel_ms = dscan.kernel_ms; h->tm.scan_launches = dscan.launches; h->tm.scan_ms = dscan.stage_ms; }
 	}
@@ -1516,24 +1541,15 @@ int ngsqc_scan_mapping_partial(ngsqc_handle* h, const ngsqc_mapping_params* p, n
 {
 	return guarded(h, [&] {
 		if (!p || !out) throw ArgError("null argument");
-		Timer total(h->stream); total.start();
-		delete h->partial; h->partial = new ngsqc_handle::Partial();
-		ngsqc_handle::Partial& st = *h->partial;
-		mapping_setup(h, p, st);
-		st.scan.in_pass_fix = false; st.scan.begin(h);
-		{ FuseGuard fg(h, &st.scan); stream_tiles(h, [&](const TileCtx& c) { st.scan.tile(h, c); return true; }); }
-		st.scan.end(h);
-		h->cur_ds = 0;
-		const unsigned long long key = st.scan.best_key;
-		out->n_records = h->tm.n_records;
-		out->first_abs = h->shard_own_members >= 0 ? h->shard_first_abs : (h->tm.n_records ? h->first_rec : -1);
-		out->exit_abs = h->shard_own_members >= 0 ? h->shard_exit_abs : (h->tm.n_records ? h->total : -1);
-		out->max_len = (int64_t)(key >> 40);
-		out->first_max_ord = key ? (int64_t)(0xFFFFFFFFFFull - (key & 0xFFFFFFFFFFull)) : -1;
-		out->first_paired_ord = st.scan.first_paired != ~0ull ? (int64_t)st.scan.first_paired : -1;
-		h->tm.scan_ms = st.scan.stage_ms; h->tm.scan_kernel_ms = st.scan.kernel_ms; h->tm.scan_launches = st.scan.launches;
-		h->tm.total_ms = total.stop();
+		ngsqc_job_desc j{}; j.mapping = p; ngsqc_job_result r{};
+		run_job(h, &j, &r, out);
 	});
+}
+// the fused job of a shard: the mapping scan in shard form (summary now, counters from ngsqc_scan_mapping_finish), the extra depth scan without its
+// prefix sum, the site pileup (its counts are additive over shards) - every BGZF member of the shard is inflated once for all of them
+int ngsqc_run_job_partial(ngsqc_handle* h, const ngsqc_job_desc* job, ngsqc_job_result* result, ngsqc_shard_summary* out)
+{
+	return guarded(h, [&] { if (!out) throw ArgError("null argument"); run_job(h, job, result, out); });
 }
 
 int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64_t* counters, double* gc_reads)
@@ -1552,10 +1568,12 @@ int ngsqc_scan_mapping_finish(ngsqc_handle* h, const ngsqc_shard_fix* fix, int64
 		{
 			HIPCHK(hipMemcpyAsync(sc.d_counters.p + A_FIX_TRIM, fx, sizeof(fx), hipMemcpyHostToDevice, h->stream));
 			const int64_t upto = std::max(f, pidx);
-			stream_tiles(h, [&](const TileCtx& c) {
+			if (upto <= st.head_n)   // the prefix lies inside the records captured by the shard job: nothing is inflated again
+				launch_prefix_fix(sc.sp, f, pidx, st.d_head.p, h->stream);
+			else stream_tiles(h, [&](const TileCtx& c) {
 				sc.sp.infl = c.infl; sc.sp.total = c.total; sc.sp.recoff = c.recoff; sc.sp.n_rec = c.n_rec; sc.sp.ord_base = c.ord_base;
 				const int64_t lf = std::min<int64_t>(std::max<int64_t>(f - c.ord_base, 0), c.n_rec), lp = std::min<int64_t>(std::max<int64_t>(pidx - c.ord_base, 0), c.n_rec);
-				launch_prefix_fix(sc.sp, lf, lp, h->stream);
+				launch_prefix_fix(sc.sp, lf, lp, nullptr, h->stream);
 				HIPCHK(hipStreamSynchronize(h->stream));
 				return c.ord_base + c.n_rec < upto;
 			});

@@ -529,7 +529,25 @@ void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_
 // A_FIX_TRIM += sum over counted records with (tile-local) ordinal < upto_max of running_max_i, A_FIX_CNT += their number
 // A_FIX_LEN  += sum over "passing" records with ordinal < upto_paired of length               [single workgroup, sequential chunks]
 // The running maximum starts at A_FIX_CARRY (records before this prefix) and is left there for the next call.
-__global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired)
+// what the order-dependent fix-ups need of a record: l_seq | counted << 30 | passing << 31
+__device__ __forceinline__ uint32_t head_word(const ScanParams& p, long long ord)
+{
+	RecView r = load_rec(p.infl, p.recoff[ord]);
+	const uint32_t flag = r.flag;
+	const bool counted = !(flag & 0x100) && !(flag & 0x800);
+	if (!counted) return 0u;
+	const bool tid_ok = r.tid >= 0 && r.tid < p.n_ref;
+	const bool passing = !(flag & 0x4) && tid_ok && p.tid_nonspecial[r.tid] && !(flag & 0x400) && (int)r.mapq >= p.min_mapq;
+	return ((uint32_t)r.l_seq & 0x3fffffffu) | (1u << 30) | (passing ? 1u << 31 : 0u);
+}
+// the first n records of a shard in that form: ngsqc_scan_mapping_finish then works without the inflated bytes
+__global__ void prefix_capture_kernel(const ScanParams p, long long n, uint32_t* __restrict__ out)
+{
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = head_word(p, i);
+}
+
+__global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, long long upto_max, long long upto_paired, const uint32_t* __restrict__ head)
 {
 	__shared__ int sh[256]; __shared__ int carry;
 	if (threadIdx.x == 0) carry = (int)p.counters[A_FIX_CARRY];   // running maximum carried in from earlier tiles
@@ -542,15 +560,8 @@ __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, lon
 		int len = 0; bool counted = false, passing = false;
 		if (ord < upto)
 		{
-			RecView r = load_rec(p.infl, p.recoff[ord]);
-			const uint32_t flag = r.flag;
-			counted = !(flag & 0x100) && !(flag & 0x800);
-			if (counted)
-			{
-				len = r.l_seq;
-				bool tid_ok = r.tid >= 0 && r.tid < p.n_ref;
-				passing = !(flag & 0x4) && tid_ok && p.tid_nonspecial[r.tid] && !(flag & 0x400) && (int)r.mapq >= p.min_mapq;
-			}
+			const uint32_t w = head ? head[ord] : head_word(p, ord);
+			counted = (w >> 30) & 1u; passing = w >> 31; len = (int)(w & 0x3fffffffu);
 		}
 		sh[threadIdx.x] = counted ? len : 0; __syncthreads();
 		for (int d = 1; d < 256; d <<= 1) { int t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] = max(sh[threadIdx.x], t); __syncthreads(); }
@@ -608,10 +619,15 @@ void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
 	KCHECK();
 }
 
-void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, hipStream_t s)
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head, hipStream_t s)
 {
 	if (upto_max <= 0 && upto_paired <= 0) return;
-	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired); KCHECK();
+	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, d_head); KCHECK();
+}
+void launch_prefix_capture(const ScanParams& p, int64_t n, uint32_t* d_head, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(prefix_capture_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, p, (long long)n, d_head); KCHECK();
 }
 
 // ---- site pileup: BamReader::getPileup (src/cppNGS/BamReader.cpp:809-885, SNP counts) for a table of known sites ----

@@ -66,7 +66,13 @@ def scan_mapping_sharded(handle, mode, device=None, group=None, **scan_kw):
 
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    mine = handle.scan_mapping_partial(mode, **scan_kw)
+    sites = scan_kw.pop("sites", None); site_params = scan_kw.pop("site_params", (1, 13, False))
+    site_counts = None
+    if sites is not None:   # MappingQC's contamination pileup rides the same decode (its counts are additive over shards)
+        job = handle.run_job(mapping=dict(scan_kw, mode=mode), sites=sites, site_params=site_params, partial=True)
+        mine, site_counts = job["summary"], job["site_counts"]
+    else:
+        mine = handle.scan_mapping_partial(mode, **scan_kw)
     if world > 1:
         t = torch.tensor(mine, dtype=torch.int64, device=device)
         parts = [torch.empty_like(t) for _ in range(world)]
@@ -99,6 +105,12 @@ def scan_mapping_sharded(handle, mode, device=None, group=None, **scan_kw):
                 dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
                 handle.depth_diff_set(d.cpu().numpy())
     handle.depth_finalize()
+    if site_counts is not None:
+        if world > 1:
+            sc = torch.from_numpy(np.ascontiguousarray(site_counts)).to(device) if device is not None else torch.from_numpy(np.ascontiguousarray(site_counts))
+            dist.all_reduce(sc, op=dist.ReduceOp.SUM, group=group)
+            site_counts = sc.cpu().numpy()
+        return counters, gc, summaries, site_counts
     return counters, gc, summaries
 
 

