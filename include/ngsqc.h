@@ -205,6 +205,23 @@ int ngsqc_depth_select(ngsqc_handle* h, int32_t which);
 int ngsqc_open_shard(const char* bam_path, int device, int shard, int n_shards, ngsqc_handle** out);
 int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, int shard, int n_shards, ngsqc_handle** out);
 
+/* ---- index-driven partial decode: what BamReader::setRegion gives the reference (src/cppNGS/BamReader.cpp:734-768, htslib sam_index_load /
+ * sam_itr_queryi): a region query reads only the BGZF blocks the BAI names. ngsqc_bai_range turns a set of regions (1-based, closed) into ONE
+ * virtual-offset range [beg, end) that holds every record overlapping any of them (found = 0: none can); NGSQC_E_IO when there is no <bam>.bai:
+ * "Could not load index of BAM/CRAM file ..." like the reference. ngsqc_open_range opens a handle over the records of such a range: only its BGZF
+ * members (and those of the BAM header) are sent to the device and inflated. Scans that only depend on the reads overlapping the regions
+ * (depth scans, site pileups, read counts) give the same result as on the whole file. */
+int ngsqc_bai_range(const char* bam_path, const ngsqc_region* regions, int64_t n_regions, int32_t n_ref, uint64_t* beg_voff, uint64_t* end_voff, int32_t* found);
+int ngsqc_open_range(const char* bam_path, int device, uint64_t beg_voff, uint64_t end_voff, ngsqc_handle** out);
+/* the same in one call for named regions (reference names as in the BAM header, with or without "chr"): header -> tids -> BAI -> range. Only the BGZF
+ * members of the header and of the range are walked on the host and sent to the device. No overlapping record: a handle without records. */
+typedef struct ngsqc_named_region { const char* chr; int32_t start, end; } ngsqc_named_region;
+int ngsqc_open_regions(const char* bam_path, int device, const ngsqc_named_region* regions, int64_t n_regions, ngsqc_handle** out);
+/* the first records of the file: the BGZF members of the BAM header and n_members behind them (what BamReader::info needs, BamReader.cpp:593-730) */
+int ngsqc_open_head(const char* bam_path, int device, int64_t n_members, ngsqc_handle** out);
+/* SAM header text of the BAM header (NUL-terminated copy into out[cap] when out != NULL); returns its length, -1 without a handle */
+int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap);
+
 typedef struct ngsqc_shard_summary {
 	int64_t n_records;         /* records owned by the shard */
 	int64_t first_abs;         /* inflated-stream offset (whole file) of the first record owned; -1: no record starts in the shard */

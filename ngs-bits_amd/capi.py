@@ -157,8 +157,20 @@ EXPORTS = [
     "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_version",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
-    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial",
+    "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
 ]
+
+
+def bai_range(bam_path, regions, n_ref):
+    """regions: [(tid, start, end)] 1-based closed. Returns (beg_voff, end_voff, found) from <bam>.bai (host only); raises NgsqcError without an index."""
+    L = lib()
+    L.ngsqc_bai_range.restype = C.c_int
+    L.ngsqc_bai_range.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    arr = _regions_array(regions); b, e, f = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+    rc = L.ngsqc_bai_range(os.fsencode(bam_path), C.cast(arr, C.c_void_p), len(regions), int(n_ref), C.byref(b), C.byref(e), C.byref(f))
+    if rc != 0:
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+    return int(b.value), int(e.value), bool(f.value)
 
 
 def plan_shard_fix(summaries, shard):
@@ -192,13 +204,23 @@ def _regions_array(regions):
 class Handle:
     """One open BAM on one GPU (ngsqc_handle)."""
 
-    def __init__(self, path=None, data=None, device=0, shard=None):
-        """shard=(i, n): own the records that start inside the i-th of n contiguous BGZF-member ranges of the BAM."""
+    def __init__(self, path=None, data=None, device=0, shard=None, voff_range=None, regions=None):
+        """shard=(i, n): own the records that start inside the i-th of n contiguous BGZF-member ranges of the BAM.
+        voff_range=(beg, end): the records of a virtual-offset range of the file at `path` (from bai_range: index-driven partial decode)."""
         L = lib()
         h = C.c_void_p()
         si, sn = (int(shard[0]), int(shard[1])) if shard is not None else (0, 1)
         self.shard = (si, sn)
-        if path is not None:
+        if regions is not None:   # [(chromosome name, start, end)] 1-based closed: header -> BAI -> one range (ngsqc_open_regions)
+            class NR(C.Structure):
+                _fields_ = [("chr", C.c_char_p), ("start", C.c_int32), ("end", C.c_int32)]
+            arr = (NR * max(len(regions), 1))(*[NR(os.fsencode(c), int(a), int(b)) for c, a, b in regions])
+            L.ngsqc_open_regions.restype = C.c_int; L.ngsqc_open_regions.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+            rc = L.ngsqc_open_regions(os.fsencode(path), device, C.cast(arr, C.c_void_p), len(regions), C.byref(h))
+        elif voff_range is not None:
+            L.ngsqc_open_range.restype = C.c_int; L.ngsqc_open_range.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+            rc = L.ngsqc_open_range(os.fsencode(path), device, int(voff_range[0]), int(voff_range[1]), C.byref(h))
+        elif path is not None:
             rc = L.ngsqc_open_shard(os.fsencode(path), device, si, sn, C.byref(h)) if shard is not None else L.ngsqc_open(os.fsencode(path), device, C.byref(h))
         else:
             buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))

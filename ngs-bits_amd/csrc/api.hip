@@ -102,7 +102,7 @@ struct ngsqc_handle
 	std::vector<BlockDesc> blocks; int64_t total = 0;   // BGZF member table of the handle (a shard: rebased to its range)
 	std::vector<uint32_t> crc;                           // CRC32 of every member's inflated bytes (from its BGZF trailer)
 	DevBuf<uint8_t> d_comp;
-	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens; int64_t first_rec = 0;
+	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens; int64_t first_rec = 0; std::string header_text;   // (SAM header text of the BAM header)
 	// ---- layout of the tile stream (plan_layout) ----
 	bool planned = false;
 	int64_t chunk = 0, nch = 0;                        // K1 chunk size (members) and count
@@ -168,11 +168,11 @@ struct ngsqc_handle
 namespace {
 
 // ---- BGZF member table (host): SAM spec §4.1 ----
-void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total)
+// members of [off, off_end) (off_end: a member start or the end of the file), at most max_members of them; upos continues at `upos`
+void walk_bgzf(const uint8_t* file, size_t n, size_t& off, size_t off_end, int64_t max_members, uint64_t& upos, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, std::vector<uint64_t>* file_off = nullptr)
 {
-	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
-	size_t off = 0; uint64_t upos = 0;
-	while (off < n)
+	int64_t k = 0;
+	while (off < n && off < off_end && k < max_members)
 	{
 		if (off + 18 > n) throw FormatError("truncated BGZF header");
 		const uint8_t* p = file + off;
@@ -184,9 +184,15 @@ void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, st
 		if (!found || bsize < xend + 8 || off + bsize > n) throw FormatError("invalid BGZF block size");
 		uint32_t isize = rd32(p + bsize - 4);
 		if (isize > 65536) throw FormatError("BGZF block inflates to more than 64 KiB");
-		if (isize) { blocks.push_back(BlockDesc{(uint64_t)(off + xend), upos, (uint32_t)(bsize - xend - 8), isize}); crc.push_back(rd32(p + bsize - 8)); }
-		upos += isize; off += bsize;
+		if (isize) { blocks.push_back(BlockDesc{(uint64_t)(off + xend), upos, (uint32_t)(bsize - xend - 8), isize}); crc.push_back(rd32(p + bsize - 8)); if (file_off) file_off->push_back((uint64_t)off); }
+		upos += isize; off += bsize; ++k;
 	}
+}
+void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total)
+{
+	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+	size_t off = 0; uint64_t upos = 0;
+	walk_bgzf(file, n, off, n, INT64_MAX, upos, blocks, crc);
 	total = (int64_t)upos;
 }
 
@@ -275,6 +281,7 @@ bool read_header(ngsqc_handle* h, int64_t avail)
 			if (memcmp(hb.data(), "BAM\1", 4) != 0) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
 			size_t o = 4; uint32_t l_text = rd32(&hb[o]); o += 4 + (size_t)l_text;
 			if (o + 4 > (size_t)bytes) break;
+			h->header_text.assign((const char*)&hb[8], (size_t)l_text);
 			uint32_t n_ref = rd32(&hb[o]); o += 4;
 			std::vector<std::string> names; std::vector<int64_t> lens; bool ok = true;
 			for (uint32_t i = 0; i < n_ref; ++i)
@@ -894,7 +901,7 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 template <class F> void for_each_tile(ngsqc_handle* h, F f) { stream_tiles(h, [&](const TileCtx&) { return f(h->cur_tile); }); }
 
 // regions -> device tables. Regions must be sorted by start within a tid, non-overlapping, and each tid contiguous.
-void setup_regions(ngsqc_handle* h, DepthSet& D, const ngsqc_region* regions, int64_t n)
+void setup_regions(ngsqc_handle* h, DepthSet& D, const ngsqc_region* regions, int64_t n, bool with_depth = true)
 {
 	const int n_ref = (int)h->ref_names.size();
 	D.regions.assign(regions, regions + (n > 0 ? n : 0));
@@ -918,9 +925,12 @@ void setup_regions(ngsqc_handle* h, DepthSet& D, const ngsqc_region* regions, in
 	D.d_tid_first.upload(tf, h->stream); D.d_tid_last.upload(tl, h->stream);
 	std::vector<int64_t> doff(D.doff.begin(), D.doff.begin() + n);
 	D.d_doff.upload(doff, h->stream);
-	D.d_depth.ensure((size_t)slots + 1);
-	D.d_tmp.ensure(scan_tmp_bytes(slots) + 64);
-	HIPCHK(hipMemsetAsync(D.d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
+	if (with_depth)   // (a read-count scan needs the region tables only)
+	{
+		D.d_depth.ensure((size_t)slots + 1);
+		D.d_tmp.ensure(scan_tmp_bytes(slots) + 64);
+		HIPCHK(hipMemsetAsync(D.d_depth.p, 0, ((size_t)slots + 1) * sizeof(int32_t), h->stream));
+	}
 	HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
 	D.depth_ready = false;
 }
@@ -1209,7 +1219,91 @@ template <typename F> int guarded(ngsqc_handle* h, F f)
 	catch (std::exception& e) { h->err = e.what(); return NGSQC_E_DEVICE; }
 }
 
-int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n, int device, int shard = 0, int n_shards = 1)
+// ---- index-driven partial decode (BamReader::setRegion, src/cppNGS/BamReader.cpp:734-768): a handle over the records of ONE virtual-offset range ----
+// Only two parts of the file are looked at: the BGZF members from the start of the file until the BAM header is complete, and the members of the range.
+// The range comes from the caller (voff) or from the BAI for a set of named regions (resolved against the header's reference names).
+struct RangeRequest { bool by_name = false; uint64_t voff[2] = {0, 0}; const ngsqc_named_region* regions = nullptr; int64_t n_regions = 0; int64_t head_members = 0; };   // head_members > 0: the first records of the file (that many BGZF members from the first record on)
+
+void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, const RangeRequest& rq)
+{
+	if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+	init_device(h, device);
+	Timer t(h->stream); t.start();
+	// ---- header: members from the start of the file, more of them until the header is complete ----
+	size_t off = 0; uint64_t upos = 0; std::vector<uint64_t> hdr_off;
+	for (int64_t k = 8;; k *= 4)
+	{
+		walk_bgzf(bytes, n, off, n, k - (int64_t)hdr_off.size() > 0 ? k - (int64_t)hdr_off.size() : k, upos, h->blocks, h->crc, &hdr_off);
+		const size_t end = h->blocks.empty() ? 0 : (size_t)(h->blocks.back().cpos + h->blocks.back().clen);
+		upload_compressed(h, bytes, 0, end);
+		h->total = (int64_t)upos;
+		if (read_header(h, (int64_t)h->blocks.size())) break;
+		if (off >= n) throw FormatError("Could not read header from BAM/CRAM file " + h->path);
+	}
+	// ---- the range ----
+	uint64_t beg = rq.voff[0], end = rq.voff[1]; bool found = true;
+	if (rq.by_name)
+	{
+		std::vector<ngsqc_region> regs;
+		for (int64_t i = 0; i < rq.n_regions; ++i)
+		{
+			const std::string want = rq.regions[i].chr ? rq.regions[i].chr : "";
+			auto norm = [](std::string c) { if (c.size() > 3 && (c.compare(0, 3, "chr") == 0 || c.compare(0, 3, "CHR") == 0)) c = c.substr(3); if (c == "M") c = "MT"; for (auto& ch : c) ch = (char)toupper((unsigned char)ch); return c; };   // (Chromosome::normalizedStringRepresentation)
+			for (size_t r = 0; r < h->ref_names.size(); ++r) if (h->ref_names[r] == want || norm(h->ref_names[r]) == norm(want)) { regs.push_back(ngsqc_region{(int32_t)r, rq.regions[i].start, rq.regions[i].end}); break; }
+		}
+		if (!bai_range(h->path, regs.data(), (int64_t)regs.size(), (int32_t)h->ref_names.size(), beg, end, found))
+			throw IoError("Could not load index of BAM/CRAM file " + h->path);   // BamReader.cpp:742-746
+	}
+	if (rq.head_members > 0)
+	{
+		// from the member that holds the first record on: its virtual offset, and the start of the member head_members further down (or the end of the file)
+		size_t k = 0; while (k + 1 < h->blocks.size() && (int64_t)(h->blocks[k].upos + h->blocks[k].usize) <= h->first_rec) ++k;
+		found = !h->blocks.empty() && h->first_rec < h->total;
+		if (!found && off < n) { walk_bgzf(bytes, n, off, n, 1, upos, h->blocks, h->crc, &hdr_off); h->total = (int64_t)upos; k = h->blocks.size() - 1; found = h->first_rec < h->total; }   // (the header ends exactly at a member end)
+		if (found)
+		{
+			beg = (hdr_off[k] << 16) | (uint64_t)(h->first_rec - (int64_t)h->blocks[k].upos);
+			size_t o3 = (size_t)hdr_off[k]; uint64_t u3 = 0; std::vector<BlockDesc> tb; std::vector<uint32_t> tc;
+			walk_bgzf(bytes, n, o3, n, rq.head_members, u3, tb, tc);
+			end = (uint64_t)o3 << 16;
+		}
+	}
+	const int64_t hdr_first_rec = h->first_rec;   // (inflated offset in the header members' numbering)
+	std::vector<BlockDesc> hdr_blocks; hdr_blocks.swap(h->blocks); h->crc.clear();
+	h->shard = 0; h->n_shards = 2;                 // like a shard that is not the last one: the last member may end inside a record behind the range
+	h->shard_u_base = 0; h->shard_own_members = 0; h->shard_limit = 0; h->total = 0; h->first_rec = 0; h->csize = 0;
+	size_t cbeg = 0, cend = 0;
+	if (found && end > beg)
+	{
+		const size_t co_beg = (size_t)(beg >> 16), co_end = (size_t)(end >> 16);
+		if (co_beg >= n || co_end > n) throw ArgError("virtual offset behind the end of the file");
+		size_t o2 = co_beg; uint64_t u2 = 0; std::vector<uint64_t> foff;
+		// members from the one that holds `beg` up to the one that holds `end` (inclusive when `end` lies inside it)
+		walk_bgzf(bytes, n, o2, (end & 0xffff) ? co_end + 1 : co_end, INT64_MAX, u2, h->blocks, h->crc, &foff);
+		if (h->blocks.empty() || foff[0] != co_beg) throw ArgError("virtual offset does not name a BGZF block of this file");
+		int64_t limit = 0;
+		if ((end & 0xffff) == 0) limit = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
+		else
+		{
+			if (foff.back() != co_end) throw ArgError("virtual offset does not name a BGZF block of this file");
+			limit = (int64_t)h->blocks.back().upos + (int64_t)(end & 0xffff);
+		}
+		int64_t first = (int64_t)(beg & 0xffff);
+		// a range that starts inside the header members: never in front of the first record
+		for (size_t i = 0; i < hdr_off.size(); ++i) if (hdr_off[i] == co_beg) first = std::max<int64_t>(first, hdr_first_rec - (int64_t)hdr_blocks[i].upos);
+		cbeg = (size_t)(h->blocks.front().cpos & ~15ull);
+		cend = (size_t)(h->blocks.back().cpos + h->blocks.back().clen);
+		for (auto& d : h->blocks) d.cpos -= cbeg;
+		h->total = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
+		h->shard_own_members = (int64_t)h->blocks.size(); h->shard_limit = std::max(limit, first); h->first_rec = first;
+	}
+	upload_compressed(h, bytes, cbeg, cend);
+	h->csize = cend - cbeg;
+	h->tm.h2d_ms = t.stop();
+	h->tm.compressed_bytes = (int64_t)(cend - cbeg); h->tm.inflated_bytes = h->shard_limit;
+}
+
+int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n, int device, int shard = 0, int n_shards = 1, const RangeRequest* range = nullptr)
 {
 	if (!out) return NGSQC_E_ARG;
 	*out = nullptr;
@@ -1235,8 +1329,8 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		else h->path = "<memory>";
 		if (!bytes && n) throw ArgError("null BAM buffer");
 		const char* ea = getenv("NGSQC_ASYNC_H2D");
-		if (path && n_shards == 1 && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
-		open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
+		if (path && n_shards == 1 && !range && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
+		if (range) open_range_common(h, (const uint8_t*)bytes, n, device, *range); else open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
 		if (h->up) { h->up->map = map; h->up->map_n = map_n; h->up->fd = fd; map = nullptr; fd = -1; }   // the mapping lives until the last piece is copied
 		const char* ep = getenv("NGSQC_ASYNC_PLAN");
 		if (h->up && (!ep || atoi(ep) != 0))
@@ -1382,6 +1476,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_reads && !r->read_stats) throw ArgError("raw-read QC job without a result buffer");
 	if (j->n_sites < 0) throw ArgError("invalid site count");
 	const double w0 = wall_ms();
+	h->tm.scan_ms = 0; h->tm.scan_kernel_ms = 0; h->tm.scan_launches = 0; h->tm.finalize_ms = 0; h->tm.depth_scan_ms = 0; h->tm.pileup_ms = 0; h->tm.reads_ms = 0; h->tm.scan_algorithmic_bytes = 0;   // (every per-consumer field of the previous job)
 	Timer total(h->stream); total.start();
 	ngsqc_handle::Partial local_map; ScanState dscan; PileupState pile; ReadsState reads;
 	if (part) { delete h->partial; h->partial = new ngsqc_handle::Partial(); }
@@ -1455,6 +1550,46 @@ int ngsqc_open(const char* bam_path, int device, ngsqc_handle** out) { if (!bam_
 int ngsqc_open_memory(const void* bam_bytes, size_t n_bytes, int device, ngsqc_handle** out) { return open_impl(out, nullptr, bam_bytes, n_bytes, device); }
 int ngsqc_open_shard(const char* bam_path, int device, int shard, int n_shards, ngsqc_handle** out) { if (!bam_path) return NGSQC_E_ARG; return open_impl(out, bam_path, nullptr, 0, device, shard, n_shards); }
 int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, int shard, int n_shards, ngsqc_handle** out) { return open_impl(out, nullptr, bam_bytes, n_bytes, device, shard, n_shards); }
+// the records of a virtual-offset range [beg, end) (both record boundaries, e.g. from ngsqc_bai_range): only the BGZF members of the range go to the device
+int ngsqc_open_range(const char* bam_path, int device, uint64_t beg_voff, uint64_t end_voff, ngsqc_handle** out)
+{
+	if (!bam_path) return NGSQC_E_ARG;
+	RangeRequest rq; rq.voff[0] = beg_voff; rq.voff[1] = end_voff;
+	return open_impl(out, bam_path, nullptr, 0, device, 0, 1, &rq);
+}
+// the first records of the file: the BGZF members of the BAM header and n_members behind them (BamReader::info looks at the first reads only, BamReader.cpp:626-641)
+int ngsqc_open_head(const char* bam_path, int device, int64_t n_members, ngsqc_handle** out)
+{
+	if (!bam_path || n_members <= 0) return NGSQC_E_ARG;
+	RangeRequest rq; rq.head_members = n_members;
+	return open_impl(out, bam_path, nullptr, 0, device, 0, 1, &rq);
+}
+// the same for a set of named regions (1-based, closed): the range comes from <bam>.bai; NGSQC_E_IO "Could not load index of BAM/CRAM file ..." without one
+int ngsqc_open_regions(const char* bam_path, int device, const ngsqc_named_region* regions, int64_t n_regions, ngsqc_handle** out)
+{
+	if (!bam_path || (!regions && n_regions > 0) || n_regions < 0) return NGSQC_E_ARG;
+	RangeRequest rq; rq.by_name = true; rq.regions = regions; rq.n_regions = n_regions;
+	return open_impl(out, bam_path, nullptr, 0, device, 0, 1, &rq);
+}
+int ngsqc_bai_range(const char* bam_path, const ngsqc_region* regions, int64_t n_regions, int32_t n_ref, uint64_t* beg_voff, uint64_t* end_voff, int32_t* found)
+{
+	if (!bam_path || (!regions && n_regions > 0) || !beg_voff || !end_voff || !found) return NGSQC_E_ARG;
+	try
+	{
+		bool f = false;
+		if (!ngsqc::bai_range(bam_path, regions, n_regions, n_ref, *beg_voff, *end_voff, f)) { g_open_error = std::string("Could not load index of BAM/CRAM file ") + bam_path; return NGSQC_E_IO; }   // BamReader.cpp:742-746
+		*found = f ? 1 : 0;
+		return NGSQC_OK;
+	}
+	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_FORMAT; }
+}
+int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap)
+{
+	if (!h) return -1;
+	const int64_t n = (int64_t)h->header_text.size();
+	if (out && cap > 0) { const int64_t k = std::min(n, cap - 1); memcpy(out, h->header_text.data(), (size_t)k); out[k] = 0; }
+	return n;
+}
 
 void ngsqc_close(ngsqc_handle* h)
 {
@@ -1746,9 +1881,13 @@ int ngsqc_region_read_counts(ngsqc_handle* h, const ngsqc_region* regions, int64
 	return guarded(h, [&] {
 		if (!regions || n_regions <= 0 || !counts) throw ArgError("read counting needs regions and a result buffer");
 		const int keep = h->cur_ds;
-		DepthSet& D = h->ds[1];   // (region tables only: the depth array of set 1 is not touched)
-		try { setup_regions(h, D, regions, n_regions); }
-		catch (ArgError&) { throw ArgError("Merged and sorted BED file required for coverage calculation!"); }   // src/BedReadCount/main.cpp:36-39
+		DepthSet D;   // private region tables, no depth array: the depth sets of the handle (and what an earlier job left in them) stay as they are
+		try { setup_regions(h, D, regions, n_regions, false); }
+		catch (ArgError& e)
+		{
+			if (std::string(e.what()).find("Merged and sorted") != std::string::npos) throw ArgError("Merged and sorted BED file required for coverage calculation!");   // src/BedReadCount/main.cpp:36-39
+			throw;
+		}
 		ScanState sc; sc.in_pass_fix = false;
 		ScanParams& sp = sc.sp; sp = ScanParams{};
 		sp.mode = MODE_COUNT; sp.min_mapq = min_mapq; sp.tid_x = -2; sp.tid_y = -2;

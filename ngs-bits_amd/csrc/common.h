@@ -19,6 +19,9 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d_out, BlockStatus* d_status,
                          const uint32_t* d_pool, const uint32_t* d_tok_first, const uint32_t* d_tok_count, const uint8_t* d_comp, hipStream_t s);
 
+// BAI index on the host (bai.hip)
+bool bai_range(const std::string& bam_path, const ngsqc_region* regions, int64_t n, int32_t n_ref, uint64_t& beg_voff, uint64_t& end_voff, bool& found);
+
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC

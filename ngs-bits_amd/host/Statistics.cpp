@@ -7,21 +7,38 @@ namespace ngsbits {
 const char* const NO_REF = "<none>";
 
 // ---------------------------------------------------------------- BamReader
-BamReader::BamReader(const std::string& bam_file, const std::string&, bool allow_shards) : bam_file_(bam_file)
+BamReader::BamReader(const std::string& bam_file, const std::string& ref, bool allow_shards) : bam_file_(bam_file) { init(ref, allow_shards, nullptr, 0); }
+BamReader::BamReader(const std::string& bam_file, const std::string& ref, bool allow_shards, const BedFile& regions) : bam_file_(bam_file) { init(ref, allow_shards, &regions, 0); }
+BamReader::BamReader(const std::string& bam_file, const std::string& ref, Head head) : bam_file_(bam_file) { init(ref, false, nullptr, head.n_members); }
+void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* regions, int64_t head_members)
 {
+	ref_file_ = ref;
 	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
 	int n_shards = 1; if (allow_shards) if (const char* e = getenv("NGSQC_SHARDS")) n_shards = std::max(1, atoi(e));
 	int n_dev = 1; if (n_shards > 1) if (const char* e = getenv("NGSQC_DEVICES")) n_dev = std::max(1, atoi(e));
+	const char* es = getenv("NGSQC_INDEX_SELECT");
+	std::string base = bam_file_; size_t dot = base.rfind('.'); std::string noext = dot == std::string::npos ? base : base.substr(0, dot);
+	const bool by_index = regions && n_shards == 1 && (!es || atoi(es) != 0) && (fileExists(bam_file_ + ".bai") || fileExists(noext + ".bai"));
 	for (int s = 0; s < n_shards; ++s)
 	{
-		ngsqc_handle* h = nullptr;
-		int rc = n_shards == 1 ? ngsqc_open(bam_file.c_str(), dev, &h) : ngsqc_open_shard(bam_file.c_str(), dev + s % n_dev, s, n_shards, &h);
+		ngsqc_handle* h = nullptr; int rc;
+		if (head_members > 0) rc = ngsqc_open_head(bam_file_.c_str(), dev, head_members, &h);
+		else if (by_index)
+		{
+			std::vector<std::string> names; std::vector<ngsqc_named_region> nr;
+			names.reserve((size_t)regions->count());
+			for (long long i = 0; i < regions->count(); ++i) names.push_back((*regions)[i].chr().str());
+			for (long long i = 0; i < regions->count(); ++i) nr.push_back(ngsqc_named_region{names[(size_t)i].c_str(), (*regions)[i].start(), (*regions)[i].end()});
+			rc = ngsqc_open_regions(bam_file_.c_str(), dev, nr.data(), (int64_t)nr.size(), &h);
+		}
+		else rc = n_shards == 1 ? ngsqc_open(bam_file_.c_str(), dev, &h) : ngsqc_open_shard(bam_file_.c_str(), dev + s % n_dev, s, n_shards, &h);
 		if (rc != NGSQC_OK)
 		{
 			std::string msg = ngsqc_last_error(nullptr);
 			for (ngsqc_handle* o : shards_) ngsqc_close(o);
 			shards_.clear();
-			if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file);   // BamReader.cpp:467
+			if (rc == NGSQC_E_IO && msg.find("Could not load index") != std::string::npos) NB_THROW(FileAccessException, msg);
+			if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file_);   // BamReader.cpp:467
 			if (rc == NGSQC_E_DEVICE) NB_THROW(Exception, "GPU backend unavailable: " + msg);
 			NB_THROW(FileAccessException, msg);
 		}
@@ -29,7 +46,94 @@ BamReader::BamReader(const std::string& bam_file, const std::string&, bool allow
 	}
 	h_ = shards_[0];
 	for (int i = 0; i < ngsqc_n_ref(h_); ++i) { chrs_.emplace_back(ngsqc_ref_name(h_, i)); sizes_.push_back(ngsqc_ref_len(h_, i)); }
+	if (getenv("NGSQC_TIMING") && (by_index || head_members > 0)) fprintf(stderr, "[ngsqc] %s: %lld BGZF members on the device\n", by_index ? "index-driven open" : "head open", (long long)ngsqc_n_bgzf_blocks(h_));
 }
+// BamReader::info (BamReader.cpp:593-730): format, genome build, mapper from the last @PG line, paired-end from the first 100 usable reads, the hg38
+// false-duplication mask from a region query, alt contigs from the header
+BamInfo BamReader::info()
+{
+	BamInfo out;
+	out.file_format = "BAM";   // (CRAM is not supported by the HIP path)
+	try { const int c1 = chromosomeSize(Chromosome("chr1")); out.build = c1 == 249250621 ? "hg19" : (c1 == 248956422 ? "hg38" : ""); } catch (...) {}
+	// paired end: the first 100 reads that are not secondary / supplementary / duplicate / unmapped and have MAPQ >= 20
+	{
+		const int64_t nbytes = ngsqc_inflated_size(h_), nrec = ngsqc_n_records(h_);
+		std::vector<uint8_t> infl((size_t)std::max<int64_t>(nbytes, 1)); std::vector<int64_t> off((size_t)std::max<int64_t>(nrec, 1));
+		if (nrec > 0) { check(ngsqc_copy_inflated(h_, infl.data(), nbytes)); check(ngsqc_copy_record_offsets(h_, off.data(), nrec)); }
+		double n_all = 0, n_paired = 0;
+		for (int64_t i = 0; i < nrec && n_all < 100.0; ++i)
+		{
+			const uint8_t* r = infl.data() + off[(size_t)i];
+			const uint32_t w = (uint32_t)r[12] | ((uint32_t)r[13] << 8), flag = (uint32_t)r[18] | ((uint32_t)r[19] << 8), mapq = w >> 8;
+			if (flag & (0x100 | 0x800 | 0x400 | 0x4)) continue;
+			if (mapq < 20) continue;
+			if (flag & 0x1) n_paired += 1.0;
+			n_all += 1.0;
+		}
+		out.paired_end = n_paired / n_all > 0.1;   // (0/0 = nan: false, like the reference)
+	}
+	// mapper: the last @PG line counts
+	{
+		std::string text((size_t)ngsqc_header_text(h_, nullptr, 0) + 1, '\0');
+		ngsqc_header_text(h_, &text[0], (int64_t)text.size()); text.resize(text.size() - 1);
+		std::vector<std::string> lines; size_t a = 0;
+		while (a <= text.size()) { size_t b = text.find('\n', a); if (b == std::string::npos) b = text.size(); if (b > a) lines.push_back(text.substr(a, b - a)); a = b + 1; }
+		auto vn = [](const std::string& line) { std::string v; size_t a = 0; while (a <= line.size()) { size_t b = line.find('\t', a); if (b == std::string::npos) b = line.size(); if (line.compare(a, 3, "VN:") == 0) v = trimmed(line.substr(a + 3, b - a - 3)); a = b + 1; } return v; };
+		for (size_t i = lines.size(); i-- > 0;)
+		{
+			const std::string& line = lines[i];
+			if (line.compare(0, 3, "@PG") != 0) continue;
+			if (line.find("PN:bwa-mem2") != std::string::npos) { out.mapper = "bwa-mem2"; out.mapper_version = vn(line); break; }
+			if (line.find("PN:bwa") != std::string::npos) { out.mapper = "bwa"; out.mapper_version = vn(line); break; }
+			if (line.find("ID: DRAGEN SW build") != std::string::npos)
+			{
+				out.mapper = "DRAGEN"; std::string v = vn(line); std::vector<std::string> parts; size_t a2 = 0;
+				while (a2 <= v.size()) { size_t b = v.find('.', a2); if (b == std::string::npos) b = v.size(); parts.push_back(v.substr(a2, b - a2)); a2 = b + 1; }
+				std::string ver; for (size_t k = parts.size() > 3 ? parts.size() - 3 : 0; k < parts.size(); ++k) ver += (ver.empty() ? "" : ".") + parts[k];
+				if (!v.empty()) out.mapper_version = ver;
+				break;
+			}
+			if (line.find("PN:minimap2") != std::string::npos) { out.mapper = "minimap2"; out.mapper_version = vn(line); break; }
+			if (line.find("PN:STAR") != std::string::npos) { out.mapper = "STAR"; std::string v = vn(line); size_t k; while ((k = v.find("STAR_")) != std::string::npos) v.erase(k, 5); out.mapper_version = v; break; }
+		}
+	}
+	// hg38: a read in the region that the false-duplication mask empties means the genome was not masked (region query through the index)
+	if (out.build == "hg38")
+	{
+		try
+		{
+			BedFile roi; roi.append(BedLine(Chromosome("chr21"), 5968000, 6160000));
+			BamReader q(bam_file_, ref_file_, false, roi);
+			q.requireIndex();
+			const int tid = q.chromosomeID(Chromosome("chr21"));
+			const int64_t nbytes = ngsqc_inflated_size(q.handle()), nrec = ngsqc_n_records(q.handle());
+			if (tid >= 0 && nrec > 0)
+			{
+				std::vector<uint8_t> infl((size_t)nbytes); std::vector<int64_t> off((size_t)nrec);
+				q.check(ngsqc_copy_inflated(q.handle(), infl.data(), nbytes)); q.check(ngsqc_copy_record_offsets(q.handle(), off.data(), nrec));
+				for (int64_t i = 0; i < nrec; ++i)
+				{
+					const uint8_t* r = infl.data() + off[(size_t)i];
+					auto rd = [&](int o) { return (int32_t)((uint32_t)r[o] | ((uint32_t)r[o + 1] << 8) | ((uint32_t)r[o + 2] << 16) | ((uint32_t)r[o + 3] << 24)); };
+					const int32_t rt = rd(4), pos = rd(8); const uint32_t l_name = r[12], n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8), flag = (uint32_t)r[18] | ((uint32_t)r[19] << 8);
+					long long ref_len = 0;
+					for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t c = (uint32_t)rd(36 + (int)l_name + 4 * (int)k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
+					const long long end = pos + ((flag & 0x4) || ref_len == 0 ? 1 : ref_len);   // bam_endpos
+					if (rt == tid && pos < 6160000 && end > 5968000 - 1) { out.false_duplications_masked = false; break; }   // the iterator's overlap rule for chr21:5968000-6160000
+				}
+			}
+		}
+		catch (...) {}   // (the reference swallows the exception of an empty range / a missing index here)
+	}
+	for (const Chromosome& c : chrs_)
+	{
+		std::string name = c.str(); for (auto& ch : name) ch = (char)tolower((unsigned char)ch);
+		auto ends = [&](const char* suf) { const size_t k = strlen(suf); return name.size() >= k && name.compare(name.size() - k, k, suf) == 0; };
+		if (ends("_alt") || ends("_hap1")) { out.contains_alt_chrs = true; break; }
+	}
+	return out;
+}
+
 BamReader::~BamReader() { for (ngsqc_handle* h : shards_) ngsqc_close(h); }
 int BamReader::chromosomeID(const Chromosome& chr) const { for (size_t i = 0; i < chrs_.size(); ++i) if (chrs_[i] == chr) return (int)i; return -1; }
 int BamReader::chromosomeSize(const Chromosome& chr) const
@@ -327,12 +431,69 @@ Scan runScan(BamReader& reader, int mode, int min_mapq, const std::vector<ngsqc_
 		NB_THROW(Exception, msg);
 	};
 	std::vector<ngsqc_shard_summary> sum((size_t)n); std::vector<int> rcs((size_t)n, NGSQC_OK);
+	// the follow-up passes MappingQC announced (Statistics::planFused) ride every shard's decode: contamination pileup (site counts are additive over the
+	// shards) and the somatic sub-panel depth (difference arrays are additive); the raw-read QC is not available on shards and keeps its own pass
+	const bool fused = fusedWanted(reader);
+	FusedState& F = g_fused; ngsqc_job_desc job{}; job.mapping = &p;
+	std::vector<std::vector<int64_t>> site_parts; std::vector<ngsqc_region> som_regions; ngsqc_depth_params dp{}; bool with_sites = false, with_somatic = false;
+	if (fused)
+	{
+		const FusedPlan& plan = F.plan;
+		if (plan.contamination)
+		{
+			try
+			{
+				F.snp = snpSites(reader, loadKnownSnps(plan.build, plan.roi_file));
+				job.sites = F.snp.sites.data(); job.n_sites = (int64_t)F.snp.sites.size();
+				job.site_min_mapq = 1; job.site_min_baseq = 13; job.site_include_npp = plan.include_not_properly_paired ? 1 : 0;
+				site_parts.assign((size_t)n, std::vector<int64_t>(F.snp.sites.size() * 8, 0)); with_sites = true;
+			}
+			catch (Exception&) { job.sites = nullptr; job.n_sites = 0; }
+		}
+		if (plan.somatic && plan.somatic_bed.isMergedAndSorted())
+		{
+			try
+			{
+				som_regions = toRegions(plan.somatic_bed, reader, false);
+				if (!som_regions.empty()) { dp.min_mapq = plan.somatic_min_mapq; dp.regions = som_regions.data(); dp.n_regions = (int64_t)som_regions.size(); job.depth = &dp; }
+				with_somatic = true;
+			}
+			catch (Exception&) { job.depth = nullptr; }
+		}
+	}
 	{
 		std::vector<std::thread> th;
-		for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[(size_t)i] = ngsqc_scan_mapping_partial(sh[(size_t)i], &p, &sum[(size_t)i]); });
+		for (int i = 0; i < n; ++i) th.emplace_back([&, i] {
+			ngsqc_job_result res{}; if (with_sites) res.site_counts = site_parts[(size_t)i].data();
+			rcs[(size_t)i] = ngsqc_run_job_partial(sh[(size_t)i], &job, &res, &sum[(size_t)i]);
+		});
 		for (auto& t : th) t.join();
 	}
 	for (int i = 0; i < n; ++i) checkShard(sh[(size_t)i], rcs[(size_t)i]);
+	if (fused)
+	{
+		if (with_sites)
+		{
+			F.site_counts.assign(F.snp.sites.size() * 8, 0);
+			for (int i = 0; i < n; ++i) for (size_t k = 0; k < F.site_counts.size(); ++k) F.site_counts[k] += site_parts[(size_t)i][k];
+			F.have_sites = true;
+		}
+		if (with_somatic)
+		{
+			if (job.depth)
+			{
+				for (int i = 0; i < n; ++i) checkShard(sh[(size_t)i], ngsqc_depth_select(sh[(size_t)i], 1));
+				checkShard(sh[0], ngsqc_depth_reduce(sh[0], sh.data() + 1, n - 1));
+				checkShard(sh[0], ngsqc_depth_finalize(sh[0]));
+			}
+			F.som = somaticFromDepth(reader, som_regions, F.plan.somatic_bed.baseCount());
+			for (int i = 0; i < n; ++i) checkShard(sh[(size_t)i], ngsqc_depth_select(sh[(size_t)i], 0));
+			F.have_somatic = true;
+		}
+		int64_t infl = 0, nb = 0;
+		for (int i = 0; i < n; ++i) { ngsqc_timings tm{}; ngsqc_get_timings(sh[(size_t)i], &tm); infl += tm.members_inflated; nb += ngsqc_n_bgzf_blocks(sh[(size_t)i]); if (i == 0) F.tm = tm; }
+		F.tm.members_inflated = infl; F.n_blocks = nb; F.ran = true;
+	}
 	for (int i = 0; i < n; ++i)
 	{
 		ngsqc_shard_fix fix{};
@@ -783,25 +944,36 @@ void runFused(BamReader& reader, const ngsqc_mapping_params& p, Scan& s)
 	FusedState& F = g_fused; const FusedPlan& plan = F.plan;
 	ngsqc_job_desc job{}; ngsqc_job_result res{};
 	job.mapping = &p; res.counters = s.c.data(); res.gc_reads = s.gc_reads.data();
+	// A follow-up pass whose inputs are broken (a known SNP on a chromosome the BAM does not have, an unmerged sub-panel ...) is left out of the job:
+	// its own call throws later - behind the read QC output, where the reference's pass order puts the error (src/MappingQC/main.cpp:80-165).
+	bool with_sites = false, with_somatic = false;
 	if (plan.contamination)
 	{
-		F.snp = snpSites(reader, loadKnownSnps(plan.build, plan.roi_file));
-		F.site_counts.assign(F.snp.sites.size() * 8, 0);
-		job.sites = F.snp.sites.data(); job.n_sites = (int64_t)F.snp.sites.size();
-		job.site_min_mapq = 1; job.site_min_baseq = 13; job.site_include_npp = plan.include_not_properly_paired ? 1 : 0;
-		res.site_counts = F.site_counts.data();
+		try
+		{
+			F.snp = snpSites(reader, loadKnownSnps(plan.build, plan.roi_file));
+			F.site_counts.assign(F.snp.sites.size() * 8, 0);
+			job.sites = F.snp.sites.data(); job.n_sites = (int64_t)F.snp.sites.size();
+			job.site_min_mapq = 1; job.site_min_baseq = 13; job.site_include_npp = plan.include_not_properly_paired ? 1 : 0;
+			res.site_counts = F.site_counts.data(); with_sites = true;
+		}
+		catch (Exception&) { job.sites = nullptr; job.n_sites = 0; res.site_counts = nullptr; }
 	}
 	if (plan.read_qc) { job.read_qc = 1; job.read_qc_single_end = plan.single_end ? 1 : 0; res.read_stats = &F.rs; }
 	std::vector<ngsqc_region> som_regions; ngsqc_depth_params dp{};
-	if (plan.somatic)
+	if (plan.somatic && plan.somatic_bed.isMergedAndSorted())   // (unmerged: Statistics::somaticCustomDepth throws, Statistics.cpp:1577-1580)
 	{
-		if (!plan.somatic_bed.isMergedAndSorted()) NB_THROW(ArgumentException, "Merged and sorted BED file required for depth details statistics!");   // Statistics.cpp:1577-1580
-		som_regions = toRegions(plan.somatic_bed, reader, false);
-		if (!som_regions.empty()) { dp.min_mapq = plan.somatic_min_mapq; dp.regions = som_regions.data(); dp.n_regions = (int64_t)som_regions.size(); job.depth = &dp; }
+		try
+		{
+			som_regions = toRegions(plan.somatic_bed, reader, false);
+			if (!som_regions.empty()) { dp.min_mapq = plan.somatic_min_mapq; dp.regions = som_regions.data(); dp.n_regions = (int64_t)som_regions.size(); job.depth = &dp; }
+			with_somatic = true;
+		}
+		catch (Exception&) { job.depth = nullptr; }
 	}
 	reader.check(ngsqc_run_job(reader.handle(), &job, &res));
 	ngsqc_get_timings(reader.handle(), &F.tm); F.n_blocks = ngsqc_n_bgzf_blocks(reader.handle());
-	F.have_sites = plan.contamination;
+	F.have_sites = with_sites;
 	if (plan.read_qc)
 	{
 		F.read_lengths.assign((size_t)F.rs.max_cycles + 1, 0);
@@ -811,7 +983,7 @@ void runFused(BamReader& reader, const ngsqc_mapping_params& p, Scan& s)
 		if (n_cyc) reader.check(ngsqc_read_cycle_stats(reader.handle(), F.cycles.data(), n_cyc));
 		F.have_reads = true;
 	}
-	if (plan.somatic)
+	if (with_somatic)
 	{
 		if (job.depth) reader.check(ngsqc_depth_select(reader.handle(), 1));
 		F.som = somaticFromDepth(reader, som_regions, plan.somatic_bed.baseCount());
@@ -933,7 +1105,7 @@ void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
 	if (bed_file.count() == 0) return;
-	BamReader reader(bam_file, ref_file, true);
+	BamReader reader(bam_file, ref_file, true, bed_file);   // (only the BGZF blocks the index names for the lines)
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
 	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = skip_mismapped ? 1 : 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
@@ -951,7 +1123,7 @@ BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string
 	if (!random_access && cutoff > 255) NB_THROW(ArgumentException, "Cutoff cannot be bigger than 255!");   // WorkerLowOrHighCoverage.cpp:149
 	BedFile output;
 	if (bed_file.count() == 0) return output;
-	BamReader reader(bam_file, "", true);
+	BamReader reader(bam_file, "", true, bed_file);
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
 	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = min_baseq; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();

@@ -8,12 +8,22 @@
 namespace ngsbits {
 
 // RAII wrapper of one open BAM on the GPU (role of BamReader for this path: BamReader.h:350-455)
+// BamReader.h:338-347
+struct BamInfo { std::string file_format, build; bool false_duplications_masked = true, contains_alt_chrs = false, paired_end = false; std::string mapper, mapper_version; };
+
 class BamReader
 {
 public:
 	// allow_shards: honour NGSQC_SHARDS=N (an extension): the BAM is split into N BGZF-member ranges, one handle each, spread
 	// round-robin over the visible GPUs (mapping scans: shard protocol of include/ngsqc.h; depth scans: summed difference arrays).
 	BamReader(const std::string& bam_file, const std::string& ref_genome = "", bool allow_shards = false);
+	// Region queries (BamReader::setRegion, BamReader.cpp:734-768): only the BGZF blocks the BAI names for the lines of `regions` are sent to the GPU
+	// (ngsqc_open_regions). Falls back to the whole file without an index next to the BAM, with NGSQC_SHARDS or NGSQC_INDEX_SELECT=0.
+	BamReader(const std::string& bam_file, const std::string& ref_genome, bool allow_shards, const BedFile& regions);
+	// the first records only (BamReader::info): header members + n_members BGZF members
+	struct Head { int64_t n_members; };
+	BamReader(const std::string& bam_file, const std::string& ref_genome, Head head);
+	BamInfo info();   // BamReader.cpp:593-730
 	~BamReader();
 	BamReader(const BamReader&) = delete; BamReader& operator=(const BamReader&) = delete;
 	const std::vector<Chromosome>& chromosomes() const { return chrs_; }
@@ -26,7 +36,8 @@ public:
 	void requireIndex() const;                                  // setRegion's "Could not load index" (BamReader.cpp:742-746)
 	void check(int rc) const;
 private:
-	std::string bam_file_; ngsqc_handle* h_ = nullptr; std::vector<ngsqc_handle*> shards_; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
+	void init(const std::string& ref_genome, bool allow_shards, const BedFile* regions, int64_t head_members);
+	std::string bam_file_, ref_file_; ngsqc_handle* h_ = nullptr; std::vector<ngsqc_handle*> shards_; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
 };
 
 // MappingQC reads the BAM up to four times in the reference (src/MappingQC/main.cpp:83-165: read QC, mapping, contamination, somatic

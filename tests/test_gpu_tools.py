@@ -182,3 +182,70 @@ def test_bedreadcount_matches_oracle(tmp_path, bam, bed, mapq):
     run("BedReadCount", "-bam", os.path.join(GI, bam), "-in", os.path.join(GI, bed), "-out", out, "-min_mapq", str(mapq))
     _, text = O.read_counts(O.Bam(os.path.join(GI, bam)), os.path.join(GI, bed), mapq)
     assert open(out).read() == f"#chr\tstart\tend\t{bam.split('.')[0]}\n" + text
+
+
+def _bam_header_and_first_reads(path, n=4000):
+    import struct, zlib
+    img = open(path, "rb").read(); pos = 0; stream = bytearray()
+    while pos < len(img) and len(stream) < 8_000_000:
+        bs = struct.unpack_from("<H", img, pos + 16)[0] + 1
+        stream += zlib.decompress(img[pos + 18:pos + bs - 8], -15); pos += bs
+    l_text = struct.unpack_from("<I", stream, 4)[0]; text = bytes(stream[8:8 + l_text]).decode(errors="replace")
+    o = 8 + l_text; n_ref = struct.unpack_from("<I", stream, o)[0]; o += 4; refs = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<I", stream, o)[0]; name = bytes(stream[o + 4:o + 4 + ln - 1]).decode(); o += 4 + ln
+        refs.append((name, struct.unpack_from("<I", stream, o)[0])); o += 4
+    recs = []
+    while o + 36 <= len(stream) and len(recs) < n:
+        bs = struct.unpack_from("<I", stream, o)[0]
+        if o + 4 + bs > len(stream): break
+        mapq = stream[o + 13]; flag = struct.unpack_from("<H", stream, o + 18)[0]; recs.append((flag, mapq)); o += 4 + bs
+    return text, refs, recs
+
+
+@pytest.mark.parametrize("name", ["MappingQC_in1.bam", "MappingQC_in5.bam", "Statistics_longread.bam", "BamReader_rna.bam", "sry.bam"])
+def test_baminfo_tool(tmp_path, name):
+    """src/BamInfo/main.cpp + BamReader::info (src/cppNGS/BamReader.cpp:593-730). The reference's expected file needs panel.bam (a missing blob), so the
+    columns are checked against the rules of BamReader::info applied to the fixture's header and first reads by this test."""
+    out = str(tmp_path / "info.tsv")
+    p = run("BamInfo", "-in", os.path.join(GI, name), "-name", "-out", out, env={"NGSQC_TIMING": "1"})
+    lines = open(out).read().splitlines()
+    assert lines[0] == "#filename\tformat\tgenome_build\tgenome_masked\tgenome_contains_alt\tmapper\tpaired-end"
+    f = lines[1].split("\t")
+    text, refs, recs = _bam_header_and_first_reads(os.path.join(GI, name))
+    chr1 = dict(refs).get("chr1", dict(refs).get("1"))
+    build = "hg19" if chr1 == 249250621 else "hg38" if chr1 == 248956422 else ""
+    usable = [fl for fl, mq in recs if not (fl & (0x100 | 0x800 | 0x400 | 0x4)) and mq >= 20][:100]
+    paired = "yes" if usable and sum(1 for fl in usable if fl & 1) / len(usable) > 0.1 else "no"
+    mapper = ""
+    for line in reversed([ln for ln in text.splitlines() if ln.startswith("@PG")]):
+        vn = ([x[3:].strip() for x in line.split("\t") if x.startswith("VN:")] or [""])[-1]
+        if "PN:bwa-mem2" in line: mapper = ("bwa-mem2 " + vn).strip(); break
+        if "PN:bwa" in line: mapper = ("bwa " + vn).strip(); break
+        if "PN:minimap2" in line: mapper = ("minimap2 " + vn).strip(); break
+        if "PN:STAR" in line: mapper = ("STAR " + vn.replace("STAR_", "")).strip(); break
+    alt = "yes" if any(n.lower().endswith("_alt") or n.lower().endswith("_hap1") for n, _ in refs) else "no"
+    assert f[0] == name and f[1] == "BAM" and f[2] == build and f[4] == alt and f[5] == mapper and f[6] == paired, (f, build, alt, mapper, paired)
+    assert f[3] in ("yes", "no")
+    assert "head open" in p.stderr   # only the header members and the first records went to the device
+
+
+def test_sry_gender_inflates_only_the_indexed_blocks(tmp_path):
+    """SampleGender -method sry / Statistics::avgCoverage on one gene: with the BAI next to the BAM only the BGZF blocks the index names for the region are
+    sent to the GPU (BamReader::setRegion, BamReader.cpp:734-768) - same output as without the index selection."""
+    bam = os.path.join(GI, "MappingQC_in3.bam")
+    a = run("SampleGender", "-in", bam, "-method", "sry", "-build", "hg19", env={"NGSQC_TIMING": "1"})
+    b = run("SampleGender", "-in", bam, "-method", "sry", "-build", "hg19", env={"NGSQC_INDEX_SELECT": "0"})
+    assert a.stdout == b.stdout
+    m = re.search(r"index-driven open: (\d+) BGZF members", a.stderr)
+    assert m, a.stderr
+    import struct
+    img = open(bam, "rb").read(); pos = 0; n_members = 0
+    while pos < len(img):
+        pos += struct.unpack_from("<H", img, pos + 16)[0] + 1; n_members += 1
+    assert int(m.group(1)) * 10 < n_members, (m.group(1), n_members)   # < 10 % of the file's members
+    # BedCoverage over a few lines: identical with and without the index selection
+    bed = str(tmp_path / "few.bed"); open(bed, "w").write("".join(open(os.path.join(GI, "MappingQC_in3.bed")).readlines()[:3]))
+    c = run("BedCoverage", "-bam", bam, "-in", bed, "-random_access"); d = run("BedCoverage", "-bam", bam, "-in", bed, "-random_access", env={"NGSQC_INDEX_SELECT": "0"})
+    assert c.stdout == d.stdout and c.stdout.count("\n") == 4
+    assert any(float(ln.split("\t")[-1]) > 0 for ln in c.stdout.splitlines()[1:])
