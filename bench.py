@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--tool", default="mappingqc", choices=["mappingqc", "bedcoverage", "bedlowcoverage"])
     ap.add_argument("--min-baseq", type=int, default=0, help="bedlowcoverage: -min_baseq")
     ap.add_argument("--ont", action="store_true", help="configs[4]: ONT-like long reads")
+    ap.add_argument("--flavor", type=int, default=0, help="short-read generator: 0 = SURVEY.md 8(d) shape (random SEQ, 4-level QUAL); bit 0: SEQ from a synthetic reference (overlapping reads share "
+                    "sequence); bits 1-2: QUAL model 1 = eight bins, 2 = forty levels")
+    ap.add_argument("--level", type=int, default=6, help="zlib level of the generated BGZF members")
     ap.add_argument("--cpu-sample-reads", type=int, default=12_000_000, help="records of the same batch timed on one host core")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
@@ -179,7 +182,7 @@ def main():
     t0 = time.time()
     image = None
     depth = 40.0 if args.ont else 30.0
-    gen_kw = dict(seed=args.seed, mode=mode, depth=depth, first_contig=0, start_pos=0, level=6, aligned=True)
+    gen_kw = dict(seed=args.seed, mode=mode, depth=depth, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=0 if args.ont else args.flavor)
     share_name = f"ngsqc_bench_{os.environ.get('MASTER_PORT', '0')}_{args.seed}_{reads}.bam"
     share = None
     if world > 1:
@@ -348,7 +351,8 @@ def main():
         k1_gbs = (c_bytes + u_bytes) / (infl_ms * 1e-3) / 1e9
         scan_bytes = int(tms[-1]["scan_algorithmic_bytes"])
         shape = ("synthetic ONT-like BAM (configs[4] shape: N50 ~20 kb, 40x, ~1 CIGAR op per 12 bp, CG-tag records)" if args.ont else
-                 "synthetic 30x WGS BAM (configs[1] shape: 2x150 bp PE, coordinate-sorted, zlib-6 BGZF)")
+                 f"synthetic 30x WGS BAM (configs[1] shape: 2x150 bp PE, coordinate-sorted, zlib-{args.level} BGZF" + ("" if not args.flavor else
+                 f"; generator flavor {args.flavor}: " + ("SEQ from a synthetic reference genome, " if args.flavor & 1 else "random SEQ, ") + {0: "4-level", 1: "8-level", 2: "40-level"}[(args.flavor >> 1) & 3] + " QUAL") + ")")
         what = {"mappingqc": "MappingQC -wgs as one fused job (mapping_wgs + OMIM ROI depth + yxRatio + contamination pileup of the known SNVs; K6 depth histogram)",
                 "bedcoverage": "BedCoverage (depth scan over the merged exome regions + per-line sums; unmerged BED with 10 % overlapping lines)",
                 "bedlowcoverage": f"BedLowCoverage -cutoff 20{' -min_baseq ' + str(args.min_baseq) if args.min_baseq else ''} (depth scan + low-coverage runs, sweep saturation)"}[tool]

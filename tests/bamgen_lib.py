@@ -20,6 +20,8 @@ def lib():
         L = C.CDLL(so)
         L.bamgen_generate_map.restype = C.c_void_p
         L.bamgen_generate_map.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.bamgen_generate_map2.restype = C.c_void_p
+        L.bamgen_generate_map2.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.bamgen_release.argtypes = [C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -56,13 +58,14 @@ class _Mapping:
             self.ptr = None
 
 
-def generate(n_reads, seed=20260821, mode=0, depth=30.0, first_contig=0, start_pos=0, level=6, aligned=True, threads=0):
+def generate(n_reads, seed=20260821, mode=0, depth=30.0, first_contig=0, start_pos=0, level=6, aligned=True, threads=0, flavor=0):
     """Returns the BAM file image as a numpy uint8 array (a zero-copy view of the generator's buffer).
-    mode 0 = short-read WGS, 1 = ONT-like long reads."""
+    mode 0 = short-read WGS, 1 = ONT-like long reads. flavor (short reads): bit 0 = SEQ from a synthetic reference genome (overlapping reads share
+    sequence), bits 1-2 = quality model (0: four levels as in SURVEY.md 8(d), 1: eight bins, 2: forty levels)."""
     if threads <= 0:
         threads = 2 * effective_cpus()   # (oversubscribing a CPU quota costs: 256 threads on a 16-CPU quota were 1.5x slower than 32)
     n, cap = C.c_size_t(0), C.c_size_t(0)
-    p = lib().bamgen_generate_map(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, C.byref(n), C.byref(cap))
+    p = lib().bamgen_generate_map2(n_reads, seed, mode, depth, first_contig, start_pos, level, int(aligned), threads, int(flavor), C.byref(n), C.byref(cap))
     if not p:
         raise MemoryError(f"bamgen: could not map {cap.value} bytes for {n_reads} reads")
     return np.asarray(_Mapping(p, n.value, cap.value))

@@ -33,6 +33,7 @@ struct Params
 {
 	int64_t n_reads; uint64_t seed; int mode;       // mode 0 = short-read WGS, 1 = long-read
 	double depth; int first_contig; int level; int aligned; int threads; int64_t start_pos;
+	int flavor = 0;   // bit 0: SEQ from a synthetic reference genome (overlapping reads share sequence, 0.5 % mismatches); bits 1-2: quality model 0 = 4 levels, 1 = 8 levels (NovaSeq-style bins), 2 = 40 levels (HiSeq-style decay)
 };
 
 void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); v.push_back((x >> 16) & 255); v.push_back((x >> 24) & 255); }
@@ -100,18 +101,60 @@ void core(std::vector<uint8_t>& r, int32_t tid, int32_t pos, uint8_t l_name, uin
 	put32(r, (uint32_t)l_seq); put32(r, (uint32_t)mtid); put32(r, (uint32_t)mpos); put32(r, (uint32_t)isize);
 }
 
-void seq_qual(std::vector<uint8_t>& r, Rng& g, int len)
+// base of the synthetic reference at (tid, pos): a pure function, so that reads that overlap on the genome carry the same sequence without a stored genome
+inline uint32_t ref_base(int32_t tid, int64_t pos) { uint64_t x = ((uint64_t)(uint32_t)tid << 40) ^ (uint64_t)pos; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return (uint32_t)(x & 3); }
+
+void seq_qual(std::vector<uint8_t>& r, Rng& g, int len, int flavor = 0, int32_t tid = 0, int64_t pos = 0)
 {
 	static const uint8_t B[4] = {1, 2, 4, 8};
-	for (int i = 0; i < (len + 1) / 2; ++i) { uint64_t x = g.next(); r.push_back((uint8_t)((B[x & 3] << 4) | B[(x >> 2) & 3])); }
-	int q = 3;
-	for (int i = 0; i < len; ++i) { uint64_t x = g.next(); if ((x & 15) == 0) q = (int)((x >> 4) & 3); else if ((x & 15) == 1 && i > len * 3 / 4) q = (int)((x >> 4) % 3); r.push_back((uint8_t)QLEVELS[q]); }
+	if (flavor & 1)
+	{
+		// the read's bases follow the reference from its position on (CIGAR details are ignored: what matters here is the redundancy between overlapping reads)
+		for (int i = 0; i < (len + 1) / 2; ++i)
+		{
+			uint32_t b0 = ref_base(tid, pos + 2 * i), b1 = ref_base(tid, pos + 2 * i + 1);
+			const uint64_t x = g.next();
+			if ((x & 255) == 0) b0 = (uint32_t)(x >> 8) & 3;        // ~0.4 % sequencing errors / variants per base
+			if (((x >> 16) & 255) == 0) b1 = (uint32_t)(x >> 24) & 3;
+			r.push_back((uint8_t)((B[b0] << 4) | B[b1]));
+		}
+	}
+	else for (int i = 0; i < (len + 1) / 2; ++i) { uint64_t x = g.next(); r.push_back((uint8_t)((B[x & 3] << 4) | B[(x >> 2) & 3])); }
+	const int qm = (flavor >> 1) & 3;
+	if (qm == 0)
+	{
+		int q = 3;
+		for (int i = 0; i < len; ++i) { uint64_t x = g.next(); if ((x & 15) == 0) q = (int)((x >> 4) & 3); else if ((x & 15) == 1 && i > len * 3 / 4) q = (int)((x >> 4) % 3); r.push_back((uint8_t)QLEVELS[q]); }
+	}
+	else if (qm == 1)
+	{
+		// eight quality bins (RTA3-style), long runs of the top bin, dips towards the read end
+		static const int Q8[8] = {2, 10, 15, 20, 25, 30, 35, 40};
+		int q = 7;
+		for (int i = 0; i < len; ++i)
+		{
+			const uint64_t x = g.next(); const uint32_t u = (uint32_t)(x & 63);
+			if (u < 3) q = 7 - (int)((x >> 8) % (i > len * 2 / 3 ? 6 : 3)); else if (u < 9) q = std::min(7, q + 1);
+			r.push_back((uint8_t)Q8[q]);
+		}
+	}
+	else
+	{
+		// forty levels: a slowly decaying mean with per-base noise (HiSeq 2000-style, un-binned)
+		double mean = 38.0;
+		for (int i = 0; i < len; ++i)
+		{
+			mean -= 0.05 + 0.0004 * i;
+			const uint64_t x = g.next(); const int noise = (int)(x & 7) - 3 + (((x >> 8) & 31) == 0 ? -(int)((x >> 16) & 15) : 0);
+			r.push_back((uint8_t)std::min(41, std::max(2, (int)std::lround(mean) + noise)));
+		}
+	}
 }
 
 uint8_t draw_mapq(Rng& g) { double u = g.uni(); return u < 0.85 ? 60 : (u < 0.91 ? 0 : (uint8_t)(1 + g.below(59))); }
 
 // short-read record at (tid,pos)
-void short_read(std::vector<uint8_t>& r, Rng& g, int32_t tid, int32_t pos, int64_t contig_len, uint64_t serial)
+void short_read(std::vector<uint8_t>& r, Rng& g, int32_t tid, int32_t pos, int64_t contig_len, uint64_t serial, int flavor = 0)
 {
 	r.clear();
 	int len = g.uni() < 0.05 ? 50 + (int)g.below(100) : 150;
@@ -157,7 +200,7 @@ void short_read(std::vector<uint8_t>& r, Rng& g, int32_t tid, int32_t pos, int64
 	core(r, tid, pos, (uint8_t)(nl + 1), mapq, (uint16_t)nc, flag, len, tid, mpos, isize);
 	r.insert(r.end(), name, name + nl + 1);
 	for (int i = 0; i < nc; ++i) put32(r, cig[i]);
-	seq_qual(r, g, len);
+	seq_qual(r, g, len, flavor, tid, pos);
 	add_aux_common(r, g, nm, len);
 	finish_record(r);
 }
@@ -270,7 +313,7 @@ Image generate(const Params& P)
 					while (tid < 24 && o >= HG38_LENS[tid]) { o -= HG38_LENS[tid]; ++tid; }
 					if (o >= HG38_LENS[tid]) o = HG38_LENS[tid] - 1;
 					uint64_t serial = (uint64_t)(c * chunk + i);
-					if (P.mode == 0) short_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial); else long_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial);
+					if (P.mode == 0) short_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial, P.flavor); else long_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial);
 					z.write(rec.data(), rec.size(), true);
 				}
 				z.flush();
@@ -298,6 +341,14 @@ Image generate(const Params& P)
 extern "C" {
 // returns an anonymous mapping of *cap_out bytes whose first *n_out bytes are the BAM image (release with bamgen_release);
 // mode 0 short-read WGS, 1 long-read; aligned=1 htslib-style member alignment. NULL when memory could not be mapped.
+// flavor: see Params (0 = the SURVEY.md 8(d) shape: random SEQ, 4-level QUAL)
+uint8_t* bamgen_generate_map2(int64_t n_reads, uint64_t seed, int mode, double depth, int first_contig, int64_t start_pos, int level, int aligned, int threads, int flavor, size_t* n_out, size_t* cap_out)
+{
+	Params P{n_reads, seed, mode, depth, first_contig, level, aligned, threads, start_pos}; P.flavor = flavor;
+	Image img = generate(P);
+	*n_out = img.n; *cap_out = img.cap;
+	return img.p;
+}
 uint8_t* bamgen_generate_map(int64_t n_reads, uint64_t seed, int mode, double depth, int first_contig, int64_t start_pos, int level, int aligned, int threads, size_t* n_out, size_t* cap_out)
 {
 	Params P{n_reads, seed, mode, depth, first_contig, level, aligned, threads, start_pos};

@@ -49,12 +49,13 @@ def main():
     reads = int(sys.argv[1]) if len(sys.argv) > 1 else 48_000_000
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     names = sys.argv[3].split(",") if len(sys.argv) > 3 else ["default", "nopipe", "nocrc"]
+    flavor = int(sys.argv[4]) if len(sys.argv) > 4 else 0; level = int(sys.argv[5]) if len(sys.argv) > 5 else 6
     t0 = time.time()
-    cache = f'/tmp/ngsqc_probe_{reads}.bam'
-    image = np.fromfile(cache, dtype=np.uint8) if os.path.exists(cache) else G.generate(reads)
+    cache = f'/tmp/ngsqc_probe_{reads}_{flavor}_{level}.bam'
+    image = np.fromfile(cache, dtype=np.uint8) if os.path.exists(cache) else G.generate(reads, flavor=flavor, level=level)
     if not os.path.exists(cache):
         image.tofile(cache)
-    print(f"[probe] generated {reads} reads, {image.size} bytes in {time.time() - t0:.1f} s on {os.cpu_count()} cpus", flush=True)
+    print(f"[probe] flavor {flavor} level {level}: generated {reads} reads, {image.size} bytes in {time.time() - t0:.1f} s on {os.cpu_count()} cpus", flush=True)
     omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
     ref = None
     for name in names:
