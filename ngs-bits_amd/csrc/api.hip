@@ -115,7 +115,9 @@ struct ngsqc_handle
 	DevBuf<uint32_t> d_sync_pool; DevBuf<BlockDesc> d_sync_desc; DevBuf<uint32_t> d_sync_u32; DevBuf<BlockStatus> d_sync_st; DevBuf<unsigned long long> d_sync_work;   // scratch of inflate_sync (kept: a hipFree waits for every queued kernel)
 	static constexpr int MAX_TILE_BUFS = 4;
 	int k1_slots = K1_SLOTS_DEFAULT;
-	DevBuf<uint8_t> buf[MAX_TILE_BUFS]; int nbuf = 2;  // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
+	DevBuf<uint8_t> buf[MAX_TILE_BUFS]; int nbuf = 2;
+	// the record chain of every member of a tile as the CRC pass of K1 found it (crc.hip), per tile buffer: K2 adopts it for htslib-style tiles
+	struct Prewalk { DevBuf<int32_t> start; DevBuf<uint32_t> cnt, exit; DevBuf<uint16_t> rel; } pw[MAX_TILE_BUFS]; bool prewalk = false; int64_t max_tile_members = 0;  // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
 	std::vector<hipEvent_t> ev_chunk;                  // 4 per chunk: p1 start/end, p2 start/end
 	std::vector<hipEvent_t> ev_tile;                   // 2 per tile: K1 done (status on the host), consumed
 	PinBuf<BlockStatus> p_status; PinBuf<int32_t> p_start; PinBuf<int64_t> p_next; PinBuf<unsigned long long> p_small;
@@ -573,6 +575,17 @@ void plan_layout_now(ngsqc_handle* h)
 	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_tok_first.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch); h->d_pool_ctr.ensure((size_t)h->nch);
 	h->d_tok.ensure((size_t)(n_slots * h->slot_pages) * K1_PAGE_WORDS + 16);
 	for (int i = 0; i < std::min(nt, h->nbuf); ++i) h->buf[i].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
+	h->max_tile_members = 0; for (auto& tl : h->tiles) h->max_tile_members = std::max(h->max_tile_members, tl.second);
+	// NGSQC_PREWALK=1: the CRC pass of K1 also follows every member's record chain, so that K2 only has to adopt it (K2 + scan of a 96 M-read shard
+	// 9.2 -> 6.6 ms un-pipelined). Off by default: the chain walk triples the life of the CRC waves, which then hold the wave slots phase 2 needs -
+	// the whole job got 9 % slower (measured, 6 tiles), and the job is what the tools wait for.
+	{ const char* e = getenv("NGSQC_PREWALK"); h->prewalk = h->verify_crc && e && atoi(e) != 0; }
+	if (h->prewalk)
+		for (int i = 0; i < std::min(nt, h->nbuf); ++i)
+		{
+			auto& w = h->pw[i]; const size_t m = (size_t)h->max_tile_members;
+			w.start.ensure(m); w.cnt.ensure(m); w.exit.ensure(m); w.rel.ensure(m * K2_REL_STRIDE);
+		}
 	h->p_status.ensure((size_t)nb);
 	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
 	while ((int)h->ev_tile.size() < 2 * nt) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_tile.push_back(e); }
@@ -624,7 +637,14 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		if (h->verify_crc)   // htslib checks every member's CRC32 (bgzf.c); a mismatch fails the read
 		{
 			if (crc_stream != h->s_p2) HIPCHK(hipStreamWaitEvent(crc_stream, e4[3], 0));
-			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream);
+			CrcWalk cw; 
+			if (h->prewalk)
+			{
+				auto& w = h->pw[t % h->nbuf];
+				cw.start = w.start.p; cw.cnt = w.cnt.p; cw.exit = w.exit.p; cw.rel = w.rel.p; cw.member0 = c0 - h->tiles[(size_t)t].first;
+				cw.exp0 = t == 0 ? std::max<int64_t>(h->first_rec, 0) - (int64_t)h->blocks[(size_t)h->tiles[0].first].upos : 0;   // (the first tile starts behind the BAM header)
+			}
+			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream, h->prewalk ? &cw : nullptr);
 		}
 	}
 	const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second;
@@ -687,9 +707,18 @@ void index_tile(ngsqc_handle* h, int t)
 	// member's chain, check the pattern on the device, scan the counts; the host reads back {violations, corrupt records, n_rec} only ----
 	launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-	// the job's first scan consumer rides the chain walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
+	// K2's chain walk was done by the CRC pass of K1 while the members' bytes were in the caches: adopted when it describes this tile (htslib-style layout)
 	h->fused_tile = -1;
-	const bool try_fuse = h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
+	bool adopted = false; const uint16_t* rel_src = h->d_rel.p;
+	if (h->prewalk && !anchor_by_guess && prefix == 0 && h->fuse_ok)
+	{
+		auto& w = h->pw[t % h->nbuf];
+		CrcWalk cw; cw.start = w.start.p; cw.cnt = w.cnt.p; cw.exit = w.exit.p; cw.rel = w.rel.p;
+		launch_index_adopt(d_desc, ne, exp0, cw, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->stream);
+		adopted = true; rel_src = w.rel.p - K2_REL_STRIDE;   // (entry e = member e - 1 of the tile)
+	}
+	// otherwise the job's first scan consumer rides K2's own walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
+	const bool try_fuse = !adopted && h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
 	const int64_t fuse_limit = h->shard_own_members >= 0 ? prefix + (h->shard_limit - u_lo) : INT64_MAX;   // a shard only scans the records that start in front of its limit
 	if (try_fuse)
 	{
@@ -697,8 +726,8 @@ void index_tile(ngsqc_handle* h, int t)
 		launch_index_guess(base, total, d_desc, ne, prefix, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
 		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, fuse_limit);
 	}
-	else launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
-	launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
+	else if (!adopted) launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	if (!adopted) launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = n_rec
 	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -707,6 +736,14 @@ void index_tile(ngsqc_handle* h, int t)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	const uint32_t n_corrupt = ((const uint32_t*)sm)[0], n_viol = ((const uint32_t*)sm)[1];
 	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
+	if (adopted && !aligned)
+	{
+		// not an htslib-style tile: K2 walks it itself (and the later tiles of this file too)
+		h->fuse_ok = false; rel_src = h->d_rel.p;
+		launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
+		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
+		launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	}
 	if (try_fuse)
 	{
 		if (aligned && n_corrupt == 0 && sm[2] <= (unsigned long long)h->d_long.n) h->fused_tile = t;
@@ -781,7 +818,7 @@ void index_tile(ngsqc_handle* h, int t)
 	}
 	int64_t n_rec = (int64_t)sm[1];
 	h->d_recoff.ensure_slack((size_t)std::max<int64_t>(n_rec, 1));
-	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
+	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_base.p, rel_src, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
 	{

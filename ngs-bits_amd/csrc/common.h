@@ -11,6 +11,8 @@
 
 namespace ngsqc {
 
+constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the member) kept per member for K2's write pass
+
 // ---- K1 ----
 // two-phase K1 (k1_kernels.h / inflate.hip): lane-per-member Huffman -> token groups in pages of a pool, then wave-per-member LZ77 resolve
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
@@ -25,10 +27,15 @@ bool bai_range(const std::string& bam_path, const ngsqc_region* regions, int64_t
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC
-void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);
+// The CRC pass can also follow each member's BAM record chain while the member's bytes are in the caches (what K2's chain walk does, for tiles laid out
+// like an htslib file): per member of the tile the assumed first-record offset, the record count, the chain exit (member-relative; WALK_BROKEN: a
+// record cut by the member end, WALK_CORRUPT: a record bam_read1 would refuse) and the member-relative record offsets (K2_REL_STRIDE per member).
+constexpr uint32_t WALK_BROKEN = 0xfffffff0u, WALK_CORRUPT = 0xfffffff1u;
+struct CrcWalk { int32_t* start = nullptr; uint32_t* cnt = nullptr; uint32_t* exit = nullptr; uint16_t* rel = nullptr; int64_t member0 = 0, exp0 = 0; };   // member0: tile index of blocks[0]; exp0: tile-local offset of the tile's first record
+void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s, const CrcWalk* walk = nullptr);
+void launch_index_adopt(const BlockDesc* d_blocks, int64_t n_entries, int64_t exp0, const CrcWalk& w, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad_viol, hipStream_t s);
 
 // ---- K2 ----
-constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the member) the count pass keeps per member for the write pass
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s);
 void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s);

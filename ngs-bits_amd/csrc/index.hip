@@ -142,6 +142,43 @@ __global__ void index_aligned_kernel(const BlockDesc* __restrict__ blocks, int64
 	if ((threadIdx.x & 63) == 0 && m) atomicAdd(viol, (uint32_t)__popcll(m));
 }
 
+// K2's chain walk done by the CRC pass of K1 (crc.hip): adopt it when it describes this tile - every member's chain starts where the tile's chain says
+// (offset 0; exp0 inside the member that holds it; no record in front of it) and leaves the member exactly at its end. bad_viol[0] counts records
+// bam_read1 would refuse, bad_viol[1] the members that do not fit (any: K2 walks the tile itself).
+__global__ void index_adopt_kernel(const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t exp0, const CrcWalk w,
+                                   int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs, uint32_t* __restrict__ bad_viol)
+{
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool viol = false, corrupt = false;
+	if (e < n_entries)
+	{
+		if (e == 0) { start[0] = -1; cnt[0] = 0; next_abs[0] = -1; }   // (nothing is carried in front of such a tile)
+		else
+		{
+			int64_t lo, hi; entry_range(blocks, e, 0, lo, hi);
+			const int32_t want = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : 0);
+			const int64_t m = e - 1;
+			start[e] = want;
+			if (w.start[m] != want) viol = true;
+			else if (want < 0) { cnt[e] = 0; next_abs[e] = -1; }
+			else
+			{
+				const uint32_t ex = w.exit[m];
+				corrupt = ex == WALK_CORRUPT;
+				viol = ex == WALK_BROKEN || (!corrupt && lo + (int64_t)ex != hi);
+				cnt[e] = w.cnt[m]; next_abs[e] = corrupt ? -2 : lo + (int64_t)ex;
+			}
+		}
+	}
+	const unsigned long long mv = __ballot(viol), mc = __ballot(corrupt);
+	if ((threadIdx.x & 63) == 0) { if (mc) atomicAdd(bad_viol, (uint32_t)__popcll(mc)); if (mv) atomicAdd(bad_viol + 1, (uint32_t)__popcll(mv)); }
+}
+void launch_index_adopt(const BlockDesc* d_blocks, int64_t n_entries, int64_t exp0, const CrcWalk& w, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad_viol, hipStream_t s)
+{
+	if (n_entries <= 0) return;
+	hipLaunchKernelGGL(index_adopt_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, exp0, w, d_start, d_cnt, d_next_abs, d_bad_viol); KCHECK();
+}
+
 // Record offsets of every entry, ONE WAVE PER ENTRY: the member-relative offsets that the count pass stored are expanded with coalesced loads
 // and stores (the chain is not walked a second time: that would read a third of the inflated tile again). Entry 0 (the carried prefix, offsets
 // may exceed 16 bits) and members with more than K2_REL_STRIDE records walk their chain on lane 0.
