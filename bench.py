@@ -544,7 +544,10 @@ def main():
         if world == 1 and tool == "mappingqc" and not args.ont and os.environ.get("NGSQC_BENCH_NO_E2E") is None:
             try:
                 import shutil
-                d_ = next((d for d in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")) if os.path.isdir(d) and shutil.disk_usage(d).free > image.size * 1.1), None)
+                # (a copy in /dev/shm is host memory: only when there is room for it next to the image itself)
+                room = host_memory_available()
+                d_ = next((d for d in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")) if os.path.isdir(d) and shutil.disk_usage(d).free > image.size * 1.1
+                           and (d != "/dev/shm" or not room or room > image.size * 1.5)), None)
                 if d_ is not None:
                     bam_path = os.path.join(d_, f"ngsqc_bench_e2e_{args.seed}_{reads}.bam")
                     image.tofile(bam_path); open(bam_path + ".bai", "wb").close()   # (the tools only check that an index exists: nothing is read from it)

@@ -143,3 +143,27 @@ def test_fused_job_equals_single_purpose_calls(tmp_path, monkeypatch, tile_membe
     assert np.array_equal(out["site_counts"][:, :6], O.site_pileup(ob, sites, 1, 13, False))
     cov, _, _ = O.avg_coverage(ob, str(sub), merge_bed=True, min_mapq=1, random_access=True)
     assert np.array_equal(sums1, cov) and int(d1.sum()) == int(cov.sum()) > 0
+
+
+@pytest.mark.parametrize("aligned,tile_members", [(True, 0), (True, 9), (False, 9)])
+def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
+    """Three ways to the record index give the same job result: the scan riding K2's chain walk (default), the chain walk inside K1's CRC pass
+    (NGSQC_PREWALK=1, adopted by K2 for htslib-style tiles, refused for members that cut records) and the plain K2 + scan (both switched off)."""
+    p = str(tmp_path / "k2.bam")
+    G.write(p, n_reads=50000, seed=77, aligned=aligned)
+    if tile_members:
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
+    res = []
+    for env in ({}, {"NGSQC_PREWALK": "1"}, {"NGSQC_NO_FUSED_SCAN": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = ngsqc.Handle(path=p)
+        regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
+        out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=H.known_sites(h.refs))
+        res.append((out["counters"].copy(), out["site_counts"].copy(), h.depth(int(out["counters"][26])).copy()))
+        h.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    assert res[0][0][0] > 0
