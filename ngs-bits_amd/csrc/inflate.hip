@@ -8,11 +8,12 @@
 namespace ngsqc {
 
 // measurement switches of the K1 launches, read when a handle is opened (not per launch)
-static struct { int park_hi = 32, p1_pad = 0, p2_pad = 0; int64_t p2_cap = (int64_t)1 << 20; } g_sw;
+static struct { int park_hi = 32, p1_pad = 0, p2_pad = 0, p1_prio = 0; int64_t p2_cap = (int64_t)1 << 20; } g_sw;
 void k1_read_switches()
 {
 	const char* e;
 	g_sw.park_hi = (e = getenv("NGSQC_P1_PARK")) ? atoi(e) : 32;                       // lanes that wait for the slow section before the wave enters it
+	g_sw.p1_prio = (e = getenv("NGSQC_P1_PRIO")) ? std::min(3, std::max(0, atoi(e))) : 0;   // s_setprio of the decoder waves
 	g_sw.p1_pad = (e = getenv("NGSQC_P1_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per decoder workgroup = fewer decoder waves per CU
 	g_sw.p2_pad = (e = getenv("NGSQC_P2_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per phase-2 workgroup = fewer phase-2 waves beside the decoder waves
 	g_sw.p2_cap = (e = getenv("NGSQC_P2_WGS")) ? std::max<int64_t>(1, atoll(e)) : (int64_t)1 << 20;   // caps the phase-2 grid: the waves then stride over the members
@@ -26,7 +27,7 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	// d_work: the launch's member queue head, d_pool_ctr: pages taken from the launch's token pool (both zeroed by the caller). One-wave workgroups.
 	const int64_t wgs = (n_blocks + 63) / 64;
 	const int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
-	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), g_sw.p1_pad, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, g_sw.park_hi);
+	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), g_sw.p1_pad, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, (g_sw.park_hi & 255) | (g_sw.p1_prio << 8));
 	KCHECK();
 }
 

@@ -126,6 +126,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	K1_SHARED uint32_t lds[P1_LDS_W];
 	const int lane = wv::lane();
 	P1Lds L{lds, lane};
+	wv::set_priority(park_hi >> 8); park_hi &= 255;   // (upper bits: wave priority of the decoder waves, NGSQC_P1_PRIO)
 	const wv::u32x4* const comp_q = (const wv::u32x4*)comp;
 	uint32_t* const tab = lds + P1_LANE_W * 64;
 	{

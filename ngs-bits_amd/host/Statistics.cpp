@@ -1,4 +1,5 @@
 #include "Statistics.hpp"
+#include <ctime>
 #include <thread>
 #include <zlib.h>
 
@@ -10,8 +11,13 @@ const char* const NO_REF = "<none>";
 BamReader::BamReader(const std::string& bam_file, const std::string& ref, bool allow_shards) : bam_file_(bam_file) { init(ref, allow_shards, nullptr, 0); }
 BamReader::BamReader(const std::string& bam_file, const std::string& ref, bool allow_shards, const BedFile& regions) : bam_file_(bam_file) { init(ref, allow_shards, &regions, 0); }
 BamReader::BamReader(const std::string& bam_file, const std::string& ref, Head head) : bam_file_(bam_file) { init(ref, false, nullptr, head.n_members); }
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static const double g_t0 = now_s();
+static void stamp(const char* what) { if (getenv("NGSQC_TIMING")) fprintf(stderr, "[ngsqc] +%.3f s %s\n", now_s() - g_t0, what); }
+
 void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* regions, int64_t head_members)
 {
+	stamp("open: start");
 	ref_file_ = ref;
 	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
 	int n_shards = 1; if (allow_shards) if (const char* e = getenv("NGSQC_SHARDS")) n_shards = std::max(1, atoi(e));
@@ -46,6 +52,7 @@ void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* r
 	}
 	h_ = shards_[0];
 	for (int i = 0; i < ngsqc_n_ref(h_); ++i) { chrs_.emplace_back(ngsqc_ref_name(h_, i)); sizes_.push_back(ngsqc_ref_len(h_, i)); }
+	stamp("open: done");
 	if (getenv("NGSQC_TIMING") && (by_index || head_members > 0)) fprintf(stderr, "[ngsqc] %s: %lld BGZF members on the device\n", by_index ? "index-driven open" : "head open", (long long)ngsqc_n_bgzf_blocks(h_));
 }
 // BamReader::info (BamReader.cpp:593-730): format, genome build, mapper from the last @PG line, paired-end from the first 100 usable reads, the hg38
@@ -134,7 +141,7 @@ BamInfo BamReader::info()
 	return out;
 }
 
-BamReader::~BamReader() { for (ngsqc_handle* h : shards_) ngsqc_close(h); }
+BamReader::~BamReader() { stamp("close: start"); for (ngsqc_handle* h : shards_) ngsqc_close(h); stamp("close: done"); }
 int BamReader::chromosomeID(const Chromosome& chr) const { for (size_t i = 0; i < chrs_.size(); ++i) if (chrs_[i] == chr) return (int)i; return -1; }
 int BamReader::chromosomeSize(const Chromosome& chr) const
 {
@@ -971,7 +978,9 @@ void runFused(BamReader& reader, const ngsqc_mapping_params& p, Scan& s)
 		}
 		catch (Exception&) { job.depth = nullptr; }
 	}
+	stamp("fused job: start");
 	reader.check(ngsqc_run_job(reader.handle(), &job, &res));
+	stamp("fused job: done");
 	ngsqc_get_timings(reader.handle(), &F.tm); F.n_blocks = ngsqc_n_bgzf_blocks(reader.handle());
 	F.have_sites = with_sites;
 	if (plan.read_qc)
