@@ -550,14 +550,29 @@ def main():
                            and (d != "/dev/shm" or not room or room > image.size * 1.5)), None)
                 if d_ is not None:
                     bam_path = os.path.join(d_, f"ngsqc_bench_e2e_{args.seed}_{reads}.bam")
-                    image.tofile(bam_path); open(bam_path + ".bai", "wb").close()   # (the tools only check that an index exists: nothing is read from it)
+                    image.tofile(bam_path); open(bam_path + ".bai", "wb").close()   # (replaced by the index the library writes, below)
                     try:
                         te = time.perf_counter()
                         h2 = ngsqc.Handle(path=bam_path, device=local_rank)
                         t_open = time.perf_counter() - te
                         o2 = h2.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont))
                         t_e2e = time.perf_counter() - te
-                        h2.upload_wait(); tm2 = h2.timings(); h2.close()
+                        h2.upload_wait(); tm2 = h2.timings()
+                        # the BAI index of the file (one more decode pass + the index kernels), then what SampleGender -method sry reads through it
+                        try:
+                            ti = time.perf_counter(); h2.write_bai(); t_bai = time.perf_counter() - ti
+                            ti = time.perf_counter()
+                            hp = ngsqc.Handle(path=bam_path, device=local_rank, regions=[("chrY", 2786989, 2787603)])
+                            tid_y = [r[0] for r in hp.refs].index("chrY")
+                            hp.scan_depth([(tid_y, 2786989, 2787603)], min_mapq=1); dsum = int(hp.depth(2787603 - 2786989 + 1).sum()); t_sry = time.perf_counter() - ti
+                            tmp_ = hp.timings(); hp.close()
+                            out["index"] = {"write_bai_s": round(t_bai, 3), "bai_bytes": os.path.getsize(bam_path + ".bai"),
+                                            "region_query": "chrY:2786989-2787603 (the SRY window of SampleGender): ngsqc_open_regions + depth scan, wall clock",
+                                            "region_query_s": round(t_sry, 4), "members_inflated": int(tmp_["members_inflated"]), "bgzf_members": n_members_file,
+                                            "region_depth_sum": dsum}
+                        except Exception as e:
+                            out["index"] = {"error": str(e)[:300]}
+                        h2.close()
                         out["end_to_end"].update({"open_plus_first_job_s": round(t_e2e, 3), "open_returns_after_s": round(t_open, 3), "h2d_ms": round(tm2["h2d_ms"], 2),
                                                   "h2d_GBps": round(c_bytes / max(tm2["h2d_ms"], 1e-9) / 1e6, 2), "value_incl_h2d": round(n_rec / t_e2e / 1e6, 3),
                                                   "counters_match": bool(np.array_equal(o2["counters"][:27], np.asarray(result)[:27])),

@@ -222,6 +222,21 @@ int ngsqc_open_head(const char* bam_path, int device, int64_t n_members, ngsqc_h
 /* SAM header text of the BAM header (NUL-terminated copy into out[cap] when out != NULL); returns its length, -1 without a handle */
 int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap);
 
+/* ---- writing the index. The reference never builds one: every indexed path above fails with "Could not load index of BAM/CRAM file"
+ * (BamReader.cpp:742-746) until `samtools index` (htslib sam_index_build: hts_idx_push / hts_idx_finish / compress_binning, hts.c) has left a
+ * <bam>.bai next to the BAM. ngsqc_write_bai writes that file (bai_path NULL: <path of the handle>.bai) from a handle on the whole BAM: one pass
+ * over the tiles (bin, 16 kb windows and run boundaries per record on the device), then htslib's chunk rules on the host. Same bins, chunks, linear
+ * index, pseudo-bins and n_no_coor as htslib (pinned on the reference's fixture indices through oracle/bai_build.py); the order of the bins inside a
+ * reference is ascending instead of htslib's hash order. NGSQC_E_FORMAT for a BAM that is not sorted by coordinate or reaches behind 2^29 (BAI limit). */
+int ngsqc_write_bai(ngsqc_handle* h, const char* bai_path);
+/* The host half alone (several shards' runs merged by the caller; tests): runs = consecutive records of one (reference, bin) in file order, each with the
+ * virtual offset of its first record (kind 0; kind 1 entries - "last record of a tile", pos clamped at 0 - only feed the sort check), lidx = first
+ * virtual offset per 16 kb window (~0: none) for the windows [lidx_first[t], lidx_first[t + 1]) of reference t, counts = (mapped, unmapped) per reference
+ * followed by the pair of the reads without reference. */
+typedef struct ngsqc_bai_run { uint64_t voff; int32_t tid; uint32_t bin; int32_t pos; uint32_t kind; } ngsqc_bai_run;
+int ngsqc_bai_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                       const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts);
+
 typedef struct ngsqc_shard_summary {
 	int64_t n_records;         /* records owned by the shard */
 	int64_t first_abs;         /* inflated-stream offset (whole file) of the first record owned; -1: no record starts in the shard */

@@ -101,6 +101,7 @@ struct ngsqc_handle
 	size_t csize = 0;
 	std::vector<BlockDesc> blocks; int64_t total = 0;   // BGZF member table of the handle (a shard: rebased to its range)
 	std::vector<uint32_t> crc;                           // CRC32 of every member's inflated bytes (from its BGZF trailer)
+	std::vector<uint64_t> member_off;                    // file offset of every member of the table (a handle on the whole file only: what ngsqc_write_bai turns into virtual offsets)
 	DevBuf<uint8_t> d_comp;
 	std::vector<std::string> ref_names; std::vector<int64_t> ref_lens; int64_t first_rec = 0; std::string header_text;   // (SAM header text of the BAM header)
 	// ---- layout of the tile stream (plan_layout) ----
@@ -190,11 +191,11 @@ void walk_bgzf(const uint8_t* file, size_t n, size_t& off, size_t off_end, int64
 		upos += isize; off += bsize; ++k;
 	}
 }
-void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total)
+void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total, std::vector<uint64_t>* file_off = nullptr)
 {
 	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
 	size_t off = 0; uint64_t upos = 0;
-	walk_bgzf(file, n, off, n, INT64_MAX, upos, blocks, crc);
+	walk_bgzf(file, n, off, n, INT64_MAX, upos, blocks, crc, file_off);
 	total = (int64_t)upos;
 }
 
@@ -441,9 +442,9 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 		if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
 		init_device(h, device);
 		upload_start(h, bytes, 0, n);
-		scan_bgzf(bytes, n, h->blocks, h->crc, h->total);
+		scan_bgzf(bytes, n, h->blocks, h->crc, h->total, n_shards == 1 ? &h->member_off : nullptr);
 	}
-	else { scan_bgzf(bytes, n, h->blocks, h->crc, h->total); init_device(h, device); }
+	else { scan_bgzf(bytes, n, h->blocks, h->crc, h->total, n_shards == 1 ? &h->member_off : nullptr); init_device(h, device); }
 	Timer t(h->stream); t.start();
 	h->shard = shard; h->n_shards = n_shards;
 	if (n_shards == 1)
@@ -1246,6 +1247,66 @@ struct ReadsState
 	}
 };
 
+// ---- BAI index of the handle's BAM (bai.hip): one pass over the tiles, then the chunk rules on the host ----
+void write_bai(ngsqc_handle* h, const char* out_path)
+{
+	if (h->n_shards != 1 || h->shard_own_members >= 0 || h->member_off.size() != h->blocks.size()) throw ArgError("an index is written from a handle on the whole BAM (ngsqc_open / ngsqc_open_memory)");
+	const std::string path = out_path ? std::string(out_path) : h->path + ".bai";
+	if (path == ".bai") throw ArgError("no path for the index");
+	const int32_t n_ref = (int32_t)h->ref_names.size();
+	// linear-index windows per reference: its length in 16 kb windows and some room (an alignment may reach behind the end of a circular contig)
+	std::vector<int64_t> first((size_t)n_ref + 1, 0);
+	for (int32_t t = 0; t < n_ref; ++t) first[(size_t)t + 1] = first[(size_t)t] + std::min<int64_t>(32768, ((std::max<int64_t>(h->ref_lens[(size_t)t], 0) + 16383) >> 14) + 8);
+	const int64_t n_win = first[(size_t)n_ref];
+	DevBuf<int64_t> d_first; DevBuf<unsigned long long> d_lidx, d_counts, d_small; DevBuf<uint64_t> d_key; DevBuf<uint32_t> d_wnd; DevBuf<BaiRun> d_runs;
+	d_first.upload(first, h->stream); d_lidx.ensure((size_t)std::max<int64_t>(n_win, 1)); d_counts.ensure(((size_t)n_ref + 1) * 2); d_small.ensure(2);
+	HIPCHK(hipMemsetAsync(d_lidx.p, 0xff, (size_t)std::max<int64_t>(n_win, 1) * 8, h->stream));
+	HIPCHK(hipMemsetAsync(d_counts.p, 0, ((size_t)n_ref + 1) * 16, h->stream));
+	HIPCHK(hipMemsetAsync(d_small.p, 0, 16, h->stream));   // [0] runs of the tile, [1] flags
+	HIPCHK(hipStreamSynchronize(h->stream));
+	std::vector<BaiRun> runs; std::vector<BaiRun> part;
+	stream_tiles(h, [&](const TileCtx& c) {
+		if (c.n_rec <= 0) return true;
+		d_key.ensure_slack((size_t)c.n_rec); d_wnd.ensure_slack((size_t)c.n_rec); d_runs.ensure_slack((size_t)c.n_rec + 1);
+		HIPCHK(hipMemsetAsync(d_small.p, 0, 8, h->stream));
+		launch_bai_keys(c.infl, c.recoff, c.n_rec, n_ref, d_key.p, d_wnd.p, d_counts.p, d_small.p + 1, h->stream);
+		launch_bai_runs(c.infl, c.recoff, c.n_rec, h->tile_u_lo - h->tile_prefix, d_key.p, d_wnd.p, d_first.p, d_lidx.p, d_runs.p, d_small.p, d_small.p + 1, h->stream);
+		unsigned long long sm[2] = {0, 0};
+		HIPCHK(hipMemcpyAsync(sm, d_small.p, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+		if (sm[1] & BAI_F_BAD_TID) throw FormatError("a record names a reference that the BAM header does not have");
+		if (sm[1] & BAI_F_UNSORTED) throw FormatError("unsorted positions: the BAM is not sorted by coordinate (a BAI index needs that)");
+		if (sm[1] & BAI_F_TOO_FAR) throw FormatError("an alignment ends behind position 2^29: it cannot be stored in a BAI index");
+		if (sm[1] & BAI_F_WINDOWS) throw FormatError("an alignment reaches more than 128 kb behind the end of its reference");
+		part.resize((size_t)sm[0]);
+		HIPCHK(hipMemcpyAsync(part.data(), d_runs.p, (size_t)sm[0] * sizeof(BaiRun), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+		// the runs of a tile come in the order of the atomic counter: file order is the order of their offsets (a tile's last-record marker behind a run that starts there)
+		std::sort(part.begin(), part.end(), [](const BaiRun& a, const BaiRun& b) { return a.u != b.u ? a.u < b.u : a.kind < b.kind; });
+		runs.insert(runs.end(), part.begin(), part.end());
+		return true;
+	});
+	std::vector<unsigned long long> lidx_u((size_t)std::max<int64_t>(n_win, 1)), cnt(((size_t)n_ref + 1) * 2);
+	HIPCHK(hipMemcpyAsync(lidx_u.data(), d_lidx.p, lidx_u.size() * 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(cnt.data(), d_counts.p, cnt.size() * 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	// inflated offset -> virtual offset as bgzf_tell reports a position between two records: a position at the end of a member is offset 0 of the member that
+	// follows in the FILE (which may be an empty one: the EOF block)
+	const std::vector<BlockDesc>& B = h->blocks;
+	auto tell = [&](uint64_t u) -> uint64_t {
+		size_t lo = 0, hi = B.size() - 1;
+		while (lo < hi) { const size_t mid = (lo + hi + 1) / 2; if (B[mid].upos < u) lo = mid; else hi = mid - 1; }   // the member that holds byte u - 1
+		const uint64_t rel = u - B[lo].upos;
+		return rel == B[lo].usize ? (B[lo].cpos + B[lo].clen + 8) << 16 : (h->member_off[lo] << 16) | rel;
+	};
+	if (B.empty()) throw FormatError("empty BAM");
+	std::vector<BaiRunV> rv(runs.size());
+	for (size_t i = 0; i < runs.size(); ++i) rv[i] = BaiRunV{tell((uint64_t)runs[i].u), runs[i].tid, runs[i].bin, runs[i].pos, runs[i].kind};
+	std::vector<uint64_t> lidx(lidx_u.size());
+	for (size_t i = 0; i < lidx.size(); ++i) lidx[i] = lidx_u[i] == ~0ull ? ~0ull : tell(lidx_u[i]);
+	std::vector<int64_t> counts(cnt.begin(), cnt.end());
+	const std::string e = bai_assemble(path, n_ref, tell((uint64_t)h->first_rec), tell((uint64_t)h->total), rv, lidx, first, counts);
+	if (!e.empty()) { if (e.compare(0, 12, "cannot write") == 0) throw IoError(e); throw FormatError(e); }
+}
+
 template <typename F> int guarded(ngsqc_handle* h, F f)
 {
 	if (!h) return NGSQC_E_ARG;
@@ -1620,6 +1681,25 @@ int ngsqc_bai_range(const char* bam_path, const ngsqc_region* regions, int64_t n
 		return NGSQC_OK;
 	}
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_FORMAT; }
+}
+int ngsqc_write_bai(ngsqc_handle* h, const char* bai_path) { return guarded(h, [&] { write_bai(h, bai_path); }); }
+int ngsqc_bai_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                       const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts)
+{
+	if (!bai_path || n_ref < 0 || n_runs < 0 || (!runs && n_runs > 0) || !lidx_first || !counts || (!lidx && lidx_first[n_ref] > 0)) return NGSQC_E_ARG;
+	try
+	{
+		static_assert(sizeof(ngsqc_bai_run) == sizeof(BaiRunV), "run layout");
+		std::vector<BaiRunV> rv((size_t)n_runs);
+		if (n_runs) memcpy(rv.data(), runs, (size_t)n_runs * sizeof(BaiRunV));
+		const std::vector<int64_t> first(lidx_first, lidx_first + n_ref + 1), cnt(counts, counts + 2 * ((size_t)n_ref + 1));
+		const std::vector<uint64_t> L(lidx, lidx + first[(size_t)n_ref]);
+		const std::string e = bai_assemble(bai_path, n_ref, first_record_voff, end_voff, rv, L, first, cnt);
+		if (e.empty()) return NGSQC_OK;
+		g_open_error = e;
+		return e.compare(0, 12, "cannot write") == 0 ? NGSQC_E_IO : NGSQC_E_FORMAT;
+	}
+	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap)
 {

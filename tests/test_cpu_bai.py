@@ -77,3 +77,41 @@ def test_missing_index_is_the_references_error(tmp_path):
     with pytest.raises(ngsqc.NgsqcError) as e:
         ngsqc.bai_range(p, [(0, 1, 100)], 25)
     assert "Could not load index of BAM/CRAM file" in str(e.value)
+
+
+# ---- writing: the host half of ngsqc_write_bai (ngsqc_bai_assemble) against oracle/bai_build.py, fed with what the device half reports ----
+import glob  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import bai_build  # noqa: E402
+
+HTSLIB_PAIRS = [p[:-4] for p in sorted(glob.glob(os.path.join(GI, "*.bam.bai"))) if os.path.basename(p) not in ("sry.bam.bai", "lowcov_bug_case1.bam.bai", "lowcov_bug_case2.bam.bai")]
+
+
+@pytest.mark.parametrize("bam", HTSLIB_PAIRS + [os.path.join(GI, "sry.bam")], ids=lambda p: os.path.basename(p))
+def test_assemble_equals_oracle(bam, tmp_path):
+    n_ref, offset0, recs, final = bai_build.read_bam(bam)
+    want = bai_build.as_parsed(bai_build.build(n_ref, offset0, recs, final["eof_block"]))
+    rng = random.Random(len(recs))
+    for cuts in ((), sorted(rng.sample(range(1, len(recs)), min(7, len(recs) - 1)))):   # one tile; several tiles
+        runs, lidx, first, counts = bai_build.device_view(n_ref, offset0, recs, cuts)
+        out = str(tmp_path / "x.bai")
+        ngsqc.bai_assemble(out, n_ref, offset0, final["eof_block"], runs, lidx, first, counts)
+        assert bai_build.parse_bai(out) == want
+    exp = bai_build.parse_bai(bam + ".bai")
+    if bai_build.build_for_bam(bam) == exp:   # a fixture of the current htslib generation: the written file equals the fixture, too
+        assert bai_build.parse_bai(out) == exp
+
+
+def test_assemble_rejects_unsorted(tmp_path):
+    out = str(tmp_path / "x.bai")
+    ok = [(100 << 16, 0, 4681, 5, 0), (200 << 16, 1, 4681, 7, 0)]
+    ngsqc.bai_assemble(out, 2, 100 << 16, 300 << 16, ok, [100 << 16, 200 << 16], [0, 1, 2], [1, 0, 1, 0, 0, 0])
+    refs, n_no_coor = bai_build.parse_bai(out)
+    assert n_no_coor == 0 and refs[0][0][4681] == [[100 << 16, 200 << 16]] and refs[0][0][37450] == [[100 << 16, 200 << 16], [1, 0]] and refs[1][1] == [200 << 16]
+    for bad in ([(100 << 16, 0, 4681, 5, 0), (150 << 16, 1, 4681, 7, 0), (200 << 16, 0, 4682, 20000, 0)],      # reference 0 twice
+                [(100 << 16, -1, 4680, -1, 0), (200 << 16, 0, 4681, 7, 0)],                                      # reads without reference in front
+                [(100 << 16, 0, 4681, 9, 0), (100 << 16, 0, 4681, 9, 1), (200 << 16, 0, 4681, 7, 0)]):          # positions go back across a tile boundary
+        with pytest.raises(ngsqc.NgsqcError):
+            ngsqc.bai_assemble(out, 2, 100 << 16, 300 << 16, bad, [100 << 16, 200 << 16], [0, 1, 2], [1, 0, 1, 0, 0, 0])

@@ -1,0 +1,142 @@
+"""ngsqc_write_bai: the BAI index the library writes equals what htslib's sam_index_build writes (oracle/bai_build.py, pinned on the reference's fixture
+indices by tests/test_oracle_bai.py) - same bins, chunks, linear index, pseudo-bins, n_no_coor - for the reference's fixture BAMs (one tile and many
+tiles), for the bench generator's BAM and for hand-made edge records; the index then drives the partial decode (ngsqc_open_regions) like a
+samtools-written one."""
+import glob
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import bamgen_lib
+from conftest import GOLDEN_IN
+
+pytestmark = pytest.mark.gpu
+ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import bai_build  # noqa: E402
+
+BAMS = sorted(p[:-4] for p in glob.glob(os.path.join(GOLDEN_IN, "*.bam.bai")))
+
+
+@pytest.mark.parametrize("bam", BAMS, ids=lambda p: os.path.basename(p))
+@pytest.mark.parametrize("tiles", ["one_tile", "tiles_of_3_members"])
+def test_written_index_equals_htslib(bam, tiles, tmp_path, monkeypatch):
+    if tiles != "one_tile":
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", "3")
+    out = str(tmp_path / "out.bai")
+    h = ngsqc.Handle(path=bam)
+    try:
+        h.write_bai(out)
+    finally:
+        h.close()
+    got = bai_build.parse_bai(out)
+    assert got == bai_build.build_for_bam(bam)
+    fixture = bai_build.parse_bai(bam + ".bai")
+    if bai_build.build_for_bam(bam) == fixture:   # a fixture index of the current htslib generation (10 of the 17)
+        assert got == fixture
+
+
+def test_from_memory_and_default_path(tmp_path):
+    src = os.path.join(GOLDEN_IN, "MappingQC_in2.bam")
+    p = str(tmp_path / "copy.bam"); open(p, "wb").write(open(src, "rb").read())
+    h = ngsqc.Handle(path=p); h.write_bai(); h.close()
+    assert bai_build.parse_bai(p + ".bai") == bai_build.build_for_bam(src)
+    h = ngsqc.Handle(data=np.fromfile(src, dtype=np.uint8)); h.write_bai(str(tmp_path / "m.bai")); h.close()
+    assert bai_build.parse_bai(str(tmp_path / "m.bai")) == bai_build.build_for_bam(src)
+    # a shard handle does not see the whole file
+    h = ngsqc.Handle(path=p, shard=(0, 2))
+    with pytest.raises(ngsqc.NgsqcError):
+        h.write_bai(str(tmp_path / "s.bai"))
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def synthetic(tmp_path_factory):
+    """the bench generator's BAM spread over the whole genome (200 k reads, ~1300 BGZF members)"""
+    p = str(tmp_path_factory.mktemp("bai") / "syn.bam")
+    bamgen_lib.write(p, n_reads=200000, seed=3, depth=0.0096)
+    return p
+
+
+@pytest.mark.parametrize("tile_members", [None, "100"])
+def test_synthetic_bam_and_index_driven_decode(synthetic, tile_members, monkeypatch):
+    if tile_members:
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", tile_members)
+    whole = ngsqc.Handle(path=synthetic)
+    whole.write_bai()
+    assert bai_build.parse_bai(synthetic + ".bai") == bai_build.build_for_bam(synthetic)
+    # SampleGender -method sry on such a file: the index names a handful of the members
+    refs = whole.refs; tid = [r[0] for r in refs].index("chrY")
+    region = ("chrY", 2_000_000, 3_000_000); regs = [(tid, region[1], region[2])]
+    part = ngsqc.Handle(path=synthetic, regions=[region])
+    try:
+        n = region[2] - region[1] + 1
+        whole.scan_depth(regs, min_mapq=1); part.scan_depth(regs, min_mapq=1)
+        d = whole.depth(n)
+        assert d.sum() > 0 and np.array_equal(d, part.depth(n))
+        assert np.array_equal(whole.region_read_counts(regs, 1), part.region_read_counts(regs, 1))
+        t_w, t_p = whole.timings(), part.timings()
+        assert t_p["members_inflated"] * 100 < t_w["members_inflated"], (t_p["members_inflated"], t_w["members_inflated"])
+    finally:
+        part.close(); whole.close()
+
+
+def _bam_image(refs, records):
+    """a BAM file image from (tid, pos, flag, cigar ops) records, one BGZF member per 50 records"""
+    def bgzf(raw):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15); body = c.compress(raw) + c.flush()
+        return b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(raw), len(raw))
+    hdr = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", len(refs))
+    for name, ln in refs:
+        hdr += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    out = bgzf(hdr); chunk = b""
+    for k, (tid, pos, flag, cigar) in enumerate(records):
+        l_seq = sum(n for n, op in cigar if op in (0, 1, 4, 7, 8)) or 10
+        name = b"r%d\0" % k
+        rec = struct.pack("<iiBBHHHiiii", tid, pos, len(name), 30, 0, len(cigar), flag, l_seq, -1, -1, 0) + name
+        rec += b"".join(struct.pack("<I", n << 4 | op) for n, op in cigar) + bytes((l_seq + 1) // 2) + bytes([30]) * l_seq
+        chunk += struct.pack("<i", len(rec)) + rec
+        if (k + 1) % 50 == 0:
+            out += bgzf(chunk); chunk = b""
+    if chunk:
+        out += bgzf(chunk)
+    return out + bgzf(b"")
+
+
+EDGE_REFS = [("chrA", 3_000_000), ("chrB", 600_000_000), ("chrC", 1000)]
+
+
+def edge_records():
+    ok = [(0, -1, 4, []), (0, 0, 0, [(50, 0)]), (0, 16380, 0, [(10, 0)]), (0, 16383, 0, [(5, 4), (40, 0), (70000, 3), (30, 0)]), (0, 2_999_990, 0, [(100, 0)]),
+          (1, 5, 4, []), (1, 5, 0, [(20, 0), (3, 1), (20, 0), (2, 2), (10, 8)]), (1, 536_870_000, 0, [(100, 0)])]
+    ok += [(1, 536_870_100 + 3 * i, 16, [(30, 7)]) for i in range(130)]
+    return ok + [(-1, -1, 4, [])] * 60
+
+
+def edge_bad():
+    ok = edge_records()
+    return {"unsorted positions": ok[:3] + [(0, 100, 0, [(10, 0)])] + ok[3:],
+            "not continuous": ok[:8] + [(0, 2_999_995, 0, [(10, 0)])],
+            "without a reference": ok + [(2, 5, 0, [(10, 0)])],
+            "2^29": ok[:8] + [(1, 536_870_900, 0, [(100, 0)])],
+            "header does not have": ok[:8] + [(7, 5, 0, [(10, 0)])]}
+
+
+def test_edge_records_and_unsorted_input(tmp_path):
+    """a read in front of position 0, reads that touch the 16 kb / 128 kb bin borders, a spliced read over several windows, unmapped reads with and
+    without a position, a reference longer than 2^29; then the inputs htslib refuses"""
+    p = str(tmp_path / "ok.bam"); open(p, "wb").write(_bam_image(EDGE_REFS, edge_records()))
+    h = ngsqc.Handle(path=p); h.write_bai(); h.close()
+    assert bai_build.parse_bai(p + ".bai") == bai_build.build_for_bam(p)
+    assert bai_build.parse_bai(p + ".bai")[1] == 60
+    for what, recs in edge_bad().items():
+        q = str(tmp_path / "bad.bam"); open(q, "wb").write(_bam_image(EDGE_REFS, recs))
+        h = ngsqc.Handle(path=q)
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            h.write_bai()
+        h.close()
+        assert what in str(e.value), (what, str(e.value))
