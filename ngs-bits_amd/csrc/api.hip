@@ -1265,7 +1265,10 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 	HIPCHK(hipMemsetAsync(d_small.p, 0, 16, h->stream));   // [0] runs of the tile, [1] flags
 	HIPCHK(hipStreamSynchronize(h->stream));
 	std::vector<BaiRun> runs; std::vector<BaiRun> part;
+	const bool dbg = getenv("NGSQC_BAI_DEBUG") != nullptr;
+	if (dbg) fprintf(stderr, "[bai] n_ref %d, windows %lld\n", n_ref, (long long)n_win);
 	stream_tiles(h, [&](const TileCtx& c) {
+		if (dbg) fprintf(stderr, "[bai] tile %d: %lld records, u_base %lld\n", c.tile, (long long)c.n_rec, (long long)(h->tile_u_lo - h->tile_prefix));
 		if (c.n_rec <= 0) return true;
 		d_key.ensure_slack((size_t)c.n_rec); d_wnd.ensure_slack((size_t)c.n_rec); d_runs.ensure_slack((size_t)c.n_rec + 1);
 		HIPCHK(hipMemsetAsync(d_small.p, 0, 8, h->stream));
@@ -1277,6 +1280,7 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 		if (sm[1] & BAI_F_UNSORTED) throw FormatError("unsorted positions: the BAM is not sorted by coordinate (a BAI index needs that)");
 		if (sm[1] & BAI_F_TOO_FAR) throw FormatError("an alignment ends behind position 2^29: it cannot be stored in a BAI index");
 		if (sm[1] & BAI_F_WINDOWS) throw FormatError("an alignment reaches more than 128 kb behind the end of its reference");
+		if (dbg) fprintf(stderr, "[bai]   %llu runs, flags %llu\n", sm[0], sm[1]);
 		part.resize((size_t)sm[0]);
 		HIPCHK(hipMemcpyAsync(part.data(), d_runs.p, (size_t)sm[0] * sizeof(BaiRun), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
 		// the runs of a tile come in the order of the atomic counter: file order is the order of their offsets (a tile's last-record marker behind a run that starts there)
@@ -1284,6 +1288,7 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 		runs.insert(runs.end(), part.begin(), part.end());
 		return true;
 	});
+	if (dbg) fprintf(stderr, "[bai] tiles done: %zu runs\n", runs.size());
 	std::vector<unsigned long long> lidx_u((size_t)std::max<int64_t>(n_win, 1)), cnt(((size_t)n_ref + 1) * 2);
 	HIPCHK(hipMemcpyAsync(lidx_u.data(), d_lidx.p, lidx_u.size() * 8, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipMemcpyAsync(cnt.data(), d_counts.p, cnt.size() * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1303,7 +1308,9 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 	std::vector<uint64_t> lidx(lidx_u.size());
 	for (size_t i = 0; i < lidx.size(); ++i) lidx[i] = lidx_u[i] == ~0ull ? ~0ull : tell(lidx_u[i]);
 	std::vector<int64_t> counts(cnt.begin(), cnt.end());
+	if (dbg) fprintf(stderr, "[bai] assemble\n");
 	const std::string e = bai_assemble(path, n_ref, tell((uint64_t)h->first_rec), tell((uint64_t)h->total), rv, lidx, first, counts);
+	if (dbg) fprintf(stderr, "[bai] assembled: %s\n", e.c_str());
 	if (!e.empty()) { if (e.compare(0, 12, "cannot write") == 0) throw IoError(e); throw FormatError(e); }
 }
 

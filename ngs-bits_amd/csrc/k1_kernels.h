@@ -574,6 +574,11 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			const uint32_t rel = g - pg_first; const bool nx = rel >= K1_PAGE_GROUPS - 1;
 			return ((const wv::u32x4*)(pool + (uint64_t)(nx ? pg_next : pg_cur) * K1_PAGE_WORDS))[nx ? rel - (K1_PAGE_GROUPS - 1) : rel];
 		};
+		// (a page's link word is only meaningful when the member has groups behind that page: a member that ends with its page was never linked further)
+		auto next_page = [&]() {
+			pg_cur = pg_next; pg_first += K1_PAGE_GROUPS - 1;
+			pg_next = ngroups - pg_first > K1_PAGE_GROUPS - 1 && ngroups > pg_first ? pool[(uint64_t)pg_cur * K1_PAGE_WORDS + K1_PAGE_WORDS - 3] : 0u;
+		};
 		uint32_t P = 0, fail = 0;   // bytes written so far
 		wv::u32x4 nxt = (uint32_t)lane < ngroups ? group((uint32_t)lane) : noop4;
 		for (uint32_t g0 = 0; g0 < ngroups;)
@@ -589,7 +594,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 				((uint32_t*)S.lit)[lane] = pool[(uint64_t)wv::readlane(t1, 0) + (uint32_t)lane];
 				wv::barrier();
 				g0 += 1;
-				if (g0 - pg_first >= K1_PAGE_GROUPS - 1) { pg_cur = pg_next; pg_first += K1_PAGE_GROUPS - 1; pg_next = pool[(uint64_t)pg_cur * K1_PAGE_WORDS + K1_PAGE_WORDS - 3]; }
+				if (g0 - pg_first >= K1_PAGE_GROUPS - 1) next_page();
 				nxt = g0 + (uint32_t)lane < ngroups ? group(g0 + (uint32_t)lane) : noop4;
 				continue;
 			}
@@ -633,7 +638,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			// the next batch's groups are requested now; they arrive while this batch is resolved
 			{
 				const uint32_t g1 = g0 + ng;
-				if (g1 - pg_first >= K1_PAGE_GROUPS - 1) { pg_cur = pg_next; pg_first += K1_PAGE_GROUPS - 1; pg_next = pool[(uint64_t)pg_cur * K1_PAGE_WORDS + K1_PAGE_WORDS - 3]; }
+				if (g1 - pg_first >= K1_PAGE_GROUPS - 1) next_page();
 				nxt = g1 + (uint32_t)lane < ngroups ? group(g1 + (uint32_t)lane) : noop4;
 			}
 

@@ -15,7 +15,7 @@ extern "C" {
 // (what the library does).
 // stats[0] = rendezvous count, stats[1] = token words written, stats[2] = no-op words among them, stats[3] = rendezvous count of phase 1,
 // stats[4] = pool pages used, stats[5] = wave iterations of the symbol loop (two trips each), stats[6] = lane trips that decoded,
-// stats[7] = wave iterations of the slow section, stats[8] = lane trips that waited for input.
+// stats[7] = wave iterations of the slow section, stats[8] = lane trips that waited for input, stats[13] = members whose token groups fill their last page exactly.
 int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uint8_t* out, BlockStatus* st, int park_hi, int tok_mode,
                     int p1_wgs, int p2_wgs, int order_mode, uint64_t* stats)
 {
@@ -36,11 +36,12 @@ int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uin
 			k1::huff_tokens_kernel(comp, blocks, n, pool.data(), (uint32_t)pages, &pool_ctr, tok_first.data(), tok_count.data(), st, &work, order_mode ? order.data() : nullptr, park_hi);
 		});
 	const uint64_t sync1 = wv::emu().n_sync;
-	uint64_t words = 0, noops = 0;
+	uint64_t words = 0, noops = 0, full_pages = 0;
 	for (int64_t i = 0; i < n; ++i)
 	{
 		if (st[i].error) continue;
 		words += 4ull * tok_count[(size_t)i];
+		if (tok_count[(size_t)i] && tok_count[(size_t)i] % (K1_PAGE_GROUPS - 1) == 0) ++full_pages;   // members whose token stream ends with its page
 		uint32_t page = tok_first[(size_t)i];
 		for (uint32_t g = 0; g < tok_count[(size_t)i]; ++g)
 		{
@@ -59,7 +60,7 @@ int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uin
 	if (stats)
 	{
 		stats[0] = wv::emu().n_sync; stats[1] = words; stats[2] = noops; stats[3] = sync1; stats[4] = pool_ctr;
-		stats[5] = wv::emu_stats()[0]; stats[6] = wv::emu_stats()[1]; stats[7] = wv::emu_stats()[2]; stats[8] = wv::emu_stats()[3]; stats[9] = wv::emu_stats()[4]; stats[10] = wv::emu_stats()[5]; stats[11] = wv::emu_stats()[6]; stats[12] = wv::emu_stats()[7];
+		stats[5] = wv::emu_stats()[0]; stats[6] = wv::emu_stats()[1]; stats[7] = wv::emu_stats()[2]; stats[8] = wv::emu_stats()[3]; stats[9] = wv::emu_stats()[4]; stats[10] = wv::emu_stats()[5]; stats[11] = wv::emu_stats()[6]; stats[12] = wv::emu_stats()[7]; stats[13] = full_pages;
 	}
 	return 0;
 }

@@ -135,6 +135,20 @@ def test_synthetic_bam_members(emul):
     assert stats[6] * 1.5 <= stats[1] - stats[2]   # more than 1.5 tokens per decoding lane trip
 
 
+def test_member_whose_tokens_end_with_their_page(emul):
+    """a member whose token groups fill the last page exactly has no page behind it: phase 2 must not follow that page's link word (whatever the pool
+    held before - here 0xdeadbeef - is not a page). Literal-only members around 510 groups (two pages; the first page of a member is linked when the second one is taken, the last
+    one never): some of them end exactly with the second page."""
+    rng = random.Random(23); cases = []
+    for n in range(1700, 2500):
+        raw = bytes(rng.randrange(64, 96) for _ in range(n))
+        cases.append((raw, deflate(raw, 6, 8, zlib.Z_HUFFMAN_ONLY)))
+    img, mem = image(cases, rng)
+    got, st, stats = run(emul, img, mem)
+    check(cases, got, st, allow_overflow=False)
+    assert stats[13] >= 1 and stats[4] >= 2 * len(cases)
+
+
 def _bgzf_members(img):
     import struct
     pos = 0; mem = []
