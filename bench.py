@@ -582,8 +582,11 @@ def main():
                         if os.path.exists(tool_bin):
                             qc = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_e2e_{args.seed}.qcML")
                             tt = time.perf_counter()
-                            rc = subprocess.run([tool_bin, "-in", bam_path, "-wgs", "-build", "hg38", "-out", qc, "-no_ref"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+                            rc = subprocess.run([tool_bin, "-in", bam_path, "-wgs", "-build", "hg38", "-out", qc, "-no_ref"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600,
+                                                env=dict(os.environ, NGSQC_TIMING="1"))
                             out["end_to_end"]["tool_wall_s"] = round(time.perf_counter() - tt, 3) if rc.returncode == 0 else None
+                            # where the tool's wall time goes (seconds since process start, NGSQC_TIMING stamps of the host layer)
+                            out["end_to_end"]["tool_stamps"] = [ln[len("[ngsqc] "):].strip() for ln in rc.stderr.decode(errors="replace").splitlines() if ln.startswith("[ngsqc] ")][:16]
                             out["end_to_end"]["tool"] = "bin/MappingQC -in <file> -wgs -build hg38 -out <qcML> -no_ref (process start to exit: open, fused job incl. contamination, qcML)"
                             if rc.returncode != 0:
                                 out["end_to_end"]["tool_error"] = rc.stderr.decode(errors="replace")[-200:]
