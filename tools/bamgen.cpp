@@ -312,6 +312,9 @@ Image generate(const Params& P)
 					int64_t o = (int64_t)offs[i] + P.start_pos; int tid = P.first_contig;
 					while (tid < 24 && o >= HG38_LENS[tid]) { o -= HG38_LENS[tid]; ++tid; }
 					if (o >= HG38_LENS[tid]) o = HG38_LENS[tid] - 1;
+					// a read keeps its start: one that would reach behind the end of the contig starts early enough instead (moving single reads back by their own
+					// reference length left the last ~150 bp of every contig out of coordinate order, which `samtools index` - and ngsqc_write_bai - refuse)
+					{ const int64_t room = P.mode == 0 ? 176 : 640000; if (o > HG38_LENS[tid] - room) o = std::max<int64_t>(0, HG38_LENS[tid] - room); }
 					uint64_t serial = (uint64_t)(c * chunk + i);
 					if (P.mode == 0) short_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial, P.flavor); else long_read(rec, g, tid, (int32_t)o, HG38_LENS[tid], serial);
 					z.write(rec.data(), rec.size(), true);
