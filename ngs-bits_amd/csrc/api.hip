@@ -170,6 +170,13 @@ struct ngsqc_handle
 
 namespace {
 
+// NGSQC_DEBUG: where the wall time of an open goes (ms since the first stamp of the process)
+void dbg_stamp(const char* what)
+{
+	static const bool on = getenv("NGSQC_DEBUG") != nullptr; static const double t0 = wall_ms();
+	if (on) fprintf(stderr, "[ngsqc] t+%.1f ms %s\n", wall_ms() - t0, what);
+}
+
 // ---- BGZF member table (host): SAM spec §4.1 ----
 // members of [off, off_end) (off_end: a member start or the end of the file), at most max_members of them; upos continues at `upos`
 void walk_bgzf(const uint8_t* file, size_t n, size_t& off, size_t off_end, int64_t max_members, uint64_t& upos, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, std::vector<uint64_t>* file_off = nullptr)
@@ -369,9 +376,12 @@ void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 {
 	ngsqc_handle::Upload* u = h->up;
 	const size_t n = end - beg;
+	dbg_stamp("upload: allocating the image buffer");
 	h->d_comp.alloc(n + 1024);
+	dbg_stamp("upload: image buffer allocated");
 	HIPCHK(hipMemsetAsync(h->d_comp.p + n, 0, 1024, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
+	dbg_stamp("upload: first device operation done");
 	u->piece = 64u << 20; if (const char* e = getenv("NGSQC_H2D_PIECE_MB")) u->piece = (size_t)std::max(1, atoi(e)) << 20;
 	u->bytes = n; u->n_pieces = (n + u->piece - 1) / u->piece; u->next = 0; u->done = 0; u->cancel = false; u->t0 = wall_ms(); u->t_done = u->t0;
 	u->recorded.assign(u->n_pieces, 0); u->ev.assign(u->n_pieces, nullptr);
@@ -400,7 +410,7 @@ void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 			}
 			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); u->cv.notify_all(); }
 			if (st) (void)hipStreamDestroy(st);
-			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
+			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) { u->t_done = wall_ms(); dbg_stamp("upload: last piece on the device"); } }
 			u->cv.notify_all();
 		});
 }
@@ -440,9 +450,13 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 	{
 		// a path: the copy starts before anything else looks at the file (the BGZF member walk below runs beside it; the header read waits for the first pieces only)
 		if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+		dbg_stamp("open: start");
 		init_device(h, device);
+		dbg_stamp("open: device and streams ready");
 		upload_start(h, bytes, 0, n);
+		dbg_stamp("open: upload threads started");
 		scan_bgzf(bytes, n, h->blocks, h->crc, h->total, n_shards == 1 ? &h->member_off : nullptr);
+		dbg_stamp("open: BGZF member table walked");
 	}
 	else { scan_bgzf(bytes, n, h->blocks, h->crc, h->total, n_shards == 1 ? &h->member_off : nullptr); init_device(h, device); }
 	Timer t(h->stream); t.start();
@@ -452,6 +466,7 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 		if (!h->up) { upload_compressed(h, bytes, 0, n); h->tm.h2d_ms = t.stop(); }
 		h->tm.compressed_bytes = (int64_t)n; h->tm.inflated_bytes = h->total;
 		read_header(h, (int64_t)h->blocks.size());
+		dbg_stamp("open: BAM header read");
 		return;
 	}
 	// ---- header: only the first members are sent to the device ----
@@ -575,8 +590,11 @@ void plan_layout_now(ngsqc_handle* h)
 	}
 	h->d_kdesc.upload(kd, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
 	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_tok_first.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch); h->d_pool_ctr.ensure((size_t)h->nch);
+	dbg_stamp("layout: member tables on the device");
 	h->d_tok.ensure((size_t)(n_slots * h->slot_pages) * K1_PAGE_WORDS + 16);
+	dbg_stamp("layout: token pool allocated");
 	for (int i = 0; i < std::min(nt, h->nbuf); ++i) h->buf[i].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
+	dbg_stamp("layout: tile buffers allocated");
 	h->max_tile_members = 0; for (auto& tl : h->tiles) h->max_tile_members = std::max(h->max_tile_members, tl.second);
 	// NGSQC_PREWALK=1: the CRC pass of K1 also follows every member's record chain, so that K2 only has to adopt it (K2 + scan of a 96 M-read shard
 	// 9.2 -> 6.6 ms un-pipelined). Off by default: the chain walk triples the life of the CRC waves, which then hold the wave slots phase 2 needs -
@@ -883,6 +901,7 @@ void sync_all(ngsqc_handle* h)
 template <class F> void stream_tiles(ngsqc_handle* h, F f)
 {
 	plan_layout(h);
+	dbg_stamp("tile stream: layout ready");
 	const int nt = (int)h->tiles.size();
 	if (nt == 0) { h->decoded = true; h->n_rec = 0; return; }
 	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(resident_ctx(h)); return; }
@@ -1441,7 +1460,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		const char* ep = getenv("NGSQC_ASYNC_PLAN");
 		if (h->up && (!ep || atoi(ep) != 0))
 			h->plan_thread = std::thread([h] {
-				try { HIPCHK(hipSetDevice(h->device)); plan_layout_now(h); }
+				try { HIPCHK(hipSetDevice(h->device)); dbg_stamp("layout thread: start"); plan_layout_now(h); dbg_stamp("layout thread: done"); }
 				catch (std::exception& e) { h->plan_err = e.what(); h->planned = false; }
 			});
 	}
@@ -1582,6 +1601,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_reads && !r->read_stats) throw ArgError("raw-read QC job without a result buffer");
 	if (j->n_sites < 0) throw ArgError("invalid site count");
 	const double w0 = wall_ms();
+	dbg_stamp("job: start");
 	h->tm.scan_ms = 0; h->tm.scan_kernel_ms = 0; h->tm.scan_launches = 0; h->tm.finalize_ms = 0; h->tm.depth_scan_ms = 0; h->tm.pileup_ms = 0; h->tm.reads_ms = 0; h->tm.scan_algorithmic_bytes = 0;   // (every per-consumer field of the previous job)
 	Timer total(h->stream); total.start();
 	ngsqc_handle::Partial local_map; ScanState dscan; PileupState pile; ReadsState reads;
