@@ -75,7 +75,7 @@ uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) 
 
 constexpr int K1_CHUNK_WAVES_PER_CU = 6;   // a K1 chunk = this many decoder waves per CU (x 64 members); the launch itself keeps up to P1_WAVES_PER_CU resident
 constexpr int P1_WAVES_PER_CU = 12;       // decoder waves a CU holds (11 KB LDS and <= 128 VGPRs each); NGSQC_P1_WAVES
-constexpr int K1_SLOTS_DEFAULT = 4;  // token ring: chunk c uses slot c % slots (phase 1 of the next chunks runs while phase 2 of c reads); NGSQC_TOKEN_SLOTS
+constexpr int K1_SLOTS_DEFAULT = 3;  // token ring: chunk c uses slot c % slots (phase 1 of the next two chunks runs while phase 2 of c reads; a fourth slot measured the same: 865 / 877 vs 890 / 884 Mreads/s on 96 M reads); NGSQC_TOKEN_SLOTS
 constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
 
 // target regions + per-base depth of one scan
@@ -1612,7 +1612,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_sites) pile.begin(h, j->sites, j->n_sites, j->site_min_mapq, j->site_min_baseq, j->site_include_npp);
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
 	const double w1 = wall_ms();
-	FuseGuard fg(h, do_map ? &map.scan : (do_depth ? &dscan : nullptr));
+	FuseGuard fg(h, do_map ? &map.scan : (do_depth && j->depth->min_baseq <= 0 ? &dscan : nullptr));
 	stream_tiles(h, [&](const TileCtx& c) {
 		if (do_map) map.scan.tile(h, c);
 		if (part && c.ord_base == 0 && c.n_rec > 0)
@@ -2009,7 +2009,9 @@ void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 	ScanState sc; sc.in_pass_fix = false;
 	depth_setup(h, p, h->ds[0], sc);
 	sc.begin(h);
-	{ FuseGuard fg(h, &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
+	// (base-quality decrements make a record's scan long: a thread per RECORD - K2, then the scan kernel - beats the thread per member of the fused walk,
+	// 147 vs 224 ms per 96 M reads with -min_baseq 20)
+	{ FuseGuard fg(h, p->min_baseq > 0 ? nullptr : &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
 	sc.end(h);
 	h->cur_ds = 0;
 	h->tm.scan_ms = sc.stage_ms; h->tm.scan_kernel_ms = sc.kernel_ms; h->tm.scan_launches = sc.launches; h->tm.scan_algorithmic_bytes = (int64_t)sc.dev[A_ALG_BYTES];

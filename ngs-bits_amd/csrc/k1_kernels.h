@@ -18,12 +18,14 @@
 //              them (v_alignbit) into 64 fresh bits - no bit buffer to shift, no refill state.
 //            * Tokens leave in groups of four slots (two trips), one 16-byte store per group, into pages of a pool that the
 //              lanes allocate from with one atomic per page.
-//   phase 2  lz77_groups_kernel : ONE WAVE PER MEMBER. A batch is up to 56 token groups (<= 224 tokens, <= P2_BMAX bytes): a
-//            wave prefix sum places every token and sets a flag on its last byte; per 64-byte chunk the flags become a lane
-//            mask (ballot) from which every OUTPUT BYTE gets its owner token (v_mbcnt), and its source in periodic form
-//            (i mod dist). Pass 1 classifies all bytes of the batch and issues every gather that reaches behind the batch
-//            (HBM) in one go; pass 2 resolves the chunks front to back: a source in an earlier chunk comes from the LDS
-//            staging bytes, one in the same chunk from the source LANE. One HBM round trip per batch instead of one per 64 bytes.
+//   phase 2  lz77_groups_kernel : ONE WAVE PER MEMBER. A batch is 64 token groups (one per lane, <= 256 tokens) cut to <= P2_BMAX bytes: a
+//            wave prefix sum places every token; per TOKEN one word says what a byte of it needs to know (literal value from the block's
+//            literal table | near / self-overlapping / far match | raw run), and a flag marks the token's last byte. Per 64-byte chunk
+//            the flags become a lane mask (ballot) from which every OUTPUT BYTE gets its owner token (v_mbcnt) and, from the token's
+//            word, its source; a self-overlapping match is put in periodic form (offset mod distance). Sub-batches of four chunks:
+//            pass 1 classifies their bytes and issues every gather that reaches behind the batch (HBM) - one wait - pass 2 resolves the
+//            chunks front to back: a source in an earlier chunk comes from the LDS staging bytes, one in the same chunk from the source
+//            LANE (iterating only while a lane's source is itself pending). Every byte is written once to LDS and once to HBM.
 //
 // Written against the wave vocabulary of wave.h only (see there). Integer work, no MFMA. RFC 1951; the reference reaches
 // zlib's inflate through htslib's bgzf.c under BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-392).
