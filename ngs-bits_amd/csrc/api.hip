@@ -513,7 +513,7 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 }
 
 // ---- layout of the tile stream: K1 chunks, tiles (whole chunks), token ring, static device tables -------------------------
-// NGSQC_TILE_MEMBERS=k (tests): chunks and tiles of k members. NGSQC_TILE_CHUNKS: chunks per tile (default 1).
+// NGSQC_TILE_MEMBERS=k (tests): chunks and tiles of k members. NGSQC_TILE_CHUNKS: chunks per tile (default 2).
 // NGSQC_K1_CHUNK_DIV: chunk = one decoder round / div. NGSQC_CARRY_MAX: bytes reserved in front of a tile for a straddling record.
 void plan_layout_now(ngsqc_handle* h)
 {
@@ -525,8 +525,9 @@ void plan_layout_now(ngsqc_handle* h)
 	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
 	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
 	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * K1_CHUNK_WAVES_PER_CU * 64 * mul / div);
-	// one K1 chunk per tile: with the round-3 kernels the job is as fast as with two (105-109 vs 107-113 ms per 96 M reads), and the three tile buffers take 19 GB instead of 38
-	int64_t cpt = 1; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
+	// two K1 chunks per tile (192 M reads, 12 chunks; job Mreads/s | un-pipelined scan-stage share of the HBM roofline): 1 chunk 919 | 0.36, 2 chunks 931-941 | 0.43-0.44, 4 chunks
+	// 930 | 0.46. The job barely cares; the chain walk of the fused scan has one thread per MEMBER, so a tile of 195 k members keeps twice the lines in flight of a 97 k one.
+	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
 	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile). NGSQC_TILE_BUFFERS=2..4.
 	h->nbuf = 3; if (const char* e = getenv("NGSQC_TILE_BUFFERS")) h->nbuf = std::min<int>(ngsqc_handle::MAX_TILE_BUFS, std::max(2, atoi(e)));
