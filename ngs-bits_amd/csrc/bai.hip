@@ -84,12 +84,29 @@ bool bai_range(const std::string& bam_path, const ngsqc_region* regions, int64_t
 		if (!R.ioffset.empty()) { const size_t w = (size_t)(beg >> 14); min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back(); }
 		bins.clear(); reg2bins(beg, end, bins);
 		std::sort(bins.begin(), bins.end());
+		uint64_t rb = ~0ull, re = 0, stop = ~0ull; bool any = false;
 		for (const auto& bc : R.bins)
 		{
-			if (bc.first == 37450u || !std::binary_search(bins.begin(), bins.end(), bc.first)) continue;   // (37450: the metadata pseudo-bin)
-			for (const BaiChunk& c : bc.second)
-				if (c.end > min_off) { beg_voff = std::min(beg_voff, c.beg); end_voff = std::max(end_voff, c.end); found = true; }
+			if (bc.first >= 37449u) continue;   // (37450: the metadata pseudo-bin)
+			if (std::binary_search(bins.begin(), bins.end(), bc.first))
+			{
+				for (const BaiChunk& c : bc.second)
+					if (c.end > min_off) { rb = std::min(rb, c.beg); re = std::max(re, c.end); any = true; }
+				continue;
+			}
+			// A bin whose interval starts at or behind the region's end holds only records that start there, so its first chunk starts at such a record. The file is
+			// sorted by start: every record that overlaps the region lies in front of that record - where the iterator of the reference stops, too (hts_itr_next:
+			// "beg >= iter->end"). Without this bound the range runs to the last chunk of the region's 8 Mb / 64 Mb super-bins.
+			int l = 0; uint32_t first = 0;
+			while (l < 5 && bc.first >= ((1u << (3 * (l + 1))) - 1u) / 7u) { ++l; first = ((1u << (3 * l)) - 1u) / 7u; }
+			const int64_t bin_start = (int64_t)(bc.first - first) << (14 + 3 * (5 - l));
+			if (bin_start >= end) for (const BaiChunk& c : bc.second) stop = std::min(stop, c.beg);
 		}
+		if (!any) continue;
+		rb = std::max(rb, min_off);             // every record that overlaps the region's first window starts at or behind the linear index' offset
+		if (stop != ~0ull && stop >= rb) re = std::min(re, stop);
+		if (re <= rb) continue;
+		beg_voff = std::min(beg_voff, rb); end_voff = std::max(end_voff, re); found = true;
 	}
 	return true;
 }

@@ -230,3 +230,19 @@ def device_view(n_ref, offset0, recs, cuts=()):
         counts[2 * (tid if tid >= 0 else n_ref) + (0 if mapped else 1)] += 1
         prev = key; start = after
     return runs, lidx, first, counts
+
+
+def write_bai(path, parsed):
+    """serialize (refs, n_no_coor) as parse_bai returns it (bins in ascending order)"""
+    refs, n_no_coor = parsed
+    out = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
+    for bins, lidx in refs:
+        out += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            out += struct.pack("<Ii", b, len(bins[b]))
+            for beg, end in bins[b]:
+                out += struct.pack("<QQ", beg, end)
+        out += struct.pack("<i", len(lidx)) + struct.pack("<%dQ" % len(lidx), *lidx)
+    if n_no_coor is not None:
+        out += struct.pack("<Q", n_no_coor)
+    open(path, "wb").write(bytes(out))

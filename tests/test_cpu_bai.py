@@ -115,3 +115,32 @@ def test_assemble_rejects_unsorted(tmp_path):
                 [(100 << 16, 0, 4681, 9, 0), (100 << 16, 0, 4681, 9, 1), (200 << 16, 0, 4681, 7, 0)]):          # positions go back across a tile boundary
         with pytest.raises(ngsqc.NgsqcError):
             ngsqc.bai_assemble(out, 2, 100 << 16, 300 << 16, bad, [100 << 16, 200 << 16], [0, 1, 2], [1, 0, 1, 0, 0, 0])
+
+
+@pytest.mark.parametrize("mode,n_reads,depth", [(0, 60000, 0.0029), (1, 3000, 0.02)], ids=["short_reads_whole_genome", "long_reads"])
+def test_bai_range_on_generated_bams(mode, n_reads, depth, tmp_path):
+    """the bench generator's BAM spread over the whole genome (every bin level is populated; long reads sit in the upper levels), indexed by the oracle: the range
+    of a region holds every overlapping record and ends where the records behind the region begin"""
+    import bamgen_lib
+    import numpy as np
+    p = str(tmp_path / "g.bam")
+    np.asarray(bamgen_lib.generate(n_reads=n_reads, seed=9, mode=mode, depth=depth, threads=4)).tofile(p)
+    bai_build.write_bai(p + ".bai", bai_build.build_for_bam(p))
+    recs, n_ref = records_with_voff(p)
+    rng = random.Random(17); mapped = [r for r in recs if r[0] >= 0]
+    total_in_range = total_hits = 0
+    for k in range(150):
+        t, p0, e0, _, _ = rng.choice(mapped)
+        width = rng.choice([1, 300, 20000, 700000, 20_000_000])
+        s1 = max(1, p0 + 1 - rng.randrange(0, width)); e1 = s1 + width
+        regions = [(t, s1, e1)]
+        if k % 3 == 0:
+            t2, q0, _, _, _ = rng.choice(mapped); regions.append((t2, q0 + 1, q0 + 1 + rng.choice([1, 5000])))
+        beg, end, found = ngsqc.bai_range(p, regions, n_ref)
+        hits = [r for r in recs if any(r[0] == g[0] and r[1] < g[2] and r[2] > g[1] - 1 for g in regions)]
+        assert hits and found
+        assert all(beg <= r[3] and r[4] <= end for r in hits), (regions, beg, end)
+        if len(regions) == 1:
+            total_hits += len(hits); total_in_range += sum(1 for r in recs if beg <= r[3] < end)
+    # tight: what a single-region range holds beyond the overlapping records is what lies in the 16 kb windows around the region, not in its 8 Mb super-bin
+    assert total_in_range <= total_hits + 100 * 40, (total_in_range, total_hits)
