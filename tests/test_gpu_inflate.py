@@ -77,13 +77,22 @@ SHAPES = {
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 @pytest.mark.parametrize("variant", ["default", "no_park", "tiles_of_2", "no_crc"])
 def test_inflate_shapes(raw_bam, shape, variant, monkeypatch):
-    # (huffman_only overflows the clen + 64 token budget of a member: it takes the second-chance path with a worst-case budget)
+    # (huffman_only needs more token pages than the library's pool holds for it: the second-chance path with a worst-case pool)
     env = {"default": {}, "no_park": {"NGSQC_P1_PARK": "0"}, "tiles_of_2": {"NGSQC_TILE_MEMBERS": "2"}, "no_crc": {"NGSQC_VERIFY_CRC": "0"}}[variant]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     kw = dict(SHAPES[shape]); sizes = kw.pop("sizes")
     n = _roundtrip(raw_bam, rebgzf(raw_bam, sizes, **kw))
     assert n == 30000
+
+
+@pytest.mark.parametrize("shape", ["level6_ragged", "huffman_only", "stored_small"])
+def test_token_pool_that_runs_dry_in_every_tile(raw_bam, shape, monkeypatch):
+    """a token pool of 1 % of the library's size runs out of pages in every chunk (literal-heavy, badly compressing members): the members that could
+    not finish report K1_ERR_TOKEN_OVERFLOW and are inflated again, in batches, with a worst-case pool - in every tile of the stream; same bytes, same records"""
+    monkeypatch.setenv("NGSQC_TILE_MEMBERS", "8"); monkeypatch.setenv("NGSQC_TOKEN_POOL_FACTOR", "0.01")
+    kw = dict(SHAPES[shape]); sizes = kw.pop("sizes")
+    assert _roundtrip(raw_bam, rebgzf(raw_bam, sizes, **kw)) == 30000
 
 
 def test_runs_and_periodic_matches():
