@@ -222,6 +222,12 @@ int ngsqc_open_head(const char* bam_path, int device, int64_t n_members, ngsqc_h
 /* SAM header text of the BAM header (NUL-terminated copy into out[cap] when out != NULL); returns its length, -1 without a handle */
 int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap);
 
+/* The BGZF member table of a BAM image on the host (SAM spec 4.1; what ngsqc_open builds before anything reaches the device; no device needed): members that
+ * inflate to nothing (the EOF block) are left out. n_threads > 1 walks the file in pieces (accepted only when the pieces join exactly; else the sequential walk).
+ * NGSQC_E_FORMAT with the message of the first broken member. */
+typedef struct ngsqc_bgzf_member { uint64_t file_offset, payload_offset, inflated_offset; uint32_t payload_bytes, inflated_bytes, crc32, walked_in_pieces /* 1: the table came from the multi-thread walk */; } ngsqc_bgzf_member;
+int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ngsqc_bgzf_member* out, int64_t cap, int64_t* n_members, int64_t* inflated_bytes);
+
 /* ---- writing the index. The reference never builds one: every indexed path above fails with "Could not load index of BAM/CRAM file"
  * (BamReader.cpp:742-746) until `samtools index` (htslib sam_index_build: hts_idx_push / hts_idx_finish / compress_binning, hts.c) has left a
  * <bam>.bai next to the BAM. ngsqc_write_bai writes that file (bai_path NULL: <path of the handle>.bai) from a handle on the whole BAM: one pass

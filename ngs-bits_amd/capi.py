@@ -158,7 +158,7 @@ EXPORTS = [
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
-    "ngsqc_write_bai", "ngsqc_bai_assemble",
+    "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan",
 ]
 
 
@@ -172,6 +172,25 @@ def bai_range(bam_path, regions, n_ref):
     if rc != 0:
         raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
     return int(b.value), int(e.value), bool(f.value)
+
+
+def bgzf_scan(data, threads=1):
+    """BGZF member table of a BAM image (host only): structured array (file_offset, payload_offset, inflated_offset, payload_bytes, inflated_bytes, crc32)
+    and the inflated size. threads > 1: the walk in pieces (falls back to the sequential walk when the pieces do not join)."""
+    L = lib()
+    L.ngsqc_bgzf_scan.restype = C.c_int
+    L.ngsqc_bgzf_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    dt = np.dtype([("file_offset", "<u8"), ("payload_offset", "<u8"), ("inflated_offset", "<u8"), ("payload_bytes", "<u4"), ("inflated_bytes", "<u4"), ("crc32", "<u4"), ("walked_in_pieces", "<u4")])
+    n, tot = C.c_int64(0), C.c_int64(0)
+    rc = L.ngsqc_bgzf_scan(a.ctypes.data, a.size, int(threads), None, 0, C.byref(n), C.byref(tot))
+    if rc != 0:
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+    out = np.zeros(max(n.value, 1), dtype=dt)
+    rc = L.ngsqc_bgzf_scan(a.ctypes.data, a.size, int(threads), out.ctypes.data, n.value, C.byref(n), C.byref(tot))
+    if rc != 0:
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+    return out[:n.value], int(tot.value)
 
 
 def bai_assemble(bai_path, n_ref, first_record_voff, end_voff, runs, lidx, lidx_first, counts):
