@@ -462,8 +462,9 @@ void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 	int T = 4; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
 	T = (int)std::min<size_t>((size_t)T, std::max<size_t>(u->n_pieces, 1));
 	uint8_t* const dst = h->d_comp.p; const uint8_t* const src = bytes + beg; const int device = h->device;
+	int delay_us = 0; if (const char* e = getenv("NGSQC_H2D_DELAY_US")) delay_us = std::max(0, atoi(e));   // (tests: a slow link, so that the chunk stream really waits for pieces)
 	for (int t = 0; t < T && u->n_pieces; ++t)
-		u->th.emplace_back([u, dst, src, device] {
+		u->th.emplace_back([u, dst, src, device, delay_us] {
 			hipStream_t st = nullptr;
 			try
 			{
@@ -474,6 +475,7 @@ void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
 					const size_t i = u->next.fetch_add(1);
 					if (i >= u->n_pieces || u->cancel) break;
 					const size_t off = i * u->piece, sz = std::min(u->piece, u->bytes - off);
+					if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
 					HIPCHK(hipMemcpyAsync(dst + off, src + off, sz, hipMemcpyHostToDevice, st));
 					HIPCHK(hipEventRecord(u->ev[i], st));
 					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
