@@ -713,20 +713,31 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;
 	const char* eks = getenv("NGSQC_K1_SERIAL"); const bool k1_serial = eks && atoi(eks) != 0;   // profiling: every K1 kernel in line on ONE stream (isolated per-kernel counters)   // 1: the next chunk's phase 1 starts when the whole previous launch is done
 	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (!ce || atoi(ce) != 0) ? h->s_crc : h->s_p2;
-	for (int64_t c = h->tile_first_chunk[(size_t)t]; c < h->tile_first_chunk[(size_t)t + 1]; ++c)
-	{
+	// NGSQC_K1_PHASED=1 (an experiment for the next measurement, off by default): the phases of a tile's chunks take turns instead of running beside each other -
+	// phase 1 of all chunks of the tile together (two decoder launches fill the decoder slots), then their phase 2 launches with the chip to themselves (phase 2
+	// next to resident decoder waves gets three waves per SIMD instead of eight and takes twice as long), and the next tile's decoders start behind them.
+	const char* eph = getenv("NGSQC_K1_PHASED"); const bool phased = eph && atoi(eph) != 0 && !k1_serial;
+	const int64_t cA = h->tile_first_chunk[(size_t)t], cB = h->tile_first_chunk[(size_t)t + 1];
+	auto launch_p1 = [&](int64_t c) {
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
+		if (phased && cA > 0) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (cA - 1) + 3)], 0));            // behind the previous tile's last phase 2
 		if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
 		HIPCHK(hipEventRecord(e4[0], s1));
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, pool, (uint32_t)h->slot_pages, h->d_pool_ctr.p + c, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_work.p + c,
 		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->p1_wgs, s1);
 		HIPCHK(hipEventRecord(e4[1], s1));
+	};
+	auto launch_p2 = [&](int64_t c) {
+		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
+		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
+		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;
 		HIPCHK(hipStreamWaitEvent(h->s_p2, e4[1], 0));
-		if (c == h->tile_first_chunk[(size_t)t] && t >= h->nbuf) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - h->nbuf) + 1)], 0));   // the buffer's previous tile is consumed
+		if (phased) for (int64_t k = cA; k < cB; ++k) if (k != c) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_chunk[(size_t)(4 * k + 1)], 0));   // every decoder launch of the tile is done
+		if (c == cA && t >= h->nbuf) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - h->nbuf) + 1)], 0));   // the buffer's previous tile is consumed
 		HIPCHK(hipEventRecord(e4[2], h->s_p2));
 		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, pool, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_comp.p, h->s_p2);
 		HIPCHK(hipEventRecord(e4[3], h->s_p2));
@@ -742,7 +753,15 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 			}
 			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream, h->prewalk ? &cw : nullptr);
 		}
+	};
+	if (phased)
+	{
+		if (cB - cA > h->k1_slots) throw ArgError("NGSQC_K1_PHASED needs at least as many token slots as chunks per tile");
+		for (int64_t c = cA; c < cB; ++c) launch_p1(c);
+		for (int64_t c = cA; c < cB; ++c) launch_p2(c);
 	}
+	else
+		for (int64_t c = cA; c < cB; ++c) { launch_p1(c); launch_p2(c); }
 	const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second;
 	hipStream_t s_last = h->verify_crc ? crc_stream : h->s_p2;
 	HIPCHK(hipMemcpyAsync(h->p_status.p + f, h->d_status.p + f, (size_t)m * sizeof(BlockStatus), hipMemcpyDeviceToHost, s_last));

@@ -17,6 +17,7 @@ import hostprep as H  # noqa: E402
 
 VARIANTS = {
     "default": {},
+    "phased": {"NGSQC_K1_PHASED": "1"}, "phased_t4": {"NGSQC_K1_PHASED": "1", "NGSQC_TILE_CHUNKS": "4", "NGSQC_TOKEN_SLOTS": "4"}, "walk8": {"NGSQC_WALK_THREADS": "8"},
     "nopipe": {"NGSQC_PIPELINE": "0"},
     "nocrc": {"NGSQC_VERIFY_CRC": "0"},
     "div2": {"NGSQC_K1_CHUNK_DIV": "2"},
