@@ -144,3 +144,36 @@ def test_bai_range_on_generated_bams(mode, n_reads, depth, tmp_path):
             total_hits += len(hits); total_in_range += sum(1 for r in recs if beg <= r[3] < end)
     # tight: what a single-region range holds beyond the overlapping records is what lies in the 16 kb windows around the region, not in its 8 Mb super-bin
     assert total_in_range <= total_hits + 100 * 40, (total_in_range, total_hits)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_assemble_equals_oracle_on_random_record_sets(seed, tmp_path):
+    """random coordinate-sorted record lists (short and very long reads, dense and sparse stretches, unmapped reads with and without a position, several references,
+    record sizes that put many or few records into a BGZF member) with synthetic virtual offsets: the library's host half against the oracle, for several tilings"""
+    rng = random.Random(seed)
+    n_ref = rng.randrange(1, 6); recs = []
+    coff = rng.randrange(100, 70000); uoff = rng.randrange(0, 60000)   # the first record's position in the file
+    def advance(nbytes):
+        nonlocal coff, uoff
+        uoff += nbytes
+        while uoff >= 65280: uoff -= 65280; coff += rng.randrange(3000, 30000)
+        return (coff << 16) | uoff
+    offset0 = (coff << 16) | uoff
+    for tid in sorted(rng.sample(range(n_ref), rng.randrange(1, n_ref + 1))):
+        pos = rng.choice([0, 0, rng.randrange(0, 200_000_000)])
+        for _ in range(rng.randrange(1, 1500)):
+            pos += rng.choice([0, 1, rng.randrange(0, 50), rng.randrange(0, 3000), rng.randrange(0, 40000), rng.randrange(0, 3_000_000)])
+            if pos >= (1 << 29) - 1_100_000: break
+            unmapped = rng.random() < 0.03
+            span = 1 if unmapped else rng.choice([rng.randrange(1, 200), rng.randrange(1, 200), rng.randrange(1, 20000), rng.randrange(1, 1_000_000)])
+            recs.append((tid, pos, pos + span, advance(rng.choice([rng.randrange(60, 500), rng.randrange(60, 500), rng.randrange(500, 200000)])), not unmapped))
+    for _ in range(rng.randrange(0, 40)):
+        recs.append((-1, -1, 0, advance(rng.randrange(60, 500)), False))
+    final = advance(0) if rng.random() < 0.5 else ((coff + 20000) << 16)
+    want = bai_build.as_parsed(bai_build.build(n_ref, offset0, recs, final))
+    for k in range(3):
+        cuts = sorted(rng.sample(range(1, len(recs)), min(len(recs) - 1, rng.choice([0, 1, 5, 40])))) if len(recs) > 1 else []
+        runs, lidx, first, counts = bai_build.device_view(n_ref, offset0, recs, cuts)
+        out = str(tmp_path / "r.bai")
+        ngsqc.bai_assemble(out, n_ref, offset0, final, runs, lidx, first, counts)
+        assert bai_build.parse_bai(out) == want, (seed, k)
