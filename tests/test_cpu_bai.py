@@ -146,11 +146,8 @@ def test_bai_range_on_generated_bams(mode, n_reads, depth, tmp_path):
     assert total_in_range <= total_hits + 100 * 40, (total_in_range, total_hits)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
-def test_assemble_equals_oracle_on_random_record_sets(seed, tmp_path):
-    """random coordinate-sorted record lists (short and very long reads, dense and sparse stretches, unmapped reads with and without a position, several references,
-    record sizes that put many or few records into a BGZF member) with synthetic virtual offsets: the library's host half against the oracle, for several tilings"""
-    rng = random.Random(seed)
+def random_records(rng):
+    """-> (n_ref, offset0, [(tid, pos, endpos, voff behind the record, mapped)], final voff): a coordinate-sorted record list with synthetic virtual offsets"""
     n_ref = rng.randrange(1, 6); recs = []
     coff = rng.randrange(100, 70000); uoff = rng.randrange(0, 60000)   # the first record's position in the file
     def advance(nbytes):
@@ -170,6 +167,15 @@ def test_assemble_equals_oracle_on_random_record_sets(seed, tmp_path):
     for _ in range(rng.randrange(0, 40)):
         recs.append((-1, -1, 0, advance(rng.randrange(60, 500)), False))
     final = advance(0) if rng.random() < 0.5 else ((coff + 20000) << 16)
+    return n_ref, offset0, recs, final
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_assemble_equals_oracle_on_random_record_sets(seed, tmp_path):
+    """random coordinate-sorted record lists (short and very long reads, dense and sparse stretches, unmapped reads with and without a position, several references,
+    record sizes that put many or few records into a BGZF member) with synthetic virtual offsets: the library's host half against the oracle, for several tilings"""
+    rng = random.Random(seed)
+    n_ref, offset0, recs, final = random_records(rng)
     want = bai_build.as_parsed(bai_build.build(n_ref, offset0, recs, final))
     for k in range(3):
         cuts = sorted(rng.sample(range(1, len(recs)), min(len(recs) - 1, rng.choice([0, 1, 5, 40])))) if len(recs) > 1 else []
@@ -177,3 +183,27 @@ def test_assemble_equals_oracle_on_random_record_sets(seed, tmp_path):
         out = str(tmp_path / "r.bai")
         ngsqc.bai_assemble(out, n_ref, offset0, final, runs, lidx, first, counts)
         assert bai_build.parse_bai(out) == want, (seed, k)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_bai_range_on_random_record_sets(seed, tmp_path):
+    """queries against the oracle-built index of a random record list (reads of up to 1 Mb sit in the upper bin levels): the range of a region set holds every
+    overlapping record - its start and its end - whatever the region's size and position relative to the bins"""
+    rng = random.Random(seed)
+    n_ref, offset0, recs, final = random_records(rng)
+    p = str(tmp_path / "x.bam")   # (only <path>.bai is read)
+    bai_build.write_bai(p + ".bai", bai_build.as_parsed(bai_build.build(n_ref, offset0, recs, final)))
+    starts = [offset0] + [r[3] for r in recs[:-1]]
+    mapped = [i for i, r in enumerate(recs) if r[0] >= 0]
+    for k in range(300):
+        i = rng.choice(mapped); t, p0, e0 = recs[i][0], recs[i][1], recs[i][2]
+        width = rng.choice([1, 100, 16384, 200_000, 5_000_000, 300_000_000])
+        s1 = max(1, rng.randrange(max(1, p0 + 1 - width), e0 + 1)); e1 = s1 + rng.randrange(0, width)
+        if not (p0 < e1 and e0 > s1 - 1): e1 = max(e1, p0 + 1)
+        regions = [(t, s1, e1)]
+        if k % 4 == 0:
+            j = rng.choice(mapped); regions.append((recs[j][0], recs[j][1] + 1, recs[j][1] + 1 + rng.choice([0, 70000])))
+        beg, end, found = ngsqc.bai_range(p, regions, n_ref)
+        hits = [q for q, r in enumerate(recs) if any(r[0] == g[0] and r[1] < g[2] and r[2] > g[1] - 1 for g in regions)]
+        assert hits and found, (seed, k, regions)
+        assert all(beg <= starts[q] and recs[q][3] <= end for q in hits), (seed, k, regions, beg, end)
