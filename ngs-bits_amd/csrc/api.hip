@@ -1379,7 +1379,7 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 	HIPCHK(hipMemsetAsync(d_small.p, 0, 16, h->stream));   // [0] runs of the tile, [1] flags
 	HIPCHK(hipStreamSynchronize(h->stream));
 	std::vector<BaiRun> runs; std::vector<BaiRun> part;
-	const bool dbg = getenv("NGSQC_BAI_DEBUG") != nullptr;
+	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
 	if (dbg) fprintf(stderr, "[bai] n_ref %d, windows %lld\n", n_ref, (long long)n_win);
 	stream_tiles(h, [&](const TileCtx& c) {
 		if (dbg) fprintf(stderr, "[bai] tile %d: %lld records, u_base %lld\n", c.tile, (long long)c.n_rec, (long long)(h->tile_u_lo - h->tile_prefix));
