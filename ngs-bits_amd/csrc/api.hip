@@ -313,16 +313,19 @@ void upload_wait(ngsqc_handle* h, size_t end_byte, hipStream_t st, int slot);   
 // Synchronous K1 of a few members on the main stream with private scratch (header read, second chance of members that found the token
 // pool of their launch used up). idx: member indices into h->blocks; desc/out: where each one goes. The pool is sized for the worst
 // case (two token slots per output byte), so the call is made in batches of bounded scratch; the scratch is kept across calls.
-void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out)
+void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out, int level = 0)
 {
-	constexpr int64_t BATCH = 2048;   // members per batch: <= 2048 x (2 x 64 Ki slots + tables) x 4 B = 1.1 GB of pool
+	// level 0: two token slots per output byte (enough unless a member holds hundreds of DEFLATE blocks: every block has its literal table in the pool), 2048
+	// members per batch = 1.1 GB of pool; level 1: the bound that holds for every valid member (k1_pool_pages_absolute: up to 17 MB per member), 32 per batch
+	const int64_t BATCH = level == 0 ? 2048 : 32;
+	std::vector<int64_t> idx2; std::vector<BlockDesc> desc2;   // members that need level 1
 	for (int64_t b0 = 0; b0 < (int64_t)idx.size(); b0 += BATCH)
 	{
 		const int64_t n = std::min<int64_t>(BATCH, (int64_t)idx.size() - b0);
 		std::vector<BlockDesc> dd(desc.begin() + b0, desc.begin() + b0 + n); std::vector<uint32_t> crc((size_t)n);
 		uint64_t sc = 0, su = 0;
 		for (int64_t i = 0; i < n; ++i) { crc[(size_t)i] = h->crc[(size_t)idx[(size_t)(b0 + i)]]; sc += dd[(size_t)i].clen; su += dd[(size_t)i].usize; }
-		const uint64_t pages = k1_pool_pages(sc, su, (uint64_t)n, true);
+		const uint64_t pages = level == 0 ? k1_pool_pages(sc, su, (uint64_t)n, true) : k1_pool_pages_absolute(sc, su, (uint64_t)n);
 		{ uint64_t cend = 0; for (const BlockDesc& d : dd) cend = std::max<uint64_t>(cend, d.cpos + d.clen + 64); upload_wait(h, (size_t)cend, h->stream, 0); }
 		h->d_sync_desc.ensure_slack((size_t)n); h->d_sync_st.ensure_slack((size_t)n); h->d_sync_work.ensure(2);
 		h->d_sync_u32.ensure_slack((size_t)(3 * n + 16));   // [first | count | crc]
@@ -337,8 +340,11 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 		std::vector<BlockStatus> st((size_t)n);
 		HIPCHK(hipMemcpyAsync(st.data(), h->d_sync_st.p, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		for (int64_t i = 0; i < n; ++i) if (st[(size_t)i].error) throw FormatError(inflate_error(h, idx[(size_t)(b0 + i)], st[(size_t)i].error));
+		for (int64_t i = 0; i < n; ++i)
+			if (st[(size_t)i].error == K1_ERR_TOKEN_OVERFLOW && level == 0) { idx2.push_back(idx[(size_t)(b0 + i)]); desc2.push_back(desc[(size_t)(b0 + i)]); }
+			else if (st[(size_t)i].error) throw FormatError(inflate_error(h, idx[(size_t)(b0 + i)], st[(size_t)i].error));
 	}
+	if (!idx2.empty()) inflate_sync(h, idx2, desc2, d_out, 1);
 }
 
 // inflate the first members until the BAM header (magic, text, reference table) is complete; parse it

@@ -42,4 +42,13 @@ inline uint64_t k1_pool_pages(uint64_t sum_clen, uint64_t sum_usize, uint64_t n_
 	return words / (K1_PAGE_WORDS - 4) + 3 * n_members + 64;
 }
 
+// The bound that holds for EVERY valid member (third chance, a few members at a time): besides the token slots (at most two per output byte) every DEFLATE
+// block may cost a table group, a 256-byte literal table and a padded last group = 76 words, and the smallest block (an empty fixed-Huffman one: 10 bits) lets a
+// member hold 0.8 blocks per payload byte - zlib's flush markers make such streams.
+inline uint64_t k1_pool_pages_absolute(uint64_t sum_clen, uint64_t sum_usize, uint64_t n_members)
+{
+	const uint64_t words = 2 * sum_usize + 64 * sum_clen + 128 * n_members;
+	return words / (K1_PAGE_WORDS - 4) + 3 * n_members + 64;
+}
+
 } // namespace ngsqc

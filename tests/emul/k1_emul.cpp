@@ -10,7 +10,7 @@ using namespace ngsqc;
 extern "C" {
 
 // comp: compressed image with at least 64 readable bytes behind the last payload. blocks[i]: payload position / output position.
-// tok_mode: 0 = the library's pool size (k1_pool_pages), 1 = worst-case pool, >= 2: a pool of exactly tok_mode pages (overflow tests).
+// tok_mode: 0 = the library's pool size (k1_pool_pages), 1 = worst-case pool (second chance), -1 = the absolute bound (third chance), >= 2: a pool of exactly tok_mode pages (overflow tests).
 // p1_wgs / p2_wgs: grid sizes (0 = one lane / one wave per member). order_mode: 1 = members handed out largest compressed size first
 // (what the library does).
 // stats[0] = rendezvous count, stats[1] = token words written, stats[2] = no-op words among them, stats[3] = rendezvous count of phase 1,
@@ -22,7 +22,7 @@ int k1_emul_inflate(const uint8_t* comp, const BlockDesc* blocks, int64_t n, uin
 	if (n <= 0) return 0;
 	uint64_t sum_c = 0, sum_u = 0;
 	for (int64_t i = 0; i < n; ++i) { sum_c += blocks[i].clen; sum_u += blocks[i].usize; }
-	const uint64_t pages = tok_mode >= 2 ? (uint64_t)tok_mode : k1_pool_pages(sum_c, sum_u, (uint64_t)n, tok_mode == 1);
+	const uint64_t pages = tok_mode >= 2 ? (uint64_t)tok_mode : (tok_mode < 0 ? k1_pool_pages_absolute(sum_c, sum_u, (uint64_t)n) : k1_pool_pages(sum_c, sum_u, (uint64_t)n, tok_mode == 1));
 	std::vector<uint32_t> pool((size_t)pages * K1_PAGE_WORDS + 16, 0xdeadbeefu), tok_first((size_t)n + 8, 0xffffffffu), tok_count((size_t)n + 8, 0), order((size_t)n);
 	uint32_t pool_ctr = 0;
 	std::iota(order.begin(), order.end(), 0u);

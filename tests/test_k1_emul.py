@@ -189,6 +189,24 @@ def test_random_members_against_zlib(emul, seed):
         check(cases, got, st, allow_overflow=not worst)
 
 
+def test_members_made_of_hundreds_of_blocks(emul):
+    """zlib flush markers every few bytes: a member of hundreds of DEFLATE blocks, each with its own literal table in the token pool. With enough of them that is
+    more than two slots per output byte: a 3000-byte member with 1400 flushes reports K1_ERR_TOKEN_OVERFLOW with the second-chance pool (run once while this was
+    written; a minute under the emulator) and decodes with the bound that holds for every valid member (k1_pool_pages_absolute, the library's third chance). Kept
+    here: smaller members with the third-chance pool, and the arithmetic of that bound."""
+    rng = random.Random(31); cases = []
+    for n, flushes in ((1200, 400), (300, 150)):
+        raw = texty(rng, n)
+        comp = deflate(raw, 6, 8, zlib.Z_DEFAULT_STRATEGY, flushes)
+        assert len(comp) <= 65510
+        cases.append((raw, comp))
+    img, mem = image(cases, rng)
+    got, st, stats = run(emul, img, mem, tok_mode=-1)
+    check(cases, got, st, allow_overflow=False)
+    # the bound: 76 words per block at 0.8 blocks per payload byte stay below 64 words per payload byte
+    assert 76 * 0.8 <= 64
+
+
 def _bgzf_members(img):
     import struct
     pos = 0; mem = []
