@@ -44,7 +44,7 @@ constexpr int P1_W_NONLIT = 26;   // the symbols 256.. of the block in code orde
 constexpr int P1_W_DSYM = 34;     // the distance symbols in code order, one byte each: symbol * 4
 constexpr int P1_LANE_W = 42;
 constexpr int P1_RING_SLOTS = 8;
-constexpr int P1_TRIPS = 4;             // trips between two service blocks (a multiple of 2: a token group is the four slots of two trips)
+constexpr int P1_TRIPS = 4;             // trips between two service blocks = the four words of a token group (one word per trip)
 constexpr int P1_WAVES_PER_SIMD = 4;   // register budget of the decoder: 128 VGPRs
 constexpr int P1_TAB_W = 128;     // per workgroup: base | extra bits << 16 of the symbols 256..287 (words 0..31) and the distance symbols (words 32..63); the rest is padding (an index byte of a damaged stream may point behind the tables)
 constexpr int P1_LDS_W = P1_LANE_W * 64 + P1_TAB_W;   // 11 264 B per one-wave workgroup
@@ -172,9 +172,9 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	wv::u32x4 pf = wv::make4(0, 0, 0, 0); bool pf_valid = false;
 	uint32_t* tptr = nullptr; uint32_t tleft = 0, ngr = 0; // next group of the member's current page, groups left in front of the page's link group, groups written
 	uint32_t ttab = 0, ttab_left = 0;                      // the lane's next free literal table (pool word offset), tables left in its table page
-	uint32_t sl[2 * P1_TRIPS];                            // the token slots of the trips between two service blocks
+	uint32_t sl[P1_TRIPS];                                // the token words of the trips between two service blocks
 	#pragma unroll
-	for (int i = 0; i < 2 * P1_TRIPS; ++i) sl[i] = K1_TOK_NOOP;
+	for (int i = 0; i < P1_TRIPS; ++i) sl[i] = K1_TOK_NOOP;
 	LimTab limL, limD;
 	#pragma unroll
 	for (int i = 0; i < 15; ++i) { limL.w[i] = W_INV | 31u; limD.w[i] = W_INV | 31u; }
@@ -216,7 +216,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	auto input_service = [&]() { input_commit(); input_request(); };
 
 	// One trip of the symbol loop: up to two literal/length symbols and one distance. At most 15 + (15 + 5) + (15 + 13) = 63 bits.
-	auto trip = [&](uint32_t& slot_a, uint32_t& slot_b) {
+	auto trip = [&](uint32_t& slot) {
 		const bool act = (state == S_SYM) & (((int)(wr - (abit >> 5)) >= 3) | ((next_q >= n_q) & !pf_valid));   // (the three window words are staged, or the member has no more input)
 		const uint32_t* p = L.ring(abit);
 		const uint32_t p0 = p[0], p1 = p[64], p2 = p[128];
@@ -249,14 +249,15 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		const uint32_t used = match ? u2 + dl + deb : ub;
 		const uint32_t nlit = lit1 ? (lit2 ? 2u : 1u) : 0u;             // literals in front of the match / the end of the block
 		const uint32_t add = match ? nlit + mlen : nlit;
-		const uint32_t tokm = (mlen << 23) + mdist + (0x80000000u - (3u << 23) - 1u);   // = bit 31 | (mlen - 3) << 23 | (mdist - 1)
+		const uint32_t tokm = (mlen << 15) + mdist - ((3u << 15) + 1u);                 // = (mlen - 3) << 15 | (mdist - 1)
 		const uint32_t inv = (sa | (lit1 ? sb : 0u) | (match ? sd | (lt >> 25) | (dt >> 25) : 0u)) & W_INV;   // (TAB_BAD >> 25 == W_INV)
 		const bool bad = inv != 0 || (match && mdist > out_n + nlit) || out_n + add > usize;
 		if ((state == S_SYM) & !act) K1_STAT(3);
 		const bool ok = act && !bad;
-		const uint32_t ta_tok = lit1 ? tok1 : (match ? tokm : K1_TOK_NOOP);
-		const uint32_t tb_tok = lit1 ? (lit2 ? tok2 : (match ? tokm : K1_TOK_NOOP)) : K1_TOK_NOOP;
-		slot_a = ok ? ta_tok : K1_TOK_NOOP; slot_b = ok ? tb_tok : K1_TOK_NOOP;
+		// the trip's word: two literals | a literal, then a match | a literal (in front of the end of the block) | a match | nothing
+		const uint32_t w_lit = lit2 ? (K1_TOK_LIT2 | tok1 | (tok2 << 8)) : (match ? (K1_TOK_LITMATCH | (tok1 << 23) | tokm) : tok1);
+		const uint32_t w_non = match ? (K1_TOK_MATCH | tokm) : K1_TOK_NOOP;
+		slot = ok ? (lit1 ? w_lit : w_non) : K1_TOK_NOOP;
 		if (ok) K1_STAT(1);
 		abit += ok ? used : 0u; out_n += ok ? add : 0u;
 		state = ok && eob ? (bfinal ? (uint32_t)S_FINISH : (uint32_t)S_HDR) : state;
@@ -499,7 +500,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 				else if ((off8 + n) * 8u > abit_end) { err = 15; state = S_FINISH; }
 				else
 				{
-					emit(0x40000000u | ((n - 1u) << 16) | (off8 - mis16), K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP);
+					emit(K1_TOK_RAW | ((n - 1u) << 16) | (off8 - mis16), K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP);
 					if (err == 0)
 					{
 						abit += 8u * n; out_n += n; raw_left -= n;
@@ -514,9 +515,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	{
 		// ---- service: commit prefetched input, store the token groups of the last trips, issue the next prefetch ----
 		input_commit();
-		#pragma unroll
-		for (int g = 0; g < 2 * P1_TRIPS; g += 4)
-			if ((sl[g] & sl[g + 1] & sl[g + 2] & sl[g + 3]) != K1_TOK_NOOP) emit(sl[g], sl[g + 1], sl[g + 2], sl[g + 3]);
+		if (((sl[0] ^ K1_TOK_NOOP) | (sl[1] ^ K1_TOK_NOOP) | (sl[2] ^ K1_TOK_NOOP) | (sl[3] ^ K1_TOK_NOOP)) != 0) emit(sl[0], sl[1], sl[2], sl[3]);
 		input_request();
 		// A lane that reaches a header (or the end of its member) parks until park_hi lanes are parked or no lane decodes symbols; then the
 		// wave runs ONLY the slow states until every parked lane is back in the symbol loop.
@@ -530,45 +529,72 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		}
 		if (lane == 0) K1_STAT(0);
 		#pragma unroll
-		for (int i = 0; i < P1_TRIPS; ++i) trip(sl[2 * i], sl[2 * i + 1]);
+		for (int i = 0; i < P1_TRIPS; ++i) trip(sl[i]);
 	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------- phase 2
-constexpr int P2_BMAX = 1088;                  // output bytes resolved per batch: at least one whole group (4 x 258 bytes) always fits
-constexpr int P2_NCH = (P2_BMAX + 63) / 64;    // 64-byte chunks per batch
-constexpr int P2_GROUPS = 64;                  // groups per batch: one per lane (256 slots, about 210 tokens = 950 bytes of BAM)
-constexpr int P2_SUB = 4;                      // chunks that are classified (and their gathers issued) before one wait resolves them
-// 2.4 KB per wave. val: token-end flags until a chunk is resolved, then its output bytes; lit: the literal table of the current DEFLATE block
-struct P2Lds { uint32_t pk[P2_GROUPS * 4 + 4]; alignas(8) uint8_t val[P2_NCH * 64]; alignas(4) uint8_t lit[256]; };
-// pk word of a token - what a byte of the token needs to know, decided once per token (the kinds are ranges of the word):
-//   literal    0x000000vv
-//   near match 0x20000000 | (distance - 1)                    the source reaches into the batch, but not into the match itself: byte j comes from j - distance
-//   periodic   0x40000000 | start << 15 | (distance - 1)      distance < length: byte j comes from start - distance + (j - start) mod distance
-//   raw run    0x60000000 | start << 16 | payload offset      (stored block)
-//   far match  PK_FAR + (P - distance): every source byte lies in front of the batch (distance >= start + length); the source of output byte j of
-//              the batch is out[j + pk - PK_FAR], nothing else to work out per byte. (negative as a signed number)
-// and of a byte after its classification (inf): < 0 gathered from memory; 0x20000000 | position: a staged byte of an earlier chunk; 0x40000000 | lane:
-// a lower lane of the same chunk; else the byte itself.
-constexpr uint32_t PK_NEAR = 0x20000000u, PK_PERIODIC = 0x40000000u, PK_RAW = 0x60000000u, PK_FAR = 0x80100000u;
-constexpr uint32_t INF_GATHERED = 0x80000000u, INF_STAGED = 0x20000000u, INF_LANE = 0x40000000u;
+// Output-DWORD centred resolve (round 4). A batch is up to 64 token groups (one per lane, <= 256 words) cut to <= P2_BMAX output bytes; a wave prefix
+// sum places every word. Per word: its literal bytes go straight to the LDS staging bytes (translated through the block's literal table), its match
+// part leaves a 32-bit descriptor pk[rank] = kind | start of the match bytes | distance, and the word's last output byte sets a bit in a bit mask.
+// Then every lane owns one aligned DWORD of a 256-byte chunk. A match is at least three bytes long, so at most TWO matches touch a dword: the one
+// that owns its first byte (A) and the one that owns its last byte (B); whatever lies between them is literals, which are in place already. The owners
+// come from the bit mask (bits below the dword: rank of A; the three bits of the dword's first bytes: where A ends, where B starts), the two
+// descriptors give a byte mask and a source each:
+//   far     every source byte lies in front of the batch (distance >= start + length): an unaligned dword load from the member's output in HBM
+//   near    the source reaches into the batch (or the 320 bytes in front of it, which stay in LDS): an unaligned LDS dword load, once every
+//           source byte is resolved - the chunk's unresolved bytes are a suffix, so "resolved" is a comparison with the frontier F
+//   pattern distance < 4: the bytes repeat the distance bytes in front of the match (v_perm_b32 with a selector per (distance, phase))
+//   raw     a stored block's bytes, from the compressed input
+// A sub-batch of P2_SUB chunks is classified first and all of its HBM loads are issued (one wait), then its chunks are resolved front to back:
+// far / raw dwords are merged, near / pattern pieces in rounds while the frontier moves (round 0 settles everything whose source lies in front of
+// the chunk: nearly always the only round). Every dword is written once to LDS and once to HBM (256 consecutive bytes per store instruction).
+constexpr int P2_CH = 256;                     // output bytes per chunk: a dword per lane
+constexpr int P2_SUB = 3;                      // chunks whose HBM loads are in flight together
+constexpr int P2_BMAX = 1536;                  // output bytes per batch: at least one whole group (4 x 259 bytes) always fits; a multiple of P2_CH
+constexpr int P2_GROUPS = 64;                  // groups per batch: one per lane
+constexpr int P2_HIST = 320;                   // output bytes in front of the batch that stay in LDS (>= 258 + 3 + 3: a near source dword starts at most 261 bytes in front)
+constexpr int P2_NW = P2_BMAX / 32 + 1;        // words of the end-bit mask (one lane each in the count scan)
+static_assert(P2_BMAX % P2_CH == 0 && P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4 == 0, "phase-2 batch geometry");
+// pk[rank]: what the match part of a word needs. kind << 29 | first match byte (batch-relative) << 16 | distance - 1 (raw: payload offset, 16 bits)
+constexpr uint32_t PK_NONE = 0, PK_NEAR = 1, PK_PAT = 2, PK_FAR = 3, PK_RAW = 4;
+struct P2Lds
+{
+	uint32_t pk[P2_GROUPS * 4 + 4];
+	uint32_t eb[2 * 64];                                   // {end-bit mask of 32 output bytes, words that end in front of them}
+	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes]
+	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
+};
 
-K1_DEV uint32_t tok_len(uint32_t t) { return t >= K1_TOK_SPECIAL ? 0u : ((t >> 31) ? ((t >> 23) & 255u) + 3u : ((t >> 30) ? ((t >> 16) & 255u) + 1u : 1u)); }
+K1_DEV uint32_t tok_len(uint32_t t)
+{
+	return t >= K1_TOK_MATCH ? ((t >> 15) & 255u) + 3u + (t >> 31) : (t < K1_TOK_RAW ? 1u + ((t >> 16) & 1u) : (t < 2u * K1_TOK_RAW ? ((t >> 16) & 255u) + 1u : 0u));
+}
 
-// Register budget of eight waves per SIMD: next to the decoder waves the register file, not LDS, decides how many phase-2 waves a CU holds.
+// Register budget of eight waves per SIMD: next to the decoder waves the register file and LDS decide how many phase-2 waves a CU holds.
 K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, const uint32_t* __restrict__ tok_first, const uint32_t* __restrict__ tok_count,
                                       const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status, const uint8_t* __restrict__ comp)
 {
 	K1_SHARED P2Lds S;
 	const int lane = wv::lane();
 	const wv::u32x4 noop4 = wv::make4(K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP);
+	uint8_t* const vb = S.val + P2_HIST;   // byte j of the batch
+	// a match of distance 1..3 repeats the distance bytes in front of it: byte k of the dword at j is pattern byte (j + k - start) mod distance
+	auto pattern = [&](uint32_t d, uint32_t j) -> uint32_t {
+		const uint32_t dist = (d & 0x7fffu) + 1u, ms = wv::bfe(d, 16, 11);
+		const uint32_t pw = wv::lds_load32u(vb + (int)ms - 4);   // the pattern = its last distance bytes
+		const uint32_t x = j + 12u - ms, r = dist == 3u ? x - 3u * ((x * 0xaaabu) >> 17) : (x & (dist - 1u));   // x mod distance
+		const uint32_t sel = dist == 1u ? 0x03030303u : (dist == 2u ? (r ? 0x02030203u : 0x03020302u) : (r == 0u ? 0x01030201u : (r == 1u ? 0x02010302u : 0x03020103u)));
+		return wv::perm(pw, pw, sel);
+	};
 	for (int64_t b = wv::block_id(); b < n_blocks; b += wv::grid_size())
 	{
 		if (status[b].error) continue;
 		const uint32_t ngroups = tok_count[b];
 		const uint32_t usize = blocks[b].usize;
-		const wv::ByteBuf out = wv::ByteBuf::make(out_base + blocks[b].upos, usize);
-		const wv::ByteBuf cin = wv::ByteBuf::make(const_cast<uint8_t*>(comp) + blocks[b].cpos, blocks[b].clen);   // raw runs (stored blocks) are copied from here
+		const wv::ByteBuf out = wv::ByteBuf::make(out_base + blocks[b].upos, usize);            // stores: exact bounds
+		const wv::ByteBuf outld = wv::ByteBuf::make(out_base + blocks[b].upos, usize + 3u);     // source dwords may end up to three bytes behind the member (mapped: the next member or the buffer's slack)
+		const wv::ByteBuf cin = wv::ByteBuf::make(const_cast<uint8_t*>(comp) + blocks[b].cpos, blocks[b].clen + 3u);   // raw runs (stored blocks) are copied from here (the gzip trailer follows)
 		// the member's pages: logical group g lives in page g / (K1_PAGE_GROUPS - 1); a batch spans at most two pages
 		uint32_t pg_cur = tok_first[b], pg_first = 0;
 		uint32_t pg_next = ngroups > K1_PAGE_GROUPS - 1 ? pool[(uint64_t)pg_cur * K1_PAGE_WORDS + K1_PAGE_WORDS - 3] : 0u;
@@ -585,10 +611,10 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 		wv::u32x4 nxt = (uint32_t)lane < ngroups ? group((uint32_t)lane) : noop4;
 		for (uint32_t g0 = 0; g0 < ngroups;)
 		{
-			// ---- place the batch: one group per lane, a prefix sum over (bytes | real tokens << 20) ----
+			// ---- place the batch: one group per lane, a prefix sum over (bytes | real words << 20) ----
 			bool valid = g0 + (uint32_t)lane < ngroups;
 			const uint32_t t0 = nxt.x, t1 = nxt.y, t2 = nxt.z, t3 = nxt.w;
-			// a table group switches the literal table for the tokens behind it: it ends the batch in front of it, or (first group) is consumed here
+			// a table group switches the literal table for the words behind it: it ends the batch in front of it, or (first group) is consumed here
 			const uint64_t tabm = wv::ballot(valid && t0 == K1_TOK_TABLE);
 			if (tabm & 1ull)
 			{
@@ -607,15 +633,20 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			const uint32_t Eb = E & 0xfffffu, Ec = E >> 20;
 			// the longest prefix of groups whose output fits the staging buffer (the sums are non-decreasing: the ballot is a prefix mask)
 			const uint32_t ng = wv::popc64(wv::ballot(valid && Eb <= (uint32_t)P2_BMAX));
-			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 258 bytes: not a token stream of phase 1
+			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 259 bytes: not a token stream of phase 1
 			const uint32_t B = wv::readlane(Eb, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
-			// per real token: its pk word; a flag on the token's last byte
+			S.eb[2 * lane] = 0u;
+			// (rare) a raw run of one or two bytes could lie strictly inside a dword, between A and B: such a run is put in place like literals
+			const bool tiny_raw = (uint32_t)lane < ng && t0 - K1_TOK_RAW < 0x20000u && l0 != 0u;   // (a raw run is the first word of its group, the others are no-ops)
+			uint32_t rb0 = 0, rb1 = 0;
+			if (wv::ballot(tiny_raw) != 0ull)
 			{
-				unsigned long long* z = (unsigned long long*)S.val;
-				z[lane] = 0ull; z[64 + lane] = 0ull; if (lane < P2_NCH * 8 - 128) z[128 + lane] = 0ull;
+				if (tiny_raw) { rb0 = cin.load(t0 & 0xffffu); rb1 = cin.load((t0 & 0xffffu) + 1u); }
+				wv::wait_vm0();
 			}
 			wv::barrier();
+			// per real word: literal bytes to their place, the descriptor of the match part, the end bit
 			if ((uint32_t)lane < ng)
 			{
 				uint32_t st = Eb - s, rk = Ec - c;
@@ -624,18 +655,38 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 				for (int k = 0; k < 4; ++k)
 					if (ll[k])
 					{
-						const uint32_t t = tt[k], d = (t & 0x7fffu) + 1u;
-						uint32_t w;
-						if (t >> 31) w = d >= st + ll[k] ? PK_FAR + P - d : (d >= ll[k] ? PK_NEAR | (d - 1u) : PK_PERIODIC | (st << 15) | (d - 1u));
-						else w = (t >> 30) ? PK_RAW | (st << 16) | (t & 0xffffu) : (uint32_t)S.lit[t & 255u];
+						const uint32_t t = tt[k];
+						uint32_t w = PK_NONE;
+						if (t >= K1_TOK_MATCH)
+						{
+							const uint32_t hl = t >> 31;
+							if (hl) vb[st] = S.lit[(t >> 23) & 255u];
+							const uint32_t ms = st + hl, ml = ((t >> 15) & 255u) + 3u, d = (t & 0x7fffu) + 1u;
+							const uint32_t kind = d >= ms + ml ? PK_FAR : (d < 4u ? PK_PAT : PK_NEAR);
+							w = (kind << 29) | (ms << 16) | (d - 1u);
+						}
+						else if (t < K1_TOK_RAW)
+						{
+							vb[st] = S.lit[t & 255u];
+							if (t & K1_TOK_LIT2) vb[st + 1] = S.lit[(t >> 8) & 255u];
+						}
+						else if (ll[k] <= 2u) { vb[st] = (uint8_t)rb0; if (ll[k] == 2u) vb[st + 1] = (uint8_t)rb1; }
+						else w = (PK_RAW << 29) | (st << 16) | (t & 0xffffu);
 						S.pk[rk] = w;
 						st += ll[k]; ++rk;
-						S.val[st - 1] = 1;
+						wv::lds_or32(&S.eb[2 * ((st - 1u) >> 5)], 1u << ((st - 1u) & 31u));
 					}
 				if ((uint32_t)lane == ng - 1) S.pk[rk] = 0;   // what the lanes behind the batch's last byte find
 			}
 			wv::barrier();
-			// stores of earlier batches must be complete before this batch gathers from the window behind P
+			{
+				// words that end in front of each 32-byte piece
+				const uint32_t m = lane < P2_NW ? S.eb[2 * lane] : 0u, cn = wv::bcnt(m);
+				const uint32_t inc = wv::scan_incl(cn);
+				if (lane < P2_NW) S.eb[2 * lane + 1] = inc - cn;
+			}
+			wv::barrier();
+			// stores of earlier batches must be complete before this batch loads from the window behind P
 			wv::wait_vm0();
 			// the next batch's groups are requested now; they arrive while this batch is resolved
 			{
@@ -645,88 +696,130 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			}
 
 			if (lane == 0) K1_STAT(7);
-			uint32_t ta = 0;   // tokens that end before the current chunk
 			#pragma nounroll
-			for (uint32_t jb = 0; jb < B; jb += P2_SUB * 64)
+			for (uint32_t jb = 0; jb < B; jb += P2_SUB * P2_CH)
 			{
-				// ---- pass 1: every byte of the sub-batch finds its token; all gathers that reach behind the batch are issued ----
-				uint32_t inf[P2_SUB], gth[P2_SUB];
+				// ---- pass 1: the two pieces of every dword; every load from HBM is issued ----
+				uint32_t dA[P2_SUB], dB[P2_SUB], mA[P2_SUB], mB[P2_SUB], gA[P2_SUB], gB[P2_SUB];
 				#pragma unroll
 				for (int ch = 0; ch < P2_SUB; ++ch)
 				{
-					inf[ch] = 0; gth[ch] = 0;
-					const uint32_t j0 = jb + (uint32_t)(ch * 64), j = j0 + (uint32_t)lane;
+					dA[ch] = 0; dB[ch] = 0; mA[ch] = 0; mB[ch] = 0; gA[ch] = 0; gB[ch] = 0;
+					const uint32_t j0 = jb + (uint32_t)(ch * P2_CH), j = j0 + 4u * (uint32_t)lane;
 					if (j0 < B)
 					{
-						// owner token of byte j = ta + #tokens ending inside the chunk before j: the end flags of the chunk as a lane mask
-						const uint64_t m = wv::ballot(S.val[j] != 0);
-						const uint32_t o = wv::mbcnt_add(m, ta);
-						ta += wv::popc64(m);
-						uint32_t f = S.pk[o];
-						uint32_t addr = j + f - PK_FAR;   // (a far match; anything else overwrites it or does not load)
-						bool ld = (int32_t)f < 0;
-						if (f - PK_NEAR < 0x60000000u)    // near, periodic, raw
-						{
-							int src = (int)j - (int)((f & 0x7fffu) + 1u);   // relative to P
-							if (f >= PK_PERIODIC)
+						const uint32_t em = S.eb[2 * (j >> 5)], ec = S.eb[2 * (j >> 5) + 1], bp = j & 31u;
+						const uint32_t o0 = ec + wv::bcnt(wv::bfe(em, 0, bp));
+						const uint32_t nib = wv::bfe(em, bp, 3);             // end bits of the dword's first three bytes
+						const uint32_t e0 = wv::ctz32(nib | 8u);             // the last byte A owns
+						const uint32_t s3 = 31u - wv::clz32(nib << 1 | 1u);  // the first byte B owns (nib == 0: A == B)
+						const uint32_t o3 = o0 + wv::bcnt(nib);
+						uint32_t pa = S.pk[o0], pb = S.pk[o3];
+						// bytes [k0, k1] of the dword belong to the piece
+						auto piece = [&](uint32_t& d, uint32_t kmin, uint32_t k1, uint32_t& m, uint32_t& g) {
+							const int ms = (int)wv::bfe(d, 16, 11) - (int)j;
+							const uint32_t k0 = ms > (int)kmin ? (uint32_t)ms : kmin;
+							const bool ok = (d >> 29) != PK_NONE && (int)k0 <= (int)k1;
+							m = ok ? (0xffffffffu >> (8u * (3u - (k1 - k0)))) << (8u * k0) : 0u;
+							d = ok ? d : 0u;
+							if ((d >> 29) == PK_FAR)
 							{
-								const uint32_t sto = (f >> 15) & 0x7ffu, d = (f & 0x7fffu) + 1u;
-								if (src >= (int)sto)   // (the first distance bytes of the match are an ordinary copy)
-								{
-									const uint32_t off = j - sto;
-									uint32_t q = (uint32_t)((float)off * wv::rcp((float)d)); int rr = (int)off - (int)(q * d);   // q is off by at most 1
-									if (rr < 0) rr += (int)d; else if (rr >= (int)d) rr -= (int)d;
-									src = (int)sto - (int)d + rr;
-								}
+								const int src = (int)(P + j) - (int)((d & 0x7fffu) + 1u);   // >= -3: the piece's own bytes have sources at >= 0
+								g = outld.load32((uint32_t)(src < 0 ? 0 : src));
 							}
-							if (f < PK_RAW)
+							else if ((d >> 29) == PK_RAW)
 							{
-								if (src < 0) { addr = P + (uint32_t)src; ld = true; f = INF_GATHERED; }
-								else if ((uint32_t)src < jb) f = S.val[src];   // resolved by an earlier sub-batch: the byte itself
-								else f = (uint32_t)src < j0 ? INF_STAGED | (uint32_t)src : INF_LANE | ((uint32_t)src & 63u);
+								const int src = (int)(d & 0xffffu) - ms;
+								g = cin.load32((uint32_t)(src < 0 ? 0 : src));
 							}
-						}
-						if (ld) gth[ch] = out.load(addr);
-						if (f - PK_RAW < 0x20000000u) { gth[ch] = cin.load((f & 0xffffu) + (j - ((f >> 16) & 0x7ffu))); f = INF_GATHERED; }   // (rare: its own load site)
-						inf[ch] = f;
+						};
+						piece(pa, 0u, e0, mA[ch], gA[ch]);
+						if (nib == 0u) pb = 0u;
+						piece(pb, s3, 3u, mB[ch], gB[ch]);
+						dA[ch] = pa; dB[ch] = pb;
 					}
 				}
-				// every gather has landed (one wait for the sub-batch: pass 2 below issues stores only)
+				// every load has landed (one wait for the sub-batch: pass 2 below issues stores only)
 				wv::wait_vm0();
-				// ---- pass 2: resolve front to back; every byte is written once to LDS and once to HBM (64 consecutive bytes per store instruction) ----
+				// ---- pass 2: resolve front to back ----
 				#pragma unroll
 				for (int ch = 0; ch < P2_SUB; ++ch)
 				{
-					const uint32_t j0 = jb + (uint32_t)(ch * 64), j = j0 + (uint32_t)lane;
+					const uint32_t j0 = jb + (uint32_t)(ch * P2_CH), j = j0 + 4u * (uint32_t)lane;
 					if (j0 < B)
 					{
-						const uint32_t f = inf[ch];
-						uint32_t vv = ((int32_t)f < 0 ? gth[ch] : f) & 255u;
-						const bool pending = f - INF_STAGED < 0x60000000u;   // a staged byte or a lower lane
 						if (lane == 0) K1_STAT(4);
-						if (wv::ballot(pending) != 0)   // (a chunk of literals and far matches skips all of this)
+						wv::barrier();   // (the bytes in front of the chunk are in LDS)
+						uint32_t cur = wv::lds_load32(vb + j);   // the literals are in place
+						uint32_t pend = 0, shA = 0, shB = 0;
+						// far / raw: the loaded dword, shifted when its first bytes lay in front of the buffer. near / pattern: a source in front of the chunk is
+						// resolved and in LDS; one inside the chunk has to wait until the lanes that hold it (sh, sh + 1) are done
+						auto first = [&](uint32_t d, uint32_t m, uint32_t g, uint32_t bit, uint32_t& sh) {
+							const uint32_t kind = d >> 29;
+							if (kind == PK_FAR || kind == PK_RAW)
+							{
+								const int src = kind == PK_FAR ? (int)(P + j) - (int)((d & 0x7fffu) + 1u) : (int)(d & 0xffffu) - ((int)wv::bfe(d, 16, 11) - (int)j);
+								cur = wv::bfi(m, src < 0 ? g << (8u * (uint32_t)(-src)) : g, cur);
+							}
+							else if (kind != PK_NONE)
+							{
+								const uint32_t dist = (d & 0x7fffu) + 1u;
+								// the first and the last source byte, and the lanes of this chunk that hold them
+								const int s0 = kind == PK_NEAR ? (int)(j + (wv::ctz32(m) >> 3)) - (int)dist : (int)wv::bfe(d, 16, 11) - (int)dist;
+								const int s1 = kind == PK_NEAR ? (int)(j + 3u - (wv::clz32(m) >> 3)) - (int)dist : (int)wv::bfe(d, 16, 11) - 1;
+								const int lo = (s0 - (int)j0) >> 2, hi = (s1 - (int)j0) >> 2;
+								if (hi < 0) cur = wv::bfi(m, kind == PK_NEAR ? wv::lds_load32u(vb + (int)j - (int)dist) : pattern(d, j), cur);
+								else { pend |= bit; sh = (uint32_t)(lo < 0 ? 0 : lo) | (hi > lo && lo >= 0 ? 0x300u : 0x100u); }   // lanes to wait for: mask << 8 | first lane
+							}
+						};
+						first(dA[ch], mA[ch], gA[ch], 1u, shA);
+						first(dB[ch], mB[ch], gB[ch], 2u, shB);
+						uint64_t pm = wv::ballot(pend != 0u);
+						wv::lds_store32(vb + j, cur);
+						if (pm != 0ull)   // (a chunk whose sources all lie in front of it skips this)
 						{
 							if (lane == 0) K1_STAT(5);
-							uint32_t rel = (uint32_t)lane;
-							if (pending)
-							{
-								if (f < INF_LANE) vv = S.val[f & 0x7ffu];
-								else { vv = 0x100u; rel = f & 63u; }   // bit 8 = still waiting for a lower lane of this chunk
-							}
-							// sources are always lower lanes, so the loop terminates; the periodic form makes its depth the number of chained TOKENS, not bytes
-							uint64_t pend = wv::ballot((vv & 0x100u) != 0);
-							while (pend)
+							for (;;)
 							{
 								if (lane == 0) K1_STAT(6);
-								const uint32_t sv = wv::shfl(vv, (int)rel);
-								if ((vv & 0x100u) && !(sv & 0x100u)) vv = sv;
-								pend = wv::ballot((vv & 0x100u) != 0);
+								wv::barrier();   // (the stores of the last round are visible)
+								const uint64_t others = pm & ~(1ull << lane);   // the bytes of this dword in front of a piece are literals or a settled piece
+								bool changed = false;
+								auto settle = [&](uint32_t d, uint32_t m, uint32_t bit, uint32_t sh) {
+									if (!(pend & bit) || ((uint32_t)(others >> (sh & 63u)) & (sh >> 8)) != 0u) return;
+									cur = wv::bfi(m, (d >> 29) == PK_NEAR ? wv::lds_load32u(vb + (int)j - (int)((d & 0x7fffu) + 1u)) : pattern(d, j), cur);
+									pend &= ~bit; changed = true;
+								};
+								const bool a_open = (pend & 1u) != 0u;
+								settle(dA[ch], mA[ch], 1u, shA);
+								if (!a_open) settle(dB[ch], mB[ch], 2u, shB);   // (B's source may be A's bytes of this very dword: not before A is in LDS)
+								wv::barrier();   // (this round's LDS reads are done)
+								if (changed) wv::lds_store32(vb + j, cur);
+								pm = wv::ballot(pend != 0u);
+								if (pm == 0ull) break;
 							}
 						}
-						if (j < B) { S.val[j] = (uint8_t)vv; out.store(P + j, vv); }
-						wv::barrier();
+						if (j + 4u <= B) out.store32(P + j, cur);
+						else if (j < B)
+						{
+							out.store(P + j, cur);
+							if (j + 1u < B) out.store(P + j + 1u, cur >> 8);
+							if (j + 2u < B) out.store(P + j + 2u, cur >> 16);
+						}
 					}
 				}
+			}
+			// the last P2_HIST bytes stay in LDS in front of the next batch
+			wv::barrier();
+			{
+				const uint32_t h0 = wv::lds_load32u(S.val + B + 4u * (uint32_t)lane);
+				wv::barrier();
+				wv::lds_store32(S.val + 4u * (uint32_t)lane, h0);
+				wv::barrier();
+				const uint32_t h1 = lane < (P2_HIST - 256) / 4 ? wv::lds_load32u(S.val + B + 256u + 4u * (uint32_t)lane) : 0u;
+				wv::barrier();
+				if (lane < (P2_HIST - 256) / 4) wv::lds_store32(S.val + 256u + 4u * (uint32_t)lane, h1);
+				wv::barrier();
 			}
 			P += B; g0 += ng;
 		}

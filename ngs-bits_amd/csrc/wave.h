@@ -44,6 +44,11 @@ K1_DEV void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): ev
 K1_DEV unsigned long long atomic_inc(unsigned long long* p) { return atomicAdd(p, 1ull); }
 K1_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 K1_DEV void lds_or(unsigned long long* p, unsigned long long v) { atomicOr(p, v); }
+K1_DEV void lds_or32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+// a dword of LDS at any byte address (gfx950 runs with unaligned access mode: one ds_read_b32) / at a 4-aligned one
+K1_DEV uint32_t lds_load32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+K1_DEV uint32_t lds_load32(const uint8_t* p) { return *(const uint32_t*)p; }
+K1_DEV void lds_store32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
 
 // A byte range in HBM behind a buffer resource: 32-bit offsets (one VALU add per address) and hardware bounds clamping
 // (loads outside read 0, stores outside are dropped). The descriptor lives in SGPRs: its inputs are made wave-uniform first.
@@ -59,6 +64,9 @@ struct ByteBuf
 	}
 	K1_DEV uint32_t load(uint32_t off) const { return __builtin_amdgcn_raw_buffer_load_b8(rs, (int)off, 0, 0); }
 	K1_DEV void store(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, rs, (int)off, 0, 0); }
+	// a dword at any byte offset (in range: off + 4 <= bytes; a dword that is not wholly inside the range reads 0 / is dropped)
+	K1_DEV uint32_t load32(uint32_t off) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0); }
+	K1_DEV void store32(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off, 0, 0); }
 };
 
 // wave priority for instruction arbitration on its SIMD (0..3)
@@ -72,5 +80,11 @@ K1_DEV uint32_t popc64(uint64_t x) { return (uint32_t)__popcll(x); }
 K1_DEV uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }   // bits of m below this lane
 K1_DEV uint32_t mbcnt_add(uint64_t m, uint32_t a) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, a)); }   // a + bits of m below this lane
 K1_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+K1_DEV uint32_t bcnt(uint32_t x) { return (uint32_t)__popc(x); }
+K1_DEV uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }     // x != 0
+K1_DEV uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }     // x != 0
+K1_DEV uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }   // x != 0
+K1_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }   // v_perm_b32: result byte k = byte sel.byte[k] of {hi, lo} (0..3: lo, 4..7: hi)
+K1_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }               // v_bfi_b32
 
 } } // namespace ngsqc::wv

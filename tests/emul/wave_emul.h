@@ -118,6 +118,10 @@ inline void set_priority(int) {}
 inline unsigned long long atomic_inc(unsigned long long* p) { return (*p)++; }
 inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void lds_or(unsigned long long* p, unsigned long long v) { *p |= v; }
+inline void lds_or32(uint32_t* p, uint32_t v) { *p |= v; }
+inline uint32_t lds_load32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint32_t lds_load32(const uint8_t* p) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_load32\n"); abort(); } uint32_t v; memcpy(&v, p, 4); return v; }
+inline void lds_store32(uint8_t* p, uint32_t v) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_store32\n"); abort(); } memcpy(p, &v, 4); }
 
 struct ByteBuf
 {
@@ -125,6 +129,9 @@ struct ByteBuf
 	static ByteBuf make(uint8_t* p, uint32_t bytes) { return ByteBuf{p, bytes}; }
 	uint32_t load(uint32_t off) const { return off < bytes ? p[off] : 0u; }
 	void store(uint32_t off, uint32_t v) const { if (off < bytes) p[off] = (uint8_t)v; }
+	// the strict reading of the hardware's range check: a dword that is not wholly inside the range reads 0 / is dropped
+	uint32_t load32(uint32_t off) const { uint32_t v = 0; if ((uint64_t)off + 4 <= bytes) memcpy(&v, p + off, 4); return v; }
+	void store32(uint32_t off, uint32_t v) const { if ((uint64_t)off + 4 <= bytes) memcpy(p + off, &v, 4); }
 };
 
 inline uint32_t brev(uint32_t x)
@@ -139,5 +146,16 @@ inline uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 inline uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << emu().cur) - 1ull)); }
 inline uint32_t mbcnt_add(uint64_t m, uint32_t a) { return a + mbcnt(m); }
 inline float rcp(float x) { return 1.0f / x; }
+inline uint32_t bcnt(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+inline uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+inline uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
+inline uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+	const uint64_t v = ((uint64_t)hi << 32) | lo; uint32_t r = 0;
+	for (int k = 0; k < 4; ++k) { const uint32_t s = (sel >> (8 * k)) & 255u; r |= (s < 8 ? (uint32_t)(v >> (8 * s)) & 255u : (s >= 13 ? 255u : 0u)) << (8 * k); }
+	return r;
+}
+inline uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
 
 } } // namespace ngsqc::wv
