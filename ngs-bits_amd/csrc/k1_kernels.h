@@ -534,34 +534,29 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------- phase 2
-// Output-DWORD centred resolve (round 4). A batch is up to 64 token groups (one per lane, <= 256 words) cut to <= P2_BMAX output bytes; a wave prefix
-// sum places every word. Per word: its literal bytes go straight to the LDS staging bytes (translated through the block's literal table), its match
-// part leaves a 32-bit descriptor pk[rank] = kind | start of the match bytes | distance, and the word's last output byte sets a bit in a bit mask.
-// Then every lane owns one aligned DWORD of a 256-byte chunk. A match is at least three bytes long, so at most TWO matches touch a dword: the one
-// that owns its first byte (A) and the one that owns its last byte (B); whatever lies between them is literals, which are in place already. The owners
-// come from the bit mask (bits below the dword: rank of A; the three bits of the dword's first bytes: where A ends, where B starts), the two
-// descriptors give a byte mask and a source each:
-//   far     every source byte lies in front of the batch (distance >= start + length): an unaligned dword load from the member's output in HBM
-//   near    the source reaches into the batch (or the 320 bytes in front of it, which stay in LDS): an unaligned LDS dword load, once every
-//           source byte is resolved - the chunk's unresolved bytes are a suffix, so "resolved" is a comparison with the frontier F
-//   pattern distance < 4: the bytes repeat the distance bytes in front of the match (v_perm_b32 with a selector per (distance, phase))
-//   raw     a stored block's bytes, from the compressed input
-// A sub-batch of P2_SUB chunks is classified first and all of its HBM loads are issued (one wait), then its chunks are resolved front to back:
-// far / raw dwords are merged, near / pattern pieces in rounds while the frontier moves (round 0 settles everything whose source lies in front of
-// the chunk: nearly always the only round). Every dword is written once to LDS and once to HBM (256 consecutive bytes per store instruction).
-constexpr int P2_CH = 256;                     // output bytes per chunk: a dword per lane
-constexpr int P2_SUB = 3;                      // chunks whose HBM loads are in flight together
-constexpr int P2_BMAX = 1536;                  // output bytes per batch: at least one whole group (4 x 259 bytes) always fits; a multiple of P2_CH
+// ITEM centred resolve (round 4). A batch is up to 64 token groups (one per lane, <= 256 words) cut to <= P2_BMAX output bytes; a wave prefix sum
+// places every word. Literal bytes go straight to the LDS staging bytes (translated through the block's literal table). Every match (and raw run)
+// is cut into ITEMS of at most 16 bytes - a match of up to 16 bytes is one item, a longer one is covered by 16-byte items whose last one overlaps
+// its predecessor - and the items of the batch are listed in LDS in output order. Then ONE LANE PER ITEM, 64 items per step:
+//   far item   (every source byte lies in front of the batch) four dword loads from the member's output in HBM at the OVERLAPPING offsets
+//              0, min(4, len - 4), min(8, len - 4), len - 4, which cover any length 4..16 exactly; they are issued one step ahead
+//   near item  the source reaches into the batch (or the 16 bytes in front of it, which stay in LDS): the same four dwords from LDS, once the
+//              items that write its source are done - a 64-bit lane mask per item (from a bit mask of item starts), tested against the
+//              ballot of unfinished lanes; the lowest unfinished lane never waits, so the rounds terminate
+//   distance 1 the byte in front of the item, repeated; an item that overlaps its own source otherwise (rare) is copied byte by byte
+// and the item's bytes are written to LDS with four dword stores at the same offsets (lengths 1..3: a 16-bit and an 8-bit store). When all steps
+// are done the batch leaves LDS for HBM as whole dwords (256 consecutive bytes per store instruction).
+constexpr int P2_BMAX = 1536;                  // output bytes per batch: at least one whole group (4 x 259 bytes) always fits
 constexpr int P2_GROUPS = 64;                  // groups per batch: one per lane
-constexpr int P2_HIST = 320;                   // output bytes in front of the batch that stay in LDS (>= 258 + 3 + 3: a near source dword starts at most 261 bytes in front)
-constexpr int P2_NW = P2_BMAX / 32 + 1;        // words of the end-bit mask (one lane each in the count scan)
-static_assert(P2_BMAX % P2_CH == 0 && P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4 == 0, "phase-2 batch geometry");
-// pk[rank]: what the match part of a word needs. kind << 29 | first match byte (batch-relative) << 16 | distance - 1 (raw: payload offset, 16 bits)
-constexpr uint32_t PK_NONE = 0, PK_NEAR = 1, PK_PAT = 2, PK_FAR = 3, PK_RAW = 4;
+constexpr int P2_HIST = 16;                    // output bytes in front of the batch that stay in LDS (a near item's source starts at most 15 bytes in front)
+constexpr int P2_NW = P2_BMAX / 32 + 1;        // words of the item-start bit mask (one lane each in the count scan)
+constexpr int P2_ITEMS = P2_GROUPS * 4 + P2_BMAX / 16;   // at most one item per word and one more per 16 output bytes
+static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4 == 0, "phase-2 batch geometry");
+// item word: first byte (batch-relative) | (length - 1) << 11 | (distance - 1) << 15; a raw run: bit 31 | payload offset << 15
 struct P2Lds
 {
-	uint32_t pk[P2_GROUPS * 4 + 4];
-	uint32_t eb[2 * 64];                                   // {end-bit mask of 32 output bytes, words that end in front of them}
+	uint32_t it[P2_ITEMS + 8];
+	uint32_t ib[2 * 64];                                   // {item-start bit mask of 32 output bytes, items that start in front of them}
 	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes]
 	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
 };
@@ -579,21 +574,13 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 	const int lane = wv::lane();
 	const wv::u32x4 noop4 = wv::make4(K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP, K1_TOK_NOOP);
 	uint8_t* const vb = S.val + P2_HIST;   // byte j of the batch
-	// a match of distance 1..3 repeats the distance bytes in front of it: byte k of the dword at j is pattern byte (j + k - start) mod distance
-	auto pattern = [&](uint32_t d, uint32_t j) -> uint32_t {
-		const uint32_t dist = (d & 0x7fffu) + 1u, ms = wv::bfe(d, 16, 11);
-		const uint32_t pw = wv::lds_load32u(vb + (int)ms - 4);   // the pattern = its last distance bytes
-		const uint32_t x = j + 12u - ms, r = dist == 3u ? x - 3u * ((x * 0xaaabu) >> 17) : (x & (dist - 1u));   // x mod distance
-		const uint32_t sel = dist == 1u ? 0x03030303u : (dist == 2u ? (r ? 0x02030203u : 0x03020302u) : (r == 0u ? 0x01030201u : (r == 1u ? 0x02010302u : 0x03020103u)));
-		return wv::perm(pw, pw, sel);
-	};
 	for (int64_t b = wv::block_id(); b < n_blocks; b += wv::grid_size())
 	{
 		if (status[b].error) continue;
 		const uint32_t ngroups = tok_count[b];
 		const uint32_t usize = blocks[b].usize;
 		const wv::ByteBuf out = wv::ByteBuf::make(out_base + blocks[b].upos, usize);            // stores: exact bounds
-		const wv::ByteBuf outld = wv::ByteBuf::make(out_base + blocks[b].upos, usize + 3u);     // source dwords may end up to three bytes behind the member (mapped: the next member or the buffer's slack)
+		const wv::ByteBuf outld = wv::ByteBuf::make(out_base + blocks[b].upos, usize + 3u);     // a source dword may end up to three bytes behind the item's source (mapped: the next member or the buffer's slack)
 		const wv::ByteBuf cin = wv::ByteBuf::make(const_cast<uint8_t*>(comp) + blocks[b].cpos, blocks[b].clen + 3u);   // raw runs (stored blocks) are copied from here (the gzip trailer follows)
 		// the member's pages: logical group g lives in page g / (K1_PAGE_GROUPS - 1); a batch spans at most two pages
 		uint32_t pg_cur = tok_first[b], pg_first = 0;
@@ -611,7 +598,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 		wv::u32x4 nxt = (uint32_t)lane < ngroups ? group((uint32_t)lane) : noop4;
 		for (uint32_t g0 = 0; g0 < ngroups;)
 		{
-			// ---- place the batch: one group per lane, a prefix sum over (bytes | real words << 20) ----
+			// ---- place the batch: one group per lane, a prefix sum over (bytes | items << 17) ----
 			bool valid = g0 + (uint32_t)lane < ngroups;
 			const uint32_t t0 = nxt.x, t1 = nxt.y, t2 = nxt.z, t3 = nxt.w;
 			// a table group switches the literal table for the words behind it: it ends the batch in front of it, or (first group) is consumed here
@@ -627,63 +614,62 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 				continue;
 			}
 			if (tabm) valid = valid && ((1ull << lane) & (tabm - 1ull) & ~tabm) != 0;   // lanes in front of the first table group
-			const uint32_t l0 = valid ? tok_len(t0) : 0u, l1 = valid ? tok_len(t1) : 0u, l2 = valid ? tok_len(t2) : 0u, l3 = valid ? tok_len(t3) : 0u;
-			const uint32_t s = l0 + l1 + l2 + l3, c = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-			const uint32_t E = wv::scan_incl(s | (c << 20));
-			const uint32_t Eb = E & 0xfffffu, Ec = E >> 20;
+			const uint32_t tt[4] = {t0, t1, t2, t3};
+			uint32_t ll[4], cl[4], s = 0, c = 0;   // per word: output bytes, bytes that are copied (match / raw run)
+			#pragma unroll
+			for (int k = 0; k < 4; ++k)
+			{
+				ll[k] = valid ? tok_len(tt[k]) : 0u;
+				cl[k] = tt[k] >= K1_TOK_MATCH ? ll[k] - (tt[k] >> 31) : (tt[k] >= K1_TOK_RAW ? ll[k] : 0u);
+				s += ll[k]; c += (cl[k] + 15u) >> 4;
+			}
+			const uint32_t E = wv::scan_incl(s | (c << 17));   // (64 groups: < 2^17 bytes, < 2^15 items)
+			const uint32_t Eb = E & 0x1ffffu, Ei = E >> 17;
 			// the longest prefix of groups whose output fits the staging buffer (the sums are non-decreasing: the ballot is a prefix mask)
 			const uint32_t ng = wv::popc64(wv::ballot(valid && Eb <= (uint32_t)P2_BMAX));
 			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 259 bytes: not a token stream of phase 1
-			const uint32_t B = wv::readlane(Eb, (int)ng - 1);
+			const uint32_t B = wv::readlane(Eb, (int)ng - 1), NI = wv::readlane(Ei, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
-			S.eb[2 * lane] = 0u;
-			// (rare) a raw run of one or two bytes could lie strictly inside a dword, between A and B: such a run is put in place like literals
-			const bool tiny_raw = (uint32_t)lane < ng && t0 - K1_TOK_RAW < 0x20000u && l0 != 0u;   // (a raw run is the first word of its group, the others are no-ops)
-			uint32_t rb0 = 0, rb1 = 0;
-			if (wv::ballot(tiny_raw) != 0ull)
-			{
-				if (tiny_raw) { rb0 = cin.load(t0 & 0xffffu); rb1 = cin.load((t0 & 0xffffu) + 1u); }
-				wv::wait_vm0();
-			}
+			S.ib[2 * lane] = 0u;
 			wv::barrier();
-			// per real word: literal bytes to their place, the descriptor of the match part, the end bit
+			// per word: literal bytes to their place, the items of the copied part
 			if ((uint32_t)lane < ng)
 			{
-				uint32_t st = Eb - s, rk = Ec - c;
-				const uint32_t tt[4] = {t0, t1, t2, t3}, ll[4] = {l0, l1, l2, l3};
+				uint32_t st = Eb - s, ix = Ei - c;
 				#pragma unroll
 				for (int k = 0; k < 4; ++k)
 					if (ll[k])
 					{
 						const uint32_t t = tt[k];
-						uint32_t w = PK_NONE;
+						uint32_t key;   // the item word without its position and length
 						if (t >= K1_TOK_MATCH)
 						{
-							const uint32_t hl = t >> 31;
-							if (hl) vb[st] = S.lit[(t >> 23) & 255u];
-							const uint32_t ms = st + hl, ml = ((t >> 15) & 255u) + 3u, d = (t & 0x7fffu) + 1u;
-							const uint32_t kind = d >= ms + ml ? PK_FAR : (d < 4u ? PK_PAT : PK_NEAR);
-							w = (kind << 29) | (ms << 16) | (d - 1u);
+							if (t >> 31) vb[st] = S.lit[(t >> 23) & 255u];
+							key = (t & 0x7fffu) << 15;
 						}
 						else if (t < K1_TOK_RAW)
 						{
 							vb[st] = S.lit[t & 255u];
 							if (t & K1_TOK_LIT2) vb[st + 1] = S.lit[(t >> 8) & 255u];
+							key = 0;
 						}
-						else if (ll[k] <= 2u) { vb[st] = (uint8_t)rb0; if (ll[k] == 2u) vb[st + 1] = (uint8_t)rb1; }
-						else w = (PK_RAW << 29) | (st << 16) | (t & 0xffffu);
-						S.pk[rk] = w;
-						st += ll[k]; ++rk;
-						wv::lds_or32(&S.eb[2 * ((st - 1u) >> 5)], 1u << ((st - 1u) & 31u));
+						else key = 0x80000000u | ((t & 0xffffu) << 15);
+						const uint32_t n = cl[k], ms = st + ll[k] - n, il = n < 16u ? n : 16u;
+						for (uint32_t o = 0; o < n; o += 16u)
+						{
+							const uint32_t off = o + il <= n ? o : n - il, d = ms + off;   // (the last item of a long match overlaps its predecessor)
+							S.it[ix++] = d | ((il - 1u) << 11) | (key + ((key >> 31) ? off << 15 : 0u));
+							wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
+						}
+						st += ll[k];
 					}
-				if ((uint32_t)lane == ng - 1) S.pk[rk] = 0;   // what the lanes behind the batch's last byte find
 			}
 			wv::barrier();
 			{
-				// words that end in front of each 32-byte piece
-				const uint32_t m = lane < P2_NW ? S.eb[2 * lane] : 0u, cn = wv::bcnt(m);
+				// items that start in front of each 32-byte piece
+				const uint32_t m = lane < P2_NW ? S.ib[2 * lane] : 0u, cn = wv::bcnt(m);
 				const uint32_t inc = wv::scan_incl(cn);
-				if (lane < P2_NW) S.eb[2 * lane + 1] = inc - cn;
+				if (lane < P2_NW) S.ib[2 * lane + 1] = inc - cn;
 			}
 			wv::barrier();
 			// stores of earlier batches must be complete before this batch loads from the window behind P
@@ -696,129 +682,111 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			}
 
 			if (lane == 0) K1_STAT(7);
-			#pragma nounroll
-			for (uint32_t jb = 0; jb < B; jb += P2_SUB * P2_CH)
-			{
-				// ---- pass 1: the two pieces of every dword; every load from HBM is issued ----
-				uint32_t dA[P2_SUB], dB[P2_SUB], mA[P2_SUB], mB[P2_SUB], gA[P2_SUB], gB[P2_SUB];
-				#pragma unroll
-				for (int ch = 0; ch < P2_SUB; ++ch)
+			// one step's worth of item state; the loads of a far (or raw) item are issued a step ahead
+			struct Item { uint32_t w, mode, g0, g1, g2, g3; };   // mode: 0 nothing to do, 1 loaded, 2 near
+			auto fetch = [&](uint32_t i0) -> Item {
+				Item q; const uint32_t idx = i0 + (uint32_t)lane;
+				q.w = idx < NI ? S.it[idx] : 0u; q.mode = 0; q.g0 = q.g1 = q.g2 = q.g3 = 0;
+				if (idx < NI)
 				{
-					dA[ch] = 0; dB[ch] = 0; mA[ch] = 0; mB[ch] = 0; gA[ch] = 0; gB[ch] = 0;
-					const uint32_t j0 = jb + (uint32_t)(ch * P2_CH), j = j0 + 4u * (uint32_t)lane;
-					if (j0 < B)
+					const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
+					const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
+					if (q.w >> 31)
 					{
-						const uint32_t em = S.eb[2 * (j >> 5)], ec = S.eb[2 * (j >> 5) + 1], bp = j & 31u;
-						const uint32_t o0 = ec + wv::bcnt(wv::bfe(em, 0, bp));
-						const uint32_t nib = wv::bfe(em, bp, 3);             // end bits of the dword's first three bytes
-						const uint32_t e0 = wv::ctz32(nib | 8u);             // the last byte A owns
-						const uint32_t s3 = 31u - wv::clz32(nib << 1 | 1u);  // the first byte B owns (nib == 0: A == B)
-						const uint32_t o3 = o0 + wv::bcnt(nib);
-						uint32_t pa = S.pk[o0], pb = S.pk[o3];
-						// bytes [k0, k1] of the dword belong to the piece
-						auto piece = [&](uint32_t& d, uint32_t kmin, uint32_t k1, uint32_t& m, uint32_t& g) {
-							const int ms = (int)wv::bfe(d, 16, 11) - (int)j;
-							const uint32_t k0 = ms > (int)kmin ? (uint32_t)ms : kmin;
-							const bool ok = (d >> 29) != PK_NONE && (int)k0 <= (int)k1;
-							m = ok ? (0xffffffffu >> (8u * (3u - (k1 - k0)))) << (8u * k0) : 0u;
-							d = ok ? d : 0u;
-							if ((d >> 29) == PK_FAR)
-							{
-								const int src = (int)(P + j) - (int)((d & 0x7fffu) + 1u);   // >= -3: the piece's own bytes have sources at >= 0
-								g = outld.load32((uint32_t)(src < 0 ? 0 : src));
-							}
-							else if ((d >> 29) == PK_RAW)
-							{
-								const int src = (int)(d & 0xffffu) - ms;
-								g = cin.load32((uint32_t)(src < 0 ? 0 : src));
-							}
-						};
-						piece(pa, 0u, e0, mA[ch], gA[ch]);
-						if (nib == 0u) pb = 0u;
-						piece(pb, s3, 3u, mB[ch], gB[ch]);
-						dA[ch] = pa; dB[ch] = pb;
+						const uint32_t a = wv::bfe(q.w, 15, 16);
+						q.g0 = cin.load32(a); q.g1 = cin.load32(a + o1); q.g2 = cin.load32(a + o2); q.g3 = cin.load32(a + o3); q.mode = 1;
+					}
+					else
+					{
+						const int src = (int)d - (int)(wv::bfe(q.w, 15, 15) + 1u);
+						if (src + (int)len <= 0)
+						{
+							const uint32_t a = P + (uint32_t)src;
+							q.g0 = outld.load32(a); q.g1 = outld.load32(a + o1); q.g2 = outld.load32(a + o2); q.g3 = outld.load32(a + o3); q.mode = 1;
+						}
+						else q.mode = 2;
 					}
 				}
-				// every load has landed (one wait for the sub-batch: pass 2 below issues stores only)
-				wv::wait_vm0();
-				// ---- pass 2: resolve front to back ----
-				#pragma unroll
-				for (int ch = 0; ch < P2_SUB; ++ch)
+				return q;
+			};
+			auto rank = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
+			Item nx = fetch(0u);
+			#pragma nounroll
+			for (uint32_t i0 = 0; i0 < NI; i0 += 64u)
+			{
+				Item q = nx;
+				if (i0 + 64u < NI) { nx = fetch(i0 + 64u); wv::wait_vm4(); } else wv::wait_vm0();   // (only loads are in flight: they return in order)
+				if (lane == 0) K1_STAT(4);
+				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
+				const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
+				const int src = (int)d - (int)dist;
+				// the lanes of this step that write into a near item's source: items that start in (src - 16, src + len), in front of this one
+				uint64_t dep = 0;
+				if (q.mode == 2u)
 				{
-					const uint32_t j0 = jb + (uint32_t)(ch * P2_CH), j = j0 + 4u * (uint32_t)lane;
-					if (j0 < B)
+					const int lo = (int)rank((uint32_t)(src > 15 ? src - 15 : 0)) - (int)i0;
+					int hi = (int)rank((uint32_t)(src + (int)len)) - 1 - (int)i0;
+					hi = hi < lane ? hi : lane - 1;
+					const int l0 = lo > 0 ? lo : 0;
+					if (hi >= l0) dep = ((2ull << (hi - l0)) - 1ull) << l0;
+				}
+				for (;;)
+				{
+					if (lane == 0) K1_STAT(6);
+					const uint64_t open = wv::ballot(q.mode != 0u);
+					if (open == 0ull) break;
+					const bool go = q.mode == 1u || (q.mode == 2u && (open & dep) == 0ull);
+					const bool rd = go && q.mode == 2u;
+					bool slow = false;
+					if (rd)
 					{
-						if (lane == 0) K1_STAT(4);
-						wv::barrier();   // (the bytes in front of the chunk are in LDS)
-						uint32_t cur = wv::lds_load32(vb + j);   // the literals are in place
-						uint32_t pend = 0, shA = 0, shB = 0;
-						// far / raw: the loaded dword, shifted when its first bytes lay in front of the buffer. near / pattern: a source in front of the chunk is
-						// resolved and in LDS; one inside the chunk has to wait until the lanes that hold it (sh, sh + 1) are done
-						auto first = [&](uint32_t d, uint32_t m, uint32_t g, uint32_t bit, uint32_t& sh) {
-							const uint32_t kind = d >> 29;
-							if (kind == PK_FAR || kind == PK_RAW)
-							{
-								const int src = kind == PK_FAR ? (int)(P + j) - (int)((d & 0x7fffu) + 1u) : (int)(d & 0xffffu) - ((int)wv::bfe(d, 16, 11) - (int)j);
-								cur = wv::bfi(m, src < 0 ? g << (8u * (uint32_t)(-src)) : g, cur);
-							}
-							else if (kind != PK_NONE)
-							{
-								const uint32_t dist = (d & 0x7fffu) + 1u;
-								// the first and the last source byte, and the lanes of this chunk that hold them
-								const int s0 = kind == PK_NEAR ? (int)(j + (wv::ctz32(m) >> 3)) - (int)dist : (int)wv::bfe(d, 16, 11) - (int)dist;
-								const int s1 = kind == PK_NEAR ? (int)(j + 3u - (wv::clz32(m) >> 3)) - (int)dist : (int)wv::bfe(d, 16, 11) - 1;
-								const int lo = (s0 - (int)j0) >> 2, hi = (s1 - (int)j0) >> 2;
-								if (hi < 0) cur = wv::bfi(m, kind == PK_NEAR ? wv::lds_load32u(vb + (int)j - (int)dist) : pattern(d, j), cur);
-								else { pend |= bit; sh = (uint32_t)(lo < 0 ? 0 : lo) | (hi > lo && lo >= 0 ? 0x300u : 0x100u); }   // lanes to wait for: mask << 8 | first lane
-							}
-						};
-						first(dA[ch], mA[ch], gA[ch], 1u, shA);
-						first(dB[ch], mB[ch], gB[ch], 2u, shB);
-						uint64_t pm = wv::ballot(pend != 0u);
-						wv::lds_store32(vb + j, cur);
-						if (pm != 0ull)   // (a chunk whose sources all lie in front of it skips this)
+						if (dist >= len)
 						{
-							if (lane == 0) K1_STAT(5);
-							for (;;)
-							{
-								if (lane == 0) K1_STAT(6);
-								wv::barrier();   // (the stores of the last round are visible)
-								const uint64_t others = pm & ~(1ull << lane);   // the bytes of this dword in front of a piece are literals or a settled piece
-								bool changed = false;
-								auto settle = [&](uint32_t d, uint32_t m, uint32_t bit, uint32_t sh) {
-									if (!(pend & bit) || ((uint32_t)(others >> (sh & 63u)) & (sh >> 8)) != 0u) return;
-									cur = wv::bfi(m, (d >> 29) == PK_NEAR ? wv::lds_load32u(vb + (int)j - (int)((d & 0x7fffu) + 1u)) : pattern(d, j), cur);
-									pend &= ~bit; changed = true;
-								};
-								const bool a_open = (pend & 1u) != 0u;
-								settle(dA[ch], mA[ch], 1u, shA);
-								if (!a_open) settle(dB[ch], mB[ch], 2u, shB);   // (B's source may be A's bytes of this very dword: not before A is in LDS)
-								wv::barrier();   // (this round's LDS reads are done)
-								if (changed) wv::lds_store32(vb + j, cur);
-								pm = wv::ballot(pend != 0u);
-								if (pm == 0ull) break;
-							}
+							q.g0 = wv::lds_load32u(vb + src); q.g1 = wv::lds_load32u(vb + src + (int)o1); q.g2 = wv::lds_load32u(vb + src + (int)o2); q.g3 = wv::lds_load32u(vb + src + (int)o3);
 						}
-						if (j + 4u <= B) out.store32(P + j, cur);
-						else if (j < B)
+						else if (dist == 1u) { q.g0 = (uint32_t)vb[src] * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
+						else slow = true;
+					}
+					if (wv::ballot(slow) != 0ull)
+					{
+						// (rare) an item that overlaps its own source with a distance of 2..15: byte by byte
+						if (slow) for (uint32_t k = 0; k < len; ++k) vb[d + k] = vb[src + (int)k];
+					}
+					if (go && !slow)
+					{
+						if (len >= 4u)
 						{
-							out.store(P + j, cur);
-							if (j + 1u < B) out.store(P + j + 1u, cur >> 8);
-							if (j + 2u < B) out.store(P + j + 2u, cur >> 16);
+							wv::lds_store32u(vb + d, q.g0); wv::lds_store32u(vb + d + o1, q.g1); wv::lds_store32u(vb + d + o2, q.g2); wv::lds_store32u(vb + d + o3, q.g3);
+						}
+						else
+						{
+							if (len >= 2u) wv::lds_store16u(vb + d, q.g0);
+							vb[d + len - 1u] = (uint8_t)(q.g0 >> (8u * (len - 1u)));
 						}
 					}
+					if (go) q.mode = 0u;
+					wv::barrier();
+				}
+			}
+			// ---- the batch leaves for HBM ----
+			wv::barrier();
+			#pragma nounroll
+			for (uint32_t j = 4u * (uint32_t)lane; j < B; j += 256u)
+			{
+				const uint32_t v = wv::lds_load32(vb + j);
+				if (j + 4u <= B) out.store32(P + j, v);
+				else
+				{
+					out.store(P + j, v);
+					if (j + 1u < B) out.store(P + j + 1u, v >> 8);
+					if (j + 2u < B) out.store(P + j + 2u, v >> 16);
 				}
 			}
 			// the last P2_HIST bytes stay in LDS in front of the next batch
-			wv::barrier();
 			{
-				const uint32_t h0 = wv::lds_load32u(S.val + B + 4u * (uint32_t)lane);
+				const uint32_t h = lane < P2_HIST / 4 ? wv::lds_load32u(vb + (int)B - P2_HIST + 4 * lane) : 0u;
 				wv::barrier();
-				wv::lds_store32(S.val + 4u * (uint32_t)lane, h0);
-				wv::barrier();
-				const uint32_t h1 = lane < (P2_HIST - 256) / 4 ? wv::lds_load32u(S.val + B + 256u + 4u * (uint32_t)lane) : 0u;
-				wv::barrier();
-				if (lane < (P2_HIST - 256) / 4) wv::lds_store32(S.val + 256u + 4u * (uint32_t)lane, h1);
+				if (lane < P2_HIST / 4) wv::lds_store32(S.val + 4 * lane, h);
 				wv::barrier();
 			}
 			P += B; g0 += ng;

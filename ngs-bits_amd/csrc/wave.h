@@ -40,7 +40,8 @@ K1_DEV uint32_t scan_incl(uint32_t x)
 }
 
 // ---- memory ----
-K1_DEV void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): every vector-memory load has returned, every store is acknowledged
+K1_DEV void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+K1_DEV void wait_vm4() { __builtin_amdgcn_s_waitcnt(0x0F74); }   // vmcnt(4): all but the last four vector-memory operations are done (loads return in order)   // vmcnt(0): every vector-memory load has returned, every store is acknowledged
 K1_DEV unsigned long long atomic_inc(unsigned long long* p) { return atomicAdd(p, 1ull); }
 K1_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 K1_DEV void lds_or(unsigned long long* p, unsigned long long v) { atomicOr(p, v); }
@@ -49,6 +50,8 @@ K1_DEV void lds_or32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 K1_DEV uint32_t lds_load32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 K1_DEV uint32_t lds_load32(const uint8_t* p) { return *(const uint32_t*)p; }
 K1_DEV void lds_store32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
+K1_DEV void lds_store32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+K1_DEV void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
 
 // A byte range in HBM behind a buffer resource: 32-bit offsets (one VALU add per address) and hardware bounds clamping
 // (loads outside read 0, stores outside are dropped). The descriptor lives in SGPRs: its inputs are made wave-uniform first.

@@ -86,7 +86,7 @@ __attribute__((noinline)) inline Xchg rendezvous(uint64_t v, const void* site)
 	for (int i = 0; i < Emu::W; ++i)
 		if (E.stamp[p][i] == k && E.site[p][i] != site)
 		{
-			fprintf(stderr, "wave_emul: cross-lane operation reached from divergent control flow (lanes %d and %d, block %lld)\n", l, i, (long long)E.block);
+			fprintf(stderr, "wave_emul: cross-lane operation reached from divergent control flow (lanes %d and %d at source lines %ld and %ld, block %lld)\n", l, i, (long)(uintptr_t)site, (long)(uintptr_t)E.site[p][i], (long long)E.block);
 			abort();
 		}
 	return Xchg{E.xv[p], E.stamp[p], k};
@@ -114,6 +114,7 @@ __attribute__((noinline)) inline uint32_t scan_incl(uint32_t v, int line = __bui
 }
 
 inline void wait_vm0() {}
+inline void wait_vm4() {}
 inline void set_priority(int) {}
 inline unsigned long long atomic_inc(unsigned long long* p) { return (*p)++; }
 inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
@@ -121,6 +122,8 @@ inline void lds_or(unsigned long long* p, unsigned long long v) { *p |= v; }
 inline void lds_or32(uint32_t* p, uint32_t v) { *p |= v; }
 inline uint32_t lds_load32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint32_t lds_load32(const uint8_t* p) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_load32\n"); abort(); } uint32_t v; memcpy(&v, p, 4); return v; }
+inline void lds_store32u(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
+inline void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; memcpy(p, &h, 2); }
 inline void lds_store32(uint8_t* p, uint32_t v) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_store32\n"); abort(); } memcpy(p, &v, 4); }
 
 struct ByteBuf
