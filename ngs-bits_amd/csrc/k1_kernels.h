@@ -552,11 +552,13 @@ constexpr int P2_HIST = 16;                    // output bytes in front of the b
 constexpr int P2_NW = P2_BMAX / 32 + 1;        // words of the item-start bit mask (one lane each in the count scan)
 constexpr int P2_ITEMS = P2_GROUPS * 4 + P2_BMAX / 16;   // at most one item per word and one more per 16 output bytes
 static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4 == 0, "phase-2 batch geometry");
-// item word: first byte (batch-relative) | (length - 1) << 11 | (distance - 1) << 15; a raw run: bit 31 | payload offset << 15
+// item word: first byte (batch-relative) | (length - 1) << 11 | (distance - 1) << 15; a raw run: bit 31 | payload offset << 15. An item of a distance-1 match
+// (a run of one byte: the usual self-overlapping match of BAM data) carries bit 30 and the distance to the byte IN FRONT OF THE MATCH instead: every item of
+// the run repeats that byte, none of them waits for its predecessor
 struct P2Lds
 {
 	uint32_t it[P2_ITEMS + 8];
-	uint32_t ib[2 * 64];                                   // {item-start bit mask of 32 output bytes, items that start in front of them}
+	uint32_t ib[4 * 64];                                   // per 32 output bytes: {item-start bit mask, item-end bit mask, items that start in front of them | items that end in front of them << 16, -}
 	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes]
 	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
 };
@@ -630,7 +632,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 259 bytes: not a token stream of phase 1
 			const uint32_t B = wv::readlane(Eb, (int)ng - 1), NI = wv::readlane(Ei, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
-			S.ib[2 * lane] = 0u;
+			S.ib[4 * lane] = 0u; S.ib[4 * lane + 1] = 0u;
 			wv::barrier();
 			// per word: literal bytes to their place, the items of the copied part
 			if ((uint32_t)lane < ng)
@@ -645,7 +647,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 						if (t >= K1_TOK_MATCH)
 						{
 							if (t >> 31) vb[st] = S.lit[(t >> 23) & 255u];
-							key = (t & 0x7fffu) << 15;
+							key = (t & 0x7fffu) == 0u ? 0x40000000u : (t & 0x7fffu) << 15;
 						}
 						else if (t < K1_TOK_RAW)
 						{
@@ -658,18 +660,19 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 						for (uint32_t o = 0; o < n; o += 16u)
 						{
 							const uint32_t off = o + il <= n ? o : n - il, d = ms + off;   // (the last item of a long match overlaps its predecessor)
-							S.it[ix++] = d | ((il - 1u) << 11) | (key + ((key >> 31) ? off << 15 : 0u));
-							wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
+							S.it[ix++] = d | ((il - 1u) << 11) | (key + ((key >> 30) ? off << 15 : 0u));   // (raw run: payload offset of the item; run of a byte: distance to the byte in front of the match)
+							wv::lds_or32(&S.ib[4 * (d >> 5)], 1u << (d & 31u));
+							wv::lds_or32(&S.ib[4 * ((d + il - 1u) >> 5) + 1], 1u << ((d + il - 1u) & 31u));
 						}
 						st += ll[k];
 					}
 			}
 			wv::barrier();
 			{
-				// items that start in front of each 32-byte piece
-				const uint32_t m = lane < P2_NW ? S.ib[2 * lane] : 0u, cn = wv::bcnt(m);
+				// items that start / end in front of each 32-byte piece
+				const uint32_t cn = lane < P2_NW ? wv::bcnt(S.ib[4 * lane]) | (wv::bcnt(S.ib[4 * lane + 1]) << 16) : 0u;
 				const uint32_t inc = wv::scan_incl(cn);
-				if (lane < P2_NW) S.ib[2 * lane + 1] = inc - cn;
+				if (lane < P2_NW) S.ib[4 * lane + 2] = inc - cn;
 			}
 			wv::barrier();
 			// stores of earlier batches must be complete before this batch loads from the window behind P
@@ -683,7 +686,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 
 			if (lane == 0) K1_STAT(7);
 			// one step's worth of item state; the loads of a far (or raw) item are issued a step ahead
-			struct Item { uint32_t w, mode, g0, g1, g2, g3; };   // mode: 0 nothing to do, 1 loaded, 2 near
+			struct Item { uint32_t w, mode, g0, g1, g2, g3; };   // mode: 0 nothing to do, 1 loaded, 2 near, 3 raw run (loaded in its step: rare)
 			auto fetch = [&](uint32_t i0) -> Item {
 				Item q; const uint32_t idx = i0 + (uint32_t)lane;
 				q.w = idx < NI ? S.it[idx] : 0u; q.mode = 0; q.g0 = q.g1 = q.g2 = q.g3 = 0;
@@ -691,60 +694,82 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 				{
 					const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
 					const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
-					if (q.w >> 31)
-					{
-						const uint32_t a = wv::bfe(q.w, 15, 16);
-						q.g0 = cin.load32(a); q.g1 = cin.load32(a + o1); q.g2 = cin.load32(a + o2); q.g3 = cin.load32(a + o3); q.mode = 1;
-					}
+					if (q.w >> 31) q.mode = 3;
 					else
 					{
 						const int src = (int)d - (int)(wv::bfe(q.w, 15, 15) + 1u);
-						if (src + (int)len <= 0)
+						const bool run = (q.w >> 30) != 0u;
+						if (src + (run ? 1 : (int)len) <= 0)
 						{
 							const uint32_t a = P + (uint32_t)src;
-							q.g0 = outld.load32(a); q.g1 = outld.load32(a + o1); q.g2 = outld.load32(a + o2); q.g3 = outld.load32(a + o3); q.mode = 1;
+							q.g0 = outld.load32(a); q.g1 = outld.load32(run ? a : a + o1); q.g2 = outld.load32(run ? a : a + o2); q.g3 = outld.load32(run ? a : a + o3); q.mode = 1;
 						}
 						else q.mode = 2;
 					}
 				}
 				return q;
 			};
-			auto rank = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
-			Item nx = fetch(0u);
-			#pragma nounroll
-			for (uint32_t i0 = 0; i0 < NI; i0 += 64u)
-			{
-				Item q = nx;
-				if (i0 + 64u < NI) { nx = fetch(i0 + 64u); wv::wait_vm4(); } else wv::wait_vm0();   // (only loads are in flight: they return in order)
+			auto starts_before = [&](uint32_t p) -> uint32_t { return (S.ib[4 * (p >> 5) + 2] & 0xffffu) + wv::bcnt(wv::bfe(S.ib[4 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
+			auto ends_before = [&](uint32_t p) -> uint32_t { return (S.ib[4 * (p >> 5) + 2] >> 16) + wv::bcnt(wv::bfe(S.ib[4 * (p >> 5) + 1], 0, p & 31u)); };      // items whose last byte lies in front of byte p
+			auto process = [&](Item& q, const uint32_t i0) {
 				if (lane == 0) K1_STAT(4);
+				if (wv::ballot(q.mode == 3u) != 0ull)
+				{
+					// (rare) a stored block's bytes come from the compressed input
+					if (q.mode == 3u)
+					{
+						const uint32_t a = wv::bfe(q.w, 15, 16), len = wv::bfe(q.w, 11, 4) + 1u;
+						const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
+						q.g0 = cin.load32(a); q.g1 = cin.load32(a + o1); q.g2 = cin.load32(a + o2); q.g3 = cin.load32(a + o3); q.mode = 1;
+					}
+					wv::wait_vm0();
+				}
 				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
 				const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
 				const int src = (int)d - (int)dist;
-				// the lanes of this step that write into a near item's source: items that start in (src - 16, src + len), in front of this one
+				const bool run = (q.w >> 30) == 1u;
+				const uint32_t slen = run ? 1u : len;   // source bytes
+				if (run && q.mode == 1u) { q.g0 = (q.g0 & 255u) * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
+				// the lanes of this step that write into a near item's source: the items (they are sorted by start and by end) from the first one that ends
+				// at or behind the source's first byte to the last one that starts in front of the source's end, as far as they lie in front of this item
 				uint64_t dep = 0;
 				if (q.mode == 2u)
 				{
-					const int lo = (int)rank((uint32_t)(src > 15 ? src - 15 : 0)) - (int)i0;
-					int hi = (int)rank((uint32_t)(src + (int)len)) - 1 - (int)i0;
+					const int lo = (int)ends_before((uint32_t)(src > 0 ? src : 0)) - (int)i0;
+					int hi = (int)starts_before((uint32_t)(src + (int)slen)) - 1 - (int)i0;
 					hi = hi < lane ? hi : lane - 1;
 					const int l0 = lo > 0 ? lo : 0;
 					if (hi >= l0) dep = ((2ull << (hi - l0)) - 1ull) << l0;
 				}
+				auto put = [&]() {
+					if (len >= 4u)
+					{
+						wv::lds_store32u(vb + d, q.g0); wv::lds_store32u(vb + d + o1, q.g1); wv::lds_store32u(vb + d + o2, q.g2); wv::lds_store32u(vb + d + o3, q.g3);
+					}
+					else
+					{
+						if (len >= 2u) wv::lds_store16u(vb + d, q.g0);
+						vb[d + len - 1u] = (uint8_t)(q.g0 >> (8u * (len - 1u)));
+					}
+				};
+				// the loaded items first: nothing in the batch depends on where they come from
+				if (q.mode == 1u) { put(); q.mode = 0u; }
+				wv::barrier();
 				for (;;)
 				{
 					if (lane == 0) K1_STAT(6);
 					const uint64_t open = wv::ballot(q.mode != 0u);
 					if (open == 0ull) break;
-					const bool go = q.mode == 1u || (q.mode == 2u && (open & dep) == 0ull);
-					const bool rd = go && q.mode == 2u;
+					const bool go = q.mode == 2u && (open & dep) == 0ull;
+					const bool rd = go;
 					bool slow = false;
 					if (rd)
 					{
-						if (dist >= len)
+						if (run) { q.g0 = (uint32_t)vb[src] * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
+						else if (dist >= len)
 						{
 							q.g0 = wv::lds_load32u(vb + src); q.g1 = wv::lds_load32u(vb + src + (int)o1); q.g2 = wv::lds_load32u(vb + src + (int)o2); q.g3 = wv::lds_load32u(vb + src + (int)o3);
 						}
-						else if (dist == 1u) { q.g0 = (uint32_t)vb[src] * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
 						else slow = true;
 					}
 					if (wv::ballot(slow) != 0ull)
@@ -752,20 +777,23 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 						// (rare) an item that overlaps its own source with a distance of 2..15: byte by byte
 						if (slow) for (uint32_t k = 0; k < len; ++k) vb[d + k] = vb[src + (int)k];
 					}
-					if (go && !slow)
-					{
-						if (len >= 4u)
-						{
-							wv::lds_store32u(vb + d, q.g0); wv::lds_store32u(vb + d + o1, q.g1); wv::lds_store32u(vb + d + o2, q.g2); wv::lds_store32u(vb + d + o3, q.g3);
-						}
-						else
-						{
-							if (len >= 2u) wv::lds_store16u(vb + d, q.g0);
-							vb[d + len - 1u] = (uint8_t)(q.g0 >> (8u * (len - 1u)));
-						}
-					}
+					if (go && !slow) put();
 					if (go) q.mode = 0u;
 					wv::barrier();
+				}
+			};
+			// two steps per trip: the loads of one step's far items are in flight while the other step is resolved (only loads are in flight: they return in order)
+			Item qa = fetch(0u), qb = qa;
+			#pragma nounroll
+			for (uint32_t i0 = 0; i0 < NI; i0 += 128u)
+			{
+				const bool hb = i0 + 64u < NI;
+				if (hb) { qb = fetch(i0 + 64u); wv::wait_vm4(); } else wv::wait_vm0();
+				process(qa, i0);
+				if (hb)
+				{
+					if (i0 + 128u < NI) { qa = fetch(i0 + 128u); wv::wait_vm4(); } else wv::wait_vm0();
+					process(qb, i0 + 64u);
 				}
 			}
 			// ---- the batch leaves for HBM ----
