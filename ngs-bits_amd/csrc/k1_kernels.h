@@ -540,11 +540,11 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 // its predecessor - and the items of the batch are listed in LDS in output order. Then ONE LANE PER ITEM, 64 items per step:
 //   far item   (every source byte lies in front of the batch) four dword loads from the member's output in HBM at the OVERLAPPING offsets
 //              0, min(4, len - 4), min(8, len - 4), len - 4, which cover any length 4..16 exactly; they are issued one step ahead
-//   near item  the source reaches into the batch (or the 16 bytes in front of it, which stay in LDS): the same four dwords from LDS, once the
+//   near item  the source reaches into the batch (or the 16 bytes in front of it, which stay in LDS): the same two pieces from LDS, once the
 //              items that write its source are done - a 64-bit lane mask per item (from a bit mask of item starts), tested against the
 //              ballot of unfinished lanes; the lowest unfinished lane never waits, so the rounds terminate
 //   distance 1 the byte in front of the item, repeated; an item that overlaps its own source otherwise (rare) is copied byte by byte
-// and the item's bytes are written to LDS with four dword stores at the same offsets (lengths 1..3: a 16-bit and an 8-bit store). When all steps
+// and the item's bytes are written to LDS with two stores at the same offsets (lengths 1..3: a 16-bit and an 8-bit store). When all steps
 // are done the batch leaves LDS for HBM as whole dwords (256 consecutive bytes per store instruction).
 constexpr int P2_BMAX = 1536;                  // output bytes per batch: at least one whole group (4 x 259 bytes) always fits
 constexpr int P2_GROUPS = 64;                  // groups per batch: one per lane
@@ -558,7 +558,7 @@ static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4
 struct P2Lds
 {
 	uint32_t it[P2_ITEMS + 8];
-	uint32_t ib[4 * 64];                                   // per 32 output bytes: {item-start bit mask, item-end bit mask, items that start in front of them | items that end in front of them << 16, -}
+	uint32_t ib[2 * 64];                                   // per 32 output bytes: {item-start bit mask, items that start in front of them}
 	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes]
 	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
 };
@@ -632,7 +632,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 259 bytes: not a token stream of phase 1
 			const uint32_t B = wv::readlane(Eb, (int)ng - 1), NI = wv::readlane(Ei, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
-			S.ib[4 * lane] = 0u; S.ib[4 * lane + 1] = 0u;
+			S.ib[2 * lane] = 0u;
 			wv::barrier();
 			// per word: literal bytes to their place, the items of the copied part
 			if ((uint32_t)lane < ng)
@@ -661,18 +661,17 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 						{
 							const uint32_t off = o + il <= n ? o : n - il, d = ms + off;   // (the last item of a long match overlaps its predecessor)
 							S.it[ix++] = d | ((il - 1u) << 11) | (key + ((key >> 30) ? off << 15 : 0u));   // (raw run: payload offset of the item; run of a byte: distance to the byte in front of the match)
-							wv::lds_or32(&S.ib[4 * (d >> 5)], 1u << (d & 31u));
-							wv::lds_or32(&S.ib[4 * ((d + il - 1u) >> 5) + 1], 1u << ((d + il - 1u) & 31u));
+							wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
 						}
 						st += ll[k];
 					}
 			}
 			wv::barrier();
 			{
-				// items that start / end in front of each 32-byte piece
-				const uint32_t cn = lane < P2_NW ? wv::bcnt(S.ib[4 * lane]) | (wv::bcnt(S.ib[4 * lane + 1]) << 16) : 0u;
+				// items that start in front of each 32-byte piece
+				const uint32_t cn = lane < P2_NW ? wv::bcnt(S.ib[2 * lane]) : 0u;
 				const uint32_t inc = wv::scan_incl(cn);
-				if (lane < P2_NW) S.ib[4 * lane + 2] = inc - cn;
+				if (lane < P2_NW) S.ib[2 * lane + 1] = inc - cn;
 			}
 			wv::barrier();
 			// stores of earlier batches must be complete before this batch loads from the window behind P
@@ -686,70 +685,71 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 
 			if (lane == 0) K1_STAT(7);
 			// one step's worth of item state; the loads of a far (or raw) item are issued a step ahead
-			struct Item { uint32_t w, mode, g0, g1, g2, g3; };   // mode: 0 nothing to do, 1 loaded, 2 near, 3 raw run (loaded in its step: rare)
+			// An item's bytes travel in two overlapping pieces: lengths 9..16 as the two 8-byte words at 0 and len - 8, lengths 4..8 as the two dwords at 0 and
+			// len - 4, shorter ones as one dword (stored as a 16-bit and an 8-bit piece) - the LDS traffic follows the item's length
+			struct Item { uint32_t w, mode, w0, w1; uint64_t lo, hi; };   // mode: 0 nothing to do, 1 loaded, 2 near, 3 raw run (loaded in its step: rare)
 			auto fetch = [&](uint32_t i0) -> Item {
 				Item q; const uint32_t idx = i0 + (uint32_t)lane;
-				q.w = idx < NI ? S.it[idx] : 0u; q.mode = 0; q.g0 = q.g1 = q.g2 = q.g3 = 0;
+				q.w = idx < NI ? S.it[idx] : 0u; q.mode = 0; q.w0 = q.w1 = 0; q.lo = q.hi = 0;
 				if (idx < NI)
 				{
-					const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
-					const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
 					if (q.w >> 31) q.mode = 3;
 					else
 					{
+						const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
 						const int src = (int)d - (int)(wv::bfe(q.w, 15, 15) + 1u);
 						const bool run = (q.w >> 30) != 0u;
 						if (src + (run ? 1 : (int)len) <= 0)
 						{
 							const uint32_t a = P + (uint32_t)src;
-							q.g0 = outld.load32(a); q.g1 = outld.load32(run ? a : a + o1); q.g2 = outld.load32(run ? a : a + o2); q.g3 = outld.load32(run ? a : a + o3); q.mode = 1;
+							if (len >= 9u && !run) { q.lo = outld.load64(a); q.hi = outld.load64(a + len - 8u); }
+							else { q.w0 = outld.load32(a); q.w1 = outld.load32(a + (len >= 4u && !run ? len - 4u : 0u)); }
+							q.mode = 1;
 						}
 						else q.mode = 2;
 					}
 				}
 				return q;
 			};
-			auto starts_before = [&](uint32_t p) -> uint32_t { return (S.ib[4 * (p >> 5) + 2] & 0xffffu) + wv::bcnt(wv::bfe(S.ib[4 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
-			auto ends_before = [&](uint32_t p) -> uint32_t { return (S.ib[4 * (p >> 5) + 2] >> 16) + wv::bcnt(wv::bfe(S.ib[4 * (p >> 5) + 1], 0, p & 31u)); };      // items whose last byte lies in front of byte p
+			auto starts_before = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
 			auto process = [&](Item& q, const uint32_t i0) {
 				if (lane == 0) K1_STAT(4);
+				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
 				if (wv::ballot(q.mode == 3u) != 0ull)
 				{
 					// (rare) a stored block's bytes come from the compressed input
 					if (q.mode == 3u)
 					{
-						const uint32_t a = wv::bfe(q.w, 15, 16), len = wv::bfe(q.w, 11, 4) + 1u;
-						const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
-						q.g0 = cin.load32(a); q.g1 = cin.load32(a + o1); q.g2 = cin.load32(a + o2); q.g3 = cin.load32(a + o3); q.mode = 1;
+						const uint32_t a = wv::bfe(q.w, 15, 16);
+						if (len >= 9u) { q.lo = cin.load64(a); q.hi = cin.load64(a + len - 8u); }
+						else { q.w0 = cin.load32(a); q.w1 = cin.load32(a + (len >= 4u ? len - 4u : 0u)); }
+						q.mode = 1;
 					}
 					wv::wait_vm0();
 				}
-				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
-				const uint32_t o3 = len >= 4u ? len - 4u : 0u, o1 = o3 < 4u ? o3 : 4u, o2 = o3 < 8u ? o3 : 8u;
 				const int src = (int)d - (int)dist;
 				const bool run = (q.w >> 30) == 1u;
 				const uint32_t slen = run ? 1u : len;   // source bytes
-				if (run && q.mode == 1u) { q.g0 = (q.g0 & 255u) * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
-				// the lanes of this step that write into a near item's source: the items (they are sorted by start and by end) from the first one that ends
-				// at or behind the source's first byte to the last one that starts in front of the source's end, as far as they lie in front of this item
+				auto spread = [&](uint32_t byte) { q.w0 = (byte & 255u) * 0x01010101u; q.w1 = q.w0; q.lo = ((uint64_t)q.w0 << 32) | q.w0; q.hi = q.lo; };
+				if (run && q.mode == 1u) spread(q.w0);
+				// the lanes of this step that may write into a near item's source: the items that start in (src - 16, src + slen), as far as they lie in front of this
+				// item (an exact first lane - from a second bit plane of item ends - saved one round in seventy)
 				uint64_t dep = 0;
 				if (q.mode == 2u)
 				{
-					const int lo = (int)ends_before((uint32_t)(src > 0 ? src : 0)) - (int)i0;
+					const int lo = (int)starts_before((uint32_t)(src > 15 ? src - 15 : 0)) - (int)i0;
 					int hi = (int)starts_before((uint32_t)(src + (int)slen)) - 1 - (int)i0;
 					hi = hi < lane ? hi : lane - 1;
 					const int l0 = lo > 0 ? lo : 0;
 					if (hi >= l0) dep = ((2ull << (hi - l0)) - 1ull) << l0;
 				}
 				auto put = [&]() {
-					if (len >= 4u)
-					{
-						wv::lds_store32u(vb + d, q.g0); wv::lds_store32u(vb + d + o1, q.g1); wv::lds_store32u(vb + d + o2, q.g2); wv::lds_store32u(vb + d + o3, q.g3);
-					}
+					if (len >= 9u) { wv::lds_store64u(vb + d, q.lo); wv::lds_store64u(vb + d + len - 8u, q.hi); }
+					else if (len >= 4u) { wv::lds_store32u(vb + d, q.w0); wv::lds_store32u(vb + d + len - 4u, q.w1); }
 					else
 					{
-						if (len >= 2u) wv::lds_store16u(vb + d, q.g0);
-						vb[d + len - 1u] = (uint8_t)(q.g0 >> (8u * (len - 1u)));
+						if (len >= 2u) wv::lds_store16u(vb + d, q.w0);
+						vb[d + len - 1u] = (uint8_t)(q.w0 >> (8u * (len - 1u)));
 					}
 				};
 				// the loaded items first: nothing in the batch depends on where they come from
@@ -761,14 +761,14 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					const uint64_t open = wv::ballot(q.mode != 0u);
 					if (open == 0ull) break;
 					const bool go = q.mode == 2u && (open & dep) == 0ull;
-					const bool rd = go;
 					bool slow = false;
-					if (rd)
+					if (go)
 					{
-						if (run) { q.g0 = (uint32_t)vb[src] * 0x01010101u; q.g1 = q.g0; q.g2 = q.g0; q.g3 = q.g0; }
+						if (run) spread((uint32_t)vb[src]);
 						else if (dist >= len)
 						{
-							q.g0 = wv::lds_load32u(vb + src); q.g1 = wv::lds_load32u(vb + src + (int)o1); q.g2 = wv::lds_load32u(vb + src + (int)o2); q.g3 = wv::lds_load32u(vb + src + (int)o3);
+							if (len >= 9u) { q.lo = wv::lds_load64u(vb + src); q.hi = wv::lds_load64u(vb + src + (int)len - 8); }
+							else { q.w0 = wv::lds_load32u(vb + src); q.w1 = wv::lds_load32u(vb + src + (len >= 4u ? (int)len - 4 : 0)); }
 						}
 						else slow = true;
 					}

@@ -51,6 +51,8 @@ K1_DEV uint32_t lds_load32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v,
 K1_DEV uint32_t lds_load32(const uint8_t* p) { return *(const uint32_t*)p; }
 K1_DEV void lds_store32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
 K1_DEV void lds_store32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+K1_DEV uint64_t lds_load64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+K1_DEV void lds_store64u(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 K1_DEV void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
 
 // A byte range in HBM behind a buffer resource: 32-bit offsets (one VALU add per address) and hardware bounds clamping
@@ -70,6 +72,7 @@ struct ByteBuf
 	// a dword at any byte offset (in range: off + 4 <= bytes; a dword that is not wholly inside the range reads 0 / is dropped)
 	K1_DEV uint32_t load32(uint32_t off) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0); }
 	K1_DEV void store32(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off, 0, 0); }
+	K1_DEV uint64_t load64(uint32_t off) const { typedef uint32_t v2 __attribute__((ext_vector_type(2))); const v2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0); return ((uint64_t)r.y << 32) | r.x; }
 };
 
 // wave priority for instruction arbitration on its SIMD (0..3)

@@ -123,6 +123,8 @@ inline void lds_or32(uint32_t* p, uint32_t v) { *p |= v; }
 inline uint32_t lds_load32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint32_t lds_load32(const uint8_t* p) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_load32\n"); abort(); } uint32_t v; memcpy(&v, p, 4); return v; }
 inline void lds_store32u(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
+inline uint64_t lds_load64u(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline void lds_store64u(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
 inline void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; memcpy(p, &h, 2); }
 inline void lds_store32(uint8_t* p, uint32_t v) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_store32\n"); abort(); } memcpy(p, &v, 4); }
 
@@ -135,6 +137,7 @@ struct ByteBuf
 	// the strict reading of the hardware's range check: a dword that is not wholly inside the range reads 0 / is dropped
 	uint32_t load32(uint32_t off) const { uint32_t v = 0; if ((uint64_t)off + 4 <= bytes) memcpy(&v, p + off, 4); return v; }
 	void store32(uint32_t off, uint32_t v) const { if ((uint64_t)off + 4 <= bytes) memcpy(p + off, &v, 4); }
+	uint64_t load64(uint32_t off) const { return (uint64_t)load32(off) | ((uint64_t)load32(off + 4) << 32); }   // (each dword is range-checked on its own)
 };
 
 inline uint32_t brev(uint32_t x)
