@@ -271,7 +271,7 @@ void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, st
 {
 	if (in_pieces) *in_pieces = false;
 	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
-	if (threads <= 0) { threads = 1; if (const char* e = getenv("NGSQC_WALK_THREADS")) threads = std::min(64, std::max(1, atoi(e))); }
+	if (threads <= 0) { threads = 8; if (const char* e = getenv("NGSQC_WALK_THREADS")) threads = std::min(64, std::max(1, atoi(e))); }   // (round 4: on by default - the first job races the copy, tests/test_gpu_tools.py)
 	if (threads > 1 && n >= ((size_t)threads << 20) && scan_bgzf_threads(file, n, threads, blocks, crc, total, file_off)) { if (in_pieces) *in_pieces = true; return; }
 	blocks.clear(); crc.clear(); if (file_off) file_off->clear();
 	size_t off = 0; uint64_t upos = 0;
@@ -315,9 +315,9 @@ void upload_wait(ngsqc_handle* h, size_t end_byte, hipStream_t st, int slot);   
 // case (two token slots per output byte), so the call is made in batches of bounded scratch; the scratch is kept across calls.
 void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::vector<BlockDesc>& desc, uint8_t* d_out, int level = 0)
 {
-	// level 0: two token slots per output byte (enough unless a member holds hundreds of DEFLATE blocks: every block has its literal table in the pool), 2048
-	// members per batch = 1.1 GB of pool; level 1: the bound that holds for every valid member (k1_pool_pages_absolute: up to 17 MB per member), 32 per batch
-	const int64_t BATCH = level == 0 ? 2048 : 32;
+	// level 0: four token words per output byte (a group holds at least one real word; enough unless a member holds hundreds of DEFLATE blocks: every block has its
+	// literal table in the pool), 1024 members per batch = 1.1 GB of pool; level 1: the bound that holds for every valid member (k1_pool_pages_absolute: up to 18 MB per member), 32 per batch
+	const int64_t BATCH = level == 0 ? 1024 : 32;
 	std::vector<int64_t> idx2; std::vector<BlockDesc> desc2;   // members that need level 1
 	for (int64_t b0 = 0; b0 < (int64_t)idx.size(); b0 += BATCH)
 	{
@@ -635,6 +635,9 @@ void plan_layout_now(ngsqc_handle* h)
 		// queue order inside the chunk: largest compressed size first (the 64 lanes of a wave finish together)
 		std::stable_sort(ord.begin() + c0, ord.begin() + c0 + cn, [&](uint32_t a, uint32_t b) { return h->blocks[(size_t)(c0 + a)].clen > h->blocks[(size_t)(c0 + b)].clen; });
 	}
+	// the kernels address a literal table by a 32-bit WORD offset into the slot (page * K1_PAGE_WORDS): a slot never holds 2^22 pages or more (16 GiB; poorly
+	// compressible payloads could ask for that) - members that then find the pool used up take the second-chance path like any other overflow
+	h->slot_pages = std::min<int64_t>(h->slot_pages, (1ll << 22) - 1);
 	h->k1_slots = K1_SLOTS_DEFAULT; if (const char* e = getenv("NGSQC_TOKEN_SLOTS")) h->k1_slots = std::min(8, std::max(2, atoi(e)));
 	const int64_t n_slots = std::min<int64_t>(h->k1_slots, h->nch);
 	// tiles: as many chunks as fit the tile buffers next to the ring (at most cpt)
@@ -719,17 +722,14 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;
 	const char* eks = getenv("NGSQC_K1_SERIAL"); const bool k1_serial = eks && atoi(eks) != 0;   // profiling: every K1 kernel in line on ONE stream (isolated per-kernel counters)   // 1: the next chunk's phase 1 starts when the whole previous launch is done
 	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (!ce || atoi(ce) != 0) ? h->s_crc : h->s_p2;
-	// NGSQC_K1_PHASED=1 (an experiment for the next measurement, off by default): the phases of a tile's chunks take turns instead of running beside each other -
-	// phase 1 of all chunks of the tile together (two decoder launches fill the decoder slots), then their phase 2 launches with the chip to themselves (phase 2
-	// next to resident decoder waves gets three waves per SIMD instead of eight and takes twice as long), and the next tile's decoders start behind them.
-	const char* eph = getenv("NGSQC_K1_PHASED"); const bool phased = eph && atoi(eph) != 0 && !k1_serial;
+	// (A "phased" schedule - a tile's decoder launches together, then its phase-2 launches alone - was measured in round 4: 876 against 896 Mreads/s on a 96 M-read
+	// shard, profiles/r04_probe_schedule.txt; removed.)
 	const int64_t cA = h->tile_first_chunk[(size_t)t], cB = h->tile_first_chunk[(size_t)t + 1];
 	auto launch_p1 = [&](int64_t c) {
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
-		if (phased && cA > 0) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (cA - 1) + 3)], 0));            // behind the previous tile's last phase 2
 		if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
 		HIPCHK(hipEventRecord(e4[0], s1));
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
@@ -742,7 +742,6 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;
 		HIPCHK(hipStreamWaitEvent(h->s_p2, e4[1], 0));
-		if (phased) for (int64_t k = cA; k < cB; ++k) if (k != c) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_chunk[(size_t)(4 * k + 1)], 0));   // every decoder launch of the tile is done
 		if (c == cA && t >= h->nbuf) HIPCHK(hipStreamWaitEvent(h->s_p2, h->ev_tile[(size_t)(2 * (t - h->nbuf) + 1)], 0));   // the buffer's previous tile is consumed
 		HIPCHK(hipEventRecord(e4[2], h->s_p2));
 		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, pool, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_comp.p, h->s_p2);
@@ -760,14 +759,7 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream, h->prewalk ? &cw : nullptr);
 		}
 	};
-	if (phased)
-	{
-		if (cB - cA > h->k1_slots) throw ArgError("NGSQC_K1_PHASED needs at least as many token slots as chunks per tile");
-		for (int64_t c = cA; c < cB; ++c) launch_p1(c);
-		for (int64_t c = cA; c < cB; ++c) launch_p2(c);
-	}
-	else
-		for (int64_t c = cA; c < cB; ++c) { launch_p1(c); launch_p2(c); }
+	for (int64_t c = cA; c < cB; ++c) { launch_p1(c); launch_p2(c); }
 	const int64_t f = h->tiles[(size_t)t].first, m = h->tiles[(size_t)t].second;
 	hipStream_t s_last = h->verify_crc ? crc_stream : h->s_p2;
 	HIPCHK(hipMemcpyAsync(h->p_status.p + f, h->d_status.p + f, (size_t)m * sizeof(BlockStatus), hipMemcpyDeviceToHost, s_last));
@@ -868,9 +860,11 @@ void index_tile(ngsqc_handle* h, int t)
 	if (try_fuse)
 	{
 		if (aligned && n_corrupt == 0 && sm[2] <= (unsigned long long)h->d_long.n) h->fused_tile = t;
-		else if (n_corrupt == 0)
+		else if (!aligned || n_corrupt == 0)
 		{
-			// not an htslib-style tile (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual
+			// not an htslib-style tile (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual.
+			// This includes a tile whose guessed chains ran into something that looks like a corrupt record (a false start guess in an unaligned layout): the
+			// general path below repairs the chain, so the walk's contributions must go whatever it met (only aligned && corrupt throws, below)
 			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, fuse_limit);
 			if (!aligned) h->fuse_ok = false; else h->d_long.ensure_slack((size_t)sm[2]);
 		}
@@ -1160,7 +1154,7 @@ struct ScanState : ngsqc_handle::FusedScan
 	void tile(ngsqc_handle* h, const TileCtx& c)
 	{
 		const bool fused = h->fuse == this && h->fused_tile == c.tile;   // K2's chain walk has scanned the tile's records already
-		h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));
+		if (!fused) h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));   // (fused: the list holds the walk's deferred records - growing it would drop them; index_tile checked that they fit)
 		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
 		sp.long_list = h->d_long.p; sp.long_cap = fused ? (int64_t)h->d_long.n : c.n_rec; sp.sgn = 1;
 		sp.entry_base = fused ? h->d_base.p : nullptr; sp.tile_slots = fused ? 1 : 0;
@@ -1499,14 +1493,20 @@ void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int devi
 	h->shard = 0; h->n_shards = 2;                 // like a shard that is not the last one: the last member may end inside a record behind the range
 	h->shard_u_base = 0; h->shard_own_members = 0; h->shard_limit = 0; h->total = 0; h->first_rec = 0; h->csize = 0;
 	size_t cbeg = 0, cend = 0;
+	std::vector<uint64_t> foff;
+	const size_t co_beg = (size_t)(beg >> 16), co_end = (size_t)(end >> 16);
 	if (found && end > beg)
 	{
-		const size_t co_beg = (size_t)(beg >> 16), co_end = (size_t)(end >> 16);
 		if (co_beg >= n || co_end > n) throw ArgError("virtual offset behind the end of the file");
-		size_t o2 = co_beg; uint64_t u2 = 0; std::vector<uint64_t> foff;
+		size_t o2 = co_beg; uint64_t u2 = 0;
 		// members from the one that holds `beg` up to the one that holds `end` (inclusive when `end` lies inside it)
 		walk_bgzf(bytes, n, o2, (end & 0xffff) ? co_end + 1 : co_end, INT64_MAX, u2, h->blocks, h->crc, &foff);
-		if (h->blocks.empty() || foff[0] != co_beg) throw ArgError("virtual offset does not name a BGZF block of this file");
+		// A virtual offset may name an EMPTY member (bgzf_tell of a record that starts right behind a member end gives offset 0 of whatever member follows):
+		// the walk drops empty members from the table, so the start is checked against the file, not against the first table entry
+		if (!bgzf_member_at(bytes, n, co_beg) || (!h->blocks.empty() && foff[0] != co_beg && (beg & 0xffff))) throw ArgError("virtual offset does not name a BGZF block of this file");
+	}
+	if (found && end > beg && !h->blocks.empty())   // (a range of empty members only: nothing to read)
+	{
 		int64_t limit = 0;
 		if ((end & 0xffff) == 0) limit = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
 		else

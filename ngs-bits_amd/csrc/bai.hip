@@ -257,6 +257,7 @@ std::string bai_assemble(const std::string& out_path, int32_t n_ref, uint64_t of
 	};
 	for (const BaiRunV& r : runs)
 	{
+		if (r.tid < -1 || r.tid >= n_ref) return "a record names a reference sequence that is not in the BAM header";   // (caller-supplied runs: ngsqc_bai_assemble)
 		if (r.kind == 1) { tail_tid = r.tid; tail_pos = r.pos; continue; }
 		if (tail_tid == r.tid && r.tid >= 0 && tail_pos > r.pos) return "unsorted positions: the BAM is not sorted by coordinate (a BAI index needs that)";
 		tail_tid = -2;

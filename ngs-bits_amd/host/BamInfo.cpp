@@ -16,6 +16,8 @@ public:
 		addOutfile("out", "Output TSV file. If unset, writes to STDOUT.", true);
 		addFlag("name", "Add filename only to output. The default is to add the canonical file path.");
 		addInfile("ref", "Reference genome for CRAM support (mandatory if CRAM is used).", true);
+		// --changelog (src/BamInfo/main.cpp)
+		changeLog(2025, 9, 6, "First version.");
 	}
 	void main() override
 	{

@@ -20,6 +20,14 @@ public:
 		addFlag("random_access", "Use random access via index to get reads from BAM/CRAM instead of chromosome-wise sweep. Random access is quite slow, especially on CRAM, so use it only if a small subset of the file needs to be accessed.");
 		addFlag("debug", "Enable debug output.");
 		addFlag("skip_mismapped", "Skip reads with mapping quality less than 20 that are not properly paired (they are often mis-mapped).");
+		// --changelog (src/BedCoverage/main.cpp)
+		changeLog(2025, 9, 15, "Added 'skip_mismapped' parameter.");
+		changeLog(2024, 6, 26, "Added 'random_access' parameter.");
+		changeLog(2022, 9, 16, "Added 'threads' parameter and removed 'dup' parameter.");
+		changeLog(2022, 8, 12, "Added parameter to clear previous annotation columns.");
+		changeLog(2022, 8, 9, "Removed mode parameter (panel mode is always used now).");
+		changeLog(2020, 11, 27, "Added CRAM support.");
+		changeLog(2017, 6, 2, "Added 'dup' parameter.");
 	}
 	void main() override
 	{

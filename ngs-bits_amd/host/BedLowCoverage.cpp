@@ -25,6 +25,20 @@ public:
 		addInfile("ref", "Reference genome for CRAM support (mandatory if CRAM is used).", true);
 		addInt("threads", "Number of threads used.", true, 1);
 		addFlag("debug", "Enable debug output.");
+		// --changelog (src/BedLowCoverage/main.cpp)
+#ifdef HIGH_COVERAGE
+		changeLog(2024, 7, 3, "Added 'random_access' and 'debug' parameters and removed 'wgs' parameter.");
+		changeLog(2022, 9, 29, "Added 'threads' parameter.");
+		changeLog(2020, 11, 27, "Added CRAM support.");
+		changeLog(2020, 5, 26, "Added parameter 'min_baseq'.");
+		changeLog(2020, 5, 14, "First version.");
+#else
+		changeLog(2024, 7, 3, "Added 'random_access' and 'debug' parameters and removed 'wgs' parameter.");
+		changeLog(2022, 9, 19, "Added 'threads' parameter.");
+		changeLog(2020, 11, 27, "Added CRAM support.");
+		changeLog(2020, 5, 26, "Added parameter 'min_baseq'.");
+		changeLog(2016, 6, 9, "The BED line name of the input BED file is now passed on to the output BED file.");
+#endif
 	}
 	void main() override
 	{

@@ -32,6 +32,8 @@ public:
 		if (!regions.empty()) reader.check(ngsqc_region_read_counts(reader.handle(), regions.data(), (int64_t)regions.size(), min_mapq, got.data()));
 		for (size_t k = 0; k < regions.size(); ++k) read_count[(size_t)line_of[k]] = got[k];
 		for (long long i = 0; i < bed_file.count(); ++i) bed_file[i].annotations().push_back(std::to_string(read_count[(size_t)i]));
+		// --changelog (src/BedReadCount/main.cpp)
+		changeLog(2020, 11, 27, "Added CRAM support.");
 	}
 	void main() override
 	{

@@ -26,6 +26,16 @@ public:
 		addOutfile("read_qc", "If set, a read QC file in qcML format is created (just like ReadQC/SeqPurge).", true);
 		addFlag("single_end", "Enable single-end mode. Use for ONT, PacBio and Roche. Illumina single-end data is auto-detected based on paired reads.");
 		addFlag("no_ref", "[ngsqc extension] Run without a reference genome: GC/AT dropout become n/a, no N-base correction in WGS mode.");
+		// --changelog (src/MappingQC/main.cpp)
+		changeLog(2026, 7, 7, "Added support for short-read single-end (Roche). Renamed long_read parameter to single_end.");
+		changeLog(2023, 11, 8, "Added long_read support.");
+		changeLog(2023, 5, 12, "Added 'read_qc' parameter.");
+		changeLog(2022, 5, 25, "Added new QC metrics to WGS mode.");
+		changeLog(2021, 2, 9, "Added new QC metrics for uniformity of coverage (QC:2000057-QC:2000061).");
+		changeLog(2020, 11, 27, "Added CRAM support.");
+		changeLog(2018, 7, 11, "Added build switch for hg38 support.");
+		changeLog(2018, 3, 29, "Removed '3exons' flag.");
+		changeLog(2016, 12, 20, "Added support for spliced RNA reads (relevant e.g. for insert size)");
 	}
 	void main() override
 	{

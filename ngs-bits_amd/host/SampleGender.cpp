@@ -22,6 +22,12 @@ public:
 		addEnum("build", "Genome build used to generate the input (methods hetx and sry).", true, {"hg19", "hg38"}, "hg38");
 		addInfile("ref", "Reference genome for CRAM support (mandatory if CRAM is used).", true);
 		addFlag("long_read", "Support long reads (> 1kb) and uses single-end reads for gender calculation.");
+		// --changelog (src/SampleGender/main.cpp)
+		changeLog(2024, 2, 29, "Added parameter to include single-end reads (long-read).");
+		changeLog(2022, 8, 5, "Ignoring duplicate, secondary and supplementary alignments in methods 'xy' and 'sry' now.");
+		changeLog(2020, 11, 27, "Added CRAM support.");
+		changeLog(2018, 7, 13, "Change of output to TSV format for batch support.");
+		changeLog(2018, 7, 11, "Added build switch for hg38 support.");
 	}
 	void main() override
 	{

@@ -17,6 +17,7 @@ static void stamp(const char* what) { if (getenv("NGSQC_TIMING")) fprintf(stderr
 
 void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* regions, int64_t head_members)
 {
+	head_members_ = head_members;
 	stamp("open: start");
 	ref_file_ = ref;
 	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
@@ -62,20 +63,36 @@ BamInfo BamReader::info()
 	BamInfo out;
 	out.file_format = "BAM";   // (CRAM is not supported by the HIP path)
 	try { const int c1 = chromosomeSize(Chromosome("chr1")); out.build = c1 == 249250621 ? "hg19" : (c1 == 248956422 ? "hg38" : ""); } catch (...) {}
-	// paired end: the first 100 reads that are not secondary / supplementary / duplicate / unmapped and have MAPQ >= 20
+	// paired end: the first 100 reads OF THE FILE that are not secondary / supplementary / duplicate / unmapped and have MAPQ >= 20 (BamReader.cpp:627-640 keeps
+	// reading until it has them). A head open only holds the first members: when those do not yield 100 such reads (MAPQ < 20 at the telomere repeats of a WGS
+	// BAM, unmapped or duplicate reads in front) the head is opened again four times as long, until it does or the file has no more records to offer
 	{
-		const int64_t nbytes = ngsqc_inflated_size(h_), nrec = ngsqc_n_records(h_);
-		std::vector<uint8_t> infl((size_t)std::max<int64_t>(nbytes, 1)); std::vector<int64_t> off((size_t)std::max<int64_t>(nrec, 1));
-		if (nrec > 0) { check(ngsqc_copy_inflated(h_, infl.data(), nbytes)); check(ngsqc_copy_record_offsets(h_, off.data(), nrec)); }
+		auto count = [](ngsqc_handle* hh, BamReader* rd, double& n_all, double& n_paired) -> int64_t {
+			const int64_t nbytes = ngsqc_inflated_size(hh), nrec = ngsqc_n_records(hh);
+			std::vector<uint8_t> infl((size_t)std::max<int64_t>(nbytes, 1)); std::vector<int64_t> off((size_t)std::max<int64_t>(nrec, 1));
+			if (nrec > 0) { rd->check(ngsqc_copy_inflated(hh, infl.data(), nbytes)); rd->check(ngsqc_copy_record_offsets(hh, off.data(), nrec)); }
+			n_all = 0; n_paired = 0;
+			for (int64_t i = 0; i < nrec && n_all < 100.0; ++i)
+			{
+				const uint8_t* r = infl.data() + off[(size_t)i];
+				const uint32_t w = (uint32_t)r[12] | ((uint32_t)r[13] << 8), flag = (uint32_t)r[18] | ((uint32_t)r[19] << 8), mapq = w >> 8;
+				if (flag & (0x100 | 0x800 | 0x400 | 0x4)) continue;
+				if (mapq < 20) continue;
+				if (flag & 0x1) n_paired += 1.0;
+				n_all += 1.0;
+			}
+			return nrec;
+		};
 		double n_all = 0, n_paired = 0;
-		for (int64_t i = 0; i < nrec && n_all < 100.0; ++i)
+		int64_t nrec = count(h_, this, n_all, n_paired), head = head_members_;
+		while (n_all < 100.0 && head > 0)
 		{
-			const uint8_t* r = infl.data() + off[(size_t)i];
-			const uint32_t w = (uint32_t)r[12] | ((uint32_t)r[13] << 8), flag = (uint32_t)r[18] | ((uint32_t)r[19] << 8), mapq = w >> 8;
-			if (flag & (0x100 | 0x800 | 0x400 | 0x4)) continue;
-			if (mapq < 20) continue;
-			if (flag & 0x1) n_paired += 1.0;
-			n_all += 1.0;
+			head = head >= (1ll << 40) ? 0 : head * 4;
+			BamReader more(bam_file_, ref_file_, Head{head > 0 ? head : (1ll << 62)});
+			double a = 0, p = 0; const int64_t n2 = count(more.handle(), &more, a, p);
+			n_all = a; n_paired = p;
+			if (n2 <= nrec) break;   // the longer head brought no further record: that was the whole file
+			nrec = n2;
 		}
 		out.paired_end = n_paired / n_all > 0.1;   // (0/0 = nan: false, like the reference)
 	}

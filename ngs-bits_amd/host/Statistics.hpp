@@ -37,6 +37,7 @@ public:
 	void check(int rc) const;
 private:
 	void init(const std::string& ref_genome, bool allow_shards, const BedFile* regions, int64_t head_members);
+	int64_t head_members_ = 0;   // > 0: a head open (BamReader::info grows it when the first members do not answer its question)
 	std::string bam_file_, ref_file_; ngsqc_handle* h_ = nullptr; std::vector<ngsqc_handle*> shards_; std::vector<Chromosome> chrs_; std::vector<long long> sizes_;
 };
 

@@ -379,7 +379,7 @@ protected:
 	void addFloat(const std::string& n, const std::string& d, bool optional, double def = 0.0) { add(n, "float", d, optional, number(def, 6)); }
 	void addFlag(const std::string& n, const std::string& d) { add(n, "flag", d, true, ""); }
 	void addEnum(const std::string& n, const std::string& d, bool optional, const std::vector<std::string>& values, const std::string& def) { add(n, "enum", d, optional, def); params_.back().values = values; }
-	void changeLog(int, int, int, const std::string&) {}
+	void changeLog(int y, int m, int d, const std::string& text) { char b[16]; snprintf(b, sizeof(b), "%04d-%02d-%02d", y, m, d); changelog_.push_back(std::string(b) + " " + text); }
 	std::string getInfile(const std::string& n) const { return get(n).value; }
 	std::vector<std::string> getInfileList(const std::string& n) const { return get(n).list; }
 	std::string getOutfile(const std::string& n) const { return get(n).value; }
@@ -396,6 +396,9 @@ private:
 	const Param& get(const std::string& n) const { for (auto& p : params_) if (p.name == n) return p; NB_THROW(ProgrammingException, "Unknown parameter '" + n + "'"); }
 	void parse();
 	void printHelp() const;
+	void printChangelog() const;
+	void storeTDX() const;
+	std::vector<std::string> changelog_; std::string settings_override_;
 	std::vector<std::string> args_; std::string description_; std::vector<std::string> ext_; std::vector<Param> params_;
 };
 
