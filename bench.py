@@ -159,6 +159,14 @@ def main():
     import bamgen_lib as G
     import hostprep as H
 
+    # the product's own collective (include/ngsqc.h ngsqc_comm_*: RCCL loaded by libngsqc_hip.so) carries every exchange of the data path; torch.distributed only
+    # starts the ranks, hands the 128-byte unique id around and provides the timing barriers of the bench contract
+    comm = None
+    if world > 1 and args.backend == "nccl" and not args.all_ranks_on_device0:
+        box = [ngsqc.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = ngsqc.Comm(rank, world, box[0], device=local_rank)
+
     # ---- workload size: the full 30x file when the host can hold the image (plus a private copy per rank for N > 1) ----
     mode = 1 if args.ont else 0
     reads = args.reads
@@ -185,7 +193,17 @@ def main():
     gen_kw = dict(seed=args.seed, mode=mode, depth=depth, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=0 if args.ont else args.flavor)
     share_name = f"ngsqc_bench_{os.environ.get('MASTER_PORT', '0')}_{args.seed}_{reads}.bam"
     share = None
-    if world > 1:
+    # SURVEY.md 8(d) config 4 is "seeds +0..7": one DIFFERENT BAM per GPU. When the host can hold world images at once every rank generates its own (seed + rank,
+    # its share of the cores, all ranks at the same time); otherwise the ranks share one image through /dev/shm (same per-GPU work, identical counters per rank)
+    per_rank_seed = False
+    if world > 1 and not args.single_bam:
+        box = [None]
+        if rank == 0:
+            avail = host_memory_available()
+            box[0] = bool(avail and avail > 1.3 * world * reads * BYTES_PER_READ_COMPRESSED and os.environ.get("NGSQC_BENCH_SHARED_IMAGE") is None)
+        dist.broadcast_object_list(box, src=0)
+        per_rank_seed = bool(box[0])
+    if world > 1 and not per_rank_seed:
         ok = torch.zeros(1, dtype=torch.int64, device=dev)   # 1 + index of the directory that took the file, 0 = none
         if rank == 0:
             try:
@@ -220,7 +238,7 @@ def main():
     if image is None and args.image_cache and os.path.exists(args.image_cache):
         image = np.fromfile(args.image_cache, dtype=np.uint8)
     if image is None:
-        threads = max(1, 2 * G.effective_cpus() // max(world, 1))
+        threads = max(1, (2 if world == 1 else 1) * G.effective_cpus() // max(world, 1))
         image = G.generate(reads, threads=threads, **dict(gen_kw, seed=args.seed + (0 if args.single_bam else rank)))
         if args.image_cache:
             image.tofile(args.image_cache)
@@ -254,7 +272,7 @@ def main():
             hh.drop_decoded()                                  # whole job from the compressed bytes, every step
             if sharded:
                 # one decode per shard for the mapping scan AND the contamination pileup (ngsqc_run_job_partial); site counts are summed over the shards
-                counters, _, _, _ = ngsqc.scan_mapping_sharded(hh, ngsqc.MODE_WGS, device=dev, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=nonspecial,
+                counters, _, _, _ = ngsqc.scan_mapping_sharded(hh, ngsqc.MODE_WGS, device=dev, comm=comm, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=nonspecial,
                                                                sites=sites_arr, site_params=(1, 13, args.ont))
             else:
                 out = hh.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, args.ont))
@@ -264,7 +282,9 @@ def main():
             hist, cov = hh.depth_stats(599, half)             # Histogram(0,599,5) input + half-depth count (Statistics.cpp:1185-1204)
             counters[27] = half; counters[28] = cov
             if world > 1 and not sharded:
-                counters = ngsqc.allreduce_counters(counters, device=dev)   # C1: RCCL reduce of the counter vectors over xGMI
+                aux["local_counters"] = np.asarray(counters, dtype=np.int64).copy()
+                # C1: RCCL reduce of the counter vectors over xGMI - the library's collective (ngsqc_comm_allreduce_counters); torch.distributed only with gloo
+                counters = comm.allreduce_counters(counters) if comm is not None else ngsqc.allreduce_counters(counters, device=dev)
             return counters, hist
 
         def step():
@@ -308,6 +328,19 @@ def main():
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
 
+    # the collective against a second channel: every rank's local counter vector gathered with torch.distributed and combined on the host must be what the
+    # library's all-reduce returned on this rank
+    coll = None
+    if world > 1 and tool == "mappingqc" and not args.single_bam and "local_counters" in aux:
+        loc = torch.tensor(aux["local_counters"], dtype=torch.int64, device=dev)
+        parts = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(parts, loc)
+        expect = ngsqc.combine_counters_local([p_.cpu().numpy() for p_ in parts])
+        oks = [None] * world
+        dist.all_gather_object(oks, bool(np.array_equal(expect, np.asarray(result, dtype=np.int64))))
+        distinct = len({tuple(p_.cpu().numpy()[:8].tolist()) for p_ in parts})
+        coll = {"library": "libngsqc_hip ngsqc_comm_allreduce_counters (RCCL, loaded by the library)" if comm is not None else "torch.distributed (" + args.backend + ")",
+                "allreduce_matches_gathered_sum_per_rank": oks, "distinct_inputs": distinct, "one_bam_per_gpu_with_its_own_seed": per_rank_seed}
     n_rec = int(tms[-1]["n_records"])
     if args.single_bam:
         nr = torch.tensor([n_rec], dtype=torch.int64, device=dev)
@@ -361,7 +394,7 @@ def main():
             "metric": "Mreads/sec + achieved HBM GB/s, MappingQC 30x WGS BAM at 1/2/4/8 MI355X",
             "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.single_bam else "weak",
-            "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic" if world == 1 else "synthetic (one generated image, a private copy per rank in HBM)",
+            "vs_baseline": None, "dtype": "u8/int32/int64", "data": "synthetic" if world == 1 else ("synthetic (one BAM per GPU, generated with seed + rank)" if per_rank_seed else "synthetic (one generated image, a private copy per rank in HBM)"),
             "config": {"workload": f"{what} on a {shape}; {'the full file' if full else 'reduced size'}: {n_rec} reads per GPU per step"
                                    f"{' (' + size_note + ')' if size_note else ''}; compressed image resident in HBM, streamed through {int(tms[-1]['n_tiles'])} tiles",
                        "reads_per_gpu_per_step": n_rec, "compressed_bytes_per_gpu": c_bytes, "inflated_bytes_per_gpu": u_bytes,
@@ -370,7 +403,7 @@ def main():
                        "parallelism": (f"one BAM sharded over {world} GPU(s) by BGZF member range, 1 process/GPU; all-gather of shard summaries, "
                                        "SUM all-reduce of counters and of the int32 difference array (RCCL)") if args.single_bam
                                       else f"{world} BAM(s), one per GPU, 1 process/GPU, RCCL all-reduce of the counter vectors"},
-            "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": dom[0], "bound": "hbm", "limited_by": "instruction issue (VALU / LDS), not HBM: see profiles/r04_sq_counters.txt", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(dom[1]),
                          "avg_launch_ms": round(dom[2], 4), "launches_per_step": k1_launches, "sum_launches_ms": round(dom[2] * k1_launches, 3),
                          "isolated": iso is not None,
@@ -538,6 +571,8 @@ def main():
             if rank == 0:
                 strong = {"error": str(e)[:300]}
     if rank == 0:
+        if coll is not None:
+            out["collective"] = coll
         if strong is not None:
             out["single_bam"] = strong
         # ---- end to end from a file: ngsqc_open(path) copies the image in the background while the first job already runs; and the tool itself ----

@@ -279,6 +279,28 @@ int ngsqc_depth_diff_set(ngsqc_handle* h, const int32_t* in, int64_t n);
 int ngsqc_depth_reduce(ngsqc_handle* dst, ngsqc_handle* const* srcs, int n_srcs);
 int ngsqc_depth_finalize(ngsqc_handle* h);                                    /* difference array -> per-base depth (K6 prefix sum) */
 
+/* ---- the collective of the multi-GPU path: RCCL over xGMI, one process per GPU (round 4; BASELINE.json north_star: "only a final RCCL reduce of the
+ * counter vectors"). The reference is a single process and has no counterpart (its parallelism: Statistics.cpp:2614-2638).
+ * Rank 0 makes a unique id and hands it to the other ranks out of band (a file, MPI, the launcher's store); every rank then makes its communicator on its
+ * own device. The calls are collective: every rank of the communicator must make them in the same order. librccl is loaded by the first of these calls.
+ *   one BAM per GPU (config 4): ngsqc_run_job on every rank -> ngsqc_comm_allreduce_counters (and _i64 for site counts, _f64 for gc_reads)
+ *   one BAM over the GPUs     : ngsqc_run_job_partial -> ngsqc_comm_allgather_summaries -> ngsqc_plan_shard_fix -> ngsqc_scan_mapping_finish ->
+ *                               ngsqc_comm_allreduce_counters / _f64 / _i64 -> ngsqc_comm_allreduce_depth (in place, device memory) -> ngsqc_depth_finalize */
+#define NGSQC_COMM_ID_BYTES 128
+typedef struct ngsqc_comm ngsqc_comm;
+int ngsqc_comm_unique_id(void* id /* NGSQC_COMM_ID_BYTES, out */);
+int ngsqc_comm_init(int rank, int world, const void* id, int device, ngsqc_comm** out);
+int ngsqc_comm_rank(const ngsqc_comm* c);
+int ngsqc_comm_world(const ngsqc_comm* c);
+const char* ngsqc_comm_last_error(const ngsqc_comm* c);
+int ngsqc_comm_destroy(ngsqc_comm* c);
+/* int64[NGSQC_NCOUNTERS] on the host, in place: SUM; MAX for max_length, paired_end, roi_bases, half_depth, yx_valid */
+int ngsqc_comm_allreduce_counters(ngsqc_comm* c, int64_t* counters);
+int ngsqc_comm_allreduce_i64(ngsqc_comm* c, int64_t* v, int64_t n, int take_max);   /* host vector in place: SUM (take_max = 0) or MAX */
+int ngsqc_comm_allreduce_f64(ngsqc_comm* c, double* v, int64_t n);                  /* host vector in place: SUM (gc_reads) */
+int ngsqc_comm_allgather_summaries(ngsqc_comm* c, const ngsqc_shard_summary* mine, ngsqc_shard_summary* all /* [world], rank order */);
+int ngsqc_comm_allreduce_depth(ngsqc_comm* c, ngsqc_handle* h);                     /* the handle's int32 difference array, in place on the device */
+
 /* ---- measurement: HIP-event timings (ms) of the stages of the last job on this handle ---- */
 typedef struct ngsqc_timings {
 	double h2d_ms, inflate_ms, index_ms, scan_ms, finalize_ms, total_ms;
@@ -297,6 +319,8 @@ typedef struct ngsqc_timings {
 	double depth_scan_ms;             /* the extra depth scan of a job */
 	double pileup_ms, reads_ms;       /* site pileup / raw-read QC consumers */
 	double job_wall_ms;               /* host wall time of the last ngsqc_run_job (setup, all tiles, result copies) */
+	int64_t members_second_chance;    /* members whose launch ran out of token pages and that were inflated again with the worst-case pool (since the handle was opened) */
+	int64_t members_third_chance;     /* ... and again with the bound that holds for every valid member (members of thousands of DEFLATE blocks) */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

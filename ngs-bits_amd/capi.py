@@ -50,7 +50,8 @@ class Timings(C.Structure):
                 ("scan_launches", C.c_int64), ("scan_algorithmic_bytes", C.c_int64), ("compressed_bytes", C.c_int64),
                 ("inflated_bytes", C.c_int64), ("n_records", C.c_int64), ("scan_kernel_ms", C.c_double), ("depth_kernel_ms", C.c_double), ("inflate_huff_ms", C.c_double), ("inflate_lz77_ms", C.c_double),
                 ("inflate_huff_launches", C.c_int64), ("n_tiles", C.c_int64), ("members_inflated", C.c_int64), ("depth_scan_ms", C.c_double),
-                ("pileup_ms", C.c_double), ("reads_ms", C.c_double), ("job_wall_ms", C.c_double)]
+                ("pileup_ms", C.c_double), ("reads_ms", C.c_double), ("job_wall_ms", C.c_double),
+                ("members_second_chance", C.c_int64), ("members_third_chance", C.c_int64)]
 
 
 class JobDesc(C.Structure):
@@ -135,6 +136,15 @@ def lib():
         L.ngsqc_read_cycle_stats.restype = i32; L.ngsqc_read_cycle_stats.argtypes = [vp, vp, i64]
         L.ngsqc_open_shard.restype = i32; L.ngsqc_open_shard.argtypes = [cp, i32, i32, i32, C.POINTER(vp)]
         L.ngsqc_open_memory_shard.restype = i32; L.ngsqc_open_memory_shard.argtypes = [vp, C.c_size_t, i32, i32, i32, C.POINTER(vp)]
+        L.ngsqc_comm_unique_id.restype = i32; L.ngsqc_comm_unique_id.argtypes = [vp]
+        L.ngsqc_comm_init.restype = i32; L.ngsqc_comm_init.argtypes = [i32, i32, vp, i32, C.POINTER(vp)]
+        L.ngsqc_comm_destroy.restype = i32; L.ngsqc_comm_destroy.argtypes = [vp]
+        L.ngsqc_comm_last_error.restype = cp; L.ngsqc_comm_last_error.argtypes = [vp]
+        L.ngsqc_comm_allreduce_counters.restype = i32; L.ngsqc_comm_allreduce_counters.argtypes = [vp, vp]
+        L.ngsqc_comm_allreduce_i64.restype = i32; L.ngsqc_comm_allreduce_i64.argtypes = [vp, vp, i64, i32]
+        L.ngsqc_comm_allreduce_f64.restype = i32; L.ngsqc_comm_allreduce_f64.argtypes = [vp, vp, i64]
+        L.ngsqc_comm_allgather_summaries.restype = i32; L.ngsqc_comm_allgather_summaries.argtypes = [vp, C.POINTER(ShardSummary), C.POINTER(ShardSummary)]
+        L.ngsqc_comm_allreduce_depth.restype = i32; L.ngsqc_comm_allreduce_depth.argtypes = [vp, vp]
         L.ngsqc_scan_mapping_partial.restype = i32; L.ngsqc_scan_mapping_partial.argtypes = [vp, C.POINTER(MappingParams), C.POINTER(ShardSummary)]
         L.ngsqc_plan_shard_fix.restype = i32; L.ngsqc_plan_shard_fix.argtypes = [C.POINTER(ShardSummary), i32, i32, C.POINTER(ShardFix)]
         L.ngsqc_scan_mapping_finish.restype = i32; L.ngsqc_scan_mapping_finish.argtypes = [vp, C.POINTER(ShardFix), vp, vp]
@@ -505,3 +515,56 @@ class Handle:
         t = Timings()
         self._chk(lib().ngsqc_get_timings(self.h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in Timings._fields_}
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """The product's own collective (include/ngsqc.h, csrc/comm.hip): RCCL over xGMI, one process per GPU. Rank 0 calls Comm.unique_id() and hands the 128 bytes to
+    the other ranks (any out-of-band channel: a file, the launcher's store); every rank then makes Comm(rank, world, id, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = lib().ngsqc_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc:
+            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+        return bytes(buf)
+
+    def __init__(self, rank, world, uid, device=0):
+        self.c = C.c_void_p(); self.rank, self.world = rank, world
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        rc = lib().ngsqc_comm_init(rank, world, C.cast(buf, C.c_void_p), device, C.byref(self.c))
+        if rc:
+            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise NgsqcError(rc, lib().ngsqc_comm_last_error(self.c).decode())
+
+    def allreduce_counters(self, counters):
+        v = np.ascontiguousarray(counters, dtype=np.int64).copy()
+        assert v.size == NCOUNTERS
+        self._chk(lib().ngsqc_comm_allreduce_counters(self.c, v.ctypes.data)); return v
+
+    def allreduce_i64(self, v, take_max=False):
+        a = np.ascontiguousarray(v, dtype=np.int64).copy()
+        self._chk(lib().ngsqc_comm_allreduce_i64(self.c, a.ctypes.data, a.size, int(take_max))); return a
+
+    def allreduce_f64(self, v):
+        a = np.ascontiguousarray(v, dtype=np.float64).copy()
+        self._chk(lib().ngsqc_comm_allreduce_f64(self.c, a.ctypes.data, a.size)); return a
+
+    def allgather_summaries(self, mine):
+        """mine: int64[6] (ngsqc_shard_summary) -> int64[world, 6] in rank order"""
+        m = ShardSummary(*[int(x) for x in mine]); allv = (ShardSummary * self.world)()
+        self._chk(lib().ngsqc_comm_allgather_summaries(self.c, C.byref(m), allv))
+        return np.array([[getattr(x, f) for f in SUMMARY_FIELDS] for x in allv], dtype=np.int64)
+
+    def allreduce_depth(self, handle):
+        self._chk(lib().ngsqc_comm_allreduce_depth(self.c, handle.h))
+
+    def close(self):
+        if self.c:
+            lib().ngsqc_comm_destroy(self.c); self.c = C.c_void_p()

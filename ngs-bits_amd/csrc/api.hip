@@ -319,6 +319,7 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 	// literal table in the pool), 1024 members per batch = 1.1 GB of pool; level 1: the bound that holds for every valid member (k1_pool_pages_absolute: up to 18 MB per member), 32 per batch
 	const int64_t BATCH = level == 0 ? 1024 : 32;
 	std::vector<int64_t> idx2; std::vector<BlockDesc> desc2;   // members that need level 1
+	(level == 0 ? h->tm.members_second_chance : h->tm.members_third_chance) += (int64_t)idx.size();
 	for (int64_t b0 = 0; b0 < (int64_t)idx.size(); b0 += BATCH)
 	{
 		const int64_t n = std::min<int64_t>(BATCH, (int64_t)idx.size() - b0);
@@ -1871,6 +1872,7 @@ void ngsqc_close(ngsqc_handle* h)
 int ngsqc_upload_wait(ngsqc_handle* h) { return guarded(h, [&] { upload_finish(h); }); }
 
 const char* ngsqc_last_error(const ngsqc_handle* h) { return h ? h->err.c_str() : g_open_error.c_str(); }
+void ngsqc_set_open_error(const char* msg) { g_open_error = msg ? msg : ""; }   // (comm.hip reports through the same channel)
 int ngsqc_n_ref(const ngsqc_handle* h) { return h ? (int)h->ref_names.size() : 0; }
 const char* ngsqc_ref_name(const ngsqc_handle* h, int tid) { return (h && tid >= 0 && tid < (int)h->ref_names.size()) ? h->ref_names[tid].c_str() : nullptr; }
 int64_t ngsqc_ref_len(const ngsqc_handle* h, int tid) { return (h && tid >= 0 && tid < (int)h->ref_lens.size()) ? h->ref_lens[tid] : -1; }

@@ -53,19 +53,22 @@ class _DeviceInt32:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 3, "strides": None}
 
 
-def scan_mapping_sharded(handle, mode, device=None, group=None, **scan_kw):
+def scan_mapping_sharded(handle, mode, device=None, group=None, comm=None, **scan_kw):
     """Rank-side driver: `handle` is this rank's shard (Handle(..., shard=(rank, world))). Every rank returns the same
     (counters, gc_reads) of the WHOLE BAM; afterwards handle.depth_stats()/depth() see the whole BAM's depth array.
 
     Collectives: all-gather of the 48-byte summaries, SUM/MAX all-reduce of the 8 KB counter vector, SUM all-reduce of
     gc_reads (808 B) and - when there is a target region - one in-place SUM all-reduce of the int32 difference array
-    (device memory of the library; RCCL over xGMI with backend "nccl", host copy with "gloo")."""
+    (device memory of the library; RCCL over xGMI with backend "nccl", host copy with "gloo").
+    comm: a capi.Comm - the product's own RCCL collectives (include/ngsqc.h ngsqc_comm_*) carry every exchange instead of torch.distributed."""
     import torch
     import torch.distributed as dist
     from .capi import plan_shard_fix
 
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
     sites = scan_kw.pop("sites", None); site_params = scan_kw.pop("site_params", (1, 13, False))
     site_counts = None
     if sites is not None:   # MappingQC's contamination pileup rides the same decode (its counts are additive over shards)
@@ -73,6 +76,16 @@ def scan_mapping_sharded(handle, mode, device=None, group=None, **scan_kw):
         mine, site_counts = job["summary"], job["site_counts"]
     else:
         mine = handle.scan_mapping_partial(mode, **scan_kw)
+    if comm is not None:
+        # the whole exchange through the library's communicator: summaries, counters, gc_reads, the difference array in place on the device, site counts
+        summaries = comm.allgather_summaries(mine)
+        counters, gc = handle.scan_mapping_finish(plan_shard_fix(summaries, rank))
+        counters = comm.allreduce_counters(counters); gc = comm.allreduce_f64(gc)
+        comm.allreduce_depth(handle)
+        handle.depth_finalize()
+        if site_counts is not None:
+            return counters, gc, summaries, comm.allreduce_i64(site_counts).reshape(np.asarray(site_counts).shape)
+        return counters, gc, summaries
     if world > 1:
         t = torch.tensor(mine, dtype=torch.int64, device=device)
         parts = [torch.empty_like(t) for _ in range(world)]

@@ -34,6 +34,32 @@ def test_no_cpu_fallback():
     assert e.value.code == -4 and "no CPU fallback" in str(e.value)
 
 
+def test_communicator_needs_a_device():
+    """ngsqc_comm_init without a HIP device: the same loud error as every other entry point (the collective has no CPU path either)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.Comm(0, 1, bytes(128), device=0)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_special_parameters_of_the_tools(tmp_path):
+    """ToolBase's special parameters (doc/tools/MappingQC.md:40-45): --changelog lists the reference's entries, --tdx writes <tool>.tdx, --settings names the only settings file"""
+    r = _tool("MappingQC", "--changelog")
+    assert r.returncode == 0 and "2023-05-12 Added 'read_qc' parameter." in r.stdout and r.stdout.startswith("MappingQC ")
+    r = subprocess.run([os.path.join(BIN, "BedCoverage"), "--tdx"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
+    tdx = (tmp_path / "BedCoverage.tdx").read_text()
+    assert r.returncode == 0 and '<Tool name="BedCoverage"' in tdx and '<Infile name="bam">' in tdx or "InfileList" in tdx
+    r = _tool("MappingQC", "--help")
+    assert "--changelog" in r.stdout and "--tdx" in r.stdout and "--settings [file]" in r.stdout
+    r = _tool("MappingQC", "-in", os.path.join(GI, "close_exons.bam"), "-wgs", "--settings", str(tmp_path / "missing.ini"))
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    ini = tmp_path / "s.ini"; ini.write_text("reference_genome = /nowhere/genome.fa\n")
+    r = _tool("MappingQC", "-in", os.path.join(GI, "close_exons.bam"), "-wgs", "--settings", str(ini))
+    assert r.returncode == 1 and "Command line parsing exception" not in r.stderr   # (parsed; it fails later: no device here, or the genome file)
+
+
 def _tool(name, *args):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):

@@ -213,3 +213,21 @@ def test_corrupt_payload_is_an_error_not_a_hang(raw_bam, seed):
     finally:
         if h is not None:
             h.close()
+
+
+def test_members_of_thousands_of_deflate_blocks_take_the_third_chance():
+    """zlib flush markers every two bytes make members of ~1500 DEFLATE blocks, each with its literal table in the token pool: more than the launch's pool AND more than
+    the second chance's worst-case pool (four words per output byte) hold - the third chance (k1_pool_pages_absolute, 32 members per batch) inflates them. VERDICT r03:
+    this path had only run under the wave emulator."""
+    raw = gzip.decompress(G.generate(2000, seed=9, threads=2).tobytes())
+    image = rebgzf(raw, [3000], level=6, flush_every=2)
+    h = ngsqc.Handle(data=np.frombuffer(image, dtype=np.uint8))
+    try:
+        h.decode()
+        got = h.inflated()
+        assert got.size == len(raw) and np.array_equal(got, np.frombuffer(raw, dtype=np.uint8))
+        assert h.n_records == 2000
+        t = h.timings()
+        assert t["members_third_chance"] > 0 and t["members_second_chance"] >= t["members_third_chance"]
+    finally:
+        h.close()

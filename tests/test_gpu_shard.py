@@ -259,3 +259,37 @@ def test_fused_shard_job_inflates_every_member_once(tmp_path, monkeypatch, n_sha
         for h in hs:
             h.close()
         whole.close()
+
+
+def test_library_communicator_world_of_one(tmp_path):
+    """The product's own collective (include/ngsqc.h ngsqc_comm_*, RCCL loaded by libngsqc_hip.so) on the one GPU of the test box: a communicator of one rank runs
+    every call of the shard protocol - all-gather of the summaries, SUM / MAX of the counters, SUM of gc_reads and site counts, the in-place all-reduce of the int32
+    difference array on the library's device memory - and the sharded driver on top of it returns what the unsharded job returns. (RCCL refuses two ranks on one
+    device; N > 1 ranks run in the driver's scaling bench, the collective there is checked against a second channel: bench.py "collective".)"""
+    path = str(tmp_path / "comm.bam")
+    G.write(path, n_reads=60_000, seed=17, start_pos=15_900_000)
+    uid = ngsqc.Comm.unique_id()
+    assert len(uid) == 128
+    comm = ngsqc.Comm(0, 1, uid, device=0)
+    try:
+        v = np.arange(ngsqc.NCOUNTERS, dtype=np.int64) * 3 + 1
+        assert np.array_equal(comm.allreduce_counters(v), v)
+        assert np.array_equal(comm.allreduce_i64(np.array([5, -7, 1 << 40]), take_max=True), np.array([5, -7, 1 << 40]))
+        assert np.array_equal(comm.allreduce_f64(np.array([0.5, 1e-9])), np.array([0.5, 1e-9]))
+        assert np.array_equal(comm.allgather_summaries(np.array([1, 2, 3, 4, 5, 6])), np.array([[1, 2, 3, 4, 5, 6]]))
+        h = ngsqc.Handle(path=path)
+        regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
+        kw = dict(regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs))
+        ref, _ = h.scan_mapping(ngsqc.MODE_WGS, **kw)
+        d_ref = h.depth(int(ref[26])).copy()
+        h.close()
+        hs = ngsqc.Handle(path=path, shard=(0, 1))
+        counters, gc, summaries = ngsqc.scan_mapping_sharded(hs, ngsqc.MODE_WGS, comm=comm, **kw)
+        assert int(summaries[0, 0]) == 60_000
+        for i in range(len(ref)):
+            if i not in SKIP:
+                assert int(counters[i]) == int(ref[i]), i
+        assert np.array_equal(hs.depth(int(counters[26])), d_ref)
+        hs.close()
+    finally:
+        comm.close()

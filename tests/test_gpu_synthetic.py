@@ -167,3 +167,91 @@ def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
     for r in res[1:]:
         assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
     assert res[0][0][0] > 0
+
+
+def _bgzf_member(payload):
+    import struct, zlib
+    c = zlib.compressobj(6, zlib.DEFLATED, -15); comp = c.compress(payload) + c.flush()
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+
+
+def _record(name, pos, l_seq, qual, flag=0, mapq=60, tid=0):
+    import struct
+    nm = name + b"\0"; cigar = struct.pack("<I", (l_seq << 4) | 0)
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(nm), mapq, 4680, 1, flag, l_seq, -1, -1, 0) + nm + cigar + bytes((l_seq + 1) // 2) + qual
+    return struct.pack("<I", len(body)) + body
+
+
+def test_false_start_guess_in_an_unaligned_tile(tmp_path):
+    """a member that starts inside a record's qualities, at bytes that look like two chained record headers followed by one bam_read1 would refuse.
+    The riding scan of K2's chain walk follows the false guess into the 'corrupt' record; the tile is not laid out like an htslib file, so the general path repairs
+    the chain - and everything the riding scan added (the two fake reads included) must have been taken back: the counters are the oracle's, not twice that."""
+    import struct
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n"
+    header = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 5) + b"chr1\0" + struct.pack("<I", 248956422)
+    fake_ok = struct.pack("<IiiBBHHHiiii", 40, 0, 5, 1, 0, 0, 0, 0, 0, -1, -1, 0) + b"\0" + bytes(7)          # 44 bytes: a plausible record (name "", no CIGAR, no bases)
+    fake_bad = struct.pack("<IiiBBHHHiiii", 40, 0, 5, 0, 0, 0, 0, 0, 0, -1, -1, 0) + bytes(8)                   # l_read_name 0: bam_read1 refuses it
+    rng = np.random.default_rng(5)
+    recs = [_record(b"r%04d" % i, 1000 + 10 * i, 100, bytes(rng.integers(2, 41, 100, dtype=np.uint8))) for i in range(60)]
+    qual = bytearray(rng.integers(2, 41, 600, dtype=np.uint8)); q0 = 200
+    qual[q0:q0 + 132] = fake_ok + fake_ok + fake_bad
+    special = _record(b"special", 1700, 600, bytes(qual))
+    tail = [_record(b"t%04d" % i, 1800 + 10 * i, 100, bytes(rng.integers(2, 41, 100, dtype=np.uint8))) for i in range(300)]
+    stream = b"".join(recs) + special + b"".join(tail)
+    cut = len(b"".join(recs)) + (len(special) - 600 + q0)      # the member border: the first fake header
+    assert stream[cut:cut + 4] == struct.pack("<I", 40)
+    members = [header, stream[:cut]]
+    rest = stream[cut:]
+    members += [rest[i:i + 20000] for i in range(0, len(rest), 20000)]
+    path = str(tmp_path / "false_guess.bam")
+    with open(path, "wb") as f:
+        for m in members:
+            f.write(_bgzf_member(m))
+        f.write(_bgzf_member(b""))
+    ob = O.Bam(path)
+    assert ob.count == 361
+    for tiles in (None, "2"):
+        if tiles:
+            os.environ["NGSQC_TILE_MEMBERS"] = tiles
+        try:
+            h = ngsqc.Handle(path=path)
+            regs, _ = H.bed_regions(OMIM, h.refs, 3)
+            tx, ty = H.xy_tids(h.refs)
+            out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)))
+            exp = O.mapping(ob, ngsqc.MODE_WGS, OMIM, merge_bed=False)
+            c = out["counters"]
+            for i in range(len(c)):
+                if i not in SKIP:
+                    assert int(c[i]) == int(exp.counters[i]), (tiles, i, int(c[i]), int(exp.counters[i]))
+            assert h.n_records == ob.count
+            h.close()
+        finally:
+            os.environ.pop("NGSQC_TILE_MEMBERS", None)
+
+
+def test_first_job_races_the_background_copy(tmp_path, monkeypatch):
+    """ngsqc_open(path) returns while the compressed image is still on its way (member table walked in pieces by NGSQC_WALK_THREADS host threads - the default since
+    round 4 - and copied by background threads); the first job starts at once and every K1 chunk waits for the pieces it reads. A slowed-down copy (1 MB pieces, a delay
+    per piece) makes the chunks really wait; the counters must be those of a handle whose image was resident, and of the sequential member walk."""
+    import time
+    path = str(tmp_path / "race.bam")
+    G.write(path, n_reads=300_000, seed=21, start_pos=15_900_000)
+
+    def job(env):
+        for k in ("NGSQC_WALK_THREADS", "NGSQC_H2D_PIECE_MB", "NGSQC_H2D_DELAY_US", "NGSQC_H2D_THREADS", "NGSQC_TILE_MEMBERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t0 = time.perf_counter(); h = ngsqc.Handle(path=path); t_open = time.perf_counter() - t0
+        regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
+        out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)))
+        h.upload_wait(); t = h.timings(); n = h.n_records; h.close()
+        return np.asarray(out["counters"]).copy(), t_open, t["h2d_ms"] * 1e-3, n
+
+    ref, _, _, n_ref = job({"NGSQC_WALK_THREADS": "1"})
+    assert n_ref == 300_000
+    c8, _, _, _ = job({})                                   # the default: eight walkers
+    assert np.array_equal(c8, ref)
+    slow, t_open, t_h2d, _ = job({"NGSQC_H2D_PIECE_MB": "1", "NGSQC_H2D_DELAY_US": "4000", "NGSQC_H2D_THREADS": "2", "NGSQC_TILE_MEMBERS": "64"})
+    assert np.array_equal(slow, ref)
+    assert t_open < 0.5 * t_h2d, (t_open, t_h2d)            # open returned long before the last piece arrived: the job ran while the copy was in flight
