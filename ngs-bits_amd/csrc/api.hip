@@ -150,8 +150,17 @@ struct ngsqc_handle
 		std::vector<hipEvent_t> ev; std::vector<char> recorded; size_t piece = 0, n_pieces = 0, bytes = 0; std::atomic<size_t> next{0}; std::atomic<bool> cancel{false};
 		std::string err; void* map = nullptr; size_t map_n = 0; int fd = -1; double t0 = 0, t_done = 0; size_t done = 0;
 		size_t waited[4] = {0, 0, 0, 0};   // pieces [0, waited[k]) have been waited for by stream slot k (main, s_p1[0], s_p1[1], s_p2)
+		// ---- streamed image (round 4): the compressed bytes are never resident as a whole. d_comp is a ring of chunk slots (K1 chunk c reads slot c % slots);
+		// every job ("pass") copies the file once more from its mapping, piece by piece in chunk order; a slot is overwritten when phase 2 of the chunk that
+		// used it is done (p2_enq: chunks whose phase 2 is enqueued - their ev_chunk events are valid to wait for) ----
+		struct SPiece { size_t src, dst, bytes; int64_t chunk; };
+		std::vector<SPiece> sp; std::vector<size_t> chunk_first;   // pieces of the pass; first piece of every chunk (size nch + 1)
+		std::atomic<int64_t> p2_enq{0}; bool pass_running = false; const uint8_t* src_base = nullptr;
 	};
 	Upload* up = nullptr;
+	bool stream_img = false; int comp_slots = 0; size_t comp_slot_bytes = 0;   // streamed image: ring geometry (plan_layout)
+	std::vector<uint64_t> chunk_lo;                                           // file offset of the first byte copied for chunk c
+	DevBuf<uint8_t> d_sync_comp;                                              // compressed bytes of the members inflate_sync works on (streamed image only)
 	std::thread plan_thread; std::string plan_err;   // plan_layout in the background of ngsqc_open (device buffers of the tile stream: allocation overlaps the H2D)
 	// the scan that rides K2's chain walk (launch_walk_scan): set by the job for its first scan consumer; fuse_ok turns false when a tile is not laid out like an
 	// htslib file (the general K2 path takes over); fused_tile = the tile whose records that scan has already seen
@@ -327,7 +336,23 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 		uint64_t sc = 0, su = 0;
 		for (int64_t i = 0; i < n; ++i) { crc[(size_t)i] = h->crc[(size_t)idx[(size_t)(b0 + i)]]; sc += dd[(size_t)i].clen; su += dd[(size_t)i].usize; }
 		const uint64_t pages = level == 0 ? k1_pool_pages(sc, su, (uint64_t)n, true) : k1_pool_pages_absolute(sc, su, (uint64_t)n);
-		{ uint64_t cend = 0; for (const BlockDesc& d : dd) cend = std::max<uint64_t>(cend, d.cpos + d.clen + 64); upload_wait(h, (size_t)cend, h->stream, 0); }
+		const uint8_t* d_comp = h->d_comp.p;
+		if (h->stream_img)
+		{
+			// the image is not resident: these members' payloads are copied from the mapping into a private buffer (16-byte aligned, 64 bytes of slack each)
+			size_t tot = 0; for (BlockDesc& d : dd) { const size_t a = (size_t)(d.cpos & 15u); tot += (a + d.clen + 64 + 15) & ~(size_t)15; }
+			std::vector<uint8_t> hc(tot + 1024, 0); size_t o = 0;
+			for (BlockDesc& d : dd)
+			{
+				const size_t a = (size_t)(d.cpos & 15u), src = (size_t)d.cpos - a, len = std::min<size_t>(a + d.clen + 64, h->up->map_n - src);
+				memcpy(hc.data() + o, h->up->src_base + src, len);
+				d.cpos = o + a; o += (a + d.clen + 64 + 15) & ~(size_t)15;
+			}
+			h->d_sync_comp.ensure_slack(hc.size());
+			HIPCHK(hipMemcpyAsync(h->d_sync_comp.p, hc.data(), hc.size(), hipMemcpyHostToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+			d_comp = h->d_sync_comp.p;
+		}
+		else { uint64_t cend = 0; for (const BlockDesc& d : dd) cend = std::max<uint64_t>(cend, d.cpos + d.clen + 64); upload_wait(h, (size_t)cend, h->stream, 0); }
 		h->d_sync_desc.ensure_slack((size_t)n); h->d_sync_st.ensure_slack((size_t)n); h->d_sync_work.ensure(2);
 		h->d_sync_u32.ensure_slack((size_t)(3 * n + 16));   // [first | count | crc]
 		h->d_sync_pool.ensure_slack((size_t)pages * K1_PAGE_WORDS + 16);
@@ -335,8 +360,8 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 		HIPCHK(hipMemcpyAsync(h->d_sync_desc.p, dd.data(), (size_t)n * sizeof(BlockDesc), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemcpyAsync(d_crc, crc.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemsetAsync(h->d_sync_work.p, 0, 2 * sizeof(unsigned long long), h->stream));   // [queue head | pool counter]
-		launch_huff_tokens(h->d_comp.p, h->d_sync_desc.p, n, h->d_sync_st.p, h->d_sync_pool.p, (uint32_t)pages, (uint32_t*)(h->d_sync_work.p + 1), d_first, d_cnt, h->d_sync_work.p, nullptr, h->p1_wgs, h->stream);
-		launch_lz77_resolve(h->d_sync_desc.p, n, d_out, h->d_sync_st.p, h->d_sync_pool.p, d_first, d_cnt, h->d_comp.p, h->stream);
+		launch_huff_tokens(d_comp, h->d_sync_desc.p, n, h->d_sync_st.p, h->d_sync_pool.p, (uint32_t)pages, (uint32_t*)(h->d_sync_work.p + 1), d_first, d_cnt, h->d_sync_work.p, nullptr, h->p1_wgs, h->stream);
+		launch_lz77_resolve(h->d_sync_desc.p, n, d_out, h->d_sync_st.p, h->d_sync_pool.p, d_first, d_cnt, d_comp, h->stream);
 		if (h->verify_crc) launch_crc32(h->d_sync_desc.p, n, d_out, d_crc, h->d_sync_st.p, h->stream);
 		std::vector<BlockStatus> st((size_t)n);
 		HIPCHK(hipMemcpyAsync(st.data(), h->d_sync_st.p, (size_t)n * sizeof(BlockStatus), hipMemcpyDeviceToHost, h->stream));
@@ -444,7 +469,7 @@ void upload_join(ngsqc_handle* h)
 {
 	ngsqc_handle::Upload* u = h->up;
 	if (!u) return;
-	u->cancel = true;
+	u->cancel = true; u->cv.notify_all();
 	for (auto& t : u->th) if (t.joinable()) t.join();
 	u->th.clear();
 	for (hipEvent_t e : u->ev) if (e) (void)hipEventDestroy(e);
@@ -513,11 +538,89 @@ void upload_wait(ngsqc_handle* h, size_t end_byte, hipStream_t st, int slot)
 	}
 	if (p1 > u->waited[slot]) u->waited[slot] = p1;
 }
+// ---- streamed image: one pass of the file through the ring of chunk slots (started by every tile stream) ----
+void stream_pass_end(ngsqc_handle* h)
+{
+	ngsqc_handle::Upload* u = h->up;
+	if (!u || !u->pass_running) return;
+	u->cancel = true; u->cv.notify_all();
+	for (auto& t : u->th) if (t.joinable()) t.join();
+	u->th.clear(); u->pass_running = false; u->cancel = false;
+}
+void stream_pass_begin(ngsqc_handle* h)
+{
+	ngsqc_handle::Upload* u = h->up;
+	stream_pass_end(h);
+	if (u->sp.empty()) return;
+	while (u->ev.size() < u->sp.size()) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); u->ev.push_back(e); }
+	u->recorded.assign(u->sp.size(), 0); u->next = 0; u->done = 0; u->p2_enq = 0; u->err.clear(); u->t0 = wall_ms(); u->t_done = u->t0;
+	for (size_t& w : u->waited) w = 0;
+	int T = 4; if (const char* e = getenv("NGSQC_H2D_THREADS")) T = std::max(1, atoi(e));
+	T = (int)std::min<size_t>((size_t)T, u->sp.size());
+	int delay_us = 0; if (const char* e = getenv("NGSQC_H2D_DELAY_US")) delay_us = std::max(0, atoi(e));
+	uint8_t* const dst = h->d_comp.p; const int device = h->device; const int slots = h->comp_slots; hipEvent_t* const ev_chunk = h->ev_chunk.data();
+	u->pass_running = true;
+	for (int t = 0; t < T; ++t)
+		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk] {
+			hipStream_t st = nullptr;
+			try
+			{
+				HIPCHK(hipSetDevice(device));
+				HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+				for (;;)
+				{
+					const size_t i = u->next.fetch_add(1);
+					if (i >= u->sp.size() || u->cancel) break;
+					const ngsqc_handle::Upload::SPiece& P = u->sp[i];
+					if (P.chunk >= slots)
+					{
+						// the slot still holds chunk P.chunk - slots: wait until its phase 2 (the last reader of the compressed bytes) has been enqueued, then until it is done
+						const int64_t prev = P.chunk - slots;
+						{ std::unique_lock<std::mutex> lk(u->mu); u->cv.wait(lk, [&] { return u->p2_enq.load() > prev || u->cancel.load(); }); }
+						if (u->cancel) break;
+						HIPCHK(hipEventSynchronize(ev_chunk[4 * prev + 3]));
+					}
+					if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+					HIPCHK(hipMemcpyAsync(dst + P.dst, u->src_base + P.src, P.bytes, hipMemcpyHostToDevice, st));
+					HIPCHK(hipEventRecord(u->ev[i], st));
+					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
+					u->cv.notify_all();
+				}
+				HIPCHK(hipStreamSynchronize(st));
+			}
+			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); }
+			if (st) (void)hipStreamDestroy(st);
+			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
+			u->cv.notify_all();
+		});
+}
+// stream st may read chunk c's compressed bytes behind this call (the host waits until the copies are issued, the stream for their events)
+void stream_wait_chunk(ngsqc_handle* h, int64_t c, hipStream_t st)
+{
+	ngsqc_handle::Upload* u = h->up;
+	for (size_t p = u->chunk_first[(size_t)c]; p < u->chunk_first[(size_t)c + 1]; ++p)
+	{
+		{
+			std::unique_lock<std::mutex> lk(u->mu);
+			u->cv.wait(lk, [&] { return u->recorded[p] || !u->err.empty(); });
+			if (!u->err.empty()) throw std::runtime_error("H2D of the compressed image failed: " + u->err);
+		}
+		HIPCHK(hipStreamWaitEvent(st, u->ev[p], 0));
+	}
+}
+void stream_p2_enqueued(ngsqc_handle* h, int64_t c)
+{
+	ngsqc_handle::Upload* u = h->up;
+	{ std::lock_guard<std::mutex> g(u->mu); u->p2_enq = c + 1; }
+	u->cv.notify_all();
+}
+
 // the whole image is on the device (ngsqc_upload_wait / timings)
 void upload_finish(ngsqc_handle* h)
 {
 	ngsqc_handle::Upload* u = h->up;
 	if (!u) return;
+	if (h->stream_img && !u->pass_running) return;   // (no pass under way: nothing in flight)
 	{ std::unique_lock<std::mutex> lk(u->mu); u->cv.wait(lk, [&] { return u->done == u->th.size() || !u->err.empty(); }); if (!u->err.empty()) throw std::runtime_error("H2D of the compressed image failed: " + u->err); }
 	h->tm.h2d_ms = u->t_done - u->t0;
 }
@@ -535,7 +638,15 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 		dbg_stamp("open: start");
 		init_device(h, device);
 		dbg_stamp("open: device and streams ready");
-		upload_start(h, bytes, 0, n);
+		// A large file is STREAMED (round 4): no 60 GB image buffer (its allocation alone took as long as the copy, and a BAM no longer has to fit HBM next to its
+		// tiles) - every job copies the file through a ring of K1-chunk slots. NGSQC_STREAM_IMAGE=1 / 0 forces / forbids it, NGSQC_STREAM_IMAGE_MIN_MB moves the
+		// threshold (default 4096: smaller files stay resident, so repeated jobs on them do not cross PCIe again).
+		{
+			const char* es = getenv("NGSQC_STREAM_IMAGE"); size_t min_mb = 4096; if (const char* em = getenv("NGSQC_STREAM_IMAGE_MIN_MB")) min_mb = (size_t)std::max(0, atoi(em));
+			h->stream_img = es ? atoi(es) != 0 : (n >> 20) >= min_mb;
+		}
+		h->up->src_base = bytes; h->up->map_n = n;
+		if (!h->stream_img) upload_start(h, bytes, 0, n);
 		dbg_stamp("open: upload threads started");
 		scan_bgzf(bytes, n, h->blocks, h->crc, h->total, n_shards == 1 ? &h->member_off : nullptr);
 		dbg_stamp("open: BGZF member table walked");
@@ -674,6 +785,34 @@ void plan_layout_now(ngsqc_handle* h)
 		for (int64_t i = f; i < f + m; ++i) { kd[(size_t)i] = h->blocks[(size_t)i]; kd[(size_t)i].upos -= u_lo; }
 		h->max_tile_bytes = std::max<int64_t>(h->max_tile_bytes, (int64_t)(h->blocks[(size_t)(f + m - 1)].upos + h->blocks[(size_t)(f + m - 1)].usize - u_lo));
 	}
+	if (h->stream_img)
+	{
+		// ring of chunk slots: chunk c's bytes [lo_c, hi_c + 64) go to slot c % slots; a member's cpos becomes its place in that slot (static: d_kdesc is built once)
+		h->comp_slots = (int)std::min<int64_t>(4, h->nch); if (const char* e = getenv("NGSQC_COMP_SLOTS")) h->comp_slots = (int)std::min<int64_t>(h->nch, std::max(2, atoi(e)));
+		h->chunk_lo.assign((size_t)h->nch, 0); std::vector<uint64_t> chunk_hi((size_t)h->nch, 0); size_t slot = 0;
+		for (int64_t c = 0; c < h->nch; ++c)
+		{
+			const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
+			h->chunk_lo[(size_t)c] = h->blocks[(size_t)c0].cpos & ~15ull;
+			chunk_hi[(size_t)c] = std::min<uint64_t>(h->blocks[(size_t)(c0 + cn - 1)].cpos + h->blocks[(size_t)(c0 + cn - 1)].clen + 64, h->up->map_n);
+			slot = std::max<size_t>(slot, (size_t)(chunk_hi[(size_t)c] - h->chunk_lo[(size_t)c]));
+		}
+		h->comp_slot_bytes = (slot + 1024 + 4095) & ~(size_t)4095;
+		h->d_comp.alloc((size_t)h->comp_slots * h->comp_slot_bytes + 1024);
+		HIPCHK(hipMemsetAsync(h->d_comp.p, 0, (size_t)h->comp_slots * h->comp_slot_bytes + 1024, h->stream));   // (the bytes behind a slot's last payload are read as padding)
+		size_t piece = 64u << 20; if (const char* e = getenv("NGSQC_H2D_PIECE_MB")) piece = (size_t)std::max(1, atoi(e)) << 20;
+		ngsqc_handle::Upload* u = h->up; u->sp.clear(); u->chunk_first.assign((size_t)h->nch + 1, 0);
+		for (int64_t c = 0; c < h->nch; ++c)
+		{
+			const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
+			const size_t base = (size_t)(c % h->comp_slots) * h->comp_slot_bytes;
+			for (int64_t i = c0; i < c0 + cn; ++i) kd[(size_t)i].cpos = base + (h->blocks[(size_t)i].cpos - h->chunk_lo[(size_t)c]);
+			u->chunk_first[(size_t)c] = u->sp.size();
+			for (uint64_t o = h->chunk_lo[(size_t)c]; o < chunk_hi[(size_t)c]; o += piece)
+				u->sp.push_back(ngsqc_handle::Upload::SPiece{(size_t)o, base + (size_t)(o - h->chunk_lo[(size_t)c]), (size_t)std::min<uint64_t>(piece, chunk_hi[(size_t)c] - o), c});
+		}
+		u->chunk_first[(size_t)h->nch] = u->sp.size();
+	}
 	h->d_kdesc.upload(kd, h->stream); h->d_order.upload(ord, h->stream); h->d_crc.upload(h->crc, h->stream);
 	h->d_tok_cnt.ensure((size_t)nb + 8); h->d_tok_first.ensure((size_t)nb + 8); h->d_status.ensure((size_t)nb); h->d_work.ensure((size_t)h->nch); h->d_pool_ctr.ensure((size_t)h->nch);
 	dbg_stamp("layout: member tables on the device");
@@ -731,7 +870,8 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
 		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
-		if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
+		if (h->stream_img) stream_wait_chunk(h, c, s1);
+		else if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
 		HIPCHK(hipEventRecord(e4[0], s1));
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, pool, (uint32_t)h->slot_pages, h->d_pool_ctr.p + c, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_work.p + c,
@@ -747,6 +887,7 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		HIPCHK(hipEventRecord(e4[2], h->s_p2));
 		launch_lz77_resolve(h->d_kdesc.p + c0, cn, out_base, h->d_status.p + c0, pool, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_comp.p, h->s_p2);
 		HIPCHK(hipEventRecord(e4[3], h->s_p2));
+		if (h->stream_img) stream_p2_enqueued(h, c);   // (the slot of this chunk's compressed bytes may be refilled once that event has fired)
 		if (h->verify_crc)   // htslib checks every member's CRC32 (bgzf.c); a mismatch fails the read
 		{
 			if (crc_stream != h->s_p2) HIPCHK(hipStreamWaitEvent(crc_stream, e4[3], 0));
@@ -1008,6 +1149,7 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	HIPCHK(hipMemsetAsync(h->d_work.p, 0, (size_t)h->nch * sizeof(unsigned long long), h->stream));
 	HIPCHK(hipMemsetAsync(h->d_pool_ctr.p, 0, (size_t)h->nch * sizeof(uint32_t), h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->stream_img) stream_pass_begin(h);
 	try
 	{
 		// K1 is queued nbuf - 1 tiles ahead of the tile the host works on (tile t + nbuf - 1 reuses the buffer of tile t - 1, whose consumers were
@@ -1033,7 +1175,13 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 			if (!pipelined && t + 1 < nt) { HIPCHK(hipStreamSynchronize(h->stream)); enqueue_k1_tile(h, t + 1); }
 		}
 	}
-	catch (...) { sync_all(h); h->decoded = false; h->cur_tile = -1; throw; }
+	catch (...) { if (h->stream_img) stream_pass_end(h); sync_all(h); h->decoded = false; h->cur_tile = -1; throw; }
+	if (h->stream_img)
+	{
+		// a tile stream that stopped early (a shard's last tile, a consumer that had enough) leaves copies nobody waits for: the pass ends here
+		if (h->k1_enq < h->nch) stream_pass_end(h);
+		else { upload_finish(h); stream_pass_end(h); }
+	}
 	// K1 timings: wall time from the first phase-1 start to the last phase-2 end, and the per-kernel sums
 	if (h->k1_enq > 0)
 	{

@@ -210,15 +210,18 @@ def test_false_start_guess_in_an_unaligned_tile(tmp_path):
         f.write(_bgzf_member(b""))
     ob = O.Bam(path)
     assert ob.count == 361
+    bed = str(tmp_path / "roi.bed")
+    with open(bed, "w") as f:
+        f.write("chr1\t900\t1500\nchr1\t1650\t1900\nchr1\t2500\t4000\n")
     for tiles in (None, "2"):
         if tiles:
             os.environ["NGSQC_TILE_MEMBERS"] = tiles
         try:
             h = ngsqc.Handle(path=path)
-            regs, _ = H.bed_regions(OMIM, h.refs, 3)
+            regs, _ = H.bed_regions(bed, h.refs, 3)
             tx, ty = H.xy_tids(h.refs)
             out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)))
-            exp = O.mapping(ob, ngsqc.MODE_WGS, OMIM, merge_bed=False)
+            exp = O.mapping(ob, ngsqc.MODE_WGS, bed, merge_bed=False)
             c = out["counters"]
             for i in range(len(c)):
                 if i not in SKIP:
@@ -255,3 +258,49 @@ def test_first_job_races_the_background_copy(tmp_path, monkeypatch):
     slow, t_open, t_h2d, _ = job({"NGSQC_H2D_PIECE_MB": "1", "NGSQC_H2D_DELAY_US": "4000", "NGSQC_H2D_THREADS": "2", "NGSQC_TILE_MEMBERS": "64"})
     assert np.array_equal(slow, ref)
     assert t_open < 0.5 * t_h2d, (t_open, t_h2d)            # open returned long before the last piece arrived: the job ran while the copy was in flight
+
+
+@pytest.mark.parametrize("tile_members", ["64", "200"])
+def test_streamed_image_equals_resident(tmp_path, monkeypatch, tile_members):
+    """Round 4: ngsqc_open(path) of a large file keeps no resident compressed image - every job copies the file through a ring of K1-chunk slots (a slot is refilled when
+    phase 2 of the chunk that used it is done). Forced here on a small file with tiny chunks (tens of chunks through four slots, slowed-down copies): same records, counters
+    and depth as the resident handle, for a second job on the same handle (the file crosses PCIe again), for the BAI pass, and with the second-chance path in the stream."""
+    path = str(tmp_path / "stream.bam")
+    G.write(path, n_reads=200_000, seed=31, start_pos=15_900_000)
+    ob = O.Bam(path)
+
+    def run(env, jobs=1):
+        for k in ("NGSQC_STREAM_IMAGE", "NGSQC_TILE_MEMBERS", "NGSQC_H2D_PIECE_MB", "NGSQC_H2D_DELAY_US", "NGSQC_TOKEN_POOL_FACTOR", "NGSQC_COMP_SLOTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = ngsqc.Handle(path=path)
+        regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
+        res = []
+        for _ in range(jobs):
+            h.drop_decoded()
+            out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=H.known_sites(h.refs))
+            res.append((np.asarray(out["counters"]).copy(), np.asarray(out["site_counts"]).copy(), h.depth(int(out["counters"][26])).copy()))
+        t = h.timings(); n = h.n_records; h.close()
+        return res, t, n
+
+    (ref,), _, n = run({"NGSQC_STREAM_IMAGE": "0", "NGSQC_TILE_MEMBERS": tile_members})
+    assert n == ob.count
+    res, t, n2 = run({"NGSQC_STREAM_IMAGE": "1", "NGSQC_TILE_MEMBERS": tile_members, "NGSQC_H2D_PIECE_MB": "1", "NGSQC_H2D_DELAY_US": "300"}, jobs=2)
+    assert n2 == ob.count and t["members_inflated"] > 0
+    for got in res:
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+    # two slots only, and a token pool that runs dry in every chunk: the second chance reads its members' bytes from the file, not from the ring
+    res, t, _ = run({"NGSQC_STREAM_IMAGE": "1", "NGSQC_TILE_MEMBERS": tile_members, "NGSQC_COMP_SLOTS": "2", "NGSQC_TOKEN_POOL_FACTOR": "0.01"})
+    assert t["members_second_chance"] > 0
+    for a, b in zip(res[0], ref):
+        assert np.array_equal(a, b)
+    # the index pass is one more trip of the file through the ring
+    monkeypatch.setenv("NGSQC_STREAM_IMAGE", "1"); monkeypatch.setenv("NGSQC_TILE_MEMBERS", tile_members); monkeypatch.delenv("NGSQC_TOKEN_POOL_FACTOR", raising=False)
+    h = ngsqc.Handle(path=path)
+    h.write_bai(str(tmp_path / "s.bai")); h.close()
+    monkeypatch.setenv("NGSQC_STREAM_IMAGE", "0")
+    h = ngsqc.Handle(path=path)
+    h.write_bai(str(tmp_path / "r.bai")); h.close()
+    assert open(str(tmp_path / "s.bai"), "rb").read() == open(str(tmp_path / "r.bai"), "rb").read()
