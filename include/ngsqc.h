@@ -212,6 +212,9 @@ int ngsqc_open_memory_shard(const void* bam_bytes, size_t n_bytes, int device, i
  * members (and those of the BAM header) are sent to the device and inflated. Scans that only depend on the reads overlapping the regions
  * (depth scans, site pileups, read counts) give the same result as on the whole file. */
 int ngsqc_bai_range(const char* bam_path, const ngsqc_region* regions, int64_t n_regions, int32_t n_ref, uint64_t* beg_voff, uint64_t* end_voff, int32_t* found);
+/* the same range for EVERY region on its own (one load of the index): beg_voff[i] / end_voff[i], end_voff[i] == 0 when no record can overlap region i. Regions that lie
+ * far apart in the file are better served by one partial handle per cluster of ranges than by the one range from the first to the last (host layer: avgCoverage). */
+int ngsqc_bai_ranges(const char* bam_path, const ngsqc_region* regions, int64_t n_regions, int32_t n_ref, uint64_t* beg_voff, uint64_t* end_voff);
 int ngsqc_open_range(const char* bam_path, int device, uint64_t beg_voff, uint64_t end_voff, ngsqc_handle** out);
 /* the same in one call for named regions (reference names as in the BAM header, with or without "chr"): header -> tids -> BAI -> range. Only the BGZF
  * members of the header and of the range are walked on the host and sent to the device. No overlapping record: a handle without records. */

@@ -21,6 +21,7 @@
 #include <atomic>
 #include <functional>
 #include <thread>
+#include <deque>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -35,11 +36,51 @@ struct FormatError : std::runtime_error { using std::runtime_error::runtime_erro
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// Giving tens of GB back to the driver takes about a second (0.9 - 1.2 s for the buffers of a 60 GB BAM, profiles/r03_tool_probe.txt): large buffers are freed by a
+// background thread, so ngsqc_close returns at once; a tool that exits right behind its last close never pays (the driver reclaims a dead process's memory itself), a
+// process that goes on opening handles finds the memory free again a moment later (an allocation that fails waits for the thread and tries once more).
+struct Reaper
+{
+	std::mutex mu; std::condition_variable cv; std::deque<std::pair<void*, int>> q; std::thread th; bool stop = false, busy = false;
+	void push(void* p)
+	{
+		int dev = 0; (void)hipGetDevice(&dev);
+		std::lock_guard<std::mutex> g(mu);
+		q.emplace_back(p, dev);
+		if (!th.joinable()) th = std::thread([this] { run(); });
+		cv.notify_all();
+	}
+	void run()
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;)
+		{
+			cv.wait(lk, [&] { return stop || !q.empty(); });
+			if (stop) return;   // (the process is going: what is still queued goes with it)
+			const auto e = q.front(); q.pop_front(); busy = true;
+			lk.unlock(); (void)hipSetDevice(e.second); (void)hipFree(e.first); lk.lock();
+			busy = false; cv.notify_all();
+		}
+	}
+	void drain() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return q.empty() && !busy; }); }
+	~Reaper() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
+Reaper& reaper() { static Reaper r; return r; }
+constexpr size_t REAP_MIN_BYTES = (size_t)256 << 20;
+
 template <typename T> struct DevBuf
 {
 	T* p = nullptr; size_t n = 0;
-	void alloc(size_t count) { release(); if (count) { HIPCHK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
-	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+	void alloc(size_t count)
+	{
+		release();
+		if (!count) return;
+		hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); reaper().drain(); e = hipMalloc((void**)&p, count * sizeof(T)); }   // (memory that is still on its way back)
+		if (e != hipSuccess) { p = nullptr; throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes"); }
+		n = count;
+	}
+	void release() { if (p) { if (n * sizeof(T) >= REAP_MIN_BYTES) reaper().push(p); else (void)hipFree(p); p = nullptr; n = 0; } }
 	void ensure(size_t count) { if (n < count) alloc(count); }
 	void ensure_slack(size_t count) { if (n < count) alloc(count + count / 4); }   // per-tile scratch: growing it means hipFree, and hipFree waits for every queued kernel of the device   // keep a big-enough allocation (hipMalloc/hipFree of multi-GB buffers can stall for a second)
 	void upload(const std::vector<T>& v, hipStream_t s) { ensure(v.size()); if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s)); }
@@ -717,10 +758,14 @@ void plan_layout_now(ngsqc_handle* h)
 	if (nb == 0) return;
 	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
 	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
+	// A streamed image is bound by PCIe (60 GB in 1.2 s against 0.57 s of K1), and what a one-shot tool waits for besides the copy is the ALLOCATION of the stream's
+	// buffers (28 GB/s when another process has just given the memory back): half-size chunks and one chunk per tile cut the ring, the token pool and the tile
+	// buffers from 65 GB to 23 GB for the 30x file; the job stays behind the copy
+	if (h->stream_img && !getenv("NGSQC_K1_CHUNK_DIV")) div = 2;
 	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * K1_CHUNK_WAVES_PER_CU * 64 * mul / div);
 	// two K1 chunks per tile (192 M reads, 12 chunks; job Mreads/s | un-pipelined scan-stage share of the HBM roofline): 1 chunk 919 | 0.36, 2 chunks 931-941 | 0.43-0.44, 4 chunks
 	// 930 | 0.46. The job barely cares; the chain walk of the fused scan has one thread per MEMBER, so a tile of 195 k members keeps twice the lines in flight of a 97 k one.
-	int64_t cpt = 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
+	int64_t cpt = h->stream_img ? 1 : 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
 	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile). NGSQC_TILE_BUFFERS=2..4.
 	h->nbuf = 3; if (const char* e = getenv("NGSQC_TILE_BUFFERS")) h->nbuf = std::min<int>(ngsqc_handle::MAX_TILE_BUFS, std::max(2, atoi(e)));
@@ -757,6 +802,7 @@ void plan_layout_now(ngsqc_handle* h)
 	if (!forced && h->nch > 1)
 	{
 		size_t free_b = 0, total_b = 0;
+		reaper().drain();   // (memory of a handle that was just closed counts as free)
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 		{
 			const double fixed = (double)n_slots * (double)h->slot_pages * (double)K1_PAGE_WORDS * 4.0 + (double)nb * 64.0 + (double)h->nbuf * (double)carry_max;
@@ -1955,6 +2001,16 @@ int ngsqc_bai_range(const char* bam_path, const ngsqc_region* regions, int64_t n
 		bool f = false;
 		if (!ngsqc::bai_range(bam_path, regions, n_regions, n_ref, *beg_voff, *end_voff, f)) { g_open_error = std::string("Could not load index of BAM/CRAM file ") + bam_path; return NGSQC_E_IO; }   // BamReader.cpp:742-746
 		*found = f ? 1 : 0;
+		return NGSQC_OK;
+	}
+	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_FORMAT; }
+}
+int ngsqc_bai_ranges(const char* bam_path, const ngsqc_region* regions, int64_t n_regions, int32_t n_ref, uint64_t* beg_voff, uint64_t* end_voff)
+{
+	if (!bam_path || n_regions < 0 || (n_regions > 0 && (!regions || !beg_voff || !end_voff))) return NGSQC_E_ARG;
+	try
+	{
+		if (!ngsqc::bai_ranges(bam_path, regions, n_regions, n_ref, beg_voff, end_voff)) { g_open_error = std::string("Could not load index of BAM/CRAM file ") + bam_path; return NGSQC_E_IO; }
 		return NGSQC_OK;
 	}
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_FORMAT; }

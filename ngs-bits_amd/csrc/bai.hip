@@ -67,47 +67,65 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& bins)
 // Virtual-offset range [beg_voff, end_voff) that contains every record overlapping any region (1-based, closed; like the iterator of
 // BamReader::setRegion: chunks of the overlapping bins that end behind the linear index' lower bound). found = 0: no record can overlap.
 // Returns false when there is no readable BAI next to the BAM (<bam>.bai or <bam without .bam>.bai).
+static bool load_bai_of(const std::string& bam_path, Bai& bai)
+{
+	bool ok = load_bai(bam_path + ".bai", bai);
+	if (!ok && bam_path.size() > 4 && bam_path.compare(bam_path.size() - 4, 4, ".bam") == 0) ok = load_bai(bam_path.substr(0, bam_path.size() - 4) + ".bai", bai);
+	return ok;
+}
+// the range of ONE region: false = no record can overlap it
+static bool region_range(const Bai& bai, const ngsqc_region& g, int32_t n_ref, uint64_t& rb, uint64_t& re)
+{
+	if (g.tid < 0 || g.tid >= n_ref || (size_t)g.tid >= bai.refs.size()) return false;
+	const BaiRef& R = bai.refs[(size_t)g.tid];
+	const int64_t beg = std::max<int64_t>((int64_t)g.start - 1, 0), end = std::max<int64_t>(g.end, beg + 1);
+	uint64_t min_off = 0;
+	if (!R.ioffset.empty()) { const size_t w = (size_t)(beg >> 14); min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back(); }
+	std::vector<uint32_t> bins; reg2bins(beg, end, bins);
+	std::sort(bins.begin(), bins.end());
+	rb = ~0ull; re = 0; uint64_t stop = ~0ull; bool any = false;
+	for (const auto& bc : R.bins)
+	{
+		if (bc.first >= 37449u) continue;   // (37450: the metadata pseudo-bin)
+		if (std::binary_search(bins.begin(), bins.end(), bc.first))
+		{
+			for (const BaiChunk& c : bc.second)
+				if (c.end > min_off) { rb = std::min(rb, c.beg); re = std::max(re, c.end); any = true; }
+			continue;
+		}
+		// A bin whose interval starts at or behind the region's end holds only records that start there, so its first chunk starts at such a record. The file is
+		// sorted by start: every record that overlaps the region lies in front of that record - where the iterator of the reference stops, too (hts_itr_next:
+		// "beg >= iter->end"). Without this bound the range runs to the last chunk of the region's 8 Mb / 64 Mb super-bins.
+		int l = 0; uint32_t first = 0;
+		while (l < 5 && bc.first >= ((1u << (3 * (l + 1))) - 1u) / 7u) { ++l; first = ((1u << (3 * l)) - 1u) / 7u; }
+		const int64_t bin_start = (int64_t)(bc.first - first) << (14 + 3 * (5 - l));
+		if (bin_start >= end) for (const BaiChunk& c : bc.second) stop = std::min(stop, c.beg);
+	}
+	if (!any) return false;
+	rb = std::max(rb, min_off);             // every record that overlaps the region's first window starts at or behind the linear index' offset
+	if (stop != ~0ull && stop >= rb) re = std::min(re, stop);
+	return re > rb;
+}
 bool bai_range(const std::string& bam_path, const ngsqc_region* regions, int64_t n, int32_t n_ref, uint64_t& beg_voff, uint64_t& end_voff, bool& found)
 {
-	Bai bai; bool ok = load_bai(bam_path + ".bai", bai);
-	if (!ok && bam_path.size() > 4 && bam_path.compare(bam_path.size() - 4, 4, ".bam") == 0) ok = load_bai(bam_path.substr(0, bam_path.size() - 4) + ".bai", bai);
-	if (!ok) return false;
+	Bai bai;
+	if (!load_bai_of(bam_path, bai)) return false;
 	beg_voff = ~0ull; end_voff = 0; found = false;
-	std::vector<uint32_t> bins;
 	for (int64_t i = 0; i < n; ++i)
 	{
-		const ngsqc_region& g = regions[i];
-		if (g.tid < 0 || g.tid >= n_ref || (size_t)g.tid >= bai.refs.size()) continue;
-		const BaiRef& R = bai.refs[(size_t)g.tid];
-		const int64_t beg = std::max<int64_t>((int64_t)g.start - 1, 0), end = std::max<int64_t>(g.end, beg + 1);
-		uint64_t min_off = 0;
-		if (!R.ioffset.empty()) { const size_t w = (size_t)(beg >> 14); min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back(); }
-		bins.clear(); reg2bins(beg, end, bins);
-		std::sort(bins.begin(), bins.end());
-		uint64_t rb = ~0ull, re = 0, stop = ~0ull; bool any = false;
-		for (const auto& bc : R.bins)
-		{
-			if (bc.first >= 37449u) continue;   // (37450: the metadata pseudo-bin)
-			if (std::binary_search(bins.begin(), bins.end(), bc.first))
-			{
-				for (const BaiChunk& c : bc.second)
-					if (c.end > min_off) { rb = std::min(rb, c.beg); re = std::max(re, c.end); any = true; }
-				continue;
-			}
-			// A bin whose interval starts at or behind the region's end holds only records that start there, so its first chunk starts at such a record. The file is
-			// sorted by start: every record that overlaps the region lies in front of that record - where the iterator of the reference stops, too (hts_itr_next:
-			// "beg >= iter->end"). Without this bound the range runs to the last chunk of the region's 8 Mb / 64 Mb super-bins.
-			int l = 0; uint32_t first = 0;
-			while (l < 5 && bc.first >= ((1u << (3 * (l + 1))) - 1u) / 7u) { ++l; first = ((1u << (3 * l)) - 1u) / 7u; }
-			const int64_t bin_start = (int64_t)(bc.first - first) << (14 + 3 * (5 - l));
-			if (bin_start >= end) for (const BaiChunk& c : bc.second) stop = std::min(stop, c.beg);
-		}
-		if (!any) continue;
-		rb = std::max(rb, min_off);             // every record that overlaps the region's first window starts at or behind the linear index' offset
-		if (stop != ~0ull && stop >= rb) re = std::min(re, stop);
-		if (re <= rb) continue;
+		uint64_t rb, re;
+		if (!region_range(bai, regions[i], n_ref, rb, re)) continue;
 		beg_voff = std::min(beg_voff, rb); end_voff = std::max(end_voff, re); found = true;
 	}
+	return true;
+}
+// the same per region (one load of the index): beg[i] / end[i], end[i] == 0 when no record can overlap region i. The host layer clusters scattered regions
+// with these (one partial handle per cluster instead of one range from the first to the last region).
+bool bai_ranges(const std::string& bam_path, const ngsqc_region* regions, int64_t n, int32_t n_ref, uint64_t* beg, uint64_t* end)
+{
+	Bai bai;
+	if (!load_bai_of(bam_path, bai)) return false;
+	for (int64_t i = 0; i < n; ++i) { uint64_t rb, re; if (region_range(bai, regions[i], n_ref, rb, re)) { beg[i] = rb; end[i] = re; } else { beg[i] = 0; end[i] = 0; } }
 	return true;
 }
 

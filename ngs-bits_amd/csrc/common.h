@@ -23,6 +23,7 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
 
 // BAI index on the host (bai.hip)
 bool bai_range(const std::string& bam_path, const ngsqc_region* regions, int64_t n, int32_t n_ref, uint64_t& beg_voff, uint64_t& end_voff, bool& found);
+bool bai_ranges(const std::string& bam_path, const ngsqc_region* regions, int64_t n, int32_t n_ref, uint64_t* beg, uint64_t* end);   // per region; end == 0: nothing can overlap
 
 // BAI construction (bai.hip): what `samtools index` (htslib sam_index_build: hts_idx_push / hts_idx_finish) writes for a coordinate-sorted BAM.
 // The device turns the records of a tile into RUNS (consecutive records of one (reference, bin)), per-reference mapped / unmapped counts and the

@@ -1127,10 +1127,58 @@ GenderEstimate Statistics::genderSRY(const std::string& build, const std::string
 	return output;
 }
 
+// Lines that lie far apart in the file (a handful of genes spread over the genome: BedCoverage -random_access, WorkerAverageCoverage.cpp:100-173 queries the index per
+// line) are served by one index-driven handle per CLUSTER of lines instead of one handle over the range from the first line to the last: the per-line ranges of the
+// BAI (ngsqc_bai_ranges) are sorted and merged while they overlap or lie closer than 8 MB of compressed bytes. Returns false when that does not pay (no index, one
+// cluster, too many lines or clusters): the caller takes the single-handle path.
+static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file, int min_mapq, int decimals, const std::string& ref_file, bool skip_mismapped)
+{
+	const char* es = getenv("NGSQC_INDEX_SELECT");
+	if ((es && atoi(es) == 0) || bed_file.count() < 2 || bed_file.count() > 4096 || getenv("NGSQC_SHARDS")) return false;
+	const std::string noext = bam_file.size() > 4 && bam_file.compare(bam_file.size() - 4, 4, ".bam") == 0 ? bam_file.substr(0, bam_file.size() - 4) : bam_file;
+	if (!fileExists(bam_file + ".bai") && !fileExists(noext + ".bai")) return false;
+	std::vector<ngsqc_region> lines; int n_ref = 0;
+	{
+		BamReader head(bam_file, ref_file, BamReader::Head{1});   // (chromosome numbering of this BAM: the header members only)
+		lines = toRegions(bed_file, head, true); n_ref = ngsqc_n_ref(head.handle());
+	}
+	const size_t n = lines.size();
+	std::vector<uint64_t> vb(n, 0), ve(n, 0);
+	if (ngsqc_bai_ranges(bam_file.c_str(), lines.data(), (int64_t)n, n_ref, vb.data(), ve.data()) != NGSQC_OK) return false;
+	std::vector<size_t> order; for (size_t i = 0; i < n; ++i) if (ve[i]) order.push_back(i);
+	std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return vb[a] != vb[b] ? vb[a] < vb[b] : a < b; });
+	std::vector<std::vector<size_t>> clusters; uint64_t cur_end = 0;
+	uint64_t GAP = 8ull << 20; if (const char* eg = getenv("NGSQC_INDEX_CLUSTER_GAP_KB")) GAP = (uint64_t)std::max(1, atoi(eg)) << 10;   // (tests: small files)
+	for (size_t i : order)
+	{
+		if (clusters.empty() || (vb[i] >> 16) > (cur_end >> 16) + GAP) { clusters.emplace_back(); cur_end = 0; }
+		clusters.back().push_back(i); cur_end = std::max(cur_end, ve[i]);
+	}
+	if (clusters.size() < 2 || clusters.size() > 64) return false;
+	std::vector<int64_t> sums(n, 0);
+	for (const std::vector<size_t>& cl : clusters)
+	{
+		BedFile sub; for (size_t i : cl) sub.append(bed_file[(long long)i]);
+		BamReader reader(bam_file, ref_file, true, sub);
+		reader.requireIndex();
+		std::vector<ngsqc_region> regions = unionRegions(sub, reader, true);
+		ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = 0; p.skip_mismapped = skip_mismapped ? 1 : 0; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
+		runDepthScan(reader, p);
+		std::vector<ngsqc_region> sl = toRegions(sub, reader, true);
+		std::vector<int64_t> ss(sl.size(), 0);
+		reader.check(ngsqc_region_sums(reader.handle(), sl.data(), (int64_t)sl.size(), ss.data()));
+		for (size_t k = 0; k < cl.size(); ++k) sums[cl[k]] = ss[k];
+	}
+	if (getenv("NGSQC_TIMING")) fprintf(stderr, "[ngsqc] index-driven open: %zu clusters of lines\n", clusters.size());
+	for (long long i = 0; i < bed_file.count(); ++i) bed_file[i].annotations().push_back(number((double)sums[(size_t)i] / bed_file[i].length(), decimals));
+	return true;
+}
+
 void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
 	if (bed_file.count() == 0) return;
+	if (avgCoverageClustered(bed_file, bam_file, min_mapq, decimals, ref_file, skip_mismapped)) return;
 	BamReader reader(bam_file, ref_file, true, bed_file);   // (only the BGZF blocks the index names for the lines)
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);

@@ -248,3 +248,27 @@ def test_sry_gender_inflates_only_the_indexed_blocks(tmp_path):
     bed = str(tmp_path / "few.bed"); open(bed, "w").write("".join(open(os.path.join(GI, "MappingQC_in3.bed")).readlines()[:3]))
     c = run("BedCoverage", "-bam", bam, "-in", bed, "-random_access"); d = run("BedCoverage", "-bam", bam, "-in", bed, "-random_access", env={"NGSQC_INDEX_SELECT": "0"})
     assert c.stdout == d.stdout and len(c.stdout.splitlines()) >= 3
+
+
+def test_bedcoverage_random_access_over_scattered_lines_stays_partial(tmp_path):
+    """VERDICT r03 #3e: lines far apart in the file. One index-driven handle per CLUSTER of lines (ngsqc_bai_ranges: the BAI range of every line, merged while they
+    lie close in the file) instead of one handle over the range from the first line to the last: three disjoint windows of a synthetic BAM, the output of the single-range
+    path and of a run without the index, and far fewer BGZF members on the device."""
+    import bamgen_lib as G
+    ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+    bam = str(tmp_path / "scatter.bam")
+    G.write(bam, n_reads=300_000, seed=41, start_pos=20_000_000)
+    h = ngsqc.Handle(path=bam); h.write_bai(); n_members = h.n_blocks; h.close()
+    bed = str(tmp_path / "three.bed")
+    open(bed, "w").write("chr1\t20100000\t20101000\nchr1\t20700000\t20700800\nchr1\t21300000\t21301500\nchr1\t20100500\t20100900\n")
+    base = ("BedCoverage", "-bam", bam, "-in", bed, "-random_access")
+    a = run(*base, env={"NGSQC_TIMING": "1", "NGSQC_INDEX_CLUSTER_GAP_KB": "512"})
+    b = run(*base, env={"NGSQC_TIMING": "1", "NGSQC_INDEX_CLUSTER_GAP_KB": "100000000"})   # one cluster: the single-range path
+    c = run(*base, env={"NGSQC_INDEX_SELECT": "0"})
+    assert a.stdout == b.stdout == c.stdout and len(a.stdout.splitlines()) >= 4
+    assert "3 clusters of lines" in a.stderr, a.stderr
+    got = sum(int(x) for x in re.findall(r"index-driven open: (\d+) BGZF members", a.stderr))
+    one = sum(int(x) for x in re.findall(r"index-driven open: (\d+) BGZF members", b.stderr))
+    assert got * 4 < one and one <= n_members, (got, one, n_members)
+    cov = [float(ln.split("\t")[-1]) for ln in a.stdout.splitlines() if not ln.startswith("#")]
+    assert all(10.0 < v < 60.0 for v in cov), cov   # ~30x everywhere
