@@ -41,7 +41,11 @@ struct IoError : std::runtime_error { using std::runtime_error::runtime_error; }
 // process that goes on opening handles finds the memory free again a moment later (an allocation that fails waits for the thread and tries once more).
 struct Reaper
 {
-	std::mutex mu; std::condition_variable cv; std::deque<std::pair<void*, int>> q; std::thread th; bool stop = false, busy = false;
+	std::mutex mu; std::condition_variable cv; std::deque<std::pair<void*, int>> q; std::thread th; bool stop = false, busy = false; int held = 0;
+	// (a hipFree of tens of GB holds the runtime's memory lock for its whole duration: while a handle is being closed the thread holds still, so that the closing
+	// thread's own small frees and stream / event teardown do not queue up behind it)
+	void hold() { std::lock_guard<std::mutex> g(mu); ++held; }
+	void unhold() { { std::lock_guard<std::mutex> g(mu); --held; } cv.notify_all(); }
 	void push(void* p)
 	{
 		int dev = 0; (void)hipGetDevice(&dev);
@@ -55,14 +59,14 @@ struct Reaper
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;)
 		{
-			cv.wait(lk, [&] { return stop || !q.empty(); });
+			cv.wait(lk, [&] { return stop || (!q.empty() && held == 0); });
 			if (stop) return;   // (the process is going: what is still queued goes with it)
 			const auto e = q.front(); q.pop_front(); busy = true;
 			lk.unlock(); (void)hipSetDevice(e.second); (void)hipFree(e.first); lk.lock();
 			busy = false; cv.notify_all();
 		}
 	}
-	void drain() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return q.empty() && !busy; }); }
+	void drain() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return (q.empty() && !busy) || held > 0; }); }
 	~Reaper() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 Reaper& reaper() { static Reaper r; return r; }
@@ -834,7 +838,7 @@ void plan_layout_now(ngsqc_handle* h)
 	if (h->stream_img)
 	{
 		// ring of chunk slots: chunk c's bytes [lo_c, hi_c + 64) go to slot c % slots; a member's cpos becomes its place in that slot (static: d_kdesc is built once)
-		h->comp_slots = (int)std::min<int64_t>(4, h->nch); if (const char* e = getenv("NGSQC_COMP_SLOTS")) h->comp_slots = (int)std::min<int64_t>(h->nch, std::max(2, atoi(e)));
+		h->comp_slots = (int)std::min<int64_t>(8, h->nch);   // (eight half-size chunks = 7.6 GB of the 30x file: the copy runs well ahead of K1, so the host rarely blocks on a piece) if (const char* e = getenv("NGSQC_COMP_SLOTS")) h->comp_slots = (int)std::min<int64_t>(h->nch, std::max(2, atoi(e)));
 		h->chunk_lo.assign((size_t)h->nch, 0); std::vector<uint64_t> chunk_hi((size_t)h->nch, 0); size_t slot = 0;
 		for (int64_t c = 0; c < h->nch; ++c)
 		{
@@ -2062,6 +2066,7 @@ int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap)
 void ngsqc_close(ngsqc_handle* h)
 {
 	if (!h) return;
+	struct Hold { Hold() { reaper().hold(); } ~Hold() { reaper().unhold(); } } hold_frees;   // (the large buffers go back when this handle is gone)
 	if (h->plan_thread.joinable()) h->plan_thread.join();
 	if (h->up) { upload_join(h); delete h->up; h->up = nullptr; }
 	if (h->stream) { (void)hipSetDevice(h->device); sync_all(h); }
