@@ -605,23 +605,17 @@ void stream_pass_begin(ngsqc_handle* h)
 	int delay_us = 0; if (const char* e = getenv("NGSQC_H2D_DELAY_US")) delay_us = std::max(0, atoi(e));
 	uint8_t* const dst = h->d_comp.p; const int device = h->device; const int slots = h->comp_slots; hipEvent_t* const ev_chunk = h->ev_chunk.data();
 	// The source of a piece is the mapping of the file (hipMemcpyAsync stages a pageable source through the runtime's pinned buffers). Reading through the mapping
-	// faults in one page-table entry per 4 KB - 15 M of them for a 60 GB file, and tearing them down again cost 0.3 - 0.75 s at close for a 19 GB file: every
-	// thread drops the entries of the piece it sent last (madvise MADV_DONTNEED: the page cache keeps the data) while the next piece is on its way.
-	// NGSQC_H2D_PREAD=1 reads the pieces into pinned buffers of its own instead (pread) - measured slower: 12.5 GB/s with four threads against 37 GB/s.
+	// faults in one page-table entry per 4 KB - 15 M of them for a 60 GB file - and tearing them down again costs 0.3 - 0.75 s at close for a 19 GB file. Measured
+	// alternatives on a 19 GB BAM (profiles/r04_tool_probe.txt): NGSQC_H2D_PREAD=1 (pieces read into pinned buffers of the copier threads) 12.5 GB/s with four threads,
+	// 24 GB/s with eight, against 37 GB/s through the mapping; dropping a sent piece's entries with madvise(MADV_DONTNEED) made the job ten times slower (the
+	// address-space lock against the other copiers' faults). The mapping stays.
 	const int fd = u->fd; size_t pmax = 0; for (const auto& P : u->sp) pmax = std::max(pmax, P.bytes);
 	const char* em = getenv("NGSQC_H2D_PREAD"); const bool from_map = fd < 0 || !(em && atoi(em) != 0);
 	u->pass_running = true;
 	for (int t = 0; t < T; ++t)
 		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, fd, pmax, from_map] {
 			hipStream_t st = nullptr; uint8_t* pin[2] = {nullptr, nullptr}; hipEvent_t pev[2] = {nullptr, nullptr}; long last = -1;
-			auto drop_last = [&]() {
-				if (last < 0 || !from_map) return;
-				(void)hipEventSynchronize(u->ev[(size_t)last]);
-				const ngsqc_handle::Upload::SPiece& L = u->sp[(size_t)last];
-				const uintptr_t a = ((uintptr_t)(u->src_base + L.src) + 4095) & ~(uintptr_t)4095, b = (uintptr_t)(u->src_base + L.src + L.bytes) & ~(uintptr_t)4095;
-				if (b > a) (void)madvise((void*)a, b - a, MADV_DONTNEED);
-				last = -1;
-			};
+			auto drop_last = [&]() { last = -1; };
 			try
 			{
 				HIPCHK(hipSetDevice(device));
