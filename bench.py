@@ -161,11 +161,29 @@ def main():
 
     # the product's own collective (include/ngsqc.h ngsqc_comm_*: RCCL loaded by libngsqc_hip.so) carries every exchange of the data path; torch.distributed only
     # starts the ranks, hands the 128-byte unique id around and provides the timing barriers of the bench contract
-    comm = None
-    if world > 1 and args.backend == "nccl" and not args.all_ranks_on_device0:
-        box = [ngsqc.Comm.unique_id() if rank == 0 else None]
+    comm = None; comm_note = None
+    if world > 1 and args.backend == "nccl" and not args.all_ranks_on_device0 and os.environ.get("NGSQC_BENCH_TORCH_COLLECTIVE") is None:
+        # (every rank must end up on the same path: a rank whose communicator could not be made sends the others back to torch.distributed)
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = ngsqc.Comm.unique_id()
+            except Exception as e:
+                comm_note = f"ngsqc_comm_unique_id failed: {e}"[:200]
         dist.broadcast_object_list(box, src=0)
-        comm = ngsqc.Comm(rank, world, box[0], device=local_rank)
+        okc = torch.ones(1, dtype=torch.int64, device=dev)
+        if box[0] is None:
+            okc.zero_()
+        else:
+            try:
+                comm = ngsqc.Comm(rank, world, box[0], device=local_rank)
+            except Exception as e:
+                comm_note = f"ngsqc_comm_init failed on rank {rank}: {e}"[:200]; okc.zero_()
+        dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+        if int(okc.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None; comm_note = comm_note or "a rank could not make the library's communicator: torch.distributed carries the collectives of this run"
 
     # ---- workload size: the full 30x file when the host can hold the image (plus a private copy per rank for N > 1) ----
     mode = 1 if args.ont else 0
@@ -341,6 +359,8 @@ def main():
         distinct = len({tuple(p_.cpu().numpy()[:8].tolist()) for p_ in parts})
         coll = {"library": "libngsqc_hip ngsqc_comm_allreduce_counters (RCCL, loaded by the library)" if comm is not None else "torch.distributed (" + args.backend + ")",
                 "allreduce_matches_gathered_sum_per_rank": oks, "distinct_inputs": distinct, "one_bam_per_gpu_with_its_own_seed": per_rank_seed}
+        if comm_note:
+            coll["note"] = comm_note
     n_rec = int(tms[-1]["n_records"])
     if args.single_bam:
         nr = torch.tensor([n_rec], dtype=torch.int64, device=dev)
@@ -441,7 +461,13 @@ def main():
         # raw FETCH_SIZE / WRITE_SIZE bytes per BGZF member (K1) or per record (scan stage), scaled to this run's launch
         try:
             per = {}
-            for ln in open(os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.txt")):
+            settings_ok = False
+            want = "k1_format=r04-word-per-trip tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
+            for ln in open(os.path.join(ROOT, "profiles", "r04_hbm_traffic_pmc.txt")):
+                if ln.startswith("# settings: "):
+                    settings_ok = want in ln   # (the per-member figures only describe launches of the same kernels under the same schedule)
+                if not settings_ok:
+                    continue
                 f = ln.rstrip("\n").split("\t")
                 if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and f[2] in ("bytes_per_member", "bytes_per_record"):
                     per[(f[0], f[1])] = float(f[3])
@@ -451,7 +477,7 @@ def main():
                 fb, wb = per[(kname, "FETCH_SIZE")] * members_per_launch, per[(kname, "WRITE_SIZE")] * members_per_launch
                 out["roofline"]["traffic"] = int(fb + wb)
                 out["roofline"]["traffic_pmc"] = {"fetch_bytes_raw": int(fb), "write_bytes_raw": int(wb), "members_per_launch": int(members_per_launch),
-                                                  "source": "profiles/r03_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
+                                                  "source": "profiles/r04_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
                                                   "ratio_to_algorithmic": round((fb + wb) / max(dom[1], 1), 2),
                                                   "note": "raw FETCH_SIZE / WRITE_SIZE x 1024 B (no x2: the K1 accesses are 16-byte pieces of 64 different member streams per "
                                                           "instruction, between the guide's narrow and wide regimes)"}
@@ -460,7 +486,7 @@ def main():
                 if keys:
                     tot = sum(per[k] for k in keys) * n_rec
                     out["roofline_scan"]["traffic"] = int(tot)
-                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r03_hbm_traffic_pmc.txt) x the records of the step; the "
+                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r04_hbm_traffic_pmc.txt) x the records of the step; the "
                                                             "kernels gather one or two 128-byte lines per record, so the guide's x2 for wide streams does not apply")
         except OSError:
             pass
