@@ -1,5 +1,28 @@
-"""Test-side host logic: BED text -> (tid,start,end) regions for the C ABI. (The shipped host layer is C++: ngs-bits_amd/host.)"""
+"""Test-side host logic: BED file -> (tid,start,end) regions for the C ABI. The BED handling itself (load, sort, merge, chunk, chromosome numbering) is the PRODUCT's:
+ngs-bits_amd/host/core.cpp behind bin/libngsqc_hostapi.so (ngs-bits_amd/host/hostapi.cpp) - bench.py and the C-ABI tests get their region tables from the host layer
+that ships, the oracle's BED loader is only its checker (bed_regions_oracle, tests/test_cpu_plumbing.py)."""
+import ctypes as C
+import os
+import subprocess
+
 import oracle_lib as O
+
+_HOST_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ngs-bits_amd", "host")
+_hostapi = None
+
+
+def hostapi():
+    global _hostapi
+    if _hostapi is None:
+        so = os.path.join(os.path.dirname(_HOST_DIR), "bin", "libngsqc_hostapi.so")
+        srcs = [os.path.join(_HOST_DIR, f) for f in ("hostapi.cpp", "core.cpp", "core.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s_) > os.path.getmtime(so) for s_ in srcs):
+            subprocess.check_call(["make", "-C", _HOST_DIR, "-s", os.path.join("..", "bin", "libngsqc_hostapi.so")])
+        L = C.CDLL(so)
+        L.ngsbits_bed_regions.restype = C.c_longlong
+        L.ngsbits_bed_regions.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        _hostapi = L
+    return _hostapi
 
 
 def chr_norm(name):
@@ -42,7 +65,23 @@ def nonspecial(refs):
 
 
 def bed_regions(bed_path, refs, merge_mode):
-    """merge_mode: 0 none, 1 merge(), 2 merge(true,true), 3 sort+merge, 4 merge+chunk(100), 5 sort+merge+chunk(100). Returns [(tid,start,end)], annotations."""
+    """merge_mode: 0 none, 1 merge(), 2 merge(true,true), 3 sort+merge, 4 merge+chunk(100), 5 sort+merge+chunk(100). Returns [(tid,start,end)], annotations (always empty
+    lists here: the C entry returns coordinates). The product's host layer does the work (BedFile::load / sort / merge / chunk, Chromosome numbering)."""
+    import numpy as np
+    L = hostapi()
+    names = (C.c_char_p * len(refs))(*[n.encode() for n, _ in refs])
+    err = C.create_string_buffer(512)
+    n = L.ngsbits_bed_regions(os.fsencode(bed_path), names, len(refs), merge_mode, None, 0, err, 512)
+    if n < 0:
+        raise RuntimeError(err.value.decode())
+    out = np.zeros((max(n, 1), 3), dtype=np.int32)
+    if L.ngsbits_bed_regions(os.fsencode(bed_path), names, len(refs), merge_mode, out.ctypes.data, n, err, 512) != n:
+        raise RuntimeError(err.value.decode())
+    return [(int(a), int(b), int(c)) for a, b, c in out[:n]], [[] for _ in range(n)]
+
+
+def bed_regions_oracle(bed_path, refs, merge_mode):
+    """the same table from the oracle's BED code (oracle/bed.hpp): the checker of bed_regions"""
     text = O.bed_roundtrip(bed_path, merge_mode)
     tm = tid_map(refs)
     regs, annos = [], []

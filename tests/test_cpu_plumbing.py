@@ -164,3 +164,24 @@ def test_counter_allreduce_gloo_world2(tmp_path):
         out, err = p.communicate(timeout=240)
         assert p.returncode == 0, err[-2000:]
         assert "ok" in out
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_region_tables_of_the_host_layer_equal_the_oracle(mode):
+    """bench.py and the C-ABI tests take their region tables from the product's BedFile / Chromosome code (bin/libngsqc_hostapi.so); the oracle's BED loader is the checker:
+    every fixture BED x every operation the reference applies to a ROI (as loaded, merge, merge with names, sort + merge, chunk(100) of both)"""
+    import glob
+    import hostprep as H
+    refs = [("chr%s" % c, 1) for c in list(range(1, 23)) + ["X", "Y", "M"]] + [("GL000192.1", 1)]
+    beds = sorted(glob.glob(os.path.join(GI, "*.bed"))) + [os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")]
+    assert len(beds) >= 5
+    n = 0
+    for bed in beds:
+        try:
+            exp, _ = H.bed_regions_oracle(bed, refs, mode)
+        except Exception:
+            continue   # (a fixture the reference's loader refuses)
+        got, _ = H.bed_regions(bed, refs, mode)
+        assert got == exp, (bed, mode)
+        n += len(got)
+    assert n > 1000
