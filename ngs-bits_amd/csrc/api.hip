@@ -41,7 +41,7 @@ struct IoError : std::runtime_error { using std::runtime_error::runtime_error; }
 // process that goes on opening handles finds the memory free again a moment later (an allocation that fails waits for the thread and tries once more).
 struct Reaper
 {
-	std::mutex mu; std::condition_variable cv; std::deque<std::pair<void*, int>> q; std::thread th; bool stop = false, busy = false; int held = 0;
+	std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::thread th; bool stop = false, busy = false; int held = 0;
 	// (a hipFree of tens of GB holds the runtime's memory lock for its whole duration: while a handle is being closed the thread holds still, so that the closing
 	// thread's own small frees and stream / event teardown do not queue up behind it)
 	void hold() { std::lock_guard<std::mutex> g(mu); ++held; }
@@ -49,8 +49,12 @@ struct Reaper
 	void push(void* p)
 	{
 		int dev = 0; (void)hipGetDevice(&dev);
+		task([p, dev] { (void)hipSetDevice(dev); (void)hipFree(p); });
+	}
+	void task(std::function<void()> f)   // (also: unmapping a file of tens of GB - one page-table entry per 4 KB that a copy went through)
+	{
 		std::lock_guard<std::mutex> g(mu);
-		q.emplace_back(p, dev);
+		q.push_back(std::move(f));
 		if (!th.joinable()) th = std::thread([this] { run(); });
 		cv.notify_all();
 	}
@@ -61,8 +65,8 @@ struct Reaper
 		{
 			cv.wait(lk, [&] { return stop || (!q.empty() && held == 0); });
 			if (stop) return;   // (the process is going: what is still queued goes with it)
-			const auto e = q.front(); q.pop_front(); busy = true;
-			lk.unlock(); (void)hipSetDevice(e.second); (void)hipFree(e.first); lk.lock();
+			const std::function<void()> f = std::move(q.front()); q.pop_front(); busy = true;
+			lk.unlock(); f(); lk.lock();
 			busy = false; cv.notify_all();
 		}
 	}
@@ -70,7 +74,7 @@ struct Reaper
 	~Reaper() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 Reaper& reaper() { static Reaper r; return r; }
-constexpr size_t REAP_MIN_BYTES = (size_t)256 << 20;
+constexpr size_t REAP_MIN_BYTES = (size_t)64 << 10;   // (a hipFree waits for the device and costs 5 - 20 ms whatever its size: a handle has about forty buffers)
 
 template <typename T> struct DevBuf
 {
@@ -200,7 +204,7 @@ struct ngsqc_handle
 		// used it is done (p2_enq: chunks whose phase 2 is enqueued - their ev_chunk events are valid to wait for) ----
 		struct SPiece { size_t src, dst, bytes; int64_t chunk; };
 		std::vector<SPiece> sp; std::vector<size_t> chunk_first;   // pieces of the pass; first piece of every chunk (size nch + 1)
-		std::atomic<int64_t> p2_enq{0}; bool pass_running = false; const uint8_t* src_base = nullptr;
+		std::atomic<int64_t> p2_enq{0}; bool pass_running = false, pass_fresh = false; const uint8_t* src_base = nullptr;   // pass_fresh: started ahead of its job (by the layout thread), nothing consumed yet
 	};
 	Upload* up = nullptr;
 	bool stream_img = false; int comp_slots = 0; size_t comp_slot_bytes = 0;   // streamed image: ring geometry (plan_layout)
@@ -519,7 +523,7 @@ void upload_join(ngsqc_handle* h)
 	u->th.clear();
 	for (hipEvent_t e : u->ev) if (e) (void)hipEventDestroy(e);
 	u->ev.clear();
-	if (u->map) { munmap(u->map, u->map_n); u->map = nullptr; }
+	if (u->map) { void* m = u->map; const size_t n = u->map_n; const int fd = u->fd; reaper().task([m, n, fd] { munmap(m, n); if (fd >= 0) ::close(fd); }); u->map = nullptr; u->fd = -1; }
 	if (u->fd >= 0) { ::close(u->fd); u->fd = -1; }
 }
 void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
@@ -773,7 +777,7 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 // ---- layout of the tile stream: K1 chunks, tiles (whole chunks), token ring, static device tables -------------------------
 // NGSQC_TILE_MEMBERS=k (tests): chunks and tiles of k members. NGSQC_TILE_CHUNKS: chunks per tile (default 2).
 // NGSQC_K1_CHUNK_DIV: chunk = one decoder round / div. NGSQC_CARRY_MAX: bytes reserved in front of a tile for a straddling record.
-void plan_layout_now(ngsqc_handle* h)
+void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 {
 	if (h->planned) return;
 	const double pl0 = wall_ms();
@@ -907,6 +911,7 @@ void plan_layout_now(ngsqc_handle* h)
 	h->p_small.ensure(64);
 	HIPCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
 	h->tm.n_tiles = nt;
+	if (h->stream_img && early_pass) { stream_pass_begin(h); h->up->pass_fresh = true; }   // (ngsqc_open's layout thread: the copy starts now)
 	if (getenv("NGSQC_DEBUG")) fprintf(stderr, "[ngsqc] layout: %d tiles, %lld chunks, token pool %.1f GB, tile buffers %.1f GB, %.1f ms\n", nt, (long long)h->nch, (double)n_slots * (double)h->slot_pages * K1_PAGE_WORDS * 4e-9, (double)std::min(nt, h->nbuf) * (double)(h->pfx + h->max_tile_bytes) * 1e-9, wall_ms() - pl0);
 }
 
@@ -1219,7 +1224,12 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	HIPCHK(hipMemsetAsync(h->d_work.p, 0, (size_t)h->nch * sizeof(unsigned long long), h->stream));
 	HIPCHK(hipMemsetAsync(h->d_pool_ctr.p, 0, (size_t)h->nch * sizeof(uint32_t), h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	if (h->stream_img) stream_pass_begin(h);
+	if (h->stream_img)
+	{
+		// (the layout thread of ngsqc_open starts the first pass as soon as the ring exists: its first slots fill while the caller still sets up its job)
+		if (!(h->up->pass_running && h->up->pass_fresh)) stream_pass_begin(h);
+		h->up->pass_fresh = false;
+	}
 	try
 	{
 		// K1 is queued nbuf - 1 tiles ahead of the tile the host works on (tile t + nbuf - 1 reuses the buffer of tile t - 1, whose consumers were
@@ -1780,7 +1790,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		const char* ep = getenv("NGSQC_ASYNC_PLAN");
 		if (h->up && (!ep || atoi(ep) != 0))
 			h->plan_thread = std::thread([h] {
-				try { HIPCHK(hipSetDevice(h->device)); dbg_stamp("layout thread: start"); plan_layout_now(h); dbg_stamp("layout thread: done"); }
+				try { HIPCHK(hipSetDevice(h->device)); dbg_stamp("layout thread: start"); plan_layout_now(h, true); dbg_stamp("layout thread: done"); }
 				catch (std::exception& e) { h->plan_err = e.what(); h->planned = false; }
 			});
 	}
