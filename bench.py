@@ -218,7 +218,9 @@ def main():
         box = [None]
         if rank == 0:
             avail = host_memory_available()
-            box[0] = bool(avail and avail > 1.3 * world * reads * BYTES_PER_READ_COMPRESSED and os.environ.get("NGSQC_BENCH_SHARED_IMAGE") is None)
+            # (N images are N times the generator's work: only when every rank gets at least 16 cores of its own - on a 16-CPU quota eight 30x images would take 40 minutes)
+            cores_ok = G.effective_cpus() >= 16 * world or reads <= 50_000_000
+            box[0] = bool(avail and avail > 1.3 * world * reads * BYTES_PER_READ_COMPRESSED and cores_ok and os.environ.get("NGSQC_BENCH_SHARED_IMAGE") is None)
         dist.broadcast_object_list(box, src=0)
         per_rank_seed = bool(box[0])
     if world > 1 and not per_rank_seed:
@@ -566,7 +568,10 @@ def main():
     # ---- the other way to use N GPUs, in the same line: ONE BAM sharded over the ranks by BGZF member range (configs[1] at N GPUs; `value` above is
     # configs[3], one BAM per GPU). Fused shard job per rank, all-gather of the summaries, SUM all-reduce of counters / site counts / difference array. ----
     strong = None
-    if tool == "mappingqc" and not args.ont and not args.single_bam and image is not None and os.environ.get("NGSQC_BENCH_NO_STRONG") is None:
+    if per_rank_seed and rank == 0:
+        strong = {"skipped": "every rank holds a different BAM in this run (one BAM per GPU, seed + rank): the one-BAM-over-N-GPUs leg needs the same image on every rank - "
+                             "run `bench.py --gpus N --single-bam`, or set NGSQC_BENCH_SHARED_IMAGE=1"}
+    if tool == "mappingqc" and not args.ont and not args.single_bam and image is not None and not per_rank_seed and os.environ.get("NGSQC_BENCH_NO_STRONG") is None:
         try:
             hs = ngsqc.Handle(data=image, device=local_rank, shard=(rank, world))
             k2 = max(1, min(args.steps, 5))

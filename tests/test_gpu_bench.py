@@ -13,8 +13,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*args, timeout=600):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout)
+def _bench(*args, timeout=600, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -37,4 +37,15 @@ def test_bench_line_on_a_small_shard():
 def test_bench_spawns_two_ranks_and_reduces_their_counters():
     d = _bench("--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo", "--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["reads_per_gpu_per_step"] == 2000000 and "private copy per rank" in d["data"]
+    assert d["config"]["reads_per_gpu_per_step"] == 2000000
+    # one BAM per GPU with its own seed (the host has room for two 0.2 GB images); the reduce is checked against a second channel on every rank
+    assert "seed + rank" in d["data"] and d["collective"]["one_bam_per_gpu_with_its_own_seed"] is True and d["collective"]["distinct_inputs"] == 2
+    assert d["collective"]["allreduce_matches_gathered_sum_per_rank"] == [True, True]
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_shared_image():
+    """the fallback when the host cannot hold one image per rank: rank 0 generates, the others map it from /dev/shm; identical inputs, the same reduce"""
+    d = _bench("--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo", "--reads", "2000000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", env={"NGSQC_BENCH_SHARED_IMAGE": "1"})
+    assert d["n_gpus"] == 2 and "private copy per rank" in d["data"] and d["collective"]["distinct_inputs"] == 1
+    assert d["collective"]["allreduce_matches_gathered_sum_per_rank"] == [True, True]
