@@ -103,6 +103,9 @@ struct ScanParams
 	int64_t* long_list; int64_t long_cap;
 	// the scan fused into K2's chain walk (launch_walk_scan): records are named (entry << 20 | k) until the counts are scanned (entry_base != null: the
 	// long list holds such names); sgn = -1 takes a tile's contributions back (a tile that turned out not to be laid out like an htslib file)
+	// the site pileup of the job riding the same walk: records whose span holds a known site leave their offset in list (list == nullptr: no pileup rides)
+	struct Pile { const int32_t* site_pos = nullptr; const int32_t* tid_first = nullptr; const int32_t* tid_last = nullptr; const int32_t* bucket = nullptr; const int64_t* tid_bucket0 = nullptr;
+	              int64_t* list = nullptr; unsigned long long* count = nullptr; int64_t cap = 0; int32_t min_mapq = 0, include_npp = 0; } pile;
 	const int64_t* entry_base = nullptr; int32_t sgn = 1; int32_t tile_slots = 0; int64_t scan_limit = INT64_MAX;   // scan_limit: (a shard) records that start at or behind this tile-local offset are walked, not scanned
 };
 

@@ -320,7 +320,7 @@ __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 
 // CIGAR sums of a short record + classify; false: the record goes to the wave-per-record kernel (long CIGAR, possible CG:B,I tag)
 template <int MODE>
-__device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist)
+__device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist, long long* ref_len_out = nullptr)
 {
 	bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
 	if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
@@ -337,8 +337,34 @@ __device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, lon
 		else if (op == 4 || op == 5) clip += len;
 		if (op == 3) spliced = true;
 	}
+	if (ref_len_out) *ref_len_out = ref_len;
 	classify<MODE>(p, r, ord, ref_len, clip, spliced && !(r.flag & 0x4u), a, lds_hist);
 	return true;
+}
+
+// The site pileup of a job riding the same walk (round 4): a record that passes the pileup's read filters (BamReader.cpp:830-836) and whose reference span holds
+// at least one known site (or whose span is not known here: a deferred long-CIGAR record) leaves its tile-local offset in a list - 0.15 % of the records of a 30x
+// WGS for the 29 k contamination sites - and pileup_kernel runs over that list instead of reading every record of the tile a second time.
+__device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecView& r, int64_t o, bool span_known, long long ref_len)
+{
+	const uint32_t flag = r.flag;
+	if (flag & (0x100u | 0x800u | 0x400u | 0x4u)) return;
+	if (!(flag & 0x2u) && !p.pile.include_npp) return;
+	if ((int)r.mapq < p.pile.min_mapq || r.tid < 0 || r.tid >= p.n_ref) return;
+	const int first = p.pile.tid_first[r.tid], last = p.pile.tid_last[r.tid];
+	if (first >= last) return;
+	if (span_known)
+	{
+		if (ref_len == 0) ref_len = 1;
+		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
+		const int64_t b0 = p.pile.tid_bucket0[r.tid], nbk = p.pile.tid_bucket0[r.tid + 1] - b0;
+		int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
+		int i = p.pile.bucket[b0 + bi];
+		while (i < last && p.pile.site_pos[i] < start1) ++i;
+		if (i >= last || p.pile.site_pos[i] > end1) return;
+	}
+	const unsigned long long k = atomicAdd(p.pile.count, 1ull);
+	if ((long long)k < p.pile.cap) p.pile.list[k] = o;
 }
 
 template <int MODE>
@@ -495,11 +521,14 @@ __global__ __launch_bounds__(64) void walk_scan_kernel(const ScanParams p, const
 				if (o < p.scan_limit)
 				{
 					const long long name = (long long)((b << 20) | (int64_t)n);
-					if (!scan_record<MODE>(p, r, name, a, lds_hist) && p.sgn > 0)
+					long long ref_len = 0;
+					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len);
+					if (!scanned && p.sgn > 0)
 					{
 						unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
 						if ((long long)k < p.long_cap) p.long_list[k] = name;
 					}
+					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len);
 				}
 				++n; o = o_next; bs = bs_next;
 			}

@@ -118,3 +118,35 @@ def test_contamination_value_of_the_tool_matches_the_oracle(tmp_path):
     # -no_cont leaves the value out
     p = subprocess.run([os.path.join(ROOT, "ngs-bits_amd", "bin", "MappingQC"), "-in", path, "-wgs", "-build", "hg38", "-no_ref", "-no_cont", "-out", out], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "SNV allele frequency deviation" not in open(out).read()
+
+
+@pytest.mark.parametrize("kind", ["short", "short_tiles", "ont", "unaligned"])
+def test_pileup_over_the_riding_scans_candidates_equals_the_full_pass(tmp_path, monkeypatch, kind):
+    """Round 4: in a fused job the scan that rides K2's chain walk names the records whose reference span holds a known site (deferred long-CIGAR records: all that pass
+    the read filters), and the site pileup reads only those. Same site counts as the pass over every record (NGSQC_NO_FUSED_PILEUP=1), as the stand-alone pileup and as
+    the oracle - short reads (one tile and tiny tiles), ONT-like reads with CG-tag CIGARs (every record deferred), unaligned members (the riding scan is taken back)."""
+    path = str(tmp_path / "p.bam")
+    gen = {"short": dict(n_reads=150_000, seed=51), "short_tiles": dict(n_reads=150_000, seed=52), "ont": dict(n_reads=1200, seed=53, mode=1, depth=40.0),
+           "unaligned": dict(n_reads=60_000, seed=54, aligned=False)}[kind]
+    G.write(path, start_pos=15_900_000, **gen)
+    if kind == "short_tiles":
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", "40")
+    ob = O.Bam(path)
+    h = ngsqc.Handle(path=path)
+    regs, _ = H.bed_regions(os.path.join(RESOURCES, "hg38_440_omim_genes.bed"), h.refs, 3); tx, ty = H.xy_tids(h.refs)
+    t1 = _tid(h, "chr1")
+    lo = 15_900_000 + 2_000; span = 600_000 if kind != "ont" else 1_500_000
+    rng = np.random.default_rng(7)
+    sites = sorted({(t1, int(p)) for p in rng.integers(lo, lo + span, 400)})
+    mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs))
+    a = h.run_job(mapping=mp, sites=sites, site_params=(1, 13, kind == "ont"))
+    h.drop_decoded()
+    monkeypatch.setenv("NGSQC_NO_FUSED_PILEUP", "1")
+    b = h.run_job(mapping=mp, sites=sites, site_params=(1, 13, kind == "ont"))
+    monkeypatch.delenv("NGSQC_NO_FUSED_PILEUP")
+    c = h.site_pileup(sites, min_mapq=1, min_baseq=13, include_not_properly_paired=(kind == "ont"))
+    h.close()
+    assert np.array_equal(a["site_counts"], b["site_counts"]) and np.array_equal(a["site_counts"], c) and np.array_equal(a["counters"], b["counters"])
+    assert int(np.asarray(a["site_counts"])[:, :6].sum()) > 1000
+    exp = O.site_pileup(ob, sites, 1, 13, kind == "ont")   # int64[n, 6]: A, C, G, T, N, deletion
+    assert np.array_equal(np.asarray(a["site_counts"])[:len(sites), :6], exp)
