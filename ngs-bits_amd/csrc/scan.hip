@@ -21,7 +21,17 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __built
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
 // per-lane partial sums (A_* in common.h), reduced per wave at the end of the kernel: one atomic per wave and counter
-struct Acc { long long v[A_COUNT]; int max_len; unsigned long long best_key; unsigned long long first_paired; };
+struct Acc
+{
+	long long v[A_COUNT]; int max_len; unsigned long long best_key; unsigned long long first_paired;
+	// A thread meets its records in ascending position (a member's record chain; a strided range of a sorted file), so the answer of the last region search holds for
+	// the next records too: lower_region(start1) == rc_idx for every start1 in (rc_lo, rc_hi] on reference rc_tid. Likewise the next known site of the pileup
+	// candidates. Round 4: the walk spends its time in the address unit (every lane its own line, ~15 load instructions per record) - these two caches take the
+	// region-table and site-table loads out of the common record.
+	int rc_tid = -2, rc_lo = 0, rc_hi = 0, rc_idx = 0, rc_last = 0, rc_start = 0;
+	int pc_tid = -2, pc_lo = 0, pc_next = 0;
+	int ns_tid = -2, ns_val = 0;   // tid_nonspecial of the last reference
+};
 
 struct RecView
 {
@@ -188,11 +198,19 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 	// indexed ROI pass of mapping_wgs (Statistics.cpp:1154-1182), fused: per (read, overlapped region) pair
 	if (MODE == NGSQC_MODE_WGS && p.n_regions && !secondary && !supp && !unmapped && tid_ok)
 	{
-		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
-		if (first < last)
+		if (a.rc_tid != r.tid || start1 <= a.rc_lo || start1 > a.rc_hi)
 		{
-			int i0 = lower_region(p.reg_end, first, last, start1);
-			for (int i = i0; i < last && p.reg_start[i] <= end1; ++i)
+			const int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
+			const int i0 = first < last ? lower_region(p.reg_end, first, last, start1) : last;
+			a.rc_tid = r.tid; a.rc_idx = i0; a.rc_last = last;
+			a.rc_lo = i0 > first ? p.reg_end[i0 - 1] : INT32_MIN;   // (start1 > reg_end[i0 - 1]: the search would still pass i0 - 1)
+			a.rc_hi = i0 < last ? p.reg_end[i0] : INT32_MAX;        // (start1 <= reg_end[i0]: it would still stop at i0)
+			a.rc_start = i0 < last ? p.reg_start[i0] : INT32_MAX;
+		}
+		const int last = a.rc_last;
+		if (a.rc_start <= end1)   // (the first region that ends at or behind the read's start begins inside the read's span: an overlap)
+		{
+			for (int i = a.rc_idx; i < last && p.reg_start[i] <= end1; ++i)
 			{
 				gc_hit(p, r.tid, start1, end1);
 				if (!dup && (int)r.mapq >= p.min_mapq)
@@ -266,7 +284,8 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		}
 		else
 		{
-			if (tid_ok && p.tid_nonspecial[r.tid])
+			if (tid_ok && a.ns_tid != r.tid) { a.ns_tid = r.tid; a.ns_val = p.tid_nonspecial[r.tid]; }
+			if (tid_ok && a.ns_val)
 			{
 				a.v[A_ONTARGET]++;
 				if (!dup && (int)r.mapq >= p.min_mapq) a.v[A_USABLE] += length; // "no overlap" share is resolved with first_paired_idx afterwards
@@ -345,24 +364,30 @@ __device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, lon
 // The site pileup of a job riding the same walk (round 4): a record that passes the pileup's read filters (BamReader.cpp:830-836) and whose reference span holds
 // at least one known site (or whose span is not known here: a deferred long-CIGAR record) leaves its tile-local offset in a list - 0.15 % of the records of a 30x
 // WGS for the 29 k contamination sites - and pileup_kernel runs over that list instead of reading every record of the tile a second time.
-__device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecView& r, int64_t o, bool span_known, long long ref_len)
+__device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecView& r, int64_t o, bool span_known, long long ref_len, Acc& a)
 {
 	const uint32_t flag = r.flag;
 	if (flag & (0x100u | 0x800u | 0x400u | 0x4u)) return;
 	if (!(flag & 0x2u) && !p.pile.include_npp) return;
 	if ((int)r.mapq < p.pile.min_mapq || r.tid < 0 || r.tid >= p.n_ref) return;
-	const int first = p.pile.tid_first[r.tid], last = p.pile.tid_last[r.tid];
-	if (first >= last) return;
-	if (span_known)
+	if (ref_len == 0) ref_len = 1;
+	const int start1 = r.pos + 1, end1 = span_known ? (int)(r.pos + ref_len) : INT32_MAX;   // (a deferred record: its span is not known here - a candidate if any site lies behind its start)
+	if (a.pc_tid != r.tid || start1 <= a.pc_lo || start1 > a.pc_next)
 	{
-		if (ref_len == 0) ref_len = 1;
-		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
-		const int64_t b0 = p.pile.tid_bucket0[r.tid], nbk = p.pile.tid_bucket0[r.tid + 1] - b0;
-		int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
-		int i = p.pile.bucket[b0 + bi];
-		while (i < last && p.pile.site_pos[i] < start1) ++i;
-		if (i >= last || p.pile.site_pos[i] > end1) return;
+		// the first site at or behind start1 (and the one in front of it): they answer every record that starts between them; a reference without sites: never
+		const int first = p.pile.tid_first[r.tid], last = p.pile.tid_last[r.tid];
+		a.pc_tid = r.tid; a.pc_lo = INT32_MIN; a.pc_next = INT32_MAX;
+		if (first < last)
+		{
+			const int64_t b0 = p.pile.tid_bucket0[r.tid], nbk = p.pile.tid_bucket0[r.tid + 1] - b0;
+			int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
+			int i = p.pile.bucket[b0 + bi];
+			while (i < last && p.pile.site_pos[i] < start1) ++i;
+			if (i < last) a.pc_next = p.pile.site_pos[i];
+			if (i > first) a.pc_lo = p.pile.site_pos[i - 1];
+		}
 	}
+	if (a.pc_next == INT32_MAX || a.pc_next > end1) return;
 	const unsigned long long k = atomicAdd(p.pile.count, 1ull);
 	if ((long long)k < p.pile.cap) p.pile.list[k] = o;
 }
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(64) void walk_scan_kernel(const ScanParams p, const
 						unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
 						if ((long long)k < p.long_cap) p.long_list[k] = name;
 					}
-					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len);
+					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a);
 				}
 				++n; o = o_next; bs = bs_next;
 			}
