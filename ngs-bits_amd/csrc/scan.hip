@@ -30,7 +30,6 @@ struct Acc
 	// region-table and site-table loads out of the common record.
 	int rc_tid = -2, rc_lo = 0, rc_hi = 0, rc_idx = 0, rc_last = 0, rc_start = 0;
 	int pc_tid = -2, pc_lo = 0, pc_next = 0;
-	int ns_tid = -2, ns_val = 0;   // tid_nonspecial of the last reference
 };
 
 struct RecView
@@ -284,8 +283,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		}
 		else
 		{
-			if (tid_ok && a.ns_tid != r.tid) { a.ns_tid = r.tid; a.ns_val = p.tid_nonspecial[r.tid]; }
-			if (tid_ok && a.ns_val)
+			if (tid_ok && p.tid_nonspecial[r.tid])
 			{
 				a.v[A_ONTARGET]++;
 				if (!dup && (int)r.mapq >= p.min_mapq) a.v[A_USABLE] += length; // "no overlap" share is resolved with first_paired_idx afterwards
@@ -514,7 +512,7 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 // results (first longest read, first paired read) are kept per tile in that form (A_TILE_KEY / A_TILE_PAIRED), the host turns them into ordinals.
 // Only for tiles laid out like an htslib file (a record starts every member): the launch happens before that is known, sgn = -1 takes it back.
 template <int MODE>
-__global__ __launch_bounds__(64) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix,
+__global__ __launch_bounds__(64, 3) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix,
                                                         const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
