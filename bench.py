@@ -250,7 +250,7 @@ def main():
                     image = np.memmap(share, dtype=np.uint8, mode="r")
                 except OSError:
                     image = None
-    if image is None and world > 1 and not args.reads and reads > 96_000_000:
+    if image is None and world > 1 and not per_rank_seed and not args.reads and reads > 96_000_000:
         # the shared image could not be written (no room in /dev/shm or TMPDIR): every rank must generate its own BAM with its share of the host's
         # cores - the full file would take world x 5 minutes, so the ranks fall back to a 96 M-read shard each and say so
         reads = 96_000_000

@@ -184,6 +184,19 @@ def bai_range(bam_path, regions, n_ref):
     return int(b.value), int(e.value), bool(f.value)
 
 
+def bai_ranges(bam_path, regions, n_ref):
+    """Per-region virtual-offset ranges from <bam>.bai (host only, one load of the index): [(beg_voff, end_voff)], end_voff == 0 when no record can overlap."""
+    L = lib()
+    L.ngsqc_bai_ranges.restype = C.c_int
+    L.ngsqc_bai_ranges.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    arr = _regions_array(regions); n = len(regions)
+    b = (C.c_uint64 * max(n, 1))(); e = (C.c_uint64 * max(n, 1))()
+    rc = L.ngsqc_bai_ranges(os.fsencode(bam_path), C.cast(arr, C.c_void_p), n, int(n_ref), b, e)
+    if rc != 0:
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+    return [(int(b[i]), int(e[i])) for i in range(n)]
+
+
 def bgzf_scan(data, threads=1):
     """BGZF member table of a BAM image (host only): structured array (file_offset, payload_offset, inflated_offset, payload_bytes, inflated_bytes, crc32)
     and the inflated size. threads > 1: the walk in pieces (falls back to the sequential walk when the pieces do not join)."""

@@ -72,6 +72,34 @@ def test_bai_range_holds_every_overlapping_record(name):
     assert not found or beg <= end
 
 
+@pytest.mark.parametrize("name", ["close_exons.bam", "sry.bam", "MappingQC_in2.bam", "Statistics_longread.bam"])
+def test_bai_ranges_per_region(name):
+    """ngsqc_bai_ranges: every region's own range holds its overlapping records and lies inside the one range over all regions; a region nothing can overlap has end 0."""
+    path = os.path.join(GI, name)
+    recs, n_ref = records_with_voff(path)
+    rng = random.Random(11)
+    mapped = [r for r in recs if r[0] >= 0]
+    regions = []
+    for _ in range(40):
+        t, p0, e0, _, _ = rng.choice(mapped)
+        s1 = max(1, p0 + 1 - rng.randrange(0, 3000)); regions.append((t, s1, max(p0 + 1, s1 + rng.randrange(1, 9000))))
+    tmax = max(r[0] for r in mapped)
+    regions.append((tmax, 240_000_000, 240_000_100))
+    each = ngsqc.bai_ranges(path, regions, n_ref)
+    ubeg, uend, found = ngsqc.bai_range(path, regions, n_ref)
+    assert found and len(each) == len(regions)
+    for g, (beg, end) in zip(regions, each):
+        hits = [r for r in recs if r[0] == g[0] and r[1] < g[2] and r[2] > g[1] - 1]
+        if end == 0:
+            assert not hits
+            continue
+        assert ubeg <= beg and end <= uend
+        assert all(beg <= r[3] and r[4] <= end for r in hits), (g, beg, end)
+        assert (beg, end) == ngsqc.bai_range(path, [g], n_ref)[:2]
+    assert min(b for b, e in each if e) == ubeg and max(e for b, e in each) == uend
+    assert ngsqc.bai_ranges(path, [], n_ref) == []
+
+
 def test_missing_index_is_the_references_error(tmp_path):
     p = str(tmp_path / "x.bam"); open(p, "wb").write(open(os.path.join(GI, "sry.bam"), "rb").read())
     with pytest.raises(ngsqc.NgsqcError) as e:
