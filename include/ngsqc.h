@@ -238,12 +238,21 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
  * index, pseudo-bins and n_no_coor as htslib (pinned on the reference's fixture indices through oracle/bai_build.py); the order of the bins inside a
  * reference is ascending instead of htslib's hash order. NGSQC_E_FORMAT for a BAM that is not sorted by coordinate or reaches behind 2^29 (BAI limit). */
 int ngsqc_write_bai(ngsqc_handle* h, const char* bai_path);
+/* The CSI form of the same index (hts-specs CSIv1; `samtools index -c -m min_shift`, htslib sam_index_build3 with min_shift > 0): the binning scheme of BAI
+ * with min_shift as given (<= 0: 14; 8 .. 30) and depth = the smallest n with longest reference + 256 <= 2^(min_shift + 3 n), loff per bin (the linear
+ * index at the bin's first window) in place of the linear index, inside a BGZF container. csi_path NULL: <path of the handle>.csi. Every indexed entry
+ * point above takes <bam>.csi before <bam>.bai, as sam_index_load (BamReader.cpp:742) does. The reference holds no .csi fixture: pinned through
+ * oracle/csi_build.py, which at BAI's geometry must reproduce the htslib-written .bai fixtures' bins, chunks and (as loff) linear index. */
+int ngsqc_write_csi(ngsqc_handle* h, const char* csi_path, int32_t min_shift);
 /* The host half alone (several shards' runs merged by the caller; tests): runs = consecutive records of one (reference, bin) in file order, each with the
  * virtual offset of its first record (kind 0; kind 1 entries - "last record of a tile", pos clamped at 0 - only feed the sort check), lidx = first
  * virtual offset per 16 kb window (~0: none) for the windows [lidx_first[t], lidx_first[t + 1]) of reference t, counts = (mapped, unmapped) per reference
  * followed by the pair of the reads without reference. */
 typedef struct ngsqc_bai_run { uint64_t voff; int32_t tid; uint32_t bin; int32_t pos; uint32_t kind; } ngsqc_bai_run;
 int ngsqc_bai_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                       const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts);
+/* the same for a CSI index: bins of the runs and windows of lidx in the geometry (min_shift, depth) */
+int ngsqc_csi_assemble(const char* csi_path, int32_t min_shift, int32_t depth, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
                        const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts);
 
 typedef struct ngsqc_shard_summary {

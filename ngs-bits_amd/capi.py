@@ -168,7 +168,7 @@ EXPORTS = [
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
-    "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan",
+    "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan", "ngsqc_write_csi", "ngsqc_csi_assemble", "ngsqc_bai_ranges",
 ]
 
 
@@ -216,19 +216,26 @@ def bgzf_scan(data, threads=1):
     return out[:n.value], int(tot.value)
 
 
-def bai_assemble(bai_path, n_ref, first_record_voff, end_voff, runs, lidx, lidx_first, counts):
-    """Host half of Handle.write_bai (no device). runs: [(voff, tid, bin, pos, kind)] in file order; lidx: uint64 per 16 kb window (2**64 - 1: none);
-    lidx_first: n_ref + 1 window offsets; counts: (mapped, unmapped) per reference, then of the reads without reference."""
+def bai_assemble(bai_path, n_ref, first_record_voff, end_voff, runs, lidx, lidx_first, counts, csi_geom=None):
+    """Host half of Handle.write_bai / write_csi (no device). runs: [(voff, tid, bin, pos, kind)] in file order; lidx: uint64 per window (16 kb for BAI;
+    2**64 - 1: none); lidx_first: n_ref + 1 window offsets; counts: (mapped, unmapped) per reference, then of the reads without reference.
+    csi_geom = (min_shift, depth): a CSI index in that geometry instead of a BAI."""
     L = lib()
     L.ngsqc_bai_assemble.restype = C.c_int
     L.ngsqc_bai_assemble.argtypes = [C.c_char_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ngsqc_csi_assemble.restype = C.c_int
+    L.ngsqc_csi_assemble.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     ra = np.zeros(max(len(runs), 1), dtype=[("voff", "<u8"), ("tid", "<i4"), ("bin", "<u4"), ("pos", "<i4"), ("kind", "<u4")])
     for i, r in enumerate(runs):
         ra[i] = tuple(r)
     la = np.ascontiguousarray(lidx, dtype=np.uint64) if len(lidx) else np.zeros(1, np.uint64)
     fa = np.ascontiguousarray(lidx_first, dtype=np.int64); ca = np.ascontiguousarray(counts, dtype=np.int64).reshape(-1)
     assert fa.size == n_ref + 1 and ca.size == 2 * (n_ref + 1)
-    rc = L.ngsqc_bai_assemble(os.fsencode(bai_path), int(n_ref), int(first_record_voff), int(end_voff), ra.ctypes.data, len(runs), la.ctypes.data, fa.ctypes.data, ca.ctypes.data)
+    if csi_geom is not None:
+        rc = L.ngsqc_csi_assemble(os.fsencode(bai_path), int(csi_geom[0]), int(csi_geom[1]), int(n_ref), int(first_record_voff), int(end_voff), ra.ctypes.data, len(runs), la.ctypes.data,
+                                  fa.ctypes.data, ca.ctypes.data)
+    else:
+        rc = L.ngsqc_bai_assemble(os.fsencode(bai_path), int(n_ref), int(first_record_voff), int(end_voff), ra.ctypes.data, len(runs), la.ctypes.data, fa.ctypes.data, ca.ctypes.data)
     if rc != 0:
         raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
 
@@ -518,6 +525,11 @@ class Handle:
         """Writes the BAI index of the BAM (what `samtools index` writes; default <path>.bai). The handle must be on the whole file."""
         L = lib(); L.ngsqc_write_bai.restype = C.c_int; L.ngsqc_write_bai.argtypes = [C.c_void_p, C.c_char_p]
         self._chk(L.ngsqc_write_bai(self.h, os.fsencode(bai_path) if bai_path is not None else None))
+
+    def write_csi(self, csi_path=None, min_shift=14):
+        """Writes the CSI index of the BAM (what `samtools index -c -m min_shift` writes; default <path>.csi). The handle must be on the whole file."""
+        L = lib(); L.ngsqc_write_csi.restype = C.c_int; L.ngsqc_write_csi.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        self._chk(L.ngsqc_write_csi(self.h, os.fsencode(csi_path) if csi_path is not None else None, int(min_shift)))
 
     def upload_wait(self):
         """The compressed image is on the device (a path is copied in the background); timings()['h2d_ms'] is final behind this call."""

@@ -1611,18 +1611,34 @@ struct ReadsState
 	}
 };
 
-// ---- BAI index of the handle's BAM (bai.hip): one pass over the tiles, then the chunk rules on the host ----
-void write_bai(ngsqc_handle* h, const char* out_path)
+// ---- BAI / CSI index of the handle's BAM (bai.hip): one pass over the tiles, then the chunk rules on the host. csi: min_shift as given (<= 0: 14), depth from the
+// longest reference as sam_index_build3 chooses it (sam.c sam_index: the smallest depth with longest + 256 <= 2^(min_shift + 3 depth)) ----
+void write_bai(ngsqc_handle* h, const char* out_path, bool csi = false, int min_shift = 14)
 {
 	if (h->n_shards != 1 || h->shard_own_members >= 0 || h->member_off.size() != h->blocks.size()) throw ArgError("an index is written from a handle on the whole BAM (ngsqc_open / ngsqc_open_memory)");
-	const std::string path = out_path ? std::string(out_path) : h->path + ".bai";
-	if (path == ".bai") throw ArgError("no path for the index");
+	const char* ext = csi ? ".csi" : ".bai";
+	const std::string path = out_path ? std::string(out_path) : h->path + ext;
+	if (path == ext) throw ArgError("no path for the index");
 	const int32_t n_ref = (int32_t)h->ref_names.size();
-	// linear-index windows per reference: its length in 16 kb windows and some room (an alignment may reach behind the end of a circular contig)
+	int depth = 5;
+	if (csi)
+	{
+		if (min_shift <= 0) min_shift = 14;
+		if (min_shift < 8 || min_shift > 30) throw ArgError("min_shift of a CSI index: 8 .. 30");
+		int64_t max_len = 0;
+		for (int64_t l : h->ref_lens) max_len = std::max(max_len, l);
+		max_len += 256;
+		depth = 0;
+		for (int64_t s = 1ll << min_shift; max_len > s; s <<= 3) ++depth;
+	}
+	else min_shift = 14;
+	// windows per reference: its length in windows of 2^min_shift (BAI: 16 kb) and some room (an alignment may reach behind the end of a circular contig)
 	std::vector<int64_t> first((size_t)n_ref + 1, 0);
-	for (int32_t t = 0; t < n_ref; ++t) first[(size_t)t + 1] = first[(size_t)t] + std::min<int64_t>(32768, ((std::max<int64_t>(h->ref_lens[(size_t)t], 0) + 16383) >> 14) + 8);
+	const int64_t wmask = (1ll << min_shift) - 1, wmax = 1ll << (3 * depth);
+	for (int32_t t = 0; t < n_ref; ++t) first[(size_t)t + 1] = first[(size_t)t] + std::min<int64_t>(wmax, ((std::max<int64_t>(h->ref_lens[(size_t)t], 0) + wmask) >> min_shift) + 8);
 	const int64_t n_win = first[(size_t)n_ref];
-	DevBuf<int64_t> d_first; DevBuf<unsigned long long> d_lidx, d_counts, d_small; DevBuf<uint64_t> d_key; DevBuf<uint32_t> d_wnd; DevBuf<BaiRun> d_runs;
+	if (n_win > (1ll << 28)) throw ArgError("too many index windows: use a larger min_shift");
+	DevBuf<int64_t> d_first; DevBuf<unsigned long long> d_lidx, d_counts, d_small; DevBuf<uint64_t> d_key; DevBuf<uint64_t> d_wnd; DevBuf<BaiRun> d_runs;
 	d_first.upload(first, h->stream); d_lidx.ensure((size_t)std::max<int64_t>(n_win, 1)); d_counts.ensure(((size_t)n_ref + 1) * 2); d_small.ensure(2);
 	HIPCHK(hipMemsetAsync(d_lidx.p, 0xff, (size_t)std::max<int64_t>(n_win, 1) * 8, h->stream));
 	HIPCHK(hipMemsetAsync(d_counts.p, 0, ((size_t)n_ref + 1) * 16, h->stream));
@@ -1636,14 +1652,15 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 		if (c.n_rec <= 0) return true;
 		d_key.ensure_slack((size_t)c.n_rec); d_wnd.ensure_slack((size_t)c.n_rec); d_runs.ensure_slack((size_t)c.n_rec + 1);
 		HIPCHK(hipMemsetAsync(d_small.p, 0, 8, h->stream));
-		launch_bai_keys(c.infl, c.recoff, c.n_rec, n_ref, d_key.p, d_wnd.p, d_counts.p, d_small.p + 1, h->stream);
+		launch_bai_keys(c.infl, c.recoff, c.n_rec, n_ref, min_shift, depth, d_key.p, d_wnd.p, d_counts.p, d_small.p + 1, h->stream);
 		launch_bai_runs(c.infl, c.recoff, c.n_rec, h->tile_u_lo - h->tile_prefix, d_key.p, d_wnd.p, d_first.p, d_lidx.p, d_runs.p, d_small.p, d_small.p + 1, h->stream);
 		unsigned long long sm[2] = {0, 0};
 		HIPCHK(hipMemcpyAsync(sm, d_small.p, 16, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
 		if (sm[1] & BAI_F_BAD_TID) throw FormatError("a record names a reference that the BAM header does not have");
 		if (sm[1] & BAI_F_UNSORTED) throw FormatError("unsorted positions: the BAM is not sorted by coordinate (a BAI index needs that)");
-		if (sm[1] & BAI_F_TOO_FAR) throw FormatError("an alignment ends behind position 2^29: it cannot be stored in a BAI index");
-		if (sm[1] & BAI_F_WINDOWS) throw FormatError("an alignment reaches more than 128 kb behind the end of its reference");
+		if (sm[1] & BAI_F_TOO_FAR) throw FormatError(csi ? "an alignment ends behind position 2^" + std::to_string(min_shift + 3 * depth) + ": it cannot be stored in a CSI index with these parameters"
+		                                                 : std::string("an alignment ends behind position 2^29: it cannot be stored in a BAI index"));
+		if (sm[1] & BAI_F_WINDOWS) throw FormatError(csi ? "an alignment reaches more than 8 index windows behind the end of its reference" : "an alignment reaches more than 128 kb behind the end of its reference");
 		if (dbg) fprintf(stderr, "[bai]   %llu runs, flags %llu\n", sm[0], sm[1]);
 		part.resize((size_t)sm[0]);
 		HIPCHK(hipMemcpyAsync(part.data(), d_runs.p, (size_t)sm[0] * sizeof(BaiRun), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
@@ -1673,7 +1690,7 @@ void write_bai(ngsqc_handle* h, const char* out_path)
 	for (size_t i = 0; i < lidx.size(); ++i) lidx[i] = lidx_u[i] == ~0ull ? ~0ull : tell(lidx_u[i]);
 	std::vector<int64_t> counts(cnt.begin(), cnt.end());
 	if (dbg) fprintf(stderr, "[bai] assemble\n");
-	const std::string e = bai_assemble(path, n_ref, tell((uint64_t)h->first_rec), tell((uint64_t)h->total), rv, lidx, first, counts);
+	const std::string e = bai_assemble(path, n_ref, tell((uint64_t)h->first_rec), tell((uint64_t)h->total), rv, lidx, first, counts, csi, min_shift, depth);
 	if (dbg) fprintf(stderr, "[bai] assembled: %s\n", e.c_str());
 	if (!e.empty()) { if (e.compare(0, 12, "cannot write") == 0) throw IoError(e); throw FormatError(e); }
 }
@@ -2089,8 +2106,22 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int ngsqc_write_bai(ngsqc_handle* h, const char* bai_path) { return guarded(h, [&] { write_bai(h, bai_path); }); }
+int ngsqc_write_csi(ngsqc_handle* h, const char* csi_path, int32_t min_shift) { return guarded(h, [&] { write_bai(h, csi_path, true, min_shift); }); }
+static int index_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                          const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts, bool csi, int min_shift, int depth);
 int ngsqc_bai_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
                        const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts)
+{
+	return index_assemble(bai_path, n_ref, first_record_voff, end_voff, runs, n_runs, lidx, lidx_first, counts, false, 14, 5);
+}
+int ngsqc_csi_assemble(const char* csi_path, int32_t min_shift, int32_t depth, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                       const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts)
+{
+	if (min_shift < 0 || min_shift > 31 || depth < 0 || depth > 10) return NGSQC_E_ARG;
+	return index_assemble(csi_path, n_ref, first_record_voff, end_voff, runs, n_runs, lidx, lidx_first, counts, true, min_shift, depth);
+}
+static int index_assemble(const char* bai_path, int32_t n_ref, uint64_t first_record_voff, uint64_t end_voff, const ngsqc_bai_run* runs, int64_t n_runs,
+                          const uint64_t* lidx, const int64_t* lidx_first, const int64_t* counts, bool csi, int min_shift, int depth)
 {
 	if (!bai_path || n_ref < 0 || n_runs < 0 || (!runs && n_runs > 0) || !lidx_first || !counts || (!lidx && lidx_first[n_ref] > 0)) return NGSQC_E_ARG;
 	try
@@ -2100,7 +2131,7 @@ int ngsqc_bai_assemble(const char* bai_path, int32_t n_ref, uint64_t first_recor
 		if (n_runs) memcpy(rv.data(), runs, (size_t)n_runs * sizeof(BaiRunV));
 		const std::vector<int64_t> first(lidx_first, lidx_first + n_ref + 1), cnt(counts, counts + 2 * ((size_t)n_ref + 1));
 		const std::vector<uint64_t> L(lidx, lidx + first[(size_t)n_ref]);
-		const std::string e = bai_assemble(bai_path, n_ref, first_record_voff, end_voff, rv, L, first, cnt);
+		const std::string e = bai_assemble(bai_path, n_ref, first_record_voff, end_voff, rv, L, first, cnt, csi, min_shift, depth);
 		if (e.empty()) return NGSQC_OK;
 		g_open_error = e;
 		return e.compare(0, 12, "cannot write") == 0 ? NGSQC_E_IO : NGSQC_E_FORMAT;

@@ -31,15 +31,15 @@ bool bai_ranges(const std::string& bam_path, const ngsqc_region* regions, int64_
 // chunk rules to the runs (bai_assemble).
 struct BaiRun { int64_t u; int32_t tid; uint32_t bin; int32_t pos; uint32_t kind; };   // u: inflated offset of the run's first record; kind 1: the LAST record of a tile (pos clamped at 0; for the order check across tiles)
 enum { BAI_F_UNSORTED = 1, BAI_F_BAD_TID = 2, BAI_F_TOO_FAR = 4, BAI_F_WINDOWS = 8 };
-void launch_bai_keys(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int32_t n_ref, uint64_t* d_key, uint32_t* d_wnd, unsigned long long* d_counts /* [(n_ref + 1)][2] */,
-                     unsigned long long* d_flags, hipStream_t s);
-void launch_bai_runs(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int64_t u_base, const uint64_t* d_key, const uint32_t* d_wnd, const int64_t* d_first /* [n_ref + 1] */,
+void launch_bai_keys(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int32_t n_ref, int min_shift, int depth, uint64_t* d_key, uint64_t* d_wnd /* first | last << 32 window */,
+                     unsigned long long* d_counts /* [(n_ref + 1)][2] */, unsigned long long* d_flags, hipStream_t s);
+void launch_bai_runs(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int64_t u_base, const uint64_t* d_key, const uint64_t* d_wnd, const int64_t* d_first /* [n_ref + 1] */,
                      unsigned long long* d_lidx, BaiRun* d_runs, unsigned long long* d_nruns, unsigned long long* d_flags, hipStream_t s);
 struct BaiRunV { uint64_t voff; int32_t tid; uint32_t bin; int32_t pos; uint32_t kind; };
 // runs in file order; lidx: virtual offsets (or ~0) for the windows [first[t], first[t + 1]) of reference t; counts: (mapped, unmapped) per reference, then the
 // reads without a reference. Returns an error text ("" = written).
 std::string bai_assemble(const std::string& out_path, int32_t n_ref, uint64_t offset0, uint64_t final_off, const std::vector<BaiRunV>& runs, const std::vector<uint64_t>& lidx,
-                         const std::vector<int64_t>& first, const std::vector<int64_t>& counts);
+                         const std::vector<int64_t>& first, const std::vector<int64_t>& counts, bool csi = false, int min_shift = 14, int depth = 5);
 
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 

@@ -24,8 +24,7 @@ void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* r
 	int n_shards = 1; if (allow_shards) if (const char* e = getenv("NGSQC_SHARDS")) n_shards = std::max(1, atoi(e));
 	int n_dev = 1; if (n_shards > 1) if (const char* e = getenv("NGSQC_DEVICES")) n_dev = std::max(1, atoi(e));
 	const char* es = getenv("NGSQC_INDEX_SELECT");
-	std::string base = bam_file_; size_t dot = base.rfind('.'); std::string noext = dot == std::string::npos ? base : base.substr(0, dot);
-	const bool by_index = regions && n_shards == 1 && (!es || atoi(es) != 0) && (fileExists(bam_file_ + ".bai") || fileExists(noext + ".bai"));
+	const bool by_index = regions && n_shards == 1 && (!es || atoi(es) != 0) && hasBamIndex(bam_file_);
 	for (int s = 0; s < n_shards; ++s)
 	{
 		ngsqc_handle* h = nullptr; int rc;
@@ -170,8 +169,7 @@ double BamReader::genomeSize(bool include_special) const { double s = 0; for (si
 void BamReader::requireIndex() const
 {
 	// the reference needs a .bai/.csi for every region query; the GPU path does not, but the error is part of the contract
-	std::string base = bam_file_; size_t dot = base.rfind('.'); std::string noext = dot == std::string::npos ? base : base.substr(0, dot);
-	if (fileExists(bam_file_ + ".bai") || fileExists(noext + ".bai") || fileExists(bam_file_ + ".csi")) return;
+	if (hasBamIndex(bam_file_)) return;
 	NB_THROW(FileAccessException, "Could not load index of BAM/CRAM file " + bam_file_);
 }
 void BamReader::check(int rc) const
@@ -1135,8 +1133,7 @@ static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file,
 {
 	const char* es = getenv("NGSQC_INDEX_SELECT");
 	if ((es && atoi(es) == 0) || bed_file.count() < 2 || bed_file.count() > 4096 || getenv("NGSQC_SHARDS")) return false;
-	const std::string noext = bam_file.size() > 4 && bam_file.compare(bam_file.size() - 4, 4, ".bam") == 0 ? bam_file.substr(0, bam_file.size() - 4) : bam_file;
-	if (!fileExists(bam_file + ".bai") && !fileExists(noext + ".bai")) return false;
+	if (!hasBamIndex(bam_file)) return false;
 	std::vector<ngsqc_region> lines; int n_ref = 0;
 	{
 		BamReader head(bam_file, ref_file, BamReader::Head{1});   // (chromosome numbering of this BAM: the header members only)

@@ -45,6 +45,12 @@ inline std::string number(double v, int prec) { char b[64]; snprintf(b, sizeof(b
 inline std::string fileName(const std::string& p) { size_t i = p.find_last_of('/'); return i == std::string::npos ? p : p.substr(i + 1); }   // QFileInfo::fileName
 inline std::string baseName(const std::string& p) { std::string f = fileName(p); size_t i = f.find('.'); return i == std::string::npos ? f : f.substr(0, i); } // QFileInfo::baseName
 inline bool fileExists(const std::string& p) { std::ifstream f(p); return (bool)f; }
+// an index next to a BAM under one of the names sam_index_load tries (htslib hts_idx_check_local: <bam>.csi, <stem>.csi, <bam>.bai, <stem>.bai)
+inline bool hasBamIndex(const std::string& bam)
+{
+	const size_t dot = bam.rfind('.'); const std::string stem = dot == std::string::npos ? bam : bam.substr(0, dot);
+	return fileExists(bam + ".csi") || fileExists(stem + ".csi") || fileExists(bam + ".bai") || fileExists(stem + ".bai");
+}
 inline std::string htmlEscaped(const std::string& s) // QString::toHtmlEscaped
 {
 	std::string o;

@@ -18,6 +18,7 @@ import struct
 import zlib
 
 MIN_SHIFT, N_LVLS = 14, 5
+BAI_GEOM = (MIN_SHIFT, N_LVLS)                   # (min_shift, n_lvls); a CSI index carries its own pair (oracle/csi_build.py)
 N_BINS = ((1 << (3 * N_LVLS + 3)) - 1) // 7      # 37449
 META_BIN = N_BINS + 1                            # 37450
 MAX_POS = 1 << (MIN_SHIFT + 3 * N_LVLS)             # 2^29
@@ -25,11 +26,23 @@ MIN_MARKER_DIST = 0x10000
 UNSET = (1 << 64) - 1
 
 
-def reg2bin(beg, end):
-    """hts_reg2bin for min_shift 14 / 5 levels (SAM spec 5.3); Python's >> is arithmetic like C's on the signed values htslib passes"""
+def n_bins(geom):
+    return ((1 << (3 * geom[1] + 3)) - 1) // 7
+
+
+def meta_bin(geom):
+    return n_bins(geom) + 1
+
+
+def max_pos(geom):
+    return 1 << (geom[0] + 3 * geom[1])
+
+
+def reg2bin(beg, end, geom=BAI_GEOM):
+    """hts_reg2bin (SAM spec 5.3; min_shift 14 / 5 levels for BAI); Python's >> is arithmetic like C's on the signed values htslib passes"""
     end -= 1
-    s, t = MIN_SHIFT, ((1 << (3 * N_LVLS)) - 1) // 7
-    l = N_LVLS
+    s, t = geom[0], ((1 << (3 * geom[1])) - 1) // 7
+    l = geom[1]
     while l > 0:
         if beg >> s == end >> s:
             return t + (beg >> s)
@@ -91,9 +104,10 @@ CURRENT = ("backward", "eof_block")
 VARIANTS = [CURRENT, ("forward", "eof_block"), ("forward", "file_end")]
 
 
-def build(n_ref, offset0, recs, final, fill="backward"):
+def build(n_ref, offset0, recs, final, fill="backward", geom=BAI_GEOM):
     """hts_idx_push for every record, then hts_idx_finish (hts.c)"""
     ix = Index(n_ref)
+    MIN_SHIFT = geom[0]; MAX_POS = max_pos(geom); META_BIN = meta_bin(geom)
     last_bin = save_bin = 0xffffffff
     last_off = save_off = off_beg = off_end = offset0
     n_mapped = n_unmapped = 0; last_coor = 0xffffffff
@@ -112,7 +126,7 @@ def build(n_ref, offset0, recs, final, fill="backward"):
             raise ValueError("unsorted positions")
         if end < beg: end = beg + 1
         if tid >= 0:
-            if beg > MAX_POS or end > MAX_POS: raise ValueError("region cannot be stored in a bai index (2^29 limit)")
+            if beg > MAX_POS or end > MAX_POS: raise ValueError("region cannot be stored in the index (2^%d limit)" % (geom[0] + 3 * geom[1]))
             if ix.bidx[tid] is None: ix.bidx[tid] = {}
             if beg < 0: beg = 0
             if end <= 0: end = 1
@@ -122,7 +136,7 @@ def build(n_ref, offset0, recs, final, fill="backward"):
                 if L[i] == UNSET: L[i] = last_off
         else:
             ix.n_no_coor += 1
-        b = reg2bin(beg, end)
+        b = reg2bin(beg, end, geom)
         if last_bin != b:
             if save_bin != 0xffffffff: insert_b(save_tid, save_bin, save_off, last_off)
             if last_bin == 0xffffffff and save_bin != 0xffffffff:
@@ -140,12 +154,21 @@ def build(n_ref, offset0, recs, final, fill="backward"):
         insert_b(save_tid, META_BIN, off_beg, final)
         insert_b(save_tid, META_BIN, n_mapped, n_unmapped)
     for t in range(n_ref):
-        update_loff(ix, t, fill); compress_binning(ix, t)
+        update_loff(ix, t, fill, geom); compress_binning(ix, t, geom)
     return ix
 
 
-def update_loff(ix, t, fill):
-    L = ix.lidx[t]
+def bin_bot(b, geom):
+    """hts_bin_bot: the first window (bottom-level slot) of a bin"""
+    l = 0; x = b
+    while x: l += 1; x = (x - 1) >> 3
+    return (b - bin_first(l)) << ((geom[1] - l) * 3)
+
+
+def update_loff(ix, t, fill, geom=BAI_GEOM):
+    """fills the windows without a read, then sets every bin's loff = the linear index at the bin's first window (0 for the pseudo-bin and for a bin
+    behind the last window) - before compress_binning, as hts_idx_finish does; a CSI file stores loff instead of the linear index"""
+    L = ix.lidx[t]; META_BIN = meta_bin(geom)
     if fill == "backward":
         # the last entry is always valid
         for l in range(len(L) - 2, -1, -1):
@@ -156,11 +179,18 @@ def update_loff(ix, t, fill):
         while l < len(L) and L[l] == UNSET: L[l] = off0; l += 1
         for l in range(1, len(L)):
             if L[l] == UNSET: L[l] = L[l - 1]
+    if ix.bidx[t] is not None:
+        if not hasattr(ix, "loff"): ix.loff = [None] * len(ix.bidx)
+        ix.loff[t] = {}
+        for b in ix.bidx[t]:
+            bot = bin_bot(b, geom) if b < n_bins(geom) else None
+            ix.loff[t][b] = L[bot] if bot is not None and bot < len(L) else 0
 
 
-def compress_binning(ix, t):
+def compress_binning(ix, t, geom=BAI_GEOM):
     B = ix.bidx[t]
     if B is None: return
+    N_LVLS = geom[1]; N_BINS = n_bins(geom)
     for l in range(N_LVLS, 0, -1):
         start = bin_first(l)
         for k in sorted(B.keys()):
@@ -207,10 +237,11 @@ def build_for_bam(path, variant=CURRENT):
     return as_parsed(build(n_ref, offset0, recs, final[variant[1]], variant[0]))
 
 
-def device_view(n_ref, offset0, recs, cuts=()):
+def device_view(n_ref, offset0, recs, cuts=(), geom=BAI_GEOM):
     """What the device half of ngsqc_write_bai hands to the host half (ngsqc_bai_assemble), computed from the record list: runs (a record whose
     (reference, bin) differs from its predecessor's; the first record behind every cut = tile boundary starts one too, and the record in front of a cut is
     reported as a kind-1 entry), first start offset per 16 kb window, mapped / unmapped counts. -> (runs, lidx, lidx_first, counts)"""
+    MIN_SHIFT = geom[0]
     nwin = [0] * n_ref
     for tid, beg, end, _, _ in recs:
         if tid >= 0: nwin[tid] = max(nwin[tid], ((max(end, 1) - 1) >> MIN_SHIFT) + 1)
@@ -224,7 +255,7 @@ def device_view(n_ref, offset0, recs, cuts=()):
             beg = max(beg, 0); end = max(end, 1)
             for w in range(beg >> MIN_SHIFT, ((end - 1) >> MIN_SHIFT) + 1):
                 lidx[first[tid] + w] = min(lidx[first[tid] + w], start)
-        key = (tid, reg2bin(beg, end))
+        key = (tid, reg2bin(beg, end, geom))
         if key != prev or i in cuts: runs.append((start, tid, key[1], recs[i][1], 0))
         if i + 1 in cuts or i + 1 == len(recs): runs.append((start, tid, key[1], max(recs[i][1], 0), 1))
         counts[2 * (tid if tid >= 0 else n_ref) + (0 if mapped else 1)] += 1

@@ -235,3 +235,95 @@ def test_bai_range_on_random_record_sets(seed, tmp_path):
         hits = [q for q, r in enumerate(recs) if any(r[0] == g[0] and r[1] < g[2] and r[2] > g[1] - 1 for g in regions)]
         assert hits and found, (seed, k, regions)
         assert all(beg <= starts[q] and recs[q][3] <= end for q in hits), (seed, k, regions, beg, end)
+
+
+# ---- CSI (hts-specs CSIv1): the host half of ngsqc_write_csi against oracle/csi_build.py, and region queries through a .csi next to the BAM ----
+import shutil  # noqa: E402
+
+import csi_build  # noqa: E402
+
+CSI_CASES = [("MappingQC_in2.bam", 14), ("BamReader_rna.bam", 12), ("close_exons.bam", 17), ("Statistics_longread.bam", 10), ("MappingQC_in5.bam", 14), ("sry.bam", 15)]
+
+
+@pytest.mark.parametrize("name,min_shift", CSI_CASES)
+def test_csi_assemble_equals_oracle(name, min_shift, tmp_path):
+    bam = os.path.join(GI, name)
+    n_ref, offset0, recs, final = bai_build.read_bam(bam)
+    depth = csi_build.depth_for(csi_build.ref_lengths(bam), min_shift)
+    for geom in ((min_shift, depth), (min_shift, depth + 1)):
+        want = csi_build.from_index(bai_build.build(n_ref, offset0, recs, final["eof_block"], "backward", geom), geom)
+        rng = random.Random(len(recs) + geom[1])
+        for cuts in ((), sorted(rng.sample(range(1, len(recs)), min(7, len(recs) - 1)))):
+            runs, lidx, first, counts = bai_build.device_view(n_ref, offset0, recs, cuts, geom)
+            out = str(tmp_path / "x.csi")
+            ngsqc.bai_assemble(out, n_ref, offset0, final["eof_block"], runs, lidx, first, counts, csi_geom=geom)
+            assert open(out, "rb").read(4) == b"\x1f\x8b\x08\x04"          # a BGZF container, as hts_idx_save writes a .csi
+            assert open(out, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # ... that ends with the EOF member
+            assert csi_build.parse_csi(out) == want
+
+
+@pytest.mark.parametrize("name,min_shift", CSI_CASES)
+@pytest.mark.parametrize("writer", ["oracle", "product"])
+def test_region_query_through_a_csi(name, min_shift, writer, tmp_path):
+    """<bam>.csi alone next to the BAM: the range of a region holds every overlapping record (sequential pass); written by the oracle (compressed and not) and by the product"""
+    src = os.path.join(GI, name); p = str(tmp_path / name); shutil.copy(src, p)
+    recs, n_ref = records_with_voff(p)
+    if writer == "oracle":
+        csi_build.write_csi(p + ".csi", csi_build.build_for_bam(p, min_shift), compress=min_shift != 12)
+    else:
+        nr, offset0, rr, final = bai_build.read_bam(p)
+        geom = (min_shift, csi_build.depth_for(csi_build.ref_lengths(p), min_shift))
+        runs, lidx, first, counts = bai_build.device_view(nr, offset0, rr, (), geom)
+        ngsqc.bai_assemble(p + ".csi", nr, offset0, final["eof_block"], runs, lidx, first, counts, csi_geom=geom)
+    rng = random.Random(17)
+    mapped = [r for r in recs if r[0] >= 0]
+    for _ in range(60):
+        t, p0, e0, _, _ = rng.choice(mapped)
+        s1 = max(1, p0 + 1 - rng.randrange(0, 5000)); e1 = max(p0 + 1, s1 + rng.randrange(1, 20000))
+        regions = [(t, s1, e1)]
+        if rng.random() < 0.4:
+            t2, q0, _, _, _ = rng.choice(mapped); regions.append((t2, q0 + 1, q0 + 300))
+        beg, end, found = ngsqc.bai_range(p, regions, n_ref)
+        hits = [r for r in recs if any(r[0] == g[0] and r[1] < g[2] and r[2] > g[1] - 1 for g in regions)]
+        assert hits and found
+        # (the file's last record ends where the reader stops: htslib's last chunk ends at the first empty member behind it, the helper's offset may name a later one)
+        assert all(beg <= r[3] and (r[4] <= end or (r is recs[-1] and r[3] < end)) for r in hits), (regions, beg, end)
+        each = ngsqc.bai_ranges(p, regions, n_ref)
+        assert min(b for b, e in each if e) == beg and max(e for b, e in each) == end
+    # the lower bound of the CSI query is the oracle's (hts_itr_query's loff walk)
+    csi = csi_build.parse_csi(p + ".csi")
+    for _ in range(40):
+        t, p0, e0, _, _ = rng.choice(mapped)
+        s0 = max(0, p0 - rng.randrange(0, 3000)); e1 = s0 + rng.randrange(1, 9000)
+        chunks = csi_build.query(csi, t, s0, e1)
+        beg, end, found = ngsqc.bai_range(p, [(t, s0 + 1, e1)], n_ref)
+        assert found == bool(chunks)
+        if chunks: assert beg == chunks[0][0] and end <= max(c[1] for c in chunks)
+
+
+def test_csi_is_taken_before_bai_and_by_stem(tmp_path):
+    """hts_idx_check_local's order: <bam>.csi, <stem>.csi, <bam>.bai, <stem>.bai"""
+    src = os.path.join(GI, "MappingQC_in2.bam"); p = str(tmp_path / "a.bam"); shutil.copy(src, p)
+    recs, n_ref = records_with_voff(p)
+    t, p0 = next((r[0], r[1]) for r in recs if r[0] >= 0)
+    want = ngsqc.bai_range(src, [(t, p0 + 1, p0 + 50)], n_ref)
+    open(p + ".bai", "wb").write(b"BAI\x01" + struct.pack("<i", 0))            # an index without references: nothing found through it
+    assert ngsqc.bai_range(p, [(t, p0 + 1, p0 + 50)], n_ref)[2] is False
+    csi_build.write_csi(str(tmp_path / "a.csi"), csi_build.build_for_bam(p, 14))   # <stem>.csi wins over <bam>.bai
+    got = ngsqc.bai_range(p, [(t, p0 + 1, p0 + 50)], n_ref)
+    assert got[2] and got[1] == want[1] and got[0] <= want[0]
+    open(p + ".csi", "wb").write(csi_build.bgzf(b"CSI\x01" + struct.pack("<iiii", 14, 5, 0, 0)))   # <bam>.csi wins over <stem>.csi
+    assert ngsqc.bai_range(p, [(t, p0 + 1, p0 + 50)], n_ref)[2] is False
+
+
+def test_damaged_csi_is_an_error(tmp_path):
+    src = os.path.join(GI, "sry.bam"); p = str(tmp_path / "s.bam"); shutil.copy(src, p)
+    good = csi_build.bgzf(csi_build.serialize(csi_build.build_for_bam(p, 14)))
+    for bad in (good[:40], good[:30] + bytes([good[30] ^ 0x55]) + good[31:], csi_build.bgzf(csi_build.serialize(csi_build.build_for_bam(p, 14))[:-30])):
+        open(p + ".csi", "wb").write(bad)
+        with pytest.raises(ngsqc.NgsqcError):
+            ngsqc.bai_range(p, [(0, 1, 100)], 25)
+    open(p + ".csi", "wb").write(b"not an index")   # not a CSI at all: skipped, and there is no .bai either
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.bai_range(p, [(0, 1, 100)], 25)
+    assert "Could not load index of BAM/CRAM file" in str(e.value)

@@ -140,3 +140,80 @@ def test_edge_records_and_unsorted_input(tmp_path):
             h.write_bai()
         h.close()
         assert what in str(e.value), (what, str(e.value))
+
+
+# ---- CSI (ngsqc_write_csi): the same pass with the geometry (min_shift, depth) of hts-specs CSIv1; checker: oracle/csi_build.py (pinned through the BAI fixtures) ----
+import shutil  # noqa: E402
+
+import csi_build  # noqa: E402
+
+
+@pytest.mark.parametrize("bam", [b for b in BAMS if os.path.basename(b) in ("MappingQC_in2.bam", "BamReader_rna.bam", "close_exons.bam", "Statistics_longread.bam", "sry.bam", "MappingQC_in5.bam")],
+                         ids=lambda p: os.path.basename(p))
+@pytest.mark.parametrize("min_shift,tiles", [(14, None), (12, "3"), (17, None)])
+def test_written_csi_equals_oracle(bam, min_shift, tiles, tmp_path, monkeypatch):
+    if tiles:
+        monkeypatch.setenv("NGSQC_TILE_MEMBERS", tiles)
+    out = str(tmp_path / "out.csi")
+    h = ngsqc.Handle(path=bam)
+    try:
+        h.write_csi(out, min_shift)
+    finally:
+        h.close()
+    assert open(out, "rb").read(4) == b"\x1f\x8b\x08\x04"
+    want = csi_build.build_for_bam(bam, min_shift)
+    assert csi_build.parse_csi(out) == want
+    if min_shift == 14 and want[0] == (14, 5):   # at BAI's geometry: the bins and chunks of the htslib-written fixture
+        fixture = bai_build.parse_bai(bam + ".bai")
+        if bai_build.build_for_bam(bam) == fixture:
+            assert [{b: c for b, (_, c) in bins.items()} for bins in want[1]] == [f[0] for f in fixture[0]]
+
+
+def test_csi_edge_records(tmp_path):
+    """a reference of 600 Mb: depth 6 at min_shift 14, and the alignment behind 2^29 that a BAI cannot hold is stored; default path and min_shift; argument errors"""
+    recs = edge_records()[:8] + [(1, 536_870_900, 0, [(100, 0)]), (1, 599_999_000, 0, [(900, 0), (5000, 3), (90, 0)])] + [(-1, -1, 4, [])] * 7
+    p = str(tmp_path / "big.bam"); open(p, "wb").write(_bam_image(EDGE_REFS, recs))
+    h = ngsqc.Handle(path=p)
+    try:
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            h.write_bai()
+        assert "2^29" in str(e.value)
+        h.write_csi()
+        got = csi_build.parse_csi(p + ".csi")
+        assert got[0] == (14, 6) and got == csi_build.build_for_bam(p, 14) and got[2] == 7
+        h.write_csi(str(tmp_path / "m0.csi"), 0)                       # min_shift <= 0: 14
+        assert csi_build.parse_csi(str(tmp_path / "m0.csi")) == got
+        h.write_csi(str(tmp_path / "m20.csi"), 20)
+        assert csi_build.parse_csi(str(tmp_path / "m20.csi")) == csi_build.build_for_bam(p, 20)
+        with pytest.raises(ngsqc.NgsqcError):
+            h.write_csi(str(tmp_path / "bad.csi"), 5)
+    finally:
+        h.close()
+    for what in ("unsorted positions", "not continuous"):
+        q = str(tmp_path / "bad.bam"); open(q, "wb").write(_bam_image(EDGE_REFS, edge_bad()[what]))
+        h = ngsqc.Handle(path=q)
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            h.write_csi()
+        h.close()
+        assert what in str(e.value)
+
+
+def test_index_driven_decode_through_a_csi(synthetic, tmp_path):
+    """only <bam>.csi next to the BAM (as after `samtools index -c`): regions open through it and give the whole file's depth and counts"""
+    p = str(tmp_path / "syn.bam"); shutil.copy(synthetic, p)
+    whole = ngsqc.Handle(path=p)
+    whole.write_csi(min_shift=13)
+    assert not os.path.exists(p + ".bai")
+    assert csi_build.parse_csi(p + ".csi") == csi_build.build_for_bam(p, 13)
+    refs = whole.refs; tid = [r[0] for r in refs].index("chrY")
+    region = ("chrY", 2_000_000, 3_000_000); regs = [(tid, region[1], region[2])]
+    part = ngsqc.Handle(path=p, regions=[region])
+    try:
+        n = region[2] - region[1] + 1
+        whole.scan_depth(regs, min_mapq=1); part.scan_depth(regs, min_mapq=1)
+        d = whole.depth(n)
+        assert d.sum() > 0 and np.array_equal(d, part.depth(n))
+        assert np.array_equal(whole.region_read_counts(regs, 1), part.region_read_counts(regs, 1))
+        assert part.timings()["members_inflated"] * 100 < whole.timings()["members_inflated"]
+    finally:
+        part.close(); whole.close()
