@@ -169,6 +169,7 @@ EXPORTS = [
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
     "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan", "ngsqc_write_csi", "ngsqc_csi_assemble", "ngsqc_bai_ranges",
+    "ngsqc_set_reference", "ngsqc_cram_to_bam",
 ]
 
 
@@ -195,6 +196,20 @@ def bai_ranges(bam_path, regions, n_ref):
     if rc != 0:
         raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
     return [(int(b[i]), int(e[i])) for i in range(n)]
+
+
+def set_reference(fasta_path):
+    """The reference genome (FASTA with .fai) CRAM files are decoded against (process-wide, like the reference's RefGenomeService); None: none."""
+    L = lib(); L.ngsqc_set_reference.restype = C.c_int; L.ngsqc_set_reference.argtypes = [C.c_char_p]
+    L.ngsqc_set_reference(os.fsencode(fasta_path) if fasta_path else None)
+
+
+def cram_to_bam(cram_path, bam_path):
+    """Host only: the records of a CRAM 3.0 file as a BAM file (BGZF members with stored blocks) - what ngsqc_open hands to the device for a CRAM."""
+    L = lib(); L.ngsqc_cram_to_bam.restype = C.c_int; L.ngsqc_cram_to_bam.argtypes = [C.c_char_p, C.c_char_p]
+    rc = L.ngsqc_cram_to_bam(os.fsencode(cram_path), os.fsencode(bam_path))
+    if rc != 0:
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
 
 
 def bgzf_scan(data, threads=1):

@@ -22,6 +22,7 @@
 #include <functional>
 #include <thread>
 #include <deque>
+#include <fstream>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -1821,8 +1822,25 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		}
 		else h->path = "<memory>";
 		if (!bytes && n) throw ArgError("null BAM buffer");
+		// CRAM 3.0 (BamReader.cpp:482-492): the container layer is decoded on the host (cram.hip) into a BAM stream in stored BGZF members; from here on the file is a BAM
+		// image in memory. Index-driven requests (a .crai names slices, not BGZF members) fall back to the whole file: a superset of what a region needs.
+		std::vector<uint8_t> cram_image;
+		const bool from_cram = is_cram((const uint8_t*)bytes, n);
+		if (from_cram)
+		{
+			std::vector<uint8_t> stream; std::string err;
+			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err);
+			if (crc == NGSQC_E_FORMAT) throw FormatError(err);
+			if (crc == NGSQC_E_IO) throw IoError(err);
+			if (crc == NGSQC_E_UNSUPPORTED) throw std::domain_error(err);
+			if (crc != NGSQC_OK) throw std::runtime_error(err);
+			bgzf_store(stream, cram_image);
+			bytes = cram_image.data(); n = cram_image.size();
+			if (range && !range->head_members) range = nullptr;
+			if (range && range->head_members) range = nullptr;   // (the first records: the whole file holds them)
+		}
 		const char* ea = getenv("NGSQC_ASYNC_H2D");
-		if (path && n_shards == 1 && !range && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
+		if (path && !from_cram && n_shards == 1 && !range && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
 		if (range) open_range_common(h, (const uint8_t*)bytes, n, device, *range); else open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
 		if (h->up) { h->up->map = map; h->up->map_n = map_n; h->up->fd = fd; map = nullptr; fd = -1; }   // the mapping lives until the last piece is copied
 		const char* ep = getenv("NGSQC_ASYNC_PLAN");
@@ -2103,6 +2121,27 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 	}
 	catch (FormatError& e) { g_open_error = e.what(); return NGSQC_E_FORMAT; }
 	catch (std::domain_error& e) { g_open_error = e.what(); return NGSQC_E_UNSUPPORTED; }
+	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
+}
+int ngsqc_set_reference(const char* fasta_path) { ngsqc::cram_set_reference(fasta_path); return NGSQC_OK; }
+int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path)
+{
+	if (!cram_path || !bam_path) return NGSQC_E_ARG;
+	try
+	{
+		std::ifstream f(cram_path, std::ios::binary);
+		if (!f) { g_open_error = std::string("Could not open BAM/CRAM file ") + cram_path; return NGSQC_E_IO; }
+		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()), stream, image; std::string err;
+		if (!ngsqc::is_cram(d.data(), d.size())) { g_open_error = std::string("not a CRAM file: ") + cram_path; return NGSQC_E_FORMAT; }
+		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err);
+		if (rc != NGSQC_OK) { g_open_error = err; return rc; }
+		ngsqc::bgzf_store(stream, image);
+		std::ofstream o(bam_path, std::ios::binary | std::ios::trunc);
+		if (o) o.write((const char*)image.data(), (std::streamsize)image.size());
+		o.close();
+		if (!o) { g_open_error = std::string("cannot write ") + bam_path; return NGSQC_E_IO; }
+		return NGSQC_OK;
+	}
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int ngsqc_write_bai(ngsqc_handle* h, const char* bai_path) { return guarded(h, [&] { write_bai(h, bai_path); }); }

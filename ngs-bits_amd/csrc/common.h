@@ -41,6 +41,13 @@ struct BaiRunV { uint64_t voff; int32_t tid; uint32_t bin; int32_t pos; uint32_t
 std::string bai_assemble(const std::string& out_path, int32_t n_ref, uint64_t offset0, uint64_t final_off, const std::vector<BaiRunV>& runs, const std::vector<uint64_t>& lidx,
                          const std::vector<int64_t>& first, const std::vector<int64_t>& counts, bool csi = false, int min_shift = 14, int depth = 5);
 
+// CRAM 3.0 input (cram.hip; host only): the file as a BAM stream / as a BGZF image with stored blocks that the BAM path takes like any other BAM
+bool is_cram(const uint8_t* d, size_t n);
+void cram_set_reference(const char* fasta);
+std::string cram_reference();
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err);   // NGSQC_OK or an NGSQC_E_* code with err
+void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image);
+
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC

@@ -1,0 +1,877 @@
+// CRAM 3.0 input (hts-specs CRAMv3). The reference reads CRAM through htslib's sam_read1 under the same BamReader as BAM (src/cppNGS/BamReader.cpp:482-492:
+// hts_set_fai_filename with the reference genome; :525-572: the required-fields switches). First slice of that row: the CONTAINER layer - file definition,
+// containers, slices, blocks (CRC-32 checked), the block codecs raw / gzip / rANS 4x8 order 0 and 1, the encodings EXTERNAL / HUFFMAN / BYTE_ARRAY_LEN /
+// BYTE_ARRAY_STOP / BETA / SUBEXP / GAMMA, read features -> CIGAR / bases / qualities, mate chains inside a slice and detached mates, the slice's reference MD5 -
+// runs on the HOST (slices in parallel on host threads) and hands the records to the device as a BAM stream in BGZF members with stored blocks, so that K1's
+// stored-block path, K2 (record index), K3 / K4 (walk, depth, counters) run unchanged on the GPU. The codecs are the next step onto the device (rANS has four
+// interleaved states per block and thousands of blocks per file). Checked against oracle/cram_decode.py, which is pinned on the reference's CRAM fixtures.
+// Host code only: no kernel in this file.
+#include "common.h"
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
+namespace ngsqc {
+
+namespace {
+struct CramError : std::runtime_error { using std::runtime_error::runtime_error; };      // a damaged file: reported like a BAM that cannot be read
+struct FormatError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct Cur
+{
+	const uint8_t* d = nullptr; size_t n = 0, p = 0;
+	Cur() {}
+	Cur(const uint8_t* d_, size_t n_, size_t p_ = 0) : d(d_), n(n_), p(p_) {}
+	uint8_t byte() { if (p >= n) throw CramError("truncated CRAM data"); return d[p++]; }
+	const uint8_t* take(size_t k) { if (k > n - p || p > n) throw CramError("truncated CRAM data"); const uint8_t* r = d + p; p += k; return r; }
+	uint32_t u32() { const uint8_t* q = take(4); return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); }
+	int32_t i32() { return (int32_t)u32(); }
+	int32_t itf8()
+	{
+		const uint32_t b0 = byte(); uint32_t v;
+		if (b0 < 0x80) v = b0;
+		else if (b0 < 0xc0) v = ((b0 & 0x3f) << 8) | byte();
+		else if (b0 < 0xe0) { v = (b0 & 0x1f) << 16; v |= (uint32_t)byte() << 8; v |= byte(); }
+		else if (b0 < 0xf0) { v = (b0 & 0x0f) << 24; v |= (uint32_t)byte() << 16; v |= (uint32_t)byte() << 8; v |= byte(); }
+		else { v = (b0 & 0x0f) << 28; v |= (uint32_t)byte() << 20; v |= (uint32_t)byte() << 12; v |= (uint32_t)byte() << 4; v |= byte() & 0x0fu; }
+		return (int32_t)v;
+	}
+	int64_t ltf8()
+	{
+		const uint32_t b0 = byte(); int k = 0;
+		while (k < 8 && (b0 & (0x80u >> k))) ++k;
+		uint64_t v = k == 8 ? 0 : (b0 & (0xffu >> (k + 1)));
+		for (int i = 0; i < k; ++i) v = (v << 8) | byte();
+		return (int64_t)v;
+	}
+	std::vector<int32_t> array_itf8() { const int32_t k = itf8(); if (k < 0 || (size_t)k > n) throw CramError("bad CRAM array"); std::vector<int32_t> a((size_t)k); for (auto& x : a) x = itf8(); return a; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- rANS 4x8 (CRAMv3 section 13)
+struct RansTable { uint16_t F[256]; uint16_t C[256]; uint8_t L[4096]; bool set = false; };
+void rans_read_freqs(Cur& c, RansTable& t)
+{
+	memset(t.F, 0, sizeof t.F); t.set = true;
+	int sym = c.byte(), last = sym, rle = 0;
+	for (;;)
+	{
+		int f = c.byte();
+		if (f >= 0x80) f = ((f & 0x7f) << 8) | c.byte();
+		t.F[sym] = (uint16_t)f;
+		if (rle) { --rle; ++sym; if (sym > 255) throw CramError("bad rANS frequency table"); }
+		else { sym = c.byte(); if (sym == last + 1) rle = c.byte(); }
+		last = sym;
+		if (sym == 0) break;
+	}
+	uint32_t acc = 0;
+	for (int s = 0; s < 256; ++s)
+	{
+		t.C[s] = (uint16_t)acc;
+		if (acc + t.F[s] > 4096) throw CramError("rANS frequencies exceed 4096");
+		memset(t.L + acc, s, t.F[s]); acc += t.F[s];
+	}
+	if (acc < 4096) memset(t.L + acc, 0, 4096 - acc);
+}
+void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out)
+{
+	if (n < 9) throw CramError("truncated rANS block");
+	const int order = d[0];
+	const uint32_t n_out = (uint32_t)d[5] | ((uint32_t)d[6] << 8) | ((uint32_t)d[7] << 16) | ((uint32_t)d[8] << 24);
+	out.assign(n_out, 0);
+	if (!n_out) return;
+	Cur c(d, n, 9);
+	uint32_t R[4];
+	auto renorm = [&](uint32_t x) { while (x < (1u << 23)) x = (x << 8) | c.byte(); return x; };
+	if (order == 0)
+	{
+		std::unique_ptr<RansTable> t(new RansTable()); rans_read_freqs(c, *t);
+		for (int j = 0; j < 4; ++j) R[j] = c.u32();
+		for (uint32_t i = 0; i < n_out; ++i)
+		{
+			const int j = i & 3; const uint32_t m = R[j] & 0xfffu; const uint8_t s = t->L[m]; out[i] = s;
+			R[j] = renorm((uint32_t)t->F[s] * (R[j] >> 12) + m - t->C[s]);
+		}
+		return;
+	}
+	if (order != 1) throw CramError("unknown rANS order");
+	std::vector<RansTable> tabs(256);
+	int ctx = c.byte(), last = ctx, rle = 0;
+	for (;;)
+	{
+		rans_read_freqs(c, tabs[(size_t)ctx]);
+		if (rle) { --rle; ++ctx; if (ctx > 255) throw CramError("bad rANS context table"); }
+		else { ctx = c.byte(); if (ctx == last + 1) rle = c.byte(); }
+		last = ctx;
+		if (ctx == 0) break;
+	}
+	for (int j = 0; j < 4; ++j) R[j] = c.u32();
+	const uint32_t q = n_out >> 2; uint32_t idx[4] = {0, q, 2 * q, 3 * q}; uint8_t prev[4] = {0, 0, 0, 0};
+	auto step = [&](int j) {
+		const RansTable& t = tabs[prev[j]];
+		if (!t.set) throw CramError("rANS order-1 context without a table");
+		const uint32_t m = R[j] & 0xfffu; const uint8_t s = t.L[m]; out[idx[j]++] = s;
+		R[j] = renorm((uint32_t)t.F[s] * (R[j] >> 12) + m - t.C[s]); prev[j] = s;
+	};
+	for (uint32_t i = 0; i < q; ++i) for (int j = 0; j < 4; ++j) step(j);
+	while (idx[3] < n_out) step(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- blocks, containers
+struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; };
+uint32_t crc_of(const uint8_t* p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
+void read_block(Cur& c, Blk& b)
+{
+	const size_t start = c.p;
+	b.method = c.byte(); b.ctype = c.byte(); b.cid = c.itf8(); const int32_t csize = c.itf8(), rsize = c.itf8();
+	if (csize < 0 || rsize < 0) throw CramError("bad CRAM block sizes");
+	const uint8_t* raw = c.take((size_t)csize);
+	const size_t crc_at = c.p; const uint32_t crc = c.u32();
+	if (crc_of(c.d + start, crc_at - start) != crc) throw CramError("CRAM block CRC mismatch");
+	if (b.method == 0) { b.p = raw; b.n = (size_t)csize; }
+	else if (b.method == 1)
+	{
+		b.own.assign((size_t)rsize, 0);
+		z_stream z; memset(&z, 0, sizeof z);
+		if (inflateInit2(&z, 15 + 16) != Z_OK) throw CramError("zlib init failed");
+		uint8_t none = 0;
+		z.next_in = const_cast<Bytef*>(raw); z.avail_in = (uInt)csize; z.next_out = rsize ? b.own.data() : &none; z.avail_out = (uInt)rsize;
+		const int rc = inflate(&z, Z_FINISH); const size_t got = z.total_out; inflateEnd(&z);
+		if (rc != Z_STREAM_END || got != (size_t)rsize) throw CramError("gzip block of the CRAM file does not inflate");
+		b.p = b.own.data(); b.n = b.own.size();
+	}
+	else if (b.method == 4) { rans_decode(raw, (size_t)csize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
+	else if (b.method == 2 || b.method == 3) throw std::domain_error(std::string("CRAM block compressed with ") + (b.method == 2 ? "bzip2" : "lzma") + " is not supported by the HIP path");
+	else throw std::domain_error("CRAM 3.1 block codec " + std::to_string(b.method) + " is not supported by the HIP path");
+	if (b.n != (size_t)rsize) throw CramError("CRAM block inflates to another size than its header says");
+}
+struct ContainerHdr { int32_t length = 0, ref_id = 0, start = 0, span = 0, n_records = 0, n_blocks = 0; int64_t counter = 0, bases = 0; std::vector<int32_t> landmarks; };
+void read_container_header(Cur& c, ContainerHdr& k)
+{
+	const size_t start = c.p;
+	k.length = c.i32(); k.ref_id = c.itf8(); k.start = c.itf8(); k.span = c.itf8(); k.n_records = c.itf8(); k.counter = c.ltf8(); k.bases = c.ltf8();
+	k.n_blocks = c.itf8(); k.landmarks = c.array_itf8();
+	const size_t crc_at = c.p; const uint32_t crc = c.u32();
+	if (crc_of(c.d + start, crc_at - start) != crc) throw CramError("CRAM container header CRC mismatch");
+	if (k.length < 0) throw CramError("bad CRAM container length");
+}
+
+// ---------------------------------------------------------------------------------------------------------------- encodings
+enum { E_NULL = 0, E_EXTERNAL = 1, E_HUFFMAN = 3, E_BYTE_ARRAY_LEN = 4, E_BYTE_ARRAY_STOP = 5, E_BETA = 6, E_SUBEXP = 7, E_GAMMA = 9 };
+struct Enc
+{
+	int kind = E_NULL; int32_t a = 0, b = 0;
+	std::vector<int32_t> syms, lens; std::unique_ptr<Enc> e1, e2;
+	struct Code { int len; uint32_t code; int32_t sym; }; std::vector<Code> codes; int max_len = 0;   // canonical Huffman codes, ascending by (len, code)
+	bool present = false;
+};
+void read_encoding(Cur& c, Enc& e)
+{
+	e.present = true;
+	e.kind = c.itf8(); const int32_t n = c.itf8();
+	if (n < 0) throw CramError("bad encoding parameters");
+	Cur p(c.take((size_t)n), (size_t)n);
+	switch (e.kind)
+	{
+	case E_NULL: break;
+	case E_EXTERNAL: e.a = p.itf8(); break;
+	case E_HUFFMAN:
+	{
+		e.syms = p.array_itf8(); e.lens = p.array_itf8();
+		if (e.syms.size() != e.lens.size() || e.syms.empty()) throw CramError("bad Huffman encoding");
+		std::vector<size_t> order(e.syms.size());
+		for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+		std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return e.lens[x] != e.lens[y] ? e.lens[x] < e.lens[y] : e.syms[x] < e.syms[y]; });
+		uint32_t code = 0; int last = 0;
+		for (size_t i : order)
+		{
+			if (e.lens[i] < 0 || e.lens[i] > 31) throw CramError("bad Huffman code length");
+			code <<= (e.lens[i] - last); last = e.lens[i];
+			e.codes.push_back(Enc::Code{e.lens[i], code, e.syms[i]}); ++code;
+			e.max_len = std::max(e.max_len, e.lens[i]);
+		}
+		break;
+	}
+	case E_BYTE_ARRAY_LEN: e.e1.reset(new Enc()); e.e2.reset(new Enc()); read_encoding(p, *e.e1); read_encoding(p, *e.e2); break;
+	case E_BYTE_ARRAY_STOP: e.a = p.byte(); e.b = p.itf8(); break;
+	case E_BETA: e.a = p.itf8(); e.b = p.itf8(); if (e.b < 0 || e.b > 32) throw CramError("bad BETA encoding"); break;
+	case E_SUBEXP: e.a = p.itf8(); e.b = p.itf8(); break;
+	case E_GAMMA: e.a = p.itf8(); break;
+	default: throw std::domain_error("CRAM encoding " + std::to_string(e.kind) + " is not supported by the HIP path");
+	}
+}
+inline uint16_t ds_key(const char* k) { return (uint16_t)(((uint8_t)k[0] << 8) | (uint8_t)k[1]); }
+struct CompHdr
+{
+	bool RN = true, AP = true, RR = true; uint8_t SM[5] = {0, 0, 0, 0, 0}; bool has_sm = false;
+	std::vector<std::vector<std::pair<uint16_t, uint8_t>>> TD;   // per tag line: (2-char tag, type)
+	std::map<uint16_t, Enc> ds; std::map<int32_t, Enc> tags;
+	char subst[5][4];   // [reference base ACGTN][code] -> read base
+	const Enc& series(const char* k) const
+	{
+		auto it = ds.find(ds_key(k));
+		if (it == ds.end()) throw CramError(std::string("CRAM data series ") + k + " is used but has no encoding");
+		return it->second;
+	}
+};
+void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
+{
+	Cur c(d, n);
+	c.itf8();
+	for (int32_t i = c.itf8(); i > 0; --i)
+	{
+		const uint8_t* k = c.take(2); const std::string key((const char*)k, 2);
+		if (key == "RN") h.RN = c.byte() != 0;
+		else if (key == "AP") h.AP = c.byte() != 0;
+		else if (key == "RR") h.RR = c.byte() != 0;
+		else if (key == "SM") { memcpy(h.SM, c.take(5), 5); h.has_sm = true; }
+		else if (key == "TD")
+		{
+			const int32_t len = c.itf8(); if (len < 0) throw CramError("bad tag dictionary");
+			const uint8_t* td = c.take((size_t)len); size_t o = 0;
+			while (o < (size_t)len)
+			{
+				size_t e = o; while (e < (size_t)len && td[e]) ++e;
+				std::vector<std::pair<uint16_t, uint8_t>> line;
+				for (size_t x = o; x + 3 <= e; x += 3) line.emplace_back((uint16_t)((td[x] << 8) | td[x + 1]), td[x + 2]);
+				h.TD.push_back(std::move(line)); o = e + 1;
+			}
+		}
+		else throw CramError("unknown CRAM preservation key " + key);
+	}
+	if (h.TD.empty()) h.TD.emplace_back();
+	c.itf8();
+	for (int32_t i = c.itf8(); i > 0; --i) { const uint8_t* k = c.take(2); Enc& e = h.ds[(uint16_t)((k[0] << 8) | k[1])]; read_encoding(c, e); }
+	c.itf8();
+	for (int32_t i = c.itf8(); i > 0; --i) { const int32_t key = c.itf8(); read_encoding(c, h.tags[key]); }
+	// substitution matrix: for every reference base the four other bases in the order of their 2-bit codes
+	const char B[6] = "ACGTN";
+	for (int r = 0; r < 5; ++r)
+	{
+		int k = 0;
+		for (int x = 0; x < 4; ++x) h.subst[r][x] = 'N';
+		for (int o = 0; o < 5; ++o) { if (o == r) continue; h.subst[r][(h.SM[r] >> (6 - 2 * k)) & 3] = B[o]; ++k; }
+	}
+}
+struct SliceHdr { int32_t ref_id = 0, start = 0, span = 0, n_records = 0, n_blocks = 0, embedded_ref = -1; int64_t counter = 0; std::vector<int32_t> content_ids; uint8_t md5[16]; };
+void read_slice_header(const uint8_t* d, size_t n, SliceHdr& s)
+{
+	Cur c(d, n);
+	s.ref_id = c.itf8(); s.start = c.itf8(); s.span = c.itf8(); s.n_records = c.itf8(); s.counter = c.ltf8(); s.n_blocks = c.itf8();
+	s.content_ids = c.array_itf8(); s.embedded_ref = c.itf8(); memcpy(s.md5, c.take(16), 16);
+	if (s.n_records < 0 || s.n_blocks < 0) throw CramError("bad CRAM slice header");
+}
+
+// ---------------------------------------------------------------------------------------------------------------- MD5 (RFC 1321) of a reference stretch
+void md5_of(const uint8_t* data, size_t n, uint8_t out[16])
+{
+	static const uint32_t K[64] = {
+		0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+		0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+		0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+		0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+	static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+	                          4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+	uint32_t a0 = 0x67452301, b0 = 0xefcdab89, c0 = 0x98badcfe, d0 = 0x10325476;
+	auto block = [&](const uint8_t* p) {
+		uint32_t M[16];
+		for (int i = 0; i < 16; ++i) M[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+		uint32_t A = a0, B = b0, C = c0, D = d0;
+		for (int i = 0; i < 64; ++i)
+		{
+			uint32_t F; int g;
+			if (i < 16) { F = (B & C) | (~B & D); g = i; }
+			else if (i < 32) { F = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
+			else if (i < 48) { F = B ^ C ^ D; g = (3 * i + 5) & 15; }
+			else { F = C ^ (B | ~D); g = (7 * i) & 15; }
+			F = F + A + K[i] + M[g]; A = D; D = C; C = B; B = B + ((F << S[i]) | (F >> (32 - S[i])));
+		}
+		a0 += A; b0 += B; c0 += C; d0 += D;
+	};
+	size_t o = 0;
+	for (; o + 64 <= n; o += 64) block(data + o);
+	uint8_t tail[128]; const size_t rem = n - o; memset(tail, 0, sizeof tail); memcpy(tail, data + o, rem); tail[rem] = 0x80;
+	const size_t tl = rem + 9 <= 64 ? 64 : 128; const uint64_t bits = (uint64_t)n * 8;
+	for (int i = 0; i < 8; ++i) tail[tl - 8 + i] = (uint8_t)(bits >> (8 * i));
+	block(tail); if (tl == 128) block(tail + 64);
+	const uint32_t r[4] = {a0, b0, c0, d0};
+	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(r[i] >> (8 * j));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the reference genome (FASTA + .fai)
+class RefGenome
+{
+public:
+	bool open(const std::string& fasta, std::string& err)
+	{
+		std::ifstream fai(fasta + ".fai");
+		if (!fai) { err = "no index " + fasta + ".fai"; return false; }
+		std::string line;
+		while (std::getline(fai, line))
+		{
+			std::istringstream is(line); Entry e; std::string name;
+			if (!(is >> name >> e.len >> e.offset >> e.line_bases >> e.line_bytes) || e.line_bases <= 0 || e.line_bytes < e.line_bases) { err = "damaged index " + fasta + ".fai"; return false; }
+			idx_[name] = e;
+		}
+		fd_ = ::open(fasta.c_str(), O_RDONLY);
+		if (fd_ < 0) { err = "cannot open " + fasta; return false; }
+		struct stat st; if (fstat(fd_, &st) != 0) { err = "cannot open " + fasta; return false; }
+		n_ = (size_t)st.st_size;
+		if (n_) { void* m = mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd_, 0); if (m == MAP_FAILED) { err = "cannot map " + fasta; return false; } map_ = (const uint8_t*)m; }
+		return true;
+	}
+	~RefGenome() { if (map_) munmap(const_cast<uint8_t*>(map_), n_); if (fd_ >= 0) ::close(fd_); }
+	bool has(const std::string& name) const { return idx_.count(name) != 0; }
+	int64_t length(const std::string& name) const { auto it = idx_.find(name); return it == idx_.end() ? -1 : it->second.len; }
+	// the whole contig, upper case (loaded on first use; slices of one contig share it)
+	std::shared_ptr<const std::string> contig(const std::string& name)
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		auto c = cache_.find(name);
+		if (c != cache_.end()) return c->second;
+		auto it = idx_.find(name);
+		if (it == idx_.end()) return nullptr;
+		const Entry& e = it->second;
+		auto s = std::make_shared<std::string>(); s->resize((size_t)e.len);
+		int64_t got = 0; size_t o = (size_t)e.offset;
+		while (got < e.len)
+		{
+			const int64_t k = std::min<int64_t>(e.line_bases, e.len - got);
+			if (o + (size_t)k > n_) throw CramError("reference genome is shorter than its index says");
+			for (int64_t i = 0; i < k; ++i) { uint8_t ch = map_[o + (size_t)i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32); (*s)[(size_t)(got + i)] = (char)ch; }
+			got += k; o += (size_t)e.line_bytes;
+		}
+		if (cache_.size() >= 4) cache_.erase(cache_.begin());   // (a sorted file walks the contigs one after the other)
+		cache_[name] = s;
+		return s;
+	}
+private:
+	struct Entry { int64_t len = 0, offset = 0, line_bases = 0, line_bytes = 0; };
+	std::map<std::string, Entry> idx_; std::map<std::string, std::shared_ptr<const std::string>> cache_; std::mutex mu_;
+	int fd_ = -1; const uint8_t* map_ = nullptr; size_t n_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- decoders of one slice
+struct BitReader
+{
+	const uint8_t* d = nullptr; size_t n = 0, p = 0; int bit = 7;
+	uint32_t bits(int k)
+	{
+		uint32_t v = 0;
+		for (int i = 0; i < k; ++i)
+		{
+			if (p >= n) throw CramError("CRAM core block is too short");
+			v = (v << 1) | ((d[p] >> bit) & 1u);
+			if (--bit < 0) { bit = 7; ++p; }
+		}
+		return v;
+	}
+};
+struct Dec
+{
+	BitReader core; std::map<int32_t, Cur> ext;
+	Cur& block(int32_t id) { auto it = ext.find(id); if (it == ext.end()) throw CramError("CRAM external block " + std::to_string(id) + " is missing in a slice"); return it->second; }
+	int32_t integer(const Enc& e)
+	{
+		switch (e.kind)
+		{
+		case E_EXTERNAL: return block(e.a).itf8();
+		case E_HUFFMAN:
+		{
+			if (e.max_len == 0) return e.codes[0].sym;
+			uint32_t code = 0; size_t at = 0;
+			for (int len = 1; len <= e.max_len; ++len)
+			{
+				code = (code << 1) | core.bits(1);
+				while (at < e.codes.size() && e.codes[at].len < len) ++at;
+				for (size_t x = at; x < e.codes.size() && e.codes[x].len == len; ++x) if (e.codes[x].code == code) return e.codes[x].sym;
+			}
+			throw CramError("bad Huffman code in the CRAM core block");
+		}
+		case E_BETA: return (int32_t)core.bits(e.b) - e.a;
+		case E_GAMMA: { int k = 0; while (core.bits(1) == 0) { if (++k > 31) throw CramError("bad GAMMA code"); } return (int32_t)((1u << k) | core.bits(k)) - e.a; }
+		case E_SUBEXP:
+		{
+			int i = 0; while (core.bits(1) == 1) { if (++i > 31) throw CramError("bad SUBEXP code"); }
+			const int nb = i == 0 ? e.b : i + e.b - 1;
+			if (nb < 0 || nb > 31) throw CramError("bad SUBEXP code");
+			const uint32_t v = i == 0 ? core.bits(nb) : ((1u << nb) | core.bits(nb));
+			return (int32_t)v - e.a;
+		}
+		default: throw CramError("CRAM encoding " + std::to_string(e.kind) + " cannot give an integer");
+		}
+	}
+	uint8_t byte(const Enc& e) { return e.kind == E_EXTERNAL ? block(e.a).byte() : (uint8_t)(integer(e) & 0xff); }
+	void bytes_n(const Enc& e, size_t k, std::vector<uint8_t>& out)
+	{
+		if (e.kind == E_EXTERNAL) { const uint8_t* p = block(e.a).take(k); out.assign(p, p + k); return; }
+		out.resize(k); for (size_t i = 0; i < k; ++i) out[i] = byte(e);
+	}
+	void array(const Enc& e, std::vector<uint8_t>& out)
+	{
+		if (e.kind == E_BYTE_ARRAY_STOP)
+		{
+			Cur& c = block(e.b); size_t q = c.p;
+			while (q < c.n && c.d[q] != (uint8_t)e.a) ++q;
+			if (q >= c.n) throw CramError("CRAM byte array without its stop byte");
+			out.assign(c.d + c.p, c.d + q); c.p = q + 1; return;
+		}
+		if (e.kind == E_BYTE_ARRAY_LEN) { const int32_t k = integer(*e.e1); if (k < 0) throw CramError("negative byte array length"); bytes_n(*e.e2, (size_t)k, out); return; }
+		throw CramError("CRAM encoding " + std::to_string(e.kind) + " cannot give a byte array");
+	}
+};
+
+enum { BAM_FPAIRED = 1, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FMREVERSE = 32, BAM_FREAD1 = 64 };
+enum { CF_QUAL_ARRAY = 1, CF_DETACHED = 2, CF_MATE_DOWNSTREAM = 4, CF_NO_SEQ = 8 };
+struct Feature { char code; int32_t pos; int32_t v = 0; uint8_t q = 0; std::vector<uint8_t> bytes; };
+struct RecInfo { uint32_t bf = 0, cf = 0; int32_t ref_id = -1, pos = 0, end = 0, mate_line = -1, mf = 0, ns = -1, np = 0, ts = 0; int32_t mate_ref = -1, mate_pos = 0; int64_t tlen = 0; bool tlen_set = false; size_t off = 0; };
+
+struct DecodeEnv
+{
+	const std::vector<std::string>* ref_names = nullptr; const std::vector<std::string>* rg_ids = nullptr;
+	RefGenome* genome = nullptr; bool no_reference = false, ignore_md5 = false; std::string path;
+};
+
+inline uint32_t reg2bin14(int64_t beg, int64_t end)
+{
+	--end;
+	if (beg >> 14 == end >> 14) return (uint32_t)(4681 + (beg >> 14));
+	if (beg >> 17 == end >> 17) return (uint32_t)(585 + (beg >> 17));
+	if (beg >> 20 == end >> 20) return (uint32_t)(73 + (beg >> 20));
+	if (beg >> 23 == end >> 23) return (uint32_t)(9 + (beg >> 23));
+	if (beg >> 26 == end >> 26) return (uint32_t)(1 + (beg >> 26));
+	return 0;
+}
+inline void put32(std::vector<uint8_t>& o, size_t at, uint32_t v) { o[at] = (uint8_t)v; o[at + 1] = (uint8_t)(v >> 8); o[at + 2] = (uint8_t)(v >> 16); o[at + 3] = (uint8_t)(v >> 24); }
+inline void add32(std::vector<uint8_t>& o, uint32_t v) { const size_t at = o.size(); o.resize(at + 4); put32(o, at, v); }
+inline void add16(std::vector<uint8_t>& o, uint32_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }
+
+// one slice -> BAM records (SAM spec 4.2), as htslib's cram_decode_slice + cram_to_bam build them
+void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& blocks, const DecodeEnv& env, std::vector<uint8_t>& out)
+{
+	Dec D; bool have_core = false;
+	for (Blk& b : blocks)
+	{
+		if (b.ctype == 5 && !have_core) { D.core.d = b.p; D.core.n = b.n; have_core = true; }
+		else if (b.ctype == 4) D.ext[b.cid] = Cur(b.p, b.n);
+	}
+	if (!have_core) throw CramError("CRAM slice without a core block");
+	const uint8_t* embedded = nullptr; size_t embedded_n = 0;
+	if (sh.embedded_ref >= 0) { Cur& e = D.block(sh.embedded_ref); embedded = e.d; embedded_n = e.n; }
+	// the reference stretch of a single-reference slice (and its MD5: htslib refuses a genome that does not match, "md5sum reference mismatch")
+	std::shared_ptr<const std::string> contig; int32_t contig_id = -3;
+	auto contig_of = [&](int32_t ref_id) -> const std::string* {
+		if (ref_id == contig_id) return contig.get();
+		contig_id = ref_id; contig.reset();
+		if (ref_id < 0 || (size_t)ref_id >= env.ref_names->size() || !env.genome) return nullptr;
+		contig = env.genome->contig((*env.ref_names)[(size_t)ref_id]);
+		return contig.get();
+	};
+	const bool needs_ref = ch.RR && !embedded && !env.no_reference;
+	if (needs_ref && sh.ref_id >= 0)
+	{
+		const std::string* c = contig_of(sh.ref_id);
+		if (!c) throw IoError("Error while setting reference genome for cram file " + env.path + ": no sequence '" + ((size_t)sh.ref_id < env.ref_names->size() ? (*env.ref_names)[(size_t)sh.ref_id] : std::string("?")) + "'");
+		static const uint8_t zero[16] = {0};
+		if (!env.ignore_md5 && memcmp(sh.md5, zero, 16) != 0 && sh.start >= 1 && sh.span > 0)
+		{
+			const int64_t a = (int64_t)sh.start - 1, b = std::min<int64_t>(a + sh.span, (int64_t)c->size());
+			uint8_t m[16]; md5_of((const uint8_t*)c->data() + std::min<int64_t>(a, (int64_t)c->size()), (size_t)std::max<int64_t>(b - a, 0), m);
+			if (memcmp(m, sh.md5, 16) != 0) throw FormatError("md5sum reference mismatch for cram file " + env.path + ": the reference genome is not the one the file was written with (sequence '" + (*env.ref_names)[(size_t)sh.ref_id] + "')");
+		}
+	}
+	auto ref_bases = [&](int32_t ref_id, int64_t p0, int64_t n, uint8_t* dst) {   // n reference bases from 0-based p0 (upper case; 'N' outside)
+		if (n <= 0) return;
+		if (embedded)
+		{
+			const int64_t o = p0 - ((int64_t)sh.start - 1);
+			for (int64_t i = 0; i < n; ++i) { const int64_t x = o + i; uint8_t c = x >= 0 && (size_t)x < embedded_n ? embedded[x] : (uint8_t)'N'; if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32); dst[i] = c; }
+			return;
+		}
+		if (env.no_reference) { memset(dst, 'N', (size_t)n); return; }
+		const std::string* c = contig_of(ref_id);
+		if (!c) throw IoError("Error while setting reference genome for cram file " + env.path + ": a read needs bases of a sequence the genome does not hold");
+		for (int64_t i = 0; i < n; ++i) { const int64_t x = p0 + i; dst[i] = x >= 0 && (size_t)x < c->size() ? (uint8_t)(*c)[(size_t)x] : (uint8_t)'N'; }
+	};
+
+	const size_t nrec = (size_t)sh.n_records;
+	std::vector<RecInfo> recs(nrec);
+	std::vector<uint8_t> name, seq, qual, tmp, tagbytes; std::vector<Feature> feats; std::vector<uint32_t> cigar;
+	const Enc &eBF = ch.series("BF"), &eCF = ch.series("CF"), &eRL = ch.series("RL"), &eAP = ch.series("AP"), &eRG = ch.series("RG"), &eTL = ch.series("TL");
+	int64_t prev_pos = sh.start;
+	static const uint8_t nt16[256] = {
+		15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,0,15,15,
+		15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15, 15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+		15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+		15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
+	for (size_t i = 0; i < nrec; ++i)
+	{
+		RecInfo& r = recs[i];
+		r.bf = (uint32_t)D.integer(eBF); r.cf = (uint32_t)D.integer(eCF);
+		r.ref_id = sh.ref_id == -2 ? D.integer(ch.series("RI")) : sh.ref_id;
+		const int32_t rl = D.integer(eRL);
+		if (rl < 0) throw CramError("negative read length");
+		const int32_t ap = D.integer(eAP);
+		if (ch.AP) { prev_pos += ap; r.pos = (int32_t)prev_pos; } else r.pos = ap;
+		const int32_t rg = D.integer(eRG);
+		name.clear(); bool have_name = false;
+		if (ch.RN) { D.array(ch.series("RN"), name); have_name = true; }
+		if (r.cf & CF_DETACHED)
+		{
+			r.mf = D.integer(ch.series("MF"));
+			if (!ch.RN) { D.array(ch.series("RN"), name); have_name = true; }
+			r.ns = D.integer(ch.series("NS")); r.np = D.integer(ch.series("NP")); r.ts = D.integer(ch.series("TS"));
+		}
+		else if (r.cf & CF_MATE_DOWNSTREAM)
+		{
+			const int32_t nf = D.integer(ch.series("NF"));
+			if (nf < 0 || i + (size_t)nf + 1 >= nrec) throw CramError("CRAM mate chain leaves the slice");
+			r.mate_line = (int32_t)(i + (size_t)nf + 1);
+		}
+		const int32_t tl = D.integer(eTL);
+		if (tl < 0 || (size_t)tl >= ch.TD.size()) throw CramError("bad tag line index");
+		tagbytes.clear();
+		for (const auto& tg : ch.TD[(size_t)tl])
+		{
+			const int32_t key = ((int32_t)(tg.first >> 8) << 16) | ((int32_t)(tg.first & 0xff) << 8) | tg.second;
+			auto it = ch.tags.find(key);
+			if (it == ch.tags.end()) throw CramError("CRAM tag without an encoding");
+			D.array(it->second, tmp);
+			tagbytes.push_back((uint8_t)(tg.first >> 8)); tagbytes.push_back((uint8_t)(tg.first & 0xff)); tagbytes.push_back(tg.second);
+			tagbytes.insert(tagbytes.end(), tmp.begin(), tmp.end());
+		}
+		cigar.clear(); int32_t mapq = 0; bool have_seq = true;
+		seq.assign((size_t)rl, 'N'); qual.assign((size_t)rl, 0xff);
+		auto add_op = [&](uint32_t op, int64_t n) {
+			if (n <= 0) return;
+			if (!cigar.empty() && (cigar.back() & 15u) == op) cigar.back() += (uint32_t)n << 4; else cigar.push_back(((uint32_t)n << 4) | op);
+		};
+		if (!(r.bf & BAM_FUNMAP))
+		{
+			const int32_t fn = D.integer(ch.series("FN"));
+			if (fn < 0) throw CramError("negative feature count");
+			feats.clear(); feats.resize((size_t)fn); int32_t fpos = 0;
+			for (Feature& f : feats)
+			{
+				f.code = (char)D.byte(ch.series("FC")); fpos += D.integer(ch.series("FP")); f.pos = fpos;
+				switch (f.code)
+				{
+				case 'B': f.v = D.byte(ch.series("BA")); f.q = D.byte(ch.series("QS")); break;
+				case 'X': f.v = D.byte(ch.series("BS")); break;
+				case 'I': D.array(ch.series("IN"), f.bytes); break;
+				case 'S': D.array(ch.series("SC"), f.bytes); break;
+				case 'H': f.v = D.integer(ch.series("HC")); break;
+				case 'P': f.v = D.integer(ch.series("PD")); break;
+				case 'D': f.v = D.integer(ch.series("DL")); break;
+				case 'N': f.v = D.integer(ch.series("RS")); break;
+				case 'i': f.v = D.byte(ch.series("BA")); break;
+				case 'b': D.array(ch.series("BB"), f.bytes); break;
+				case 'q': D.array(ch.series("QQ"), f.bytes); break;
+				case 'Q': f.q = D.byte(ch.series("QS")); break;
+				default: throw CramError(std::string("unknown CRAM read feature '") + f.code + "'");
+				}
+			}
+			mapq = D.integer(ch.series("MQ"));
+			const bool qarr = (r.cf & CF_QUAL_ARRAY) != 0;
+			if (qarr) D.bytes_n(ch.series("QS"), (size_t)rl, qual);
+			// read features -> CIGAR, bases, qualities (CRAMv3 section 10.6); between features the read follows the reference
+			int64_t ref_pos = (int64_t)r.pos - 1, read_pos = 0;
+			auto match_to = [&](int64_t upto) {
+				const int64_t n = upto - read_pos;
+				if (n > 0) { ref_bases(r.ref_id, ref_pos, n, seq.data() + read_pos); add_op(0, n); ref_pos += n; read_pos = upto; }
+			};
+			auto span_ok = [&](int64_t at, size_t n) { if (at < 0 || at + (int64_t)n > rl) throw CramError("CRAM read feature outside the read"); };
+			for (const Feature& f : feats)
+			{
+				const int64_t at = (int64_t)f.pos - 1;
+				if (f.code == 'Q') { span_ok(at, 1); if (!qarr) qual[(size_t)at] = f.q; continue; }
+				if (f.code == 'q') { span_ok(at, f.bytes.size()); if (!qarr) memcpy(qual.data() + at, f.bytes.data(), f.bytes.size()); continue; }
+				if (at < read_pos) throw CramError("CRAM read features are not ordered");
+				span_ok(at, 0);
+				match_to(at);
+				switch (f.code)
+				{
+				case 'B': span_ok(at, 1); seq[(size_t)at] = (uint8_t)f.v; if (!qarr) qual[(size_t)at] = f.q; add_op(0, 1); ++ref_pos; ++read_pos; break;
+				case 'X':
+				{
+					span_ok(at, 1);
+					uint8_t rb = 'N'; ref_bases(r.ref_id, ref_pos, 1, &rb);
+					const int ri = rb == 'A' ? 0 : rb == 'C' ? 1 : rb == 'G' ? 2 : rb == 'T' ? 3 : 4;
+					seq[(size_t)at] = (uint8_t)ch.subst[ri][f.v & 3]; add_op(0, 1); ++ref_pos; ++read_pos; break;
+				}
+				case 'I': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(1, (int64_t)f.bytes.size()); read_pos += (int64_t)f.bytes.size(); break;
+				case 'i': span_ok(at, 1); seq[(size_t)at] = (uint8_t)f.v; add_op(1, 1); ++read_pos; break;
+				case 'S': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(4, (int64_t)f.bytes.size()); read_pos += (int64_t)f.bytes.size(); break;
+				case 'b': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(0, (int64_t)f.bytes.size()); ref_pos += (int64_t)f.bytes.size(); read_pos += (int64_t)f.bytes.size(); break;
+				case 'D': add_op(2, f.v); ref_pos += f.v; break;
+				case 'N': add_op(3, f.v); ref_pos += f.v; break;
+				case 'H': add_op(5, f.v); break;
+				case 'P': add_op(6, f.v); break;
+				}
+			}
+			match_to(rl);
+			r.end = cigar.empty() ? r.pos : (int32_t)ref_pos;
+			if (r.cf & CF_NO_SEQ) have_seq = false;
+		}
+		else
+		{
+			if (r.cf & CF_NO_SEQ) have_seq = false; else D.bytes_n(ch.series("BA"), (size_t)rl, seq);
+			if (r.cf & CF_QUAL_ARRAY) D.bytes_n(ch.series("QS"), (size_t)rl, qual);
+			r.end = r.pos;
+		}
+		// ---- the BAM record; flag, mate fields and template length are patched when the slice's chains are resolved ----
+		r.off = out.size();
+		const size_t l_seq = have_seq ? (size_t)rl : 0;
+		if (!have_name) name.assign(1, '*');
+		if (name.size() > 254) throw CramError("read name longer than 254 bytes");
+		add32(out, 0);   // block_size
+		add32(out, (uint32_t)r.ref_id); add32(out, (uint32_t)(r.pos - 1));
+		out.push_back((uint8_t)(name.size() + 1)); out.push_back((uint8_t)mapq);
+		const int64_t pos0 = (int64_t)r.pos - 1, end0 = cigar.empty() ? pos0 + 1 : (int64_t)r.end;
+		add16(out, pos0 < 0 ? 4680u : reg2bin14(pos0, end0));
+		add16(out, (uint32_t)cigar.size()); add16(out, r.bf); add32(out, (uint32_t)l_seq);
+		add32(out, 0xffffffffu); add32(out, 0xffffffffu); add32(out, 0);   // next_refID, next_pos, tlen
+		out.insert(out.end(), name.begin(), name.end()); out.push_back(0);
+		for (uint32_t c : cigar) add32(out, c);
+		const size_t sq = out.size(); out.resize(sq + (l_seq + 1) / 2, 0);
+		for (size_t x = 0; x < l_seq; ++x) out[sq + (x >> 1)] |= (uint8_t)(nt16[seq[x]] << ((x & 1) ? 0 : 4));
+		out.insert(out.end(), qual.begin(), qual.begin() + (long)l_seq);
+		out.insert(out.end(), tagbytes.begin(), tagbytes.end());
+		if (rg >= 0 && (size_t)rg < env.rg_ids->size())
+		{
+			const std::string& id = (*env.rg_ids)[(size_t)rg];
+			out.push_back('R'); out.push_back('G'); out.push_back('Z'); out.insert(out.end(), id.begin(), id.end()); out.push_back(0);
+		}
+		put32(out, r.off, (uint32_t)(out.size() - r.off - 4));
+	}
+	// ---- mates (htslib cram_decode_slice_xref) ----
+	for (size_t i = 0; i < nrec; ++i)
+	{
+		RecInfo& r = recs[i];
+		if (r.cf & CF_DETACHED)
+		{
+			r.mate_ref = r.ns; r.mate_pos = r.np; r.tlen = r.ts; r.tlen_set = true;
+			if (r.mf & 1) r.bf |= BAM_FMREVERSE;
+			if (r.mf & 2) r.bf |= BAM_FMUNMAP;
+			continue;
+		}
+		if (r.mate_line < 0) continue;
+		if (!r.tlen_set)
+		{
+			int64_t left = r.pos, right = r.end; int left_cnt = 0; int32_t ref = r.ref_id; size_t j = i; std::vector<size_t> chain;
+			for (;;)
+			{
+				RecInfo& m = recs[j]; chain.push_back(j);
+				if (m.pos < left) { left = m.pos; left_cnt = 1; } else if (m.pos == left) ++left_cnt;
+				if (m.end > right) right = m.end;
+				if (m.ref_id != ref) ref = -1;
+				if (m.mate_line == -1) { m.mate_line = (int32_t)i; break; }
+				if ((size_t)m.mate_line <= j || (size_t)m.mate_line >= nrec) throw CramError("bad CRAM mate chain");
+				j = (size_t)m.mate_line;
+			}
+			const int64_t tlen = right - left + 1;
+			for (size_t x : chain)
+			{
+				RecInfo& m = recs[x]; m.tlen_set = true;
+				if (ref == -1) m.tlen = 0;
+				else if (m.pos == left && (left_cnt == 1 || (m.bf & BAM_FREAD1))) m.tlen = tlen;
+				else m.tlen = -tlen;
+			}
+		}
+		const RecInfo& mate = recs[(size_t)r.mate_line];
+		r.mate_ref = mate.ref_id; r.mate_pos = mate.pos;
+		r.bf |= BAM_FPAIRED;
+		if (mate.bf & BAM_FUNMAP) { r.bf |= BAM_FMUNMAP; r.tlen = 0; }
+		if (r.bf & BAM_FUNMAP) r.tlen = 0;
+		if (mate.bf & BAM_FREVERSE) r.bf |= BAM_FMREVERSE;
+	}
+	for (const RecInfo& r : recs)
+	{
+		out[r.off + 18] = (uint8_t)r.bf; out[r.off + 19] = (uint8_t)(r.bf >> 8);
+		put32(out, r.off + 24, (uint32_t)r.mate_ref); put32(out, r.off + 28, (uint32_t)(r.mate_pos - 1)); put32(out, r.off + 32, (uint32_t)(int32_t)r.tlen);
+	}
+}
+
+struct SliceJob { const CompHdr* ch = nullptr; SliceHdr sh; size_t blocks_at = 0; std::vector<uint8_t> out; };
+
+std::mutex g_ref_mu; std::string g_reference;
+} // namespace
+
+void cram_set_reference(const char* fasta) { std::lock_guard<std::mutex> g(g_ref_mu); g_reference = fasta ? fasta : ""; }
+std::string cram_reference()
+{
+	{ std::lock_guard<std::mutex> g(g_ref_mu); if (!g_reference.empty()) return g_reference; }
+	const char* e = getenv("NGSQC_REFERENCE");
+	return e ? e : "";
+}
+bool is_cram(const uint8_t* d, size_t n) { return n >= 4 && memcmp(d, "CRAM", 4) == 0; }
+
+namespace {
+// the whole CRAM as an uncompressed BAM stream ("BAM\1", header, records in file order). Throws FormatError / IoError / std::domain_error.
+void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream)
+{
+	try
+	{
+		if (n < 26 || memcmp(d, "CRAM", 4) != 0) throw CramError("not a CRAM file");
+		if (d[4] != 3 || d[5] != 0) throw std::domain_error("CRAM " + std::to_string(d[4]) + "." + std::to_string(d[5]) + " input is not supported by the HIP path (CRAM 3.0 only)");
+		Cur c(d, n, 26);
+		// ---- the SAM header ----
+		ContainerHdr k; read_container_header(c, k);
+		size_t end = c.p + (size_t)k.length;
+		if (end > n) throw CramError("truncated CRAM data");
+		std::string text;
+		{
+			Blk b; read_block(c, b);
+			if (b.ctype != 0 || b.n < 4) throw CramError("the first container does not hold the SAM header");
+			const int32_t l_text = (int32_t)((uint32_t)b.p[0] | ((uint32_t)b.p[1] << 8) | ((uint32_t)b.p[2] << 16) | ((uint32_t)b.p[3] << 24));
+			if (l_text < 0 || (size_t)l_text + 4 > b.n) throw CramError("damaged SAM header of the CRAM file");
+			text.assign((const char*)b.p + 4, (size_t)l_text);
+		}
+		c.p = end;
+		std::vector<std::string> ref_names, rg_ids; std::vector<int64_t> ref_lens;
+		{
+			std::istringstream is(text); std::string line;
+			while (std::getline(is, line))
+			{
+				const bool sq = line.compare(0, 3, "@SQ") == 0, rg = line.compare(0, 3, "@RG") == 0;
+				if (!sq && !rg) continue;
+				std::string nm; int64_t ln = 0; size_t o = 3;
+				while (o < line.size())
+				{
+					const size_t e2 = line.find('\t', o + 1); const std::string f = line.substr(o + 1, (e2 == std::string::npos ? line.size() : e2) - o - 1);
+					if (sq && f.compare(0, 3, "SN:") == 0) nm = f.substr(3);
+					if (sq && f.compare(0, 3, "LN:") == 0) ln = atoll(f.c_str() + 3);
+					if (rg && f.compare(0, 3, "ID:") == 0) nm = f.substr(3);
+					if (e2 == std::string::npos) break;
+					o = e2;
+				}
+				if (sq) { ref_names.push_back(nm); ref_lens.push_back(ln); } else rg_ids.push_back(nm);
+			}
+		}
+		// ---- containers -> slice jobs ----
+		std::vector<std::unique_ptr<CompHdr>> headers; std::vector<SliceJob> jobs; std::vector<Blk> blocks; bool any_rr = false, eof = false;
+		while (c.p < n)
+		{
+			read_container_header(c, k); end = c.p + (size_t)k.length;
+			if (end > n) throw CramError("truncated CRAM data");
+			if (k.n_records == 0 && k.ref_id == -1 && k.start == 4542278) { eof = true; c.p = end; continue; }
+			if (k.n_blocks == 0) { c.p = end; continue; }
+			Blk hb; read_block(c, hb);
+			if (hb.ctype != 1) throw CramError("compression header expected");
+			headers.emplace_back(new CompHdr()); read_compression_header(hb.p, hb.n, *headers.back());
+			any_rr = any_rr || headers.back()->RR;
+			while (c.p < end)
+			{
+				Blk sb; read_block(c, sb);
+				if (sb.ctype != 2) throw CramError("slice header expected");
+				SliceJob j; j.ch = headers.back().get(); read_slice_header(sb.p, sb.n, j.sh); j.blocks_at = c.p;
+				// (the blocks are inflated by the slice's worker: skip over them here)
+				for (int32_t b = 0; b < j.sh.n_blocks; ++b) { c.byte(); c.byte(); c.itf8(); const int32_t cs = c.itf8(); c.itf8(); if (cs < 0) throw CramError("bad CRAM block sizes"); c.take((size_t)cs + 4); }
+				jobs.push_back(std::move(j));
+			}
+			c.p = end;
+		}
+		(void)eof;   // (htslib warns about a missing EOF container and goes on)
+		// ---- the genome ----
+		DecodeEnv env; env.ref_names = &ref_names; env.rg_ids = &rg_ids; env.path = path;
+		const char* e1 = getenv("NGSQC_CRAM_NO_REFERENCE"); env.no_reference = e1 && atoi(e1) != 0;
+		const char* e2 = getenv("NGSQC_CRAM_IGNORE_MD5"); env.ignore_md5 = e2 && atoi(e2) != 0;
+		RefGenome genome;
+		if (any_rr && !env.no_reference)
+		{
+			const std::string fasta = cram_reference(); std::string err;
+			if (fasta.empty() || !genome.open(fasta, err)) throw IoError("Error while setting reference genome '" + fasta + "'for cram file " + path);   // BamReader.cpp:486-489
+			// checkChromosomeLengths (BamReader.cpp:491): the genome must hold the file's sequences at their lengths
+			for (size_t i = 0; i < ref_names.size(); ++i)
+			{
+				const int64_t l = genome.length(ref_names[i]);
+				if (l >= 0 && l != ref_lens[i]) throw FormatError("The length of chromosome '" + ref_names[i] + "' in the reference genome '" + fasta + "' differs from the length in the BAM/CRAM file '" + path + "'");
+			}
+			env.genome = &genome;
+		}
+		// ---- slices in parallel ----
+		int nthreads = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+		if (const char* et = getenv("NGSQC_CRAM_THREADS")) nthreads = std::max(1, atoi(et));
+		nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(jobs.size(), 1));
+		std::atomic<size_t> next(0); std::mutex err_mu; std::exception_ptr first_err;
+		auto work = [&] {
+			for (;;)
+			{
+				const size_t i = next.fetch_add(1);
+				if (i >= jobs.size()) return;
+				{ std::lock_guard<std::mutex> g(err_mu); if (first_err) return; }
+				try
+				{
+					SliceJob& j = jobs[i]; Cur bc(d, n, j.blocks_at);
+					std::vector<Blk> bl((size_t)j.sh.n_blocks);
+					for (Blk& b : bl) read_block(bc, b);
+					decode_slice(*j.ch, j.sh, bl, env, j.out);
+				}
+				catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!first_err) first_err = std::current_exception(); return; }
+			}
+		};
+		std::vector<std::thread> pool;
+		for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+		work();
+		for (auto& t : pool) t.join();
+		if (first_err) std::rethrow_exception(first_err);
+		// ---- BAM header + records ----
+		size_t total = 12 + text.size();
+		for (size_t i = 0; i < ref_names.size(); ++i) total += 9 + ref_names[i].size();
+		for (const SliceJob& j : jobs) total += j.out.size();
+		stream.clear(); stream.reserve(total);
+		stream.insert(stream.end(), {'B', 'A', 'M', 1}); add32(stream, (uint32_t)text.size()); stream.insert(stream.end(), text.begin(), text.end());
+		add32(stream, (uint32_t)ref_names.size());
+		for (size_t i = 0; i < ref_names.size(); ++i)
+		{
+			add32(stream, (uint32_t)ref_names[i].size() + 1); stream.insert(stream.end(), ref_names[i].begin(), ref_names[i].end()); stream.push_back(0);
+			add32(stream, (uint32_t)ref_lens[i]);
+		}
+		for (SliceJob& j : jobs) { stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out); }
+	}
+	catch (CramError& e) { throw FormatError("Could not read next alignment in BAM/CRAM file " + path + " (" + e.what() + ")"); }
+}
+} // namespace
+
+// NGSQC_OK or NGSQC_E_FORMAT / NGSQC_E_IO / NGSQC_E_UNSUPPORTED / NGSQC_E_DEVICE with the message in err
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err)
+{
+	try { cram_to_bam_stream_impl(d, n, path, stream); return NGSQC_OK; }
+	catch (FormatError& e) { err = e.what(); return NGSQC_E_FORMAT; }
+	catch (IoError& e) { err = e.what(); return NGSQC_E_IO; }
+	catch (std::domain_error& e) { err = e.what(); return NGSQC_E_UNSUPPORTED; }
+	catch (std::exception& e) { err = e.what(); return NGSQC_E_DEVICE; }
+}
+
+// the stream in BGZF members with STORED deflate blocks (RFC 1951 3.2.4) and the EOF member: what K1's stored-block path copies on the device
+void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image)
+{
+	const size_t piece = 0xff00, nm = (stream.size() + piece - 1) / piece;
+	image.clear(); image.reserve(stream.size() + (nm + 1) * 31 + 28);
+	auto member = [&](const uint8_t* p, size_t n) {
+		const uint32_t bsize = (uint32_t)(n + 5 + 25);
+		const uint8_t h[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8)};
+		image.insert(image.end(), h, h + 18);
+		const uint8_t sb[5] = {1, (uint8_t)(n & 255), (uint8_t)(n >> 8), (uint8_t)(~n & 255), (uint8_t)((~n >> 8) & 255)};
+		image.insert(image.end(), sb, sb + 5);
+		image.insert(image.end(), p, p + n);
+		uint8_t none = 0; const uint32_t crc = crc_of(n ? p : &none, n);
+		add32(image, crc); add32(image, (uint32_t)n);
+	};
+	for (size_t o = 0; o < stream.size(); o += piece) member(stream.data() + o, std::min(piece, stream.size() - o));
+	static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	image.insert(image.end(), eof, eof + 28);
+}
+
+} // namespace ngsqc

@@ -383,12 +383,15 @@ def build_alignment(ch, sh, r, ref_fetch, embedded):
             seq[read_pos:upto] = ref_bases(ref_pos, n); add("M", n); ref_pos += n; read_pos = upto
     for code, fpos, v in r.features:
         at = fpos - 1
-        if code in "qQ":
-            if code == "Q": qual[at] = v
-            else: qual[at:at + len(v)] = v
+        if code in "qQ":       # (htslib reads the quality array behind the features: where one is stored it overwrites what the features set)
+            if r.qual is None:
+                if code == "Q": qual[at] = v
+                else: qual[at:at + len(v)] = v
             continue
         match_to(at)
-        if code == "B": seq[at] = v[0]; qual[at] = v[1]; add("M", 1); ref_pos += 1; read_pos += 1
+        if code == "B":
+            seq[at] = v[0]; add("M", 1); ref_pos += 1; read_pos += 1
+            if r.qual is None: qual[at] = v[1]
         elif code == "X":
             rb = ref_bases(ref_pos, 1).decode()
             if rb not in "ACGTN": rb = "N"
@@ -411,7 +414,9 @@ def build_alignment(ch, sh, r, ref_fetch, embedded):
 
 
 def resolve_mates(recs):
-    """mate fields of the records of one slice (htslib cram_decode_slice_xref): detached records carry them; a chain linked by NF takes them from its members"""
+    """mate fields of the records of one slice (htslib cram_decode.c cram_decode_slice_xref): detached records carry them; the members of a chain linked by NF
+    take them from each other, and the template length is computed over the chain"""
+    n = len(recs)
     for r in recs:
         r.mate_ref = -1; r.mate_pos = 0; r.tlen = None
     for i, r in enumerate(recs):
@@ -419,11 +424,11 @@ def resolve_mates(recs):
             r.mate_ref = r.ns; r.mate_pos = r.np; r.tlen = r.ts
             if r.mf & 1: r.bf |= BAM_FMREVERSE
             if r.mf & 2: r.bf |= BAM_FMUNMAP
-    n = len(recs)
-    for i, r in enumerate(recs):
-        if r.mate_line < 0 or r.cf & CF_DETACHED: continue
+            continue
+        if r.mate_line < 0: continue
+        if r.mate_line >= n: raise ValueError("mate chain leaves the slice")
         if r.tlen is None:
-            # walk the chain: leftmost start, rightmost end, whether all members sit on one reference
+            # the first member of a chain: leftmost start, rightmost end, how many members start leftmost, whether all sit on one reference
             left = r.pos; right = r.end; left_cnt = 0; ref = r.ref_id; j = i; chain = []
             while True:
                 m = recs[j]; chain.append(j)
@@ -432,23 +437,23 @@ def resolve_mates(recs):
                 if m.end > right: right = m.end
                 if m.ref_id != ref: ref = -1
                 if m.mate_line == -1:
-                    m.mate_line = i; break
+                    m.mate_line = i; break          # the last member points back at the first
                 if m.mate_line <= j or m.mate_line >= n: raise ValueError("bad mate chain")
                 j = m.mate_line
-            tlen = right - left + 1 if ref != -1 else 0
+            tlen = right - left + 1
             for j in chain:
                 m = recs[j]
                 if ref == -1: m.tlen = 0
-                elif m.pos == left and (left_cnt == 1 or m.bf & BAM_FREAD1): m.tlen = tlen
+                elif m.pos == left and (left_cnt == 1 or m.bf & BAM_FREAD1): m.tlen = tlen    # ties: the first read of the template takes the positive length
                 else: m.tlen = -tlen
         mate = recs[r.mate_line]
         r.mate_ref = mate.ref_id; r.mate_pos = mate.pos
-        if mate.bf & BAM_FUNMAP: r.bf |= BAM_FMUNMAP
+        r.bf |= BAM_FPAIRED
+        if mate.bf & BAM_FUNMAP: r.bf |= BAM_FMUNMAP; r.tlen = 0
+        if r.bf & BAM_FUNMAP: r.tlen = 0
         if mate.bf & BAM_FREVERSE: r.bf |= BAM_FMREVERSE
-    for i, r in enumerate(recs):   # the last member of a chain points back at the first: its mate fields come from there
+    for r in recs:
         if r.tlen is None: r.tlen = 0
-        if not r.cf & CF_DETACHED and r.mate_line >= 0 and r.mate_ref == -1 and recs[r.mate_line].ref_id >= 0:
-            mate = recs[r.mate_line]; r.mate_ref = mate.ref_id; r.mate_pos = mate.pos
 
 
 # ------------------------------------------------------------------------------------------------------------------------------ whole file
