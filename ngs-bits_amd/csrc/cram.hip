@@ -788,7 +788,9 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		const char* e1 = getenv("NGSQC_CRAM_NO_REFERENCE"); env.no_reference = e1 && atoi(e1) != 0;
 		const char* e2 = getenv("NGSQC_CRAM_IGNORE_MD5"); env.ignore_md5 = e2 && atoi(e2) != 0;
 		RefGenome genome;
-		if (any_rr && !env.no_reference)
+		bool need_genome = false;   // a slice of mapped reads whose bases are neither all in the file (RR = false) nor in an embedded reference block
+		for (const SliceJob& j : jobs) need_genome = need_genome || (j.ch->RR && j.sh.embedded_ref < 0 && j.sh.ref_id != -1);
+		if (any_rr && need_genome && !env.no_reference)
 		{
 			const std::string fasta = cram_reference(); std::string err;
 			if (fasta.empty() || !genome.open(fasta, err)) throw IoError("Error while setting reference genome '" + fasta + "'for cram file " + path);   // BamReader.cpp:486-489

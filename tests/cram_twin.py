@@ -1,0 +1,102 @@
+"""Test helper: a BAM / CRAM / genome triple ("twin") built from one of the reference's BAM fixtures. The fixture's reads are moved onto short contigs (a window of
+each chromosome, positions shifted: the real contigs are hundreds of Mb and no genome for them is in the tree), a genome is made up for those contigs from the
+reads themselves plus noise (so that most bases match it and some do not), and oracle/cram_encode.py writes the CRAM. Reading the CRAM must give back the BAM."""
+import os
+import random
+import struct
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import cram_decode as CD  # noqa: E402
+import cram_encode as CE  # noqa: E402
+
+
+def _bgzf(raw, level=6):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15); body = c.compress(raw) + c.flush()
+    return b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(raw), len(raw))
+
+
+def write_bam(path, text, refs, raw_records):
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for name, ln in refs: hdr += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    out = bytearray(_bgzf(hdr)); chunk = bytearray()
+    for r in raw_records:
+        chunk += r
+        if len(chunk) > 60000: out += _bgzf(bytes(chunk[:60000])); del chunk[:60000]
+    while chunk: out += _bgzf(bytes(chunk[:60000])); del chunk[:60000]
+    open(path, "wb").write(bytes(out) + _bgzf(b""))
+
+
+def make_twin(src_bam, out_dir, window=250_000, seed=1, max_records=None):
+    """-> dict(bam, fasta, genome, text, refs, records (raw bytes))"""
+    text, refs, recs = CE.read_bam(src_bam)
+    first = {}
+    for r in recs:
+        if r["ref_id"] >= 0 and r["pos"] >= 1: first.setdefault(r["ref_id"], r["pos"])
+    keep = []
+    for r in recs:
+        t = r["ref_id"]
+        if t < 0: keep.append(r); continue
+        if r["pos"] < 1 or r["pos"] >= first[t] + window: continue
+        keep.append(r)
+    if max_records: keep = keep[:max_records]
+    shift = {t: p - 101 for t, p in first.items()}
+    new_len = {}
+    for r in keep:
+        t = r["ref_id"]
+        if t >= 0: new_len[t] = max(new_len.get(t, 0), CE.ref_end(r) - shift[t] + 300)
+    new_refs = [(n, new_len.get(i, 1000)) for i, (n, _) in enumerate(refs)]
+    lines = []
+    for ln in text.split("\n"):
+        if ln.startswith("@SQ"):
+            f = ln.split("\t"); name = [x for x in f if x.startswith("SN:")][0][3:]
+            i = [n for n, _ in refs].index(name)
+            f = [("LN:%d" % new_refs[i][1]) if x.startswith("LN:") else x for x in f if not x.startswith(("M5:", "UR:"))]
+            ln = "\t".join(f)
+        lines.append(ln)
+    new_text = "\n".join(lines)
+    rng = random.Random(seed)
+    genome = {n: bytearray(rng.choice(b"ACGT") for _ in range(l)) if i in new_len else bytearray(b"ACGT" * (l // 4 + 1))[:l] for i, (n, l) in enumerate(new_refs)}
+    seen = {n: bytearray(l) for n, l in new_refs}
+    raws = []
+    for r in keep:
+        t = r["ref_id"]; pos = r["pos"] - shift[t] if t >= 0 else r["pos"]
+        mt = r["mate_ref"]; mpos = r["mate_pos"]
+        if mt >= 0 and mt in shift: mpos = max(0, mpos - shift[mt])
+        end = pos
+        if t >= 0 and not r["flag"] & 4:
+            g = genome[refs[t][0]]; s = seen[refs[t][0]]; rp = 0; gp = pos - 1
+            for op, k in r["cigar"]:
+                if op in "M=X":
+                    for x in range(k):
+                        if gp + x < len(g) and not s[gp + x] and r["seq"] and chr(r["seq"][rp + x]) in "ACGT": g[gp + x] = r["seq"][rp + x]; s[gp + x] = 1
+                    rp += k; gp += k
+                elif op in "IS": rp += k
+                elif op in "DN": gp += k
+            end = gp if r["cigar"] else pos
+        raw = bytearray(r["raw"])
+        pos0 = pos - 1; end0 = end if (t >= 0 and not r["flag"] & 4 and r["cigar"]) else pos0 + 1
+        struct.pack_into("<i", raw, 8, pos0); struct.pack_into("<H", raw, 14, CD.reg2bin(pos0, end0) if pos0 >= 0 else 4680); struct.pack_into("<i", raw, 28, mpos - 1)
+        raws.append(bytes(raw))
+    # a few genome positions that no read agrees with, some N, and lower case in the FASTA (readers fold case)
+    for n, g in genome.items():
+        for _ in range(len(g) // 700): g[rng.randrange(len(g))] = rng.choice(b"ACGTN")
+    os.makedirs(out_dir, exist_ok=True)
+    bam = os.path.join(out_dir, "twin.bam"); fasta = os.path.join(out_dir, "genome.fa")
+    write_bam(bam, new_text, new_refs, raws)
+    with open(fasta, "wb") as f, open(fasta + ".fai", "w") as fai:
+        for n, l in new_refs:
+            f.write(b">" + n.encode() + b" made up\n"); off = f.tell(); g = bytes(genome[n])
+            body = bytearray()
+            for o in range(0, l, 60):
+                line = g[o:o + 60]
+                body += (line.lower() if (o // 60) % 7 == 3 else line) + b"\n"
+            f.write(body); fai.write("%s\t%d\t%d\t60\t61\n" % (n, l, off))
+    return dict(bam=bam, fasta=fasta, genome={n: bytes(g) for n, g in genome.items()}, text=new_text, refs=new_refs, records=raws)
+
+
+def ref_fetch_of(twin):
+    names = [n for n, _ in twin["refs"]]
+    return lambda ref_id, p0, n: twin["genome"][names[ref_id]][p0:p0 + n]

@@ -81,3 +81,82 @@ def test_damaged_and_unsupported_files(tmp_path, monkeypatch):
     assert e.value.code == ngsqc.capi.E_UNSUPPORTED if hasattr(ngsqc, "capi") and hasattr(ngsqc.capi, "E_UNSUPPORTED") else "3.1" in str(e.value)
     with pytest.raises(ngsqc.NgsqcError):
         ngsqc.cram_to_bam(os.path.join(GI, "sry.bam"), out)
+
+
+# ---- BAM truth: CRAM files written by oracle/cram_encode.py from the reference's BAM fixtures (moved onto short contigs with a made-up genome: tests/cram_twin.py) ----
+import cram_encode as CE  # noqa: E402
+import cram_twin  # noqa: E402
+from test_oracle_cram import VARIANTS  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def twins(tmp_path_factory):
+    out = {}
+    for src in ("MappingQC_in2.bam", "BamReader_rna.bam", "MappingQC_in5.bam"):
+        d = str(tmp_path_factory.mktemp("twin_" + src[:-4]))
+        out[src] = cram_twin.make_twin(os.path.join(GI, src), d, max_records=6000)
+    return out
+
+
+@pytest.mark.parametrize("src", ["MappingQC_in2.bam", "BamReader_rna.bam", "MappingQC_in5.bam"])
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_cram_of_a_bam_gives_back_the_bam(twins, src, variant, tmp_path, monkeypatch):
+    twin = twins[src]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "back.bam")
+    CE.encode(twin["bam"], cram, twin["genome"], **VARIANTS[variant])
+    monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False)
+    if variant in ("no_genome_needed", "embedded_reference"):
+        ngsqc.set_reference(None)                      # every base is in the file
+    else:
+        ngsqc.set_reference(twin["fasta"])
+    try:
+        ngsqc.cram_to_bam(cram, out)
+    finally:
+        ngsqc.set_reference(None)
+    text, refs, recs = split_bam(bam_stream(out)[0])
+    assert text.decode() == twin["text"] and refs == twin["refs"]
+    assert len(recs) == len(twin["records"]) > 500
+    for i, (got, want) in enumerate(zip(recs, twin["records"])):
+        assert got == want, (i, got[:48].hex(), want[:48].hex())
+
+
+def test_genome_errors(twins, tmp_path, monkeypatch):
+    twin = twins["MappingQC_in2.bam"]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "o.bam")
+    CE.encode(twin["bam"], cram, twin["genome"])
+    monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False); monkeypatch.delenv("NGSQC_REFERENCE", raising=False)
+    # the genome through the environment
+    monkeypatch.setenv("NGSQC_REFERENCE", twin["fasta"]); ngsqc.set_reference(None)
+    ngsqc.cram_to_bam(cram, out)
+    monkeypatch.delenv("NGSQC_REFERENCE")
+    # no genome, a path that does not exist: BamReader.cpp:486-489
+    for ref in (None, str(tmp_path / "nothing.fa")):
+        ngsqc.set_reference(ref)
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            ngsqc.cram_to_bam(cram, out)
+        assert "Error while setting reference genome" in str(e.value)
+    # another genome of the same lengths: the slices' MD5 does not match (htslib: "md5sum reference mismatch")
+    used = next(n for n, l in twin["refs"] if l > 1000)
+    other = str(tmp_path / "other.fa")
+    with open(other, "wb") as f, open(other + ".fai", "w") as fai:
+        for n, l in twin["refs"]:
+            f.write(b">" + n.encode() + b"\n"); off = f.tell()
+            g = bytearray(twin["genome"][n])
+            if n == used: g[150] = ord("A") if g[150] != ord("A") else ord("C")
+            f.write(bytes(g) + b"\n"); fai.write("%s\t%d\t%d\t%d\t%d\n" % (n, l, off, l, l + 1))
+    ngsqc.set_reference(other)
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.cram_to_bam(cram, out)
+    assert "md5sum reference mismatch" in str(e.value)
+    monkeypatch.setenv("NGSQC_CRAM_IGNORE_MD5", "1")
+    ngsqc.cram_to_bam(cram, out)                        # (htslib's ignore_md5 option)
+    monkeypatch.delenv("NGSQC_CRAM_IGNORE_MD5")
+    # a genome whose contig has another length: BamReader::checkChromosomeLengths (BamReader.cpp:491)
+    short = str(tmp_path / "short.fa")
+    with open(short, "wb") as f, open(short + ".fai", "w") as fai:
+        for n, l in twin["refs"]:
+            l2 = l - 5 if n == used else l
+            f.write(b">" + n.encode() + b"\n"); off = f.tell(); f.write(twin["genome"][n][:l2] + b"\n"); fai.write("%s\t%d\t%d\t%d\t%d\n" % (n, l2, off, l2, l2 + 1))
+    ngsqc.set_reference(short)
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.cram_to_bam(cram, out)
+    assert "differs from the length" in str(e.value)
+    ngsqc.set_reference(None)

@@ -135,3 +135,43 @@ def test_mate_chains_agree_with_the_mc_tag():
                     assert r.tlen == -m.tlen
                 assert bool(r.bf & 0x20) == bool(m.bf & 0x10) and bool(m.bf & 0x20) == bool(r.bf & 0x10)
     assert checked > 10000
+
+
+# ---- the CRAM writer of the oracle (oracle/cram_encode.py: what gives the product's CRAM input a BAM truth): read back by the pinned decoder it returns the BAM's records ----
+import cram_encode as CE  # noqa: E402
+import cram_twin  # noqa: E402
+
+VARIANTS = {"default": {}, "no_genome_needed": dict(rr=False), "multi_reference_slices": dict(multi_ref=True, slice_records=700), "embedded_reference": dict(embed_ref=True),
+            "plain_external": dict(variety=False, chains=False), "small_slices": dict(slice_records=150)}
+
+
+def test_eof_container_equals_the_fixtures():
+    tail = open(os.path.join(GI, "cramTest.cram"), "rb").read()[-38:]
+    assert CE.eof_container() == tail == open(os.path.join(GI, "SampleIdentity_in_rna.cram"), "rb").read()[-38:]
+
+
+def test_rans_encoder_round_trips():
+    import random
+    rng = random.Random(2)
+    for n in (0, 1, 3, 4, 5, 17, 1000, 70001):
+        for data in (bytes(rng.randrange(256) for _ in range(n)), bytes(rng.choice(b"AAAAACGT") for _ in range(n)), bytes([7]) * n):
+            for order in (0, 1):
+                assert CD.rans_decode(CE.rans_encode(data, order)) == data
+
+
+@pytest.mark.parametrize("src", ["MappingQC_in2.bam", "BamReader_rna.bam"])
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_written_cram_reads_back_as_the_bam(src, variant, tmp_path):
+    twin = cram_twin.make_twin(os.path.join(GI, src), str(tmp_path), max_records=4000)
+    cram = str(tmp_path / "twin.cram")
+    CE.encode(twin["bam"], cram, twin["genome"], **VARIANTS[variant])
+    f = CD.read_cram(cram, cram_twin.ref_fetch_of(twin))
+    rgs = CD.read_groups(f.header)
+    assert f.header == twin["text"] and len(f.records) == len(twin["records"]) > 500
+    assert not any(r.bases_from_ref for r in f.records)
+    for r, raw in zip(f.records, twin["records"]):
+        assert CD.to_bam_record(r, rgs) == raw, (r.name, CD.to_bam_record(r, rgs)[:48].hex(), raw[:48].hex())
+    kinds = {c for r in f.records for c, _, _ in r.features}
+    if variant == "default":
+        assert {"X", "S"} <= kinds and any(r.nf is not None for r in f.records) and any(r.cf & CD.CF_DETACHED for r in f.records)
+    if variant == "no_genome_needed": assert "b" in kinds and "X" not in kinds
