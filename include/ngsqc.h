@@ -37,7 +37,7 @@ typedef struct ngsqc_handle ngsqc_handle;
 #define NGSQC_E_FORMAT     -2   /* not BGZF / not BAM / corrupt record           BamReader.h:389-392  */
 #define NGSQC_E_ARG        -3   /* invalid argument (ArgumentException cases)    */
 #define NGSQC_E_DEVICE     -4   /* HIP runtime error / no device / out of memory */
-#define NGSQC_E_UNSUPPORTED -5  /* CRAM input (not implemented), etc.            */
+#define NGSQC_E_UNSUPPORTED -5  /* CRAM 3.1 codecs, bzip2 / lzma CRAM blocks     */
 
 /* ---- lifecycle (replaces BamReader ctor/dtor, BamReader.cpp:462-523) ---- */
 int  ngsqc_open(const char* bam_path, int device, ngsqc_handle** out);

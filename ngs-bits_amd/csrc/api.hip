@@ -143,6 +143,7 @@ struct TileCtx { const uint8_t* infl; int64_t total; const int64_t* recoff; int6
 struct ngsqc_handle
 {
 	std::string err, path;
+	bool from_cram = false;                        // the image is the BAM stream the host made of a CRAM 3.0 file (cram.hip)
 	int device = 0; int n_cu = 256;
 	hipStream_t stream = nullptr;                 // main stream: K2, consumers, setup copies
 	hipStream_t s_p1[2] = {nullptr, nullptr};      // K1 phase 1 (alternating: the next chunk's waves fill in as the previous chunk's finish)
@@ -1617,6 +1618,7 @@ struct ReadsState
 void write_bai(ngsqc_handle* h, const char* out_path, bool csi = false, int min_shift = 14)
 {
 	if (h->n_shards != 1 || h->shard_own_members >= 0 || h->member_off.size() != h->blocks.size()) throw ArgError("an index is written from a handle on the whole BAM (ngsqc_open / ngsqc_open_memory)");
+	if (h->from_cram) throw ArgError("the handle is on a CRAM file: its index is a .crai (samtools index), not a .bai / .csi");
 	const char* ext = csi ? ".csi" : ".bai";
 	const std::string path = out_path ? std::string(out_path) : h->path + ext;
 	if (path == ext) throw ArgError("no path for the index");
@@ -1835,9 +1837,8 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 			if (crc == NGSQC_E_UNSUPPORTED) throw std::domain_error(err);
 			if (crc != NGSQC_OK) throw std::runtime_error(err);
 			bgzf_store(stream, cram_image);
-			bytes = cram_image.data(); n = cram_image.size();
-			if (range && !range->head_members) range = nullptr;
-			if (range && range->head_members) range = nullptr;   // (the first records: the whole file holds them)
+			bytes = cram_image.data(); n = cram_image.size(); h->from_cram = true;
+			range = nullptr;   // (regions, a record range, the first records: the whole file holds them)
 		}
 		const char* ea = getenv("NGSQC_ASYNC_H2D");
 		if (path && !from_cram && n_shards == 1 && !range && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();

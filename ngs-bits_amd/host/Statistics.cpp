@@ -20,6 +20,8 @@ void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* r
 	head_members_ = head_members;
 	stamp("open: start");
 	ref_file_ = ref;
+	// CRAM input (BamReader.cpp:482-492: hts_set_fai_filename with the genome the caller names, else the one of the settings): the library decodes against it
+	if (ref != NO_REF) { std::string r = ref.empty() ? defaultReferenceGenome() : ref; ngsqc_set_reference(r.empty() ? nullptr : r.c_str()); }
 	int dev = 0; if (const char* e = getenv("NGSQC_DEVICE")) dev = atoi(e);
 	int n_shards = 1; if (allow_shards) if (const char* e = getenv("NGSQC_SHARDS")) n_shards = std::max(1, atoi(e));
 	int n_dev = 1; if (n_shards > 1) if (const char* e = getenv("NGSQC_DEVICES")) n_dev = std::max(1, atoi(e));

@@ -78,6 +78,8 @@ void QCCollection::storeToQCML(const std::string& filename, const std::vector<st
 	fwrite(o.data(), 1, o.size(), f); fclose(f);
 }
 
+std::string& defaultReferenceGenome() { static std::string g; return g; }
+
 std::string ToolBase::settingsString(const std::string& key) const
 {
 	// --settings <file>: that file only (doc/tools/*.md "Settings override file (no other settings files are used)")
@@ -191,6 +193,7 @@ int ToolBase::execute()
 				settings_override_ = args_[i + 1]; args_.erase(args_.begin() + (long)i, args_.begin() + (long)i + 2); --i;
 			}
 		parse();
+		defaultReferenceGenome() = settingsString("reference_genome");   // (RefGenomeService::getReferenceGenome: what a BamReader without an explicit genome opens a CRAM with)
 		main();
 		// The outputs are written and closed. Leaving through exit() would run the static destructors and the HIP runtime's teardown, which gives tens of GB of
 		// device memory back page by page (0.9 s for the buffers of a 60 GB BAM, profiles/r03_tool_probe.txt); the driver reclaims them at once when the process is gone.

@@ -44,11 +44,13 @@ inline std::string join(const std::vector<std::string>& v, const std::string& se
 inline std::string number(double v, int prec) { char b[64]; snprintf(b, sizeof(b), "%.*f", prec, v); return b; }  // QString::number(d,'f',prec)
 inline std::string fileName(const std::string& p) { size_t i = p.find_last_of('/'); return i == std::string::npos ? p : p.substr(i + 1); }   // QFileInfo::fileName
 inline std::string baseName(const std::string& p) { std::string f = fileName(p); size_t i = f.find('.'); return i == std::string::npos ? f : f.substr(0, i); } // QFileInfo::baseName
+std::string& defaultReferenceGenome();   // the genome of the settings (src/cppNGS/RefGenomeService.h), set by ToolBase before main()
 inline bool fileExists(const std::string& p) { std::ifstream f(p); return (bool)f; }
 // an index next to a BAM under one of the names sam_index_load tries (htslib hts_idx_check_local: <bam>.csi, <stem>.csi, <bam>.bai, <stem>.bai)
 inline bool hasBamIndex(const std::string& bam)
 {
 	const size_t dot = bam.rfind('.'); const std::string stem = dot == std::string::npos ? bam : bam.substr(0, dot);
+	if (bam.size() > 5 && bam.compare(bam.size() - 5, 5, ".cram") == 0) return fileExists(bam + ".crai") || fileExists(stem + ".crai");   // (a CRAM is indexed by a .crai)
 	return fileExists(bam + ".csi") || fileExists(stem + ".csi") || fileExists(bam + ".bai") || fileExists(stem + ".bai");
 }
 inline std::string htmlEscaped(const std::string& s) // QString::toHtmlEscaped

@@ -1,0 +1,119 @@
+"""CRAM 3.0 input through the product on the device (BamReader.cpp:482-492: the reference opens CRAM with the same reader as BAM): a handle on a CRAM gives the
+counters, depth and read statistics of the BAM with the same records - for twins of the reference's BAM fixtures (tests/cram_twin.py: CRAM written by
+oracle/cram_encode.py, a made-up genome) and for the reference's own CRAM fixture that carries all its bases (SampleIdentity_in_rna.cram, against the BAM that
+oracle/cram_decode.py makes of it); the tools take `-in x.cram -ref genome.fa` and write what they write for the BAM."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hostprep as H
+from conftest import GOLDEN_IN as GI, ROOT
+
+pytestmark = pytest.mark.gpu
+ngsqc = __import__("importlib").import_module("ngs-bits_amd")
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import cram_decode as CD  # noqa: E402
+import cram_encode as CE  # noqa: E402
+import cram_twin  # noqa: E402
+
+BIN = os.path.join(ROOT, "ngs-bits_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def twin(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("cram_twin"))
+    t = cram_twin.make_twin(os.path.join(GI, "MappingQC_in2.bam"), d, max_records=20000)
+    t["cram"] = os.path.join(d, "twin.cram"); CE.encode(t["bam"], t["cram"], t["genome"])
+    t["cram_multi"] = os.path.join(d, "multi.cram"); CE.encode(t["bam"], t["cram_multi"], t["genome"], multi_ref=True, slice_records=900)
+    t["cram_norr"] = os.path.join(d, "norr.cram"); CE.encode(t["bam"], t["cram_norr"], t["genome"], rr=False)
+    return t
+
+
+def _mapping(h):
+    tx, ty = H.xy_tids(h.refs)
+    return h.scan_mapping(ngsqc.MODE_WGS, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs))
+
+
+def _same_results(a, b):
+    assert a.refs == b.refs and a.n_records == b.n_records > 1000
+    ca, _ = _mapping(a); cb, _ = _mapping(b)
+    assert np.array_equal(ca, cb) and int(ca.sum()) > 0
+    assert np.array_equal(a.inflated(), b.inflated())                 # the same BAM stream, byte for byte
+    assert np.array_equal(a.record_offsets(), b.record_offsets())
+    tid = next(i for i, (n, l) in enumerate(a.refs) if l > 5000)
+    regs = [(tid, 1, min(a.refs[tid][1], 60000))]
+    a.scan_depth(regs, min_mapq=1); b.scan_depth(regs, min_mapq=1)
+    n = regs[0][2]
+    assert np.array_equal(a.depth(n), b.depth(n)) and int(a.depth(n).sum()) > 0
+
+
+@pytest.mark.parametrize("which", ["cram", "cram_multi", "cram_norr"])
+def test_handle_on_a_cram_equals_the_handle_on_its_bam(twin, which):
+    ngsqc.set_reference(None if which == "cram_norr" else twin["fasta"])
+    try:
+        a = ngsqc.Handle(path=twin[which]); b = ngsqc.Handle(path=twin["bam"])
+        try:
+            _same_results(a, b)
+        finally:
+            a.close(); b.close()
+        data = np.fromfile(twin[which], dtype=np.uint8)               # ngsqc_open_memory takes a CRAM image as well
+        a = ngsqc.Handle(data=data); b = ngsqc.Handle(path=twin["bam"])
+        try:
+            assert a.n_records == b.n_records
+            assert np.array_equal(_mapping(a)[0], _mapping(b)[0])
+        finally:
+            a.close(); b.close()
+    finally:
+        ngsqc.set_reference(None)
+
+
+def test_cram_without_its_genome_is_the_references_error(twin):
+    ngsqc.set_reference(None)
+    with pytest.raises(ngsqc.NgsqcError) as e:
+        ngsqc.Handle(path=twin["cram"])
+    assert "Error while setting reference genome" in str(e.value)
+
+
+def test_reference_fixture_that_carries_its_bases(tmp_path):
+    """SampleIdentity_in_rna.cram (htslib-written, RR = false): the handle's BAM stream is the oracle's record for record, and the counters equal those of that BAM"""
+    src = os.path.join(GI, "SampleIdentity_in_rna.cram")
+    f = CD.read_cram(src); rgs = CD.read_groups(f.header)
+    bam = str(tmp_path / "rna.bam")
+    cram_twin.write_bam(bam, f.header, CD.ref_names(f.header), [CD.to_bam_record(r, rgs) for r in f.records])
+    a = ngsqc.Handle(path=src); b = ngsqc.Handle(path=bam)
+    try:
+        assert a.n_records == b.n_records == len(f.records)
+        assert np.array_equal(a.inflated(), b.inflated())
+        assert np.array_equal(_mapping(a)[0], _mapping(b)[0])
+    finally:
+        a.close(); b.close()
+
+
+def _run(tool, *args, env=None, ok=True):
+    p = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=300)
+    if ok: assert p.returncode == 0, p.stderr
+    return p
+
+
+def test_tools_on_a_cram_write_what_they_write_for_the_bam(twin, tmp_path):
+    strip = re.compile(r"creation |<binary>|source file|twin\.(bam|cram)")
+    outs = {}
+    for kind in ("bam", "cram"):
+        o = str(tmp_path / (kind + ".qcML"))
+        # (-no_ref: no GC / AT dropout from the made-up genome; the CRAM decoder then takes the genome from NGSQC_REFERENCE)
+        _run("MappingQC", "-in", twin[kind], "-wgs", "-build", "hg19", "-no_ref", "-out", o, env={"NGSQC_REFERENCE": twin["fasta"]})
+        outs[kind] = [ln for ln in open(o).read().splitlines() if not strip.search(ln)]
+    assert outs["bam"] == outs["cram"] and len(outs["bam"]) > 30
+    name = next(n for n, l in twin["refs"] if l > 5000)
+    bed = str(tmp_path / "r.bed"); open(bed, "w").write("%s\t100\t3000\n%s\t4000\t4800\n" % (name, name))
+    cov = {k: _run("BedCoverage", "-bam", twin[k], "-in", bed, "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
+    assert cov["bam"].replace("twin.bam", "X") == cov["cram"].replace("twin.cram", "X") and len(cov["bam"].splitlines()) >= 2
+    low = {k: _run("BedLowCoverage", "-bam", twin[k], "-in", bed, "-cutoff", "20", "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
+    assert low["bam"] == low["cram"]
+    # without a genome: the reference's error (BamReader.cpp:486-489), exit code 1
+    p = _run("BedCoverage", "-bam", twin["cram"], "-in", bed, ok=False, env={"NGSQC_REFERENCE": ""})
+    assert p.returncode != 0 and "Error while setting reference genome" in (p.stderr + p.stdout)
