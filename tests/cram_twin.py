@@ -21,11 +21,11 @@ def _bgzf(raw, level=6):
 def write_bam(path, text, refs, raw_records):
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
     for name, ln in refs: hdr += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
-    out = bytearray(_bgzf(hdr)); chunk = bytearray()
+    out = bytearray(); chunk = bytearray(hdr)          # (a header of thousands of contigs spans several members, like the records)
     for r in raw_records:
         chunk += r
-        if len(chunk) > 60000: out += _bgzf(bytes(chunk[:60000])); del chunk[:60000]
-    while chunk: out += _bgzf(bytes(chunk[:60000])); del chunk[:60000]
+        while len(chunk) > 60000: out += _bgzf(bytes(chunk[:60000])); del chunk[:60000]
+    if chunk: out += _bgzf(bytes(chunk))
     open(path, "wb").write(bytes(out) + _bgzf(b""))
 
 
