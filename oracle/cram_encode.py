@@ -298,11 +298,16 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
         if cur and ((not multi_ref and key != cur[0]["ref_id"]) or len(cur) >= slice_records): groups.append(cur); cur = []
         cur.append(r)
     if cur: groups.append(cur)
-    counter = 0
+    counter = 0; crai = []
     for g in groups:
-        out += encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter); counter += len(g)
+        at = len(out)
+        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter); counter += len(g)
+        out += c; crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (line[0], line[1], line[2], at, line[3], line[4]))
     out += eof_container()
     open(out_path, "wb").write(bytes(out))
+    # the index `samtools index` writes for a CRAM (.crai: gzip text - reference, start, span, container offset, slice offset in the container, slice size)
+    import gzip
+    with gzip.open(out_path + ".crai", "wb") as f: f.write("".join(crai).encode())
 
 
 def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter):
@@ -459,7 +464,7 @@ def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety
     sh = itf8(slice_ref) + itf8(start) + itf8(span) + itf8(len(g)) + ltf8(counter) + itf8(1 + len(ext_blocks)) + array_itf8(content_ids) + itf8(emb_id) + md5
     sh_block = block(0, 2, 0, sh)
     blocks = [ch_block, sh_block, core] + ext_blocks
-    return container(slice_ref, start, span, len(g), counter, bases, blocks, [len(ch_block)])
+    return container(slice_ref, start, span, len(g), counter, bases, blocks, [len(ch_block)]), (slice_ref, start, span, len(ch_block), sum(len(b) for b in blocks[1:]))
 
 
 def chain_reproduces(a, b):
