@@ -46,6 +46,7 @@ void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* r
 			for (ngsqc_handle* o : shards_) ngsqc_close(o);
 			shards_.clear();
 			if (rc == NGSQC_E_IO && msg.find("Could not load index") != std::string::npos) NB_THROW(FileAccessException, msg);
+			if (rc == NGSQC_E_IO && msg.find("Error while setting reference genome") != std::string::npos) NB_THROW(FileAccessException, msg);   // BamReader.cpp:486-489 (CRAM)
 			if (rc == NGSQC_E_IO) NB_THROW(FileAccessException, "Could not open BAM/CRAM file " + bam_file_);   // BamReader.cpp:467
 			if (rc == NGSQC_E_DEVICE) NB_THROW(Exception, "GPU backend unavailable: " + msg);
 			NB_THROW(FileAccessException, msg);
@@ -1190,13 +1191,13 @@ void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int
 	for (long long i = 0; i < bed_file.count(); ++i) bed_file[i].annotations().push_back(number((double)sums[(size_t)i] / bed_file[i].length(), decimals));
 }
 
-BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access)
+BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access, const std::string& ref_file)
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
 	if (!random_access && cutoff > 255) NB_THROW(ArgumentException, "Cutoff cannot be bigger than 255!");   // WorkerLowOrHighCoverage.cpp:149
 	BedFile output;
 	if (bed_file.count() == 0) return output;
-	BamReader reader(bam_file, "", true, bed_file);
+	BamReader reader(bam_file, ref_file, true, bed_file);
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);
 	ngsqc_depth_params p{}; p.min_mapq = min_mapq; p.min_baseq = min_baseq; p.regions = regions.data(); p.n_regions = (int64_t)regions.size();
@@ -1210,7 +1211,7 @@ BedFile Statistics::lowOrHighCoverage(const BedFile& bed_file, const std::string
 	output.merge(true, true, true);   // Statistics.cpp:2655
 	return output;
 }
-BedFile Statistics::lowCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string&, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, false, random_access); }
-BedFile Statistics::highCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string&, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, true, random_access); }
+BedFile Statistics::lowCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string& ref_file, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, false, random_access, ref_file); }
+BedFile Statistics::highCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, int, const std::string& ref_file, bool random_access, bool) { return lowOrHighCoverage(bed_file, bam_file, cutoff, min_mapq, min_baseq, true, random_access, ref_file); }
 
 } // namespace ngsbits

@@ -84,7 +84,7 @@ public:
 	static void addQcValue(QCCollection& output, const std::string& accession, const std::string& name, const std::string& value);
 	static void addQcPlot(QCCollection& output, const std::string& accession, const std::string& name, const std::vector<double>& x, const std::vector<std::vector<double>>& lines);
 private:
-	static BedFile lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access);
+	static BedFile lowOrHighCoverage(const BedFile& bed_file, const std::string& bam_file, int cutoff, int min_mapq, int min_baseq, bool is_high, bool random_access, const std::string& ref_file = "");
 };
 
 // Raw-read QC of a BAM (src/cppNGS/StatisticsReads.h; MappingQC -read_qc, src/MappingQC/main.cpp:83-98). The reference feeds
