@@ -114,7 +114,7 @@ def test_tools_on_a_cram_write_what_they_write_for_the_bam(twin, tmp_path):
     cov = {k: _run("BedCoverage", "-bam", twin[k], "-in", bed, "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
     assert cov["bam"].replace("twin.bam", "X") == cov["cram"].replace("twin.cram", "X") and len(cov["bam"].splitlines()) >= 2
     low = {k: _run("BedLowCoverage", "-bam", twin[k], "-in", bed, "-cutoff", "20", "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
-    assert low["bam"] == low["cram"]
+    assert low["bam"].replace("twin.bam", "X") == low["cram"].replace("twin.cram", "X") and len(low["bam"].splitlines()) > 3
     # without a genome: the reference's error (BamReader.cpp:486-489), exit code 1
     p = _run("BedCoverage", "-bam", twin["cram"], "-in", bed, ok=False, env={"NGSQC_REFERENCE": ""})
     assert p.returncode != 0 and "Error while setting reference genome" in (p.stderr + p.stdout)
