@@ -235,12 +235,13 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
  * (hts_set_fai_filename). Here every ngsqc_open* entry point takes a CRAM 3.0 file: its container layer (containers, slices, blocks with CRC-32, gzip and rANS
  * 4x8 blocks, the encodings, read features, mate chains, the slices' reference MD5) is decoded on the HOST into BAM records, which reach the device as a BAM image
  * whose BGZF members hold stored blocks - the device path (K1's stored-block copy, CRC, record index, walk, depth, counters) is the BAM path. Index-driven
- * requests on a CRAM decode the whole file (a superset). ngsqc_set_reference names the genome (FASTA with .fai; NULL / "": none; NGSQC_REFERENCE is the
+ * requests on a CRAM (ngsqc_open_regions) decode only the slices whose headers overlap a region - what the .crai names, read from the slice headers themselves;
+ * ngsqc_open_head the first two slices; ngsqc_open_range the whole file. ngsqc_set_reference names the genome (FASTA with .fai; NULL / "": none; NGSQC_REFERENCE is the
  * fallback) for files that need one (preservation key RR); without it: NGSQC_E_IO "Error while setting reference genome ...", a genome that does not match a
  * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1 codecs, bzip2 and lzma blocks: NGSQC_E_UNSUPPORTED. ngsqc_cram_to_bam writes the decoded records as a BAM file
  * (host only; the checker of the decoder: tests compare it record by record with oracle/cram_decode.py). */
 int ngsqc_set_reference(const char* fasta_path);
-int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path);
+int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions);   /* regions NULL / 0: every record */
 
 /* ---- writing the index. The reference never builds one: every indexed path above fails with "Could not load index of BAM/CRAM file"
  * (BamReader.cpp:742-746) until `samtools index` (htslib sam_index_build: hts_idx_push / hts_idx_finish / compress_binning, hts.c) has left a

@@ -204,10 +204,15 @@ def set_reference(fasta_path):
     L.ngsqc_set_reference(os.fsencode(fasta_path) if fasta_path else None)
 
 
-def cram_to_bam(cram_path, bam_path):
-    """Host only: the records of a CRAM 3.0 file as a BAM file (BGZF members with stored blocks) - what ngsqc_open hands to the device for a CRAM."""
-    L = lib(); L.ngsqc_cram_to_bam.restype = C.c_int; L.ngsqc_cram_to_bam.argtypes = [C.c_char_p, C.c_char_p]
-    rc = L.ngsqc_cram_to_bam(os.fsencode(cram_path), os.fsencode(bam_path))
+def cram_to_bam(cram_path, bam_path, regions=None):
+    """Host only: the records of a CRAM 3.0 file as a BAM file (BGZF members with stored blocks) - what ngsqc_open hands to the device for a CRAM.
+    regions [(chromosome name, start, end)]: only the slices that can hold their records (what ngsqc_open_regions decodes)."""
+    class NR(C.Structure):
+        _fields_ = [("chr", C.c_char_p), ("start", C.c_int32), ("end", C.c_int32)]
+    L = lib(); L.ngsqc_cram_to_bam.restype = C.c_int; L.ngsqc_cram_to_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64]
+    regions = regions or []
+    arr = (NR * max(len(regions), 1))(*[NR(os.fsencode(c), int(a), int(b)) for c, a, b in regions])
+    rc = L.ngsqc_cram_to_bam(os.fsencode(cram_path), os.fsencode(bam_path), C.cast(arr, C.c_void_p) if regions else None, len(regions))
     if rc != 0:
         raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
 

@@ -1831,7 +1831,12 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		if (from_cram)
 		{
 			std::vector<uint8_t> stream; std::string err;
-			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err);
+			// regions: the slices whose headers overlap them (what the .crai of `samtools index` would name; the slice headers themselves are read instead);
+			// the first records: the first two slices; a virtual-offset range means nothing in a CRAM: the whole file
+			CramSelect sel;
+			if (range && range->by_name) for (int64_t i = 0; i < range->n_regions; ++i) sel.regions.push_back(CramSelect::Region{range->regions[i].chr ? range->regions[i].chr : "", range->regions[i].start, range->regions[i].end});
+			if (range && range->head_members > 0) sel.max_slices = 2;
+			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err, &sel);
 			if (crc == NGSQC_E_FORMAT) throw FormatError(err);
 			if (crc == NGSQC_E_IO) throw IoError(err);
 			if (crc == NGSQC_E_UNSUPPORTED) throw std::domain_error(err);
@@ -2125,16 +2130,18 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int ngsqc_set_reference(const char* fasta_path) { ngsqc::cram_set_reference(fasta_path); return NGSQC_OK; }
-int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path)
+int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions)
 {
-	if (!cram_path || !bam_path) return NGSQC_E_ARG;
+	if (!cram_path || !bam_path || n_regions < 0 || (!regions && n_regions > 0)) return NGSQC_E_ARG;
 	try
 	{
 		std::ifstream f(cram_path, std::ios::binary);
 		if (!f) { g_open_error = std::string("Could not open BAM/CRAM file ") + cram_path; return NGSQC_E_IO; }
 		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()), stream, image; std::string err;
 		if (!ngsqc::is_cram(d.data(), d.size())) { g_open_error = std::string("not a CRAM file: ") + cram_path; return NGSQC_E_FORMAT; }
-		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err);
+		ngsqc::CramSelect sel;
+		for (int64_t i = 0; i < n_regions; ++i) sel.regions.push_back(ngsqc::CramSelect::Region{regions[i].chr ? regions[i].chr : "", regions[i].start, regions[i].end});
+		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err, &sel);
 		if (rc != NGSQC_OK) { g_open_error = err; return rc; }
 		ngsqc::bgzf_store(stream, image);
 		std::ofstream o(bam_path, std::ios::binary | std::ios::trunc);

@@ -45,7 +45,8 @@ std::string bai_assemble(const std::string& out_path, int32_t n_ref, uint64_t of
 bool is_cram(const uint8_t* d, size_t n);
 void cram_set_reference(const char* fasta);
 std::string cram_reference();
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err);   // NGSQC_OK or an NGSQC_E_* code with err
+struct CramSelect { struct Region { std::string chr; int32_t start, end; }; std::vector<Region> regions; int64_t max_slices = 0; };   // regions: only slices that can hold their records; max_slices: the first slices only
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
 void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image);
 
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)

@@ -719,7 +719,7 @@ bool is_cram(const uint8_t* d, size_t n) { return n >= 4 && memcmp(d, "CRAM", 4)
 
 namespace {
 // the whole CRAM as an uncompressed BAM stream ("BAM\1", header, records in file order). Throws FormatError / IoError / std::domain_error.
-void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream)
+void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, const CramSelect* sel)
 {
 	try
 	{
@@ -760,6 +760,19 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			}
 		}
 		// ---- containers -> slice jobs ----
+		// a selection (index-driven requests): named regions -> reference ids (names as in the header, with or without "chr", like the BAM path); a slice is kept when
+		// its own header says it can hold a record of a region (multi-reference slices always) - the slice headers are read, the other blocks only skipped, so no
+		// .crai is needed to find them. A region on a sequence the file does not have selects nothing.
+		std::vector<ngsqc_region> want;
+		if (sel) for (const CramSelect::Region& g : sel->regions)
+		{
+			int32_t tid = -1;
+			auto bare = [](const std::string& x) { return x.compare(0, 3, "chr") == 0 ? x.substr(3) : x; };
+			for (size_t i = 0; i < ref_names.size() && tid < 0; ++i) if (ref_names[i] == g.chr) tid = (int32_t)i;
+			for (size_t i = 0; i < ref_names.size() && tid < 0; ++i) if (bare(ref_names[i]) == bare(g.chr)) tid = (int32_t)i;
+			if (tid >= 0) want.push_back(ngsqc_region{tid, g.start, g.end});
+		}
+		const bool by_region = sel && !sel->regions.empty(); size_t n_seen = 0;
 		std::vector<std::unique_ptr<CompHdr>> headers; std::vector<SliceJob> jobs; std::vector<Blk> blocks; bool any_rr = false, eof = false;
 		while (c.p < n)
 		{
@@ -778,7 +791,15 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 				SliceJob j; j.ch = headers.back().get(); read_slice_header(sb.p, sb.n, j.sh); j.blocks_at = c.p;
 				// (the blocks are inflated by the slice's worker: skip over them here)
 				for (int32_t b = 0; b < j.sh.n_blocks; ++b) { c.byte(); c.byte(); c.itf8(); const int32_t cs = c.itf8(); c.itf8(); if (cs < 0) throw CramError("bad CRAM block sizes"); c.take((size_t)cs + 4); }
-				jobs.push_back(std::move(j));
+				++n_seen;
+				bool keep = true;
+				if (by_region)
+				{
+					keep = j.sh.ref_id == -2;
+					if (j.sh.ref_id >= 0) for (const ngsqc_region& g : want) keep = keep || (g.tid == j.sh.ref_id && (int64_t)g.start <= (int64_t)j.sh.start + j.sh.span - 1 && (int64_t)g.end >= j.sh.start);
+				}
+				if (sel && sel->max_slices > 0 && n_seen > (size_t)sel->max_slices) keep = false;
+				if (keep) jobs.push_back(std::move(j));
 			}
 			c.p = end;
 		}
@@ -847,9 +868,9 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 } // namespace
 
 // NGSQC_OK or NGSQC_E_FORMAT / NGSQC_E_IO / NGSQC_E_UNSUPPORTED / NGSQC_E_DEVICE with the message in err
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err)
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel)
 {
-	try { cram_to_bam_stream_impl(d, n, path, stream); return NGSQC_OK; }
+	try { cram_to_bam_stream_impl(d, n, path, stream, sel); return NGSQC_OK; }
 	catch (FormatError& e) { err = e.what(); return NGSQC_E_FORMAT; }
 	catch (IoError& e) { err = e.what(); return NGSQC_E_IO; }
 	catch (std::domain_error& e) { err = e.what(); return NGSQC_E_UNSUPPORTED; }

@@ -160,3 +160,28 @@ def test_genome_errors(twins, tmp_path, monkeypatch):
         ngsqc.cram_to_bam(cram, out)
     assert "differs from the length" in str(e.value)
     ngsqc.set_reference(None)
+
+
+def test_region_selection_decodes_only_the_overlapping_slices(twins, tmp_path):
+    """what ngsqc_open_regions does with a CRAM: slices whose headers overlap a region (read from the slice headers, no .crai needed) - every record that overlaps the
+    region is there, in file order, and far fewer records are decoded than the file holds"""
+    twin = twins["MappingQC_in5.bam"]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "part.bam")
+    CE.encode(twin["bam"], cram, twin["genome"], slice_records=200)
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        parsed = [CE.parse_record(r) for r in twin["records"]]
+        names = [n for n, _ in twin["refs"]]
+        used = sorted({r["ref_id"] for r in parsed if r["ref_id"] >= 0 and not r["flag"] & 4})
+        t = used[len(used) // 2]; on_t = [r for r in parsed if r["ref_id"] == t]
+        mid = on_t[len(on_t) // 2]["pos"]; region = (names[t], mid, mid + 150)
+        for chrom in (region[0], region[0][3:] if region[0].startswith("chr") else "chr" + region[0]):   # with and without "chr"
+            ngsqc.cram_to_bam(cram, out, regions=[(chrom, region[1], region[2])])
+            _, _, recs = split_bam(bam_stream(out)[0])
+            want = [r["raw"] for r in parsed if r["ref_id"] == t and r["pos"] <= region[2] and CE.ref_end(r) >= region[1]]
+            assert want and 0 < len(recs) < len(parsed) // 3
+            it = iter(recs)
+            assert all(any(w == g for g in it) for w in want)       # all of them, in order
+        ngsqc.cram_to_bam(cram, out, regions=[("no_such_contig", 1, 100)])
+        assert split_bam(bam_stream(out)[0])[2] == []
+    finally:
+        ngsqc.set_reference(None)

@@ -118,3 +118,27 @@ def test_tools_on_a_cram_write_what_they_write_for_the_bam(twin, tmp_path):
     # without a genome: the reference's error (BamReader.cpp:486-489), exit code 1
     p = _run("BedCoverage", "-bam", twin["cram"], "-in", bed, ok=False, env={"NGSQC_REFERENCE": ""})
     assert p.returncode != 0 and "Error while setting reference genome" in (p.stderr + p.stdout)
+
+
+def test_regions_on_a_cram_decode_only_their_slices(twin, tmp_path):
+    """ngsqc_open_regions on a CRAM (BamReader::setRegion on a CRAM goes through the .crai): the slices whose headers overlap the regions, the depth and read counts
+    of the whole file inside the region"""
+    cram = str(tmp_path / "small_slices.cram"); CE.encode(twin["bam"], cram, twin["genome"], slice_records=300)
+    name, ln = max(twin["refs"], key=lambda x: x[1]); tid = [n for n, _ in twin["refs"]].index(name)
+    region = (name, ln // 2, ln // 2 + 200); regs = [(tid, region[1], region[2])]
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        whole = ngsqc.Handle(path=cram); part = ngsqc.Handle(path=cram, regions=[region]); head = ngsqc.Handle(path=twin["bam"])
+        try:
+            n = region[2] - region[1] + 1
+            whole.scan_depth(regs, min_mapq=1); part.scan_depth(regs, min_mapq=1); head.scan_depth(regs, min_mapq=1)
+            d = whole.depth(n)
+            assert d.sum() > 0 and np.array_equal(d, part.depth(n)) and np.array_equal(d, head.depth(n))
+            assert np.array_equal(whole.region_read_counts(regs, 1), part.region_read_counts(regs, 1))
+            assert 0 < part.n_records < whole.n_records // 2
+            with pytest.raises(ngsqc.NgsqcError):
+                part.write_bai(str(tmp_path / "x.bai"))          # the index of a CRAM is a .crai
+        finally:
+            whole.close(); part.close(); head.close()
+    finally:
+        ngsqc.set_reference(None)
