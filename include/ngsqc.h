@@ -37,7 +37,7 @@ typedef struct ngsqc_handle ngsqc_handle;
 #define NGSQC_E_FORMAT     -2   /* not BGZF / not BAM / corrupt record           BamReader.h:389-392  */
 #define NGSQC_E_ARG        -3   /* invalid argument (ArgumentException cases)    */
 #define NGSQC_E_DEVICE     -4   /* HIP runtime error / no device / out of memory */
-#define NGSQC_E_UNSUPPORTED -5  /* CRAM 3.1 codecs, bzip2 / lzma CRAM blocks     */
+#define NGSQC_E_UNSUPPORTED -5  /* CRAM 3.1 codecs                               */
 
 /* ---- lifecycle (replaces BamReader ctor/dtor, BamReader.cpp:462-523) ---- */
 int  ngsqc_open(const char* bam_path, int device, ngsqc_handle** out);
@@ -238,7 +238,7 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
  * requests on a CRAM (ngsqc_open_regions) decode only the slices whose headers overlap a region - what the .crai names, read from the slice headers themselves;
  * ngsqc_open_head the first two slices; ngsqc_open_range the whole file. ngsqc_set_reference names the genome (FASTA with .fai; NULL / "": none; NGSQC_REFERENCE is the
  * fallback) for files that need one (preservation key RR); without it: NGSQC_E_IO "Error while setting reference genome ...", a genome that does not match a
- * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1 codecs, bzip2 and lzma blocks: NGSQC_E_UNSUPPORTED. ngsqc_cram_to_bam writes the decoded records as a BAM file
+ * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1 codecs: NGSQC_E_UNSUPPORTED (bzip2 / lzma blocks need libbz2 / liblzma on the machine, loaded on first use). ngsqc_cram_to_bam writes the decoded records as a BAM file
  * (host only; the checker of the decoder: tests compare it record by record with oracle/cram_decode.py). */
 int ngsqc_set_reference(const char* fasta_path);
 int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions);   /* regions NULL / 0: every record */

@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 namespace ngsqc {
 
@@ -128,6 +129,35 @@ void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out)
 	while (idx[3] < n_out) step(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- bzip2 / lzma blocks
+// (what `samtools view -O cram,use_bzip2 / use_lzma` writes for some series.) The image carries the runtime libraries but not their headers: the two one-shot
+// entry points are declared here as bzlib.h / lzma.h declare them and the libraries are loaded on first use; without them such a block is NGSQC_E_UNSUPPORTED.
+typedef int (*bz2_decompress_fn)(char* dest, unsigned int* dest_len, char* source, unsigned int source_len, int small, int verbosity);   // BZ2_bzBuffToBuffDecompress
+typedef int (*lzma_decode_fn)(uint64_t* memlimit, uint32_t flags, const void* allocator, const uint8_t* in, size_t* in_pos, size_t in_size, uint8_t* out, size_t* out_pos, size_t out_size);   // lzma_stream_buffer_decode
+void* load_symbol(const char* const* libs, const char* name)
+{
+	for (; *libs; ++libs) if (void* h = dlopen(*libs, RTLD_NOW | RTLD_GLOBAL)) if (void* f = dlsym(h, name)) return f;
+	return nullptr;
+}
+void bz2_block(const uint8_t* raw, size_t csize, size_t rsize, std::vector<uint8_t>& out)
+{
+	static const char* const libs[] = {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so", nullptr};
+	static bz2_decompress_fn fn = (bz2_decompress_fn)load_symbol(libs, "BZ2_bzBuffToBuffDecompress");
+	if (!fn) throw std::domain_error("CRAM block compressed with bzip2 and no libbz2 on this machine");
+	out.assign(rsize ? rsize : 1, 0); unsigned int got = (unsigned int)out.size();
+	if (fn((char*)out.data(), &got, (char*)const_cast<uint8_t*>(raw), (unsigned int)csize, 0, 0) != 0 || got != rsize) throw CramError("bzip2 block of the CRAM file does not decompress");
+	out.resize(rsize);
+}
+void lzma_block(const uint8_t* raw, size_t csize, size_t rsize, std::vector<uint8_t>& out)
+{
+	static const char* const libs[] = {"liblzma.so.5", "liblzma.so", nullptr};
+	static lzma_decode_fn fn = (lzma_decode_fn)load_symbol(libs, "lzma_stream_buffer_decode");
+	if (!fn) throw std::domain_error("CRAM block compressed with lzma and no liblzma on this machine");
+	out.assign(rsize ? rsize : 1, 0); uint64_t memlimit = 1ull << 31; size_t in_pos = 0, out_pos = 0;
+	if (fn(&memlimit, 0, nullptr, raw, &in_pos, csize, out.data(), &out_pos, rsize) != 0 || out_pos != rsize) throw CramError("lzma block of the CRAM file does not decompress");
+	out.resize(rsize);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- blocks, containers
 struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; };
 uint32_t crc_of(const uint8_t* p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
@@ -135,7 +165,7 @@ void read_block(Cur& c, Blk& b)
 {
 	const size_t start = c.p;
 	b.method = c.byte(); b.ctype = c.byte(); b.cid = c.itf8(); const int32_t csize = c.itf8(), rsize = c.itf8();
-	if (csize < 0 || rsize < 0) throw CramError("bad CRAM block sizes");
+	if (csize < 0 || rsize < 0 || rsize > (1 << 30)) throw CramError("bad CRAM block sizes");
 	const uint8_t* raw = c.take((size_t)csize);
 	const size_t crc_at = c.p; const uint32_t crc = c.u32();
 	if (crc_of(c.d + start, crc_at - start) != crc) throw CramError("CRAM block CRC mismatch");
@@ -152,7 +182,8 @@ void read_block(Cur& c, Blk& b)
 		b.p = b.own.data(); b.n = b.own.size();
 	}
 	else if (b.method == 4) { rans_decode(raw, (size_t)csize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
-	else if (b.method == 2 || b.method == 3) throw std::domain_error(std::string("CRAM block compressed with ") + (b.method == 2 ? "bzip2" : "lzma") + " is not supported by the HIP path");
+	else if (b.method == 2) { bz2_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
+	else if (b.method == 3) { lzma_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
 	else throw std::domain_error("CRAM 3.1 block codec " + std::to_string(b.method) + " is not supported by the HIP path");
 	if (b.n != (size_t)rsize) throw CramError("CRAM block inflates to another size than its header says");
 }
@@ -270,7 +301,7 @@ void read_slice_header(const uint8_t* d, size_t n, SliceHdr& s)
 	Cur c(d, n);
 	s.ref_id = c.itf8(); s.start = c.itf8(); s.span = c.itf8(); s.n_records = c.itf8(); s.counter = c.ltf8(); s.n_blocks = c.itf8();
 	s.content_ids = c.array_itf8(); s.embedded_ref = c.itf8(); memcpy(s.md5, c.take(16), 16);
-	if (s.n_records < 0 || s.n_blocks < 0) throw CramError("bad CRAM slice header");
+	if (s.n_records < 0 || s.n_records > (1 << 27) || s.n_blocks < 0 || s.n_blocks > (1 << 20)) throw CramError("bad CRAM slice header");
 }
 
 // ---------------------------------------------------------------------------------------------------------------- MD5 (RFC 1321) of a reference stretch
@@ -521,7 +552,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		r.bf = (uint32_t)D.integer(eBF); r.cf = (uint32_t)D.integer(eCF);
 		r.ref_id = sh.ref_id == -2 ? D.integer(ch.series("RI")) : sh.ref_id;
 		const int32_t rl = D.integer(eRL);
-		if (rl < 0) throw CramError("negative read length");
+		if (rl < 0 || rl > (1 << 28)) throw CramError("read length out of range");
 		const int32_t ap = D.integer(eAP);
 		if (ch.AP) { prev_pos += ap; r.pos = (int32_t)prev_pos; } else r.pos = ap;
 		const int32_t rg = D.integer(eRG);
@@ -560,7 +591,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		if (!(r.bf & BAM_FUNMAP))
 		{
 			const int32_t fn = D.integer(ch.series("FN"));
-			if (fn < 0) throw CramError("negative feature count");
+			if (fn < 0 || fn > 2 * rl + 64) throw CramError("feature count out of range");
 			feats.clear(); feats.resize((size_t)fn); int32_t fpos = 0;
 			for (Feature& f : feats)
 			{

@@ -130,6 +130,10 @@ def block(method, ctype, cid, data):
     if method == 0: comp = data
     elif method == 1:
         c = zlib.compressobj(6, zlib.DEFLATED, 31); comp = c.compress(data) + c.flush()
+    elif method == 2:
+        import bz2; comp = bz2.compress(data)
+    elif method == 3:
+        import lzma; comp = lzma.compress(data)
     elif method == 4: comp = rans_encode(data, 0)
     elif method == 41: comp = rans_encode(data, 1); method = 4
     else: raise ValueError("block method")
@@ -283,7 +287,7 @@ def huffman_lengths(values):
     return syms, [depth[s] for s in syms]
 
 
-def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True):
+def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None):
     """genome: {contig name: bytes, upper case}. rr = False writes every base into the file ('b' features: no genome needed to read it). multi_ref packs several
     references into one slice (RI series, absolute positions). embed_ref stores the slice's reference stretch in the file. variety = False: raw EXTERNAL only."""
     text, refs, recs = read_bam(bam_path)
@@ -301,7 +305,7 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
     counter = 0; crai = []
     for g in groups:
         at = len(out)
-        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter); counter += len(g)
+        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, methods); counter += len(g)
         out += c; crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (line[0], line[1], line[2], at, line[3], line[4]))
     out += eof_container()
     open(out_path, "wb").write(bytes(out))
@@ -310,7 +314,7 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
     with gzip.open(out_path + ".crai", "wb") as f: f.write("".join(crai).encode())
 
 
-def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter):
+def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods=None):
     ref_ids = sorted({r["ref_id"] for r in g})
     slice_ref = ref_ids[0] if len(ref_ids) == 1 and not multi_ref else -2
     mapped = [r for r in g if r["ref_id"] >= 0 and r["pos"] >= 1]
@@ -448,10 +452,10 @@ def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety
     ch_block = block(0, 1, 0, ch)
     # ---- blocks ----
     ext_blocks = []; content_ids = []
-    methods = [0, 1, 4, 41] if variety else [0]
+    methods = block_methods or ([0, 1, 4, 41] if variety else [0])
     for k, (cid, data) in enumerate(sorted(W.ext.items())):
         m = methods[k % len(methods)]
-        if cid == ids.get("QS") and variety: m = 41
+        if cid == ids.get("QS") and variety and not block_methods: m = 41
         if m in (4, 41) and len(data) > 400000: m = 1
         ext_blocks.append(block(m, 4, cid, bytes(data))); content_ids.append(cid)
     emb_id = -1
