@@ -181,7 +181,7 @@ def bai_range(bam_path, regions, n_ref):
     arr = _regions_array(regions); b, e, f = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
     rc = L.ngsqc_bai_range(os.fsencode(bam_path), C.cast(arr, C.c_void_p), len(regions), int(n_ref), C.byref(b), C.byref(e), C.byref(f))
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
     return int(b.value), int(e.value), bool(f.value)
 
 
@@ -194,7 +194,7 @@ def bai_ranges(bam_path, regions, n_ref):
     b = (C.c_uint64 * max(n, 1))(); e = (C.c_uint64 * max(n, 1))()
     rc = L.ngsqc_bai_ranges(os.fsencode(bam_path), C.cast(arr, C.c_void_p), n, int(n_ref), b, e)
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
     return [(int(b[i]), int(e[i])) for i in range(n)]
 
 
@@ -214,7 +214,7 @@ def cram_to_bam(cram_path, bam_path, regions=None):
     arr = (NR * max(len(regions), 1))(*[NR(os.fsencode(c), int(a), int(b)) for c, a, b in regions])
     rc = L.ngsqc_cram_to_bam(os.fsencode(cram_path), os.fsencode(bam_path), C.cast(arr, C.c_void_p) if regions else None, len(regions))
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
 
 
 def bgzf_scan(data, threads=1):
@@ -228,11 +228,11 @@ def bgzf_scan(data, threads=1):
     n, tot = C.c_int64(0), C.c_int64(0)
     rc = L.ngsqc_bgzf_scan(a.ctypes.data, a.size, int(threads), None, 0, C.byref(n), C.byref(tot))
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
     out = np.zeros(max(n.value, 1), dtype=dt)
     rc = L.ngsqc_bgzf_scan(a.ctypes.data, a.size, int(threads), out.ctypes.data, n.value, C.byref(n), C.byref(tot))
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
     return out[:n.value], int(tot.value)
 
 
@@ -257,7 +257,7 @@ def bai_assemble(bai_path, n_ref, first_record_voff, end_voff, runs, lidx, lidx_
     else:
         rc = L.ngsqc_bai_assemble(os.fsencode(bai_path), int(n_ref), int(first_record_voff), int(end_voff), ra.ctypes.data, len(runs), la.ctypes.data, fa.ctypes.data, ca.ctypes.data)
     if rc != 0:
-        raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
 
 
 def plan_shard_fix(summaries, shard):
@@ -271,7 +271,7 @@ def plan_shard_fix(summaries, shard):
     fix = ShardFix()
     rc = lib().ngsqc_plan_shard_fix(arr, a.shape[0], int(shard), C.byref(fix))
     if rc != 0:
-        raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+        raise NgsqcError(rc, lib().ngsqc_last_error(None).decode("utf-8", "replace"))
     return fix
 
 
@@ -314,7 +314,7 @@ class Handle:
             rc = (L.ngsqc_open_memory_shard(buf.ctypes.data, buf.size, device, si, sn, C.byref(h)) if shard is not None
                   else L.ngsqc_open_memory(buf.ctypes.data, buf.size, device, C.byref(h)))
         if rc != 0:
-            raise NgsqcError(rc, L.ngsqc_last_error(None).decode())
+            raise NgsqcError(rc, L.ngsqc_last_error(None).decode("utf-8", "replace"))
         self.h = h
 
     def close(self):
@@ -326,7 +326,7 @@ class Handle:
 
     def _chk(self, rc):
         if rc != 0:
-            raise NgsqcError(rc, lib().ngsqc_last_error(self.h).decode())
+            raise NgsqcError(rc, lib().ngsqc_last_error(self.h).decode("utf-8", "replace"))
 
     @property
     def refs(self):
@@ -574,7 +574,7 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES)()
         rc = lib().ngsqc_comm_unique_id(C.cast(buf, C.c_void_p))
         if rc:
-            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode("utf-8", "replace"))
         return bytes(buf)
 
     def __init__(self, rank, world, uid, device=0):
@@ -582,7 +582,7 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
         rc = lib().ngsqc_comm_init(rank, world, C.cast(buf, C.c_void_p), device, C.byref(self.c))
         if rc:
-            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode())
+            raise NgsqcError(rc, lib().ngsqc_last_error(None).decode("utf-8", "replace"))
 
     def _chk(self, rc):
         if rc:

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <chrono>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -279,7 +280,7 @@ void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
 				h.TD.push_back(std::move(line)); o = e + 1;
 			}
 		}
-		else throw CramError("unknown CRAM preservation key " + key);
+		else throw CramError("unknown CRAM preservation key " + std::to_string((int)k[0]) + " " + std::to_string((int)k[1]));
 	}
 	if (h.TD.empty()) h.TD.emplace_back();
 	c.itf8();
@@ -411,8 +412,17 @@ struct BitReader
 };
 struct Dec
 {
-	BitReader core; std::map<int32_t, Cur> ext;
-	Cur& block(int32_t id) { auto it = ext.find(id); if (it == ext.end()) throw CramError("CRAM external block " + std::to_string(id) + " is missing in a slice"); return it->second; }
+	BitReader core; std::map<int32_t, Cur> ext; std::vector<Cur*> flat;   // flat: the cursors by content id (ids are small numbers in practice)
+	void index()
+	{
+		flat.clear();
+		for (auto& kv : ext) if (kv.first >= 0 && kv.first < 4096) { if ((size_t)kv.first >= flat.size()) flat.resize((size_t)kv.first + 1, nullptr); flat[(size_t)kv.first] = &kv.second; }
+	}
+	Cur& block(int32_t id)
+	{
+		if (id >= 0 && (size_t)id < flat.size() && flat[(size_t)id]) return *flat[(size_t)id];
+		auto it = ext.find(id); if (it == ext.end()) throw CramError("CRAM external block " + std::to_string(id) + " is missing in a slice"); return it->second;
+	}
 	int32_t integer(const Enc& e)
 	{
 		switch (e.kind)
@@ -498,6 +508,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		else if (b.ctype == 4) D.ext[b.cid] = Cur(b.p, b.n);
 	}
 	if (!have_core) throw CramError("CRAM slice without a core block");
+	D.index();
 	const uint8_t* embedded = nullptr; size_t embedded_n = 0;
 	if (sh.embedded_ref >= 0) { Cur& e = D.block(sh.embedded_ref); embedded = e.d; embedded_n = e.n; }
 	// the reference stretch of a single-reference slice (and its MD5: htslib refuses a genome that does not match, "md5sum reference mismatch")
@@ -540,6 +551,21 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 	std::vector<RecInfo> recs(nrec);
 	std::vector<uint8_t> name, seq, qual, tmp, tagbytes; std::vector<Feature> feats; std::vector<uint32_t> cigar;
 	const Enc &eBF = ch.series("BF"), &eCF = ch.series("CF"), &eRL = ch.series("RL"), &eAP = ch.series("AP"), &eRG = ch.series("RG"), &eTL = ch.series("TL");
+	struct Lazy   // the other series: looked up once, an error only when a record needs one the header does not define
+	{
+		const CompHdr& ch; const char* key; const Enc* e = nullptr; bool tried = false;
+		Lazy(const CompHdr& c, const char* k) : ch(c), key(k) {}
+		const Enc& get() { if (!tried) { tried = true; auto it = ch.ds.find(ds_key(key)); if (it != ch.ds.end()) e = &it->second; } if (!e) throw CramError(std::string("CRAM data series ") + key + " is used but has no encoding"); return *e; }
+	};
+	Lazy sRI(ch, "RI"), sRN(ch, "RN"), sMF(ch, "MF"), sNS(ch, "NS"), sNP(ch, "NP"), sTS(ch, "TS"), sNF(ch, "NF"), sFN(ch, "FN"), sFC(ch, "FC"), sFP(ch, "FP"), sBA(ch, "BA"), sQS(ch, "QS"),
+	     sBS(ch, "BS"), sIN(ch, "IN"), sSC(ch, "SC"), sHC(ch, "HC"), sPD(ch, "PD"), sDL(ch, "DL"), sRS(ch, "RS"), sBB(ch, "BB"), sQQ(ch, "QQ"), sMQ(ch, "MQ");
+	// the tag encodings of every tag line, resolved once
+	std::vector<std::vector<const Enc*>> td_enc(ch.TD.size());
+	for (size_t l = 0; l < ch.TD.size(); ++l) for (const auto& tg : ch.TD[l])
+	{
+		const int32_t key = ((int32_t)(tg.first >> 8) << 16) | ((int32_t)(tg.first & 0xff) << 8) | tg.second;
+		auto it = ch.tags.find(key); td_enc[l].push_back(it == ch.tags.end() ? nullptr : &it->second);
+	}
 	int64_t prev_pos = sh.start;
 	static const uint8_t nt16[256] = {
 		15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,0,15,15,
@@ -550,35 +576,34 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 	{
 		RecInfo& r = recs[i];
 		r.bf = (uint32_t)D.integer(eBF); r.cf = (uint32_t)D.integer(eCF);
-		r.ref_id = sh.ref_id == -2 ? D.integer(ch.series("RI")) : sh.ref_id;
+		r.ref_id = sh.ref_id == -2 ? D.integer(sRI.get()) : sh.ref_id;
 		const int32_t rl = D.integer(eRL);
 		if (rl < 0 || rl > (1 << 28)) throw CramError("read length out of range");
 		const int32_t ap = D.integer(eAP);
 		if (ch.AP) { prev_pos += ap; r.pos = (int32_t)prev_pos; } else r.pos = ap;
 		const int32_t rg = D.integer(eRG);
 		name.clear(); bool have_name = false;
-		if (ch.RN) { D.array(ch.series("RN"), name); have_name = true; }
+		if (ch.RN) { D.array(sRN.get(), name); have_name = true; }
 		if (r.cf & CF_DETACHED)
 		{
-			r.mf = D.integer(ch.series("MF"));
-			if (!ch.RN) { D.array(ch.series("RN"), name); have_name = true; }
-			r.ns = D.integer(ch.series("NS")); r.np = D.integer(ch.series("NP")); r.ts = D.integer(ch.series("TS"));
+			r.mf = D.integer(sMF.get());
+			if (!ch.RN) { D.array(sRN.get(), name); have_name = true; }
+			r.ns = D.integer(sNS.get()); r.np = D.integer(sNP.get()); r.ts = D.integer(sTS.get());
 		}
 		else if (r.cf & CF_MATE_DOWNSTREAM)
 		{
-			const int32_t nf = D.integer(ch.series("NF"));
+			const int32_t nf = D.integer(sNF.get());
 			if (nf < 0 || i + (size_t)nf + 1 >= nrec) throw CramError("CRAM mate chain leaves the slice");
 			r.mate_line = (int32_t)(i + (size_t)nf + 1);
 		}
 		const int32_t tl = D.integer(eTL);
 		if (tl < 0 || (size_t)tl >= ch.TD.size()) throw CramError("bad tag line index");
 		tagbytes.clear();
-		for (const auto& tg : ch.TD[(size_t)tl])
+		for (size_t ti = 0; ti < ch.TD[(size_t)tl].size(); ++ti)
 		{
-			const int32_t key = ((int32_t)(tg.first >> 8) << 16) | ((int32_t)(tg.first & 0xff) << 8) | tg.second;
-			auto it = ch.tags.find(key);
-			if (it == ch.tags.end()) throw CramError("CRAM tag without an encoding");
-			D.array(it->second, tmp);
+			const auto& tg = ch.TD[(size_t)tl][ti]; const Enc* te = td_enc[(size_t)tl][ti];
+			if (!te) throw CramError("CRAM tag without an encoding");
+			D.array(*te, tmp);
 			tagbytes.push_back((uint8_t)(tg.first >> 8)); tagbytes.push_back((uint8_t)(tg.first & 0xff)); tagbytes.push_back(tg.second);
 			tagbytes.insert(tagbytes.end(), tmp.begin(), tmp.end());
 		}
@@ -590,32 +615,32 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		};
 		if (!(r.bf & BAM_FUNMAP))
 		{
-			const int32_t fn = D.integer(ch.series("FN"));
+			const int32_t fn = D.integer(sFN.get());
 			if (fn < 0 || fn > 2 * rl + 64) throw CramError("feature count out of range");
 			feats.clear(); feats.resize((size_t)fn); int32_t fpos = 0;
 			for (Feature& f : feats)
 			{
-				f.code = (char)D.byte(ch.series("FC")); fpos += D.integer(ch.series("FP")); f.pos = fpos;
+				f.code = (char)D.byte(sFC.get()); fpos += D.integer(sFP.get()); f.pos = fpos;
 				switch (f.code)
 				{
-				case 'B': f.v = D.byte(ch.series("BA")); f.q = D.byte(ch.series("QS")); break;
-				case 'X': f.v = D.byte(ch.series("BS")); break;
-				case 'I': D.array(ch.series("IN"), f.bytes); break;
-				case 'S': D.array(ch.series("SC"), f.bytes); break;
-				case 'H': f.v = D.integer(ch.series("HC")); break;
-				case 'P': f.v = D.integer(ch.series("PD")); break;
-				case 'D': f.v = D.integer(ch.series("DL")); break;
-				case 'N': f.v = D.integer(ch.series("RS")); break;
-				case 'i': f.v = D.byte(ch.series("BA")); break;
-				case 'b': D.array(ch.series("BB"), f.bytes); break;
-				case 'q': D.array(ch.series("QQ"), f.bytes); break;
-				case 'Q': f.q = D.byte(ch.series("QS")); break;
-				default: throw CramError(std::string("unknown CRAM read feature '") + f.code + "'");
+				case 'B': f.v = D.byte(sBA.get()); f.q = D.byte(sQS.get()); break;
+				case 'X': f.v = D.byte(sBS.get()); break;
+				case 'I': D.array(sIN.get(), f.bytes); break;
+				case 'S': D.array(sSC.get(), f.bytes); break;
+				case 'H': f.v = D.integer(sHC.get()); break;
+				case 'P': f.v = D.integer(sPD.get()); break;
+				case 'D': f.v = D.integer(sDL.get()); break;
+				case 'N': f.v = D.integer(sRS.get()); break;
+				case 'i': f.v = D.byte(sBA.get()); break;
+				case 'b': D.array(sBB.get(), f.bytes); break;
+				case 'q': D.array(sQQ.get(), f.bytes); break;
+				case 'Q': f.q = D.byte(sQS.get()); break;
+				default: throw CramError("unknown CRAM read feature code " + std::to_string((int)(uint8_t)f.code));
 				}
 			}
-			mapq = D.integer(ch.series("MQ"));
+			mapq = D.integer(sMQ.get());
 			const bool qarr = (r.cf & CF_QUAL_ARRAY) != 0;
-			if (qarr) D.bytes_n(ch.series("QS"), (size_t)rl, qual);
+			if (qarr) D.bytes_n(sQS.get(), (size_t)rl, qual);
 			// read features -> CIGAR, bases, qualities (CRAMv3 section 10.6); between features the read follows the reference
 			int64_t ref_pos = (int64_t)r.pos - 1, read_pos = 0;
 			auto match_to = [&](int64_t upto) {
@@ -657,8 +682,8 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		}
 		else
 		{
-			if (r.cf & CF_NO_SEQ) have_seq = false; else D.bytes_n(ch.series("BA"), (size_t)rl, seq);
-			if (r.cf & CF_QUAL_ARRAY) D.bytes_n(ch.series("QS"), (size_t)rl, qual);
+			if (r.cf & CF_NO_SEQ) have_seq = false; else D.bytes_n(sBA.get(), (size_t)rl, seq);
+			if (r.cf & CF_QUAL_ARRAY) D.bytes_n(sQS.get(), (size_t)rl, qual);
 			r.end = r.pos;
 		}
 		// ---- the BAM record; flag, mate fields and template length are patched when the slice's chains are resolved ----
@@ -754,6 +779,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 {
 	try
 	{
+		const auto t0 = std::chrono::steady_clock::now();
+		auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
 		if (n < 26 || memcmp(d, "CRAM", 4) != 0) throw CramError("not a CRAM file");
 		if (d[4] != 3 || d[5] != 0) throw std::domain_error("CRAM " + std::to_string(d[4]) + "." + std::to_string(d[5]) + " input is not supported by the HIP path (CRAM 3.0 only)");
 		Cur c(d, n, 26);
@@ -854,6 +881,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			}
 			env.genome = &genome;
 		}
+		const double t_parse = since();
 		// ---- slices in parallel ----
 		int nthreads = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
 		if (const char* et = getenv("NGSQC_CRAM_THREADS")) nthreads = std::max(1, atoi(et));
@@ -880,6 +908,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		work();
 		for (auto& t : pool) t.join();
 		if (first_err) std::rethrow_exception(first_err);
+		const double t_decode = since();
 		// ---- BAM header + records ----
 		size_t total = 12 + text.size();
 		for (size_t i = 0; i < ref_names.size(); ++i) total += 9 + ref_names[i].size();
@@ -893,6 +922,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			add32(stream, (uint32_t)ref_lens[i]);
 		}
 		for (SliceJob& j : jobs) { stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out); }
+		if (getenv("NGSQC_TIMING"))
+			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms\n", jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode);
 	}
 	catch (CramError& e) { throw FormatError("Could not read next alignment in BAM/CRAM file " + path + " (" + e.what() + ")"); }
 }
