@@ -1835,7 +1835,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 			// the first records: the first two slices; a virtual-offset range means nothing in a CRAM: the whole file
 			CramSelect sel;
 			if (range && range->by_name) for (int64_t i = 0; i < range->n_regions; ++i) sel.regions.push_back(CramSelect::Region{range->regions[i].chr ? range->regions[i].chr : "", range->regions[i].start, range->regions[i].end});
-			if (range && range->head_members > 0) sel.max_slices = 2;
+			if (range && range->head_members > 0) sel.max_slices = std::max<int64_t>(2, range->head_members / 64);   // (a caller that asks for a longer head gets more slices)
 			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err, &sel);
 			if (crc == NGSQC_E_FORMAT) throw FormatError(err);
 			if (crc == NGSQC_E_IO) throw IoError(err);

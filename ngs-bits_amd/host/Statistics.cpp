@@ -63,7 +63,11 @@ void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* r
 BamInfo BamReader::info()
 {
 	BamInfo out;
-	out.file_format = "BAM";   // (CRAM is not supported by the HIP path)
+	out.file_format = "BAM";
+	{   // CRAM container version (BamReader.cpp:603-617)
+		std::ifstream f(bam_file_, std::ios::binary); char hd[6] = {0, 0, 0, 0, 0, 0};
+		if (f.read(hd, 6) && memcmp(hd, "CRAM", 4) == 0) out.file_format = "CRAM " + std::to_string((int)(uint8_t)hd[4]) + "." + std::to_string((int)(uint8_t)hd[5]);
+	}
 	try { const int c1 = chromosomeSize(Chromosome("chr1")); out.build = c1 == 249250621 ? "hg19" : (c1 == 248956422 ? "hg38" : ""); } catch (...) {}
 	// paired end: the first 100 reads OF THE FILE that are not secondary / supplementary / duplicate / unmapped and have MAPQ >= 20 (BamReader.cpp:627-640 keeps
 	// reading until it has them). A head open only holds the first members: when those do not yield 100 such reads (MAPQ < 20 at the telomere repeats of a WGS

@@ -142,3 +142,19 @@ def test_regions_on_a_cram_decode_only_their_slices(twin, tmp_path):
             whole.close(); part.close(); head.close()
     finally:
         ngsqc.set_reference(None)
+
+
+def test_baminfo_and_readcount_on_a_cram(twin, tmp_path):
+    """BamInfo names the container version (BamReader.cpp:603-617: "CRAM 3.0") and finds mapper / paired-end from the first slices; BedReadCount counts like on the BAM"""
+    rows = {}
+    for kind in ("bam", "cram"):
+        out = _run("BamInfo", "-in", twin[kind], "-name", "-ref", twin["fasta"]).stdout.splitlines()
+        assert out[0].startswith("#filename\tformat") and len(out) == 2
+        rows[kind] = out[1].split("\t")
+    assert rows["bam"][1] == "BAM" and rows["cram"][1] == "CRAM 3.0"
+    assert rows["bam"][2:] == rows["cram"][2:] and rows["bam"][6] in ("yes", "no")
+    name, ln = max(twin["refs"], key=lambda x: x[1])
+    bed = str(tmp_path / "r.bed"); open(bed, "w").write("%s\t100\t%d\n%s\t%d\t%d\n" % (name, ln // 2, name, ln // 2 + 50, ln - 10))
+    cnt = {k: _run("BedReadCount", "-bam", twin[k], "-in", bed, "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
+    assert cnt["bam"] == cnt["cram"] and len(cnt["bam"].splitlines()) >= 2
+    assert any(int(ln_.split("\t")[-1]) > 0 for ln_ in cnt["bam"].splitlines() if not ln_.startswith("#"))
