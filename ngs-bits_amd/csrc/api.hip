@@ -1732,6 +1732,7 @@ void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int devi
 	}
 	// ---- the range ----
 	uint64_t beg = rq.voff[0], end = rq.voff[1]; bool found = true;
+	uint64_t own_end = 0;   // head requests: the records that START in front of this member boundary are the handle's; members behind it only complete the last of them
 	if (rq.by_name)
 	{
 		std::vector<ngsqc_region> regs;
@@ -1756,6 +1757,10 @@ void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int devi
 			size_t o3 = (size_t)hdr_off[k]; uint64_t u3 = 0; std::vector<BlockDesc> tb; std::vector<uint32_t> tc;
 			walk_bgzf(bytes, n, o3, n, rq.head_members, u3, tb, tc);
 			end = (uint64_t)o3 << 16;
+			// a writer that does not keep records inside one BGZF member (htslib does, bam_write1's bgzf_flush_try; others do not) may cut a record at that boundary:
+			// like a shard, the handle takes members behind its own ones to complete it
+			int64_t tail = SHARD_TAIL_MEMBERS; if (const char* e = getenv("NGSQC_SHARD_TAIL_MEMBERS")) tail = std::max<int64_t>(0, atoll(e));
+			if (o3 < n && tail > 0) { own_end = end; walk_bgzf(bytes, n, o3, n, tail, u3, tb, tc); end = (uint64_t)o3 << 16; if (end == own_end) own_end = 0; }
 		}
 	}
 	const int64_t hdr_first_rec = h->first_rec;   // (inflated offset in the header members' numbering)
@@ -1778,7 +1783,12 @@ void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int devi
 	if (found && end > beg && !h->blocks.empty())   // (a range of empty members only: nothing to read)
 	{
 		int64_t limit = 0;
-		if ((end & 0xffff) == 0) limit = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
+		if (own_end)
+		{
+			limit = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
+			for (size_t i = 0; i < foff.size(); ++i) if (foff[i] >= (own_end >> 16)) { limit = (int64_t)h->blocks[i].upos; break; }
+		}
+		else if ((end & 0xffff) == 0) limit = (int64_t)(h->blocks.back().upos + h->blocks.back().usize);
 		else
 		{
 			if (foff.back() != co_end) throw ArgError("virtual offset does not name a BGZF block of this file");

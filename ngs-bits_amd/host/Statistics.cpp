@@ -75,6 +75,7 @@ BamInfo BamReader::info()
 	{
 		auto count = [](ngsqc_handle* hh, BamReader* rd, double& n_all, double& n_paired) -> int64_t {
 			const int64_t nbytes = ngsqc_inflated_size(hh), nrec = ngsqc_n_records(hh);
+			if (nrec < 0) rd->check((int)nrec);   // (an error code: not "no reads")
 			std::vector<uint8_t> infl((size_t)std::max<int64_t>(nbytes, 1)); std::vector<int64_t> off((size_t)std::max<int64_t>(nrec, 1));
 			if (nrec > 0) { rd->check(ngsqc_copy_inflated(hh, infl.data(), nbytes)); rd->check(ngsqc_copy_record_offsets(hh, off.data(), nrec)); }
 			n_all = 0; n_paired = 0;

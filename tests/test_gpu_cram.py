@@ -152,7 +152,9 @@ def test_baminfo_and_readcount_on_a_cram(twin, tmp_path):
         assert out[0].startswith("#filename\tformat") and len(out) == 2
         rows[kind] = out[1].split("\t")
     assert rows["bam"][1] == "BAM" and rows["cram"][1] == "CRAM 3.0"
-    assert rows["bam"][2:] == rows["cram"][2:] and rows["bam"][6] in ("yes", "no")
+    # (the twin BAM's header spans several BGZF members and its records are cut by member boundaries - writers other than htslib do that: the head request completes
+    # the record that the end of the head cuts from the members behind it)
+    assert rows["bam"][2:] == rows["cram"][2:] and rows["bam"][6] == "yes" and "bwa" in rows["bam"][5]
     name, ln = max(twin["refs"], key=lambda x: x[1])
     bed = str(tmp_path / "r.bed"); open(bed, "w").write("%s\t100\t%d\n%s\t%d\t%d\n" % (name, ln // 2, name, ln // 2 + 50, ln - 10))
     cnt = {k: _run("BedReadCount", "-bam", twin[k], "-in", bed, "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}
