@@ -1836,7 +1836,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		if (!bytes && n) throw ArgError("null BAM buffer");
 		// CRAM 3.0 (BamReader.cpp:482-492): the container layer is decoded on the host (cram.hip) into a BAM stream in stored BGZF members; from here on the file is a BAM
 		// image in memory. Index-driven requests (a .crai names slices, not BGZF members) fall back to the whole file: a superset of what a region needs.
-		std::vector<uint8_t> cram_image;
+		std::vector<uint8_t> cram_image; CramQualPlan qplan; const uint8_t* cram_src = nullptr;
 		const bool from_cram = is_cram((const uint8_t*)bytes, n);
 		if (from_cram)
 		{
@@ -1846,7 +1846,12 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 			CramSelect sel;
 			if (range && range->by_name) for (int64_t i = 0; i < range->n_regions; ++i) sel.regions.push_back(CramSelect::Region{range->regions[i].chr ? range->regions[i].chr : "", range->regions[i].start, range->regions[i].end});
 			if (range && range->head_members > 0) sel.max_slices = std::max<int64_t>(2, range->head_members / 64);   // (a caller that asks for a longer head gets more slices)
-			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err, &sel);
+			// the quality arrays (rANS blocks, about half of the records' bytes) stay compressed and are decoded on the device into the uploaded image (cram_dev.hip):
+			// whole-file handles only (a shard uploads a part of the image); NGSQC_CRAM_DEVICE_QUALS=0 keeps them on the host
+			const char* eq = getenv("NGSQC_CRAM_DEVICE_QUALS");
+			const bool dev_quals = n_shards == 1 && (!eq || atoi(eq) != 0);
+			cram_src = (const uint8_t*)bytes;
+			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err, &sel, dev_quals ? &qplan : nullptr);
 			if (crc == NGSQC_E_FORMAT) throw FormatError(err);
 			if (crc == NGSQC_E_IO) throw IoError(err);
 			if (crc == NGSQC_E_UNSUPPORTED) throw std::domain_error(err);
@@ -1858,6 +1863,13 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		const char* ea = getenv("NGSQC_ASYNC_H2D");
 		if (path && !from_cram && n_shards == 1 && !range && (!ea || atoi(ea) != 0)) h->up = new ngsqc_handle::Upload();
 		if (range) open_range_common(h, (const uint8_t*)bytes, n, device, *range); else open_common(h, (const uint8_t*)bytes, n, device, shard, n_shards);
+		if (from_cram && !qplan.jobs.empty())
+		{
+			// (the BGZF wrapper of the image is our own and its CRC-32s were taken over blank qualities; every CRAM block was CRC-checked on the host)
+			h->verify_crc = false;
+			const double ms = cram_device_quals(cram_src, qplan, h->d_comp.p, cram_image.size(), h->stream);
+			if (getenv("NGSQC_TIMING")) fprintf(stderr, "[ngsqc] cram: %zu quality blocks (%llu bytes, %zu records) decoded on the device in %.3f ms\n", qplan.jobs.size(), (unsigned long long)qplan.out_bytes, qplan.patches.size(), ms);
+		}
 		if (h->up) { h->up->map = map; h->up->map_n = map_n; h->up->fd = fd; map = nullptr; fd = -1; }   // the mapping lives until the last piece is copied
 		const char* ep = getenv("NGSQC_ASYNC_PLAN");
 		if (h->up && (!ep || atoi(ep) != 0))
@@ -2151,8 +2163,19 @@ int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_n
 		if (!ngsqc::is_cram(d.data(), d.size())) { g_open_error = std::string("not a CRAM file: ") + cram_path; return NGSQC_E_FORMAT; }
 		ngsqc::CramSelect sel;
 		for (int64_t i = 0; i < n_regions; ++i) sel.regions.push_back(ngsqc::CramSelect::Region{regions[i].chr ? regions[i].chr : "", regions[i].start, regions[i].end});
-		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err, &sel);
+		// NGSQC_CRAM_PLAN_DUMP=<file> (tests): the records with the quality arrays left blank, as the device path uploads them, and the plan of the quality blocks in <file>
+		// (counts, then the arrays of CramQualPlan) - tests/test_cpu_cram.py replays the device kernels of cram_dev.hip on it
+		const char* dump = getenv("NGSQC_CRAM_PLAN_DUMP"); ngsqc::CramQualPlan plan;
+		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err, &sel, dump ? &plan : nullptr);
 		if (rc != NGSQC_OK) { g_open_error = err; return rc; }
+		if (dump)
+		{
+			std::ofstream pf(dump, std::ios::binary | std::ios::trunc);
+			const uint64_t hd[5] = {plan.jobs.size(), plan.tabs.size(), plan.syms.size(), plan.patches.size(), plan.out_bytes};
+			static_assert(sizeof(ngsqc::CramQualPlan::Job) == 40 && sizeof(ngsqc::CramQualPlan::Patch) == 24, "plan layout");
+			pf.write((const char*)hd, sizeof hd); pf.write((const char*)plan.jobs.data(), (std::streamsize)(plan.jobs.size() * 40)); pf.write((const char*)plan.tabs.data(), (std::streamsize)(plan.tabs.size() * 2));
+			pf.write((const char*)plan.syms.data(), (std::streamsize)plan.syms.size()); pf.write((const char*)plan.patches.data(), (std::streamsize)(plan.patches.size() * 24));
+		}
 		ngsqc::bgzf_store(stream, image);
 		std::ofstream o(bam_path, std::ios::binary | std::ios::trunc);
 		if (o) o.write((const char*)image.data(), (std::streamsize)image.size());

@@ -46,7 +46,19 @@ bool is_cram(const uint8_t* d, size_t n);
 void cram_set_reference(const char* fasta);
 std::string cram_reference();
 struct CramSelect { struct Region { std::string chr; int32_t start, end; }; std::vector<Region> regions; int64_t max_slices = 0; };   // regions: only slices that can hold their records; max_slices: the first slices only
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
+// The quality arrays of a CRAM (QS series: one rANS 4x8 block per slice, about half of a BAM record's bytes) can stay compressed on the host: the plan names every such
+// block (where its four rANS states start in the CRAM image, its frequency tables in a compact form) and, per record, where its qualities go in the BAM stream; the
+// device decodes the blocks and writes the qualities into the uploaded image (cram_dev.hip).
+struct CramQualPlan
+{
+	struct Job { uint64_t in_off; uint64_t out_off; uint32_t in_len, n_out, tab_off, sym_off; uint32_t order, nsym; };   // in_off: the states + byte stream in the CRAM image; out_off: into the decoded quality bytes of all jobs
+	struct Patch { uint64_t dst, src; uint32_t len, pad; };                                                       // dst: offset in the BAM stream; src: offset in the decoded quality bytes
+	std::vector<Job> jobs; std::vector<uint16_t> tabs; std::vector<uint8_t> syms; std::vector<Patch> patches; uint64_t out_bytes = 0;
+	// tabs: per job (order 0: one row; order 1: nsym rows, row = index of the previous symbol) of nsym + 1 cumulative frequencies; syms: per job 64 symbols + 256 bytes "byte -> index"
+};
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel = nullptr, CramQualPlan* defer = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
+// decodes the plan's blocks on the device and writes the qualities into the BAM image (stored BGZF members of 65 280 bytes, as bgzf_store lays them out) at d_image; returns the kernel time in ms
+double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, uint8_t* d_image, size_t image_bytes, hipStream_t s);
 void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image);
 
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)

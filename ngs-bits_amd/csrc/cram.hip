@@ -17,6 +17,7 @@
 #include <sstream>
 #include <thread>
 #include <chrono>
+#include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -130,6 +131,55 @@ void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out)
 	while (idx[3] < n_out) step(3);
 }
 
+// the plan of one rANS block for the device decoder (cram_dev.hip): false = not eligible (the host decodes it): more than 64 different symbols, a short block,
+// tables that do not parse
+bool rans_plan(const uint8_t* d, size_t n, uint64_t file_off, size_t rsize, CramQualPlan::Job& job, std::vector<uint16_t>& tabs, std::vector<uint8_t>& syms)
+{
+	if (n < 9 || d[0] > 1) return false;
+	const int order = d[0];
+	const uint32_t n_out = (uint32_t)d[5] | ((uint32_t)d[6] << 8) | ((uint32_t)d[7] << 16) | ((uint32_t)d[8] << 24);
+	if ((size_t)n_out != rsize || n_out < 2048) return false;
+	Cur c(d, n, 9);
+	std::vector<RansTable> T(order ? 256 : 1);
+	try
+	{
+		if (!order) rans_read_freqs(c, T[0]);
+		else
+		{
+			int ctx = c.byte(), last = ctx, rle = 0;
+			for (;;)
+			{
+				rans_read_freqs(c, T[(size_t)ctx]);
+				if (rle) { --rle; ++ctx; if (ctx > 255) return false; }
+				else { ctx = c.byte(); if (ctx == last + 1) rle = c.byte(); }
+				last = ctx;
+				if (ctx == 0) break;
+			}
+		}
+	}
+	catch (CramError&) { return false; }
+	if (n - c.p < 16) return false;
+	bool used[256]; memset(used, 0, sizeof used); used[0] = order == 1;   // (order 1 starts in context 0)
+	for (size_t t = 0; t < T.size(); ++t) if (T[t].set) { if (order) used[t] = true; for (int x = 0; x < 256; ++x) if (T[t].F[x]) used[x] = true; }
+	int ns = 0; uint8_t list[64];
+	for (int x = 0; x < 256; ++x) if (used[x]) { if (ns == 64) return false; list[ns++] = (uint8_t)x; }
+	if (ns == 0) return false;
+	syms.assign(320, 0xff);
+	for (int k = 0; k < ns; ++k) { syms[(size_t)k] = list[k]; syms[64 + (size_t)list[k]] = (uint8_t)k; }
+	const int rows = order ? ns : 1;
+	tabs.assign((size_t)rows * (size_t)(ns + 1), 0);
+	for (int r = 0; r < rows; ++r)
+	{
+		const RansTable& t = T[order ? (size_t)list[r] : 0];
+		if (!t.set) continue;   // (a context nothing is coded in: a row of zeros - the kernel flags its use)
+		uint16_t* C = &tabs[(size_t)r * (size_t)(ns + 1)];
+		for (int k = 0; k < ns; ++k) C[k] = t.C[list[k]];
+		C[ns] = (uint16_t)(t.C[list[ns - 1]] + t.F[list[ns - 1]]);
+	}
+	job = CramQualPlan::Job{file_off + c.p, 0, (uint32_t)(n - c.p), n_out, 0, 0, (uint32_t)order, (uint32_t)ns};
+	return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- bzip2 / lzma blocks
 // (what `samtools view -O cram,use_bzip2 / use_lzma` writes for some series.) The image carries the runtime libraries but not their headers: the two one-shot
 // entry points are declared here as bzlib.h / lzma.h declare them and the libraries are loaded on first use; without them such a block is NGSQC_E_UNSUPPORTED.
@@ -160,9 +210,9 @@ void lzma_block(const uint8_t* raw, size_t csize, size_t rsize, std::vector<uint
 }
 
 // ---------------------------------------------------------------------------------------------------------------- blocks, containers
-struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; };
+struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; const uint8_t* raw = nullptr; size_t raw_n = 0; bool lazy = false; };
 uint32_t crc_of(const uint8_t* p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
-void read_block(Cur& c, Blk& b)
+void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1)   // lazy_cid: an external rANS block with this content id stays compressed (b.lazy; b.n = its decoded size)
 {
 	const size_t start = c.p;
 	b.method = c.byte(); b.ctype = c.byte(); b.cid = c.itf8(); const int32_t csize = c.itf8(), rsize = c.itf8();
@@ -170,6 +220,8 @@ void read_block(Cur& c, Blk& b)
 	const uint8_t* raw = c.take((size_t)csize);
 	const size_t crc_at = c.p; const uint32_t crc = c.u32();
 	if (crc_of(c.d + start, crc_at - start) != crc) throw CramError("CRAM block CRC mismatch");
+	b.raw = raw; b.raw_n = (size_t)csize;
+	if (lazy_cid >= 0 && b.ctype == 4 && b.cid == lazy_cid && b.method == 4) { b.lazy = true; b.p = nullptr; b.n = (size_t)rsize; return; }
 	if (b.method == 0) { b.p = raw; b.n = (size_t)csize; }
 	else if (b.method == 1)
 	{
@@ -250,6 +302,7 @@ struct CompHdr
 	std::vector<std::vector<std::pair<uint16_t, uint8_t>>> TD;   // per tag line: (2-char tag, type)
 	std::map<uint16_t, Enc> ds; std::map<int32_t, Enc> tags;
 	char subst[5][4];   // [reference base ACGTN][code] -> read base
+	int32_t qs_only_id = -1;   // content id of the external block that ONLY the QS series reads (-1: none): the block the device may decode
 	const Enc& series(const char* k) const
 	{
 		auto it = ds.find(ds_key(k));
@@ -287,6 +340,22 @@ void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
 	for (int32_t i = c.itf8(); i > 0; --i) { const uint8_t* k = c.take(2); Enc& e = h.ds[(uint16_t)((k[0] << 8) | k[1])]; read_encoding(c, e); }
 	c.itf8();
 	for (int32_t i = c.itf8(); i > 0; --i) { const int32_t key = c.itf8(); read_encoding(c, h.tags[key]); }
+	{
+		auto qs = h.ds.find(ds_key("QS"));
+		if (qs != h.ds.end() && qs->second.kind == E_EXTERNAL)
+		{
+			const int32_t id = qs->second.a; int users = 0;
+			std::function<void(const Enc&)> walk = [&](const Enc& e) {
+				if (e.kind == E_EXTERNAL && e.a == id) ++users;
+				if (e.kind == E_BYTE_ARRAY_STOP && e.b == id) ++users;
+				if (e.e1) walk(*e.e1);
+				if (e.e2) walk(*e.e2);
+			};
+			for (const auto& kv : h.ds) walk(kv.second);
+			for (const auto& kv : h.tags) walk(kv.second);
+			if (users == 1) h.qs_only_id = id;
+		}
+	}
 	// substitution matrix: for every reference base the four other bases in the order of their 2-bit codes
 	const char B[6] = "ACGTN";
 	for (int r = 0; r < 5; ++r)
@@ -395,6 +464,7 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------------------------- decoders of one slice
+struct NeedHostQuals {};
 struct BitReader
 {
 	const uint8_t* d = nullptr; size_t n = 0, p = 0; int bit = 7;
@@ -413,6 +483,7 @@ struct BitReader
 struct Dec
 {
 	BitReader core; std::map<int32_t, Cur> ext; std::vector<Cur*> flat;   // flat: the cursors by content id (ids are small numbers in practice)
+	int32_t defer_id = -1; uint64_t defer_pos = 0, defer_n = 0, last_src = 0; bool took = false;   // the quality block that stays compressed: only its cursor moves
 	void index()
 	{
 		flat.clear();
@@ -420,6 +491,7 @@ struct Dec
 	}
 	Cur& block(int32_t id)
 	{
+		if (id == defer_id && defer_id >= 0) throw NeedHostQuals();   // something other than a quality ARRAY reads the block: the slice is decoded again with the block on the host
 		if (id >= 0 && (size_t)id < flat.size() && flat[(size_t)id]) return *flat[(size_t)id];
 		auto it = ext.find(id); if (it == ext.end()) throw CramError("CRAM external block " + std::to_string(id) + " is missing in a slice"); return it->second;
 	}
@@ -456,6 +528,11 @@ struct Dec
 	uint8_t byte(const Enc& e) { return e.kind == E_EXTERNAL ? block(e.a).byte() : (uint8_t)(integer(e) & 0xff); }
 	void bytes_n(const Enc& e, size_t k, std::vector<uint8_t>& out)
 	{
+		if (e.kind == E_EXTERNAL && e.a == defer_id && defer_id >= 0)
+		{
+			if (defer_pos + k > defer_n) throw CramError("truncated CRAM data");
+			out.assign(k, 0); last_src = defer_pos; defer_pos += k; took = true; return;
+		}
 		if (e.kind == E_EXTERNAL) { const uint8_t* p = block(e.a).take(k); out.assign(p, p + k); return; }
 		out.resize(k); for (size_t i = 0; i < k; ++i) out[i] = byte(e);
 	}
@@ -499,12 +576,13 @@ inline void add32(std::vector<uint8_t>& o, uint32_t v) { const size_t at = o.siz
 inline void add16(std::vector<uint8_t>& o, uint32_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }
 
 // one slice -> BAM records (SAM spec 4.2), as htslib's cram_decode_slice + cram_to_bam build them
-void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& blocks, const DecodeEnv& env, std::vector<uint8_t>& out)
+void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& blocks, const DecodeEnv& env, std::vector<uint8_t>& out, std::vector<CramQualPlan::Patch>* patches = nullptr)
 {
 	Dec D; bool have_core = false;
 	for (Blk& b : blocks)
 	{
 		if (b.ctype == 5 && !have_core) { D.core.d = b.p; D.core.n = b.n; have_core = true; }
+		else if (b.ctype == 4 && b.lazy) { D.defer_id = b.cid; D.defer_n = b.n; }
 		else if (b.ctype == 4) D.ext[b.cid] = Cur(b.p, b.n);
 	}
 	if (!have_core) throw CramError("CRAM slice without a core block");
@@ -702,6 +780,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		for (uint32_t c : cigar) add32(out, c);
 		const size_t sq = out.size(); out.resize(sq + (l_seq + 1) / 2, 0);
 		for (size_t x = 0; x < l_seq; ++x) out[sq + (x >> 1)] |= (uint8_t)(nt16[seq[x]] << ((x & 1) ? 0 : 4));
+		if (D.took) { if (patches && l_seq) patches->push_back(CramQualPlan::Patch{(uint64_t)out.size(), D.last_src, (uint32_t)l_seq, 0u}); D.took = false; }
 		out.insert(out.end(), qual.begin(), qual.begin() + (long)l_seq);
 		out.insert(out.end(), tagbytes.begin(), tagbytes.end());
 		if (rg >= 0 && (size_t)rg < env.rg_ids->size())
@@ -759,7 +838,11 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 	}
 }
 
-struct SliceJob { const CompHdr* ch = nullptr; SliceHdr sh; size_t blocks_at = 0; std::vector<uint8_t> out; };
+struct SliceJob
+{
+	const CompHdr* ch = nullptr; SliceHdr sh; size_t blocks_at = 0; std::vector<uint8_t> out;
+	bool has_q = false; CramQualPlan::Job qjob; std::vector<uint16_t> qtabs; std::vector<uint8_t> qsyms; std::vector<CramQualPlan::Patch> patches;   // the slice's quality block, left to the device
+};
 
 std::mutex g_ref_mu; std::string g_reference;
 } // namespace
@@ -775,7 +858,7 @@ bool is_cram(const uint8_t* d, size_t n) { return n >= 4 && memcmp(d, "CRAM", 4)
 
 namespace {
 // the whole CRAM as an uncompressed BAM stream ("BAM\1", header, records in file order). Throws FormatError / IoError / std::domain_error.
-void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, const CramSelect* sel)
+void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, const CramSelect* sel, CramQualPlan* defer)
 {
 	try
 	{
@@ -897,8 +980,17 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 				{
 					SliceJob& j = jobs[i]; Cur bc(d, n, j.blocks_at);
 					std::vector<Blk> bl((size_t)j.sh.n_blocks);
-					for (Blk& b : bl) read_block(bc, b);
-					decode_slice(*j.ch, j.sh, bl, env, j.out);
+					for (Blk& b : bl) read_block(bc, b, defer ? j.ch->qs_only_id : -1);
+					auto on_host = [&](Blk& b) { rans_decode(b.raw, b.raw_n, b.own); if (b.own.size() != b.n) throw CramError("CRAM block inflates to another size than its header says"); b.p = b.own.data(); b.lazy = false; };
+					for (Blk& b : bl) if (b.lazy) { if (rans_plan(b.raw, b.raw_n, (uint64_t)(b.raw - d), b.n, j.qjob, j.qtabs, j.qsyms)) j.has_q = true; else on_host(b); }
+					try { decode_slice(*j.ch, j.sh, bl, env, j.out, j.has_q ? &j.patches : nullptr); }
+					catch (NeedHostQuals&)
+					{
+						// a record takes single qualities out of the block (features without a quality array): this slice's block is decoded here after all
+						for (Blk& b : bl) if (b.lazy) on_host(b);
+						j.has_q = false; j.out.clear(); j.patches.clear();
+						decode_slice(*j.ch, j.sh, bl, env, j.out, nullptr);
+					}
 				}
 				catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!first_err) first_err = std::current_exception(); return; }
 			}
@@ -921,18 +1013,32 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			add32(stream, (uint32_t)ref_names[i].size() + 1); stream.insert(stream.end(), ref_names[i].begin(), ref_names[i].end()); stream.push_back(0);
 			add32(stream, (uint32_t)ref_lens[i]);
 		}
-		for (SliceJob& j : jobs) { stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out); }
+		size_t n_q = 0;
+		for (SliceJob& j : jobs)
+		{
+			if (j.has_q && defer)
+			{
+				const uint64_t base = stream.size();
+				CramQualPlan::Job q = j.qjob; q.out_off = defer->out_bytes; q.tab_off = (uint32_t)defer->tabs.size(); q.sym_off = (uint32_t)defer->syms.size();
+				defer->jobs.push_back(q); defer->tabs.insert(defer->tabs.end(), j.qtabs.begin(), j.qtabs.end()); defer->syms.insert(defer->syms.end(), j.qsyms.begin(), j.qsyms.end());
+				for (CramQualPlan::Patch pt : j.patches) { pt.dst += base; pt.src += q.out_off; defer->patches.push_back(pt); }
+				defer->out_bytes += q.n_out; ++n_q;
+			}
+			stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out);
+		}
 		if (getenv("NGSQC_TIMING"))
-			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms\n", jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode);
+			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms; quality blocks left to the device: %zu (%llu bytes)\n",
+			        jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode, n_q, defer ? (unsigned long long)defer->out_bytes : 0ull);
 	}
 	catch (CramError& e) { throw FormatError("Could not read next alignment in BAM/CRAM file " + path + " (" + e.what() + ")"); }
 }
 } // namespace
 
 // NGSQC_OK or NGSQC_E_FORMAT / NGSQC_E_IO / NGSQC_E_UNSUPPORTED / NGSQC_E_DEVICE with the message in err
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel)
+int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel, CramQualPlan* defer)
 {
-	try { cram_to_bam_stream_impl(d, n, path, stream, sel); return NGSQC_OK; }
+	if (defer) *defer = CramQualPlan();
+	try { cram_to_bam_stream_impl(d, n, path, stream, sel, defer); return NGSQC_OK; }
 	catch (FormatError& e) { err = e.what(); return NGSQC_E_FORMAT; }
 	catch (IoError& e) { err = e.what(); return NGSQC_E_IO; }
 	catch (std::domain_error& e) { err = e.what(); return NGSQC_E_UNSUPPORTED; }

@@ -185,3 +185,68 @@ def test_region_selection_decodes_only_the_overlapping_slices(twins, tmp_path):
         assert split_bam(bam_stream(out)[0])[2] == []
     finally:
         ngsqc.set_reference(None)
+
+
+# ---- the quality arrays on the device (csrc/cram_dev.hip): the host leaves the QS blocks compressed and writes a plan; here the plan is replayed in Python the way the
+# kernels do it (compact cumulative tables, linear search, four states over one byte stream; then the per-record copy) - the GPU tests run the kernels themselves ----
+import numpy as np  # noqa: E402
+
+
+def _replay_plan(cram_bytes, plan_path, stream):
+    d = open(plan_path, "rb").read()
+    nj, nt, ns_, npch, out_bytes = struct.unpack_from("<5Q", d, 0); o = 40
+    jobs = [struct.unpack_from("<QQIIIIII", d, o + 40 * i) for i in range(nj)]; o += 40 * nj
+    tabs = np.frombuffer(d, dtype="<u2", count=nt, offset=o); o += 2 * nt
+    syms = d[o:o + ns_]; o += ns_
+    patches = [struct.unpack_from("<QQII", d, o + 24 * i) for i in range(npch)]
+    qs = bytearray(out_bytes)
+    for in_off, out_off, in_len, n_out, tab_off, sym_off, order, ns in jobs:
+        p = in_off; end = in_off + in_len; sym = syms[sym_off:sym_off + 64]; lut = syms[sym_off + 64:sym_off + 320]; row = ns + 1
+        R = list(struct.unpack_from("<4I", cram_bytes, p)); p += 16
+
+        def step(j, C0):
+            nonlocal p
+            m = R[j] & 0xfff; k = 0
+            while k + 1 < ns and tabs[C0 + k + 1] <= m: k += 1
+            c0 = int(tabs[C0 + k]); f = int(tabs[C0 + k + 1]) - c0
+            assert f > 0 and c0 <= m < c0 + f
+            v = f * (R[j] >> 12) + m - c0
+            while v < (1 << 23): assert p < end; v = (v << 8) | cram_bytes[p]; p += 1
+            R[j] = v
+            return k
+        if order == 0:
+            for i in range(n_out): qs[out_off + i] = sym[step(i & 3, tab_off)]
+        else:
+            q = n_out >> 2; idx = [0, q, 2 * q, 3 * q]; pk = [lut[0]] * 4; assert lut[0] < ns
+            for _ in range(q):
+                for j in range(4):
+                    k = step(j, tab_off + pk[j] * row); qs[out_off + idx[j]] = sym[k]; idx[j] += 1; pk[j] = k
+            while idx[3] < n_out:
+                k = step(3, tab_off + pk[3] * row); qs[out_off + idx[3]] = sym[k]; idx[3] += 1; pk[3] = k
+    out = bytearray(stream)
+    for dst, src, ln, _ in patches:
+        assert all(b == 0 for b in out[dst:dst + ln]) and src + ln <= out_bytes
+        out[dst:dst + ln] = qs[src:src + ln]
+    return bytes(out), nj, npch
+
+
+@pytest.mark.parametrize("case", ["SampleIdentity_in_rna.cram", "cramTest.cram", "twin", "twin_order0", "twin_plain"])
+def test_device_quality_plan_replayed(case, twins, tmp_path, monkeypatch):
+    if case.startswith("twin"):
+        twin = twins["MappingQC_in5.bam"]; src = str(tmp_path / "t.cram")
+        kw = {"twin": {}, "twin_order0": dict(methods=[4]), "twin_plain": dict(variety=False)}[case]
+        CE.encode(twin["bam"], src, twin["genome"], slice_records=1200, **kw); ngsqc.set_reference(twin["fasta"])
+    else:
+        src = os.path.join(GI, case); monkeypatch.setenv("NGSQC_CRAM_NO_REFERENCE", "1")
+    try:
+        full = str(tmp_path / "full.bam"); blank = str(tmp_path / "blank.bam"); plan = str(tmp_path / "plan.bin")
+        ngsqc.cram_to_bam(src, full)
+        monkeypatch.setenv("NGSQC_CRAM_PLAN_DUMP", plan)
+        ngsqc.cram_to_bam(src, blank)
+        monkeypatch.delenv("NGSQC_CRAM_PLAN_DUMP")
+    finally:
+        ngsqc.set_reference(None)
+    want = bam_stream(full)[0]; got, n_jobs, n_patches = _replay_plan(open(src, "rb").read(), plan, bam_stream(blank)[0])
+    assert got == want
+    if case == "twin_plain": assert n_jobs == 0 and n_patches == 0        # raw quality blocks: nothing to decode
+    else: assert n_jobs >= 1 and n_patches > 500 and bam_stream(blank)[0] != want

@@ -52,8 +52,11 @@ def _same_results(a, b):
     assert np.array_equal(a.depth(n), b.depth(n)) and int(a.depth(n).sum()) > 0
 
 
+@pytest.mark.parametrize("quals", ["device", "host"])
 @pytest.mark.parametrize("which", ["cram", "cram_multi", "cram_norr"])
-def test_handle_on_a_cram_equals_the_handle_on_its_bam(twin, which):
+def test_handle_on_a_cram_equals_the_handle_on_its_bam(twin, which, quals, monkeypatch):
+    """quals: the quality arrays (rANS blocks) decoded by the kernels of csrc/cram_dev.hip into the uploaded image (the default), or on the host like the rest"""
+    if quals == "host": monkeypatch.setenv("NGSQC_CRAM_DEVICE_QUALS", "0")
     ngsqc.set_reference(None if which == "cram_norr" else twin["fasta"])
     try:
         a = ngsqc.Handle(path=twin[which]); b = ngsqc.Handle(path=twin["bam"])
@@ -106,8 +109,12 @@ def test_tools_on_a_cram_write_what_they_write_for_the_bam(twin, tmp_path):
     for kind in ("bam", "cram"):
         o = str(tmp_path / (kind + ".qcML"))
         # (-no_ref: no GC / AT dropout from the made-up genome; the CRAM decoder then takes the genome from NGSQC_REFERENCE)
-        _run("MappingQC", "-in", twin[kind], "-wgs", "-build", "hg19", "-no_ref", "-out", o, env={"NGSQC_REFERENCE": twin["fasta"]})
+        p = _run("MappingQC", "-in", twin[kind], "-wgs", "-build", "hg19", "-no_ref", "-out", o, env={"NGSQC_REFERENCE": twin["fasta"], "NGSQC_TIMING": "1"})
         outs[kind] = [ln for ln in open(o).read().splitlines() if not strip.search(ln)]
+        if kind == "cram":   # the quality blocks went through the device decoder
+            m = re.search(r"cram: (\d+) quality blocks \((\d+) bytes, (\d+) records\) decoded on the device in ([0-9.]+) ms", p.stderr)
+            assert m and int(m.group(1)) >= 3 and int(m.group(3)) > 1000, p.stderr[-2000:]
+            print("device quality decode:", m.group(0))
     assert outs["bam"] == outs["cram"] and len(outs["bam"]) > 30
     name, ln = max(twin["refs"], key=lambda x: x[1])
     bed = str(tmp_path / "r.bed"); open(bed, "w").write("%s\t100\t%d\n%s\t%d\t%d\n" % (name, ln // 2, name, ln // 2 + 50, ln - 10))
