@@ -58,6 +58,111 @@ __global__ __launch_bounds__(64) void cram_rans_kernel(const uint8_t* __restrict
 	if (bad) atomicOr(status, 2u);
 }
 
+// The same with the job's tables in LDS (a search step is an LDS read instead of a dependent global load: the first kernel spent ~5 us per symbol on those) and one
+// WORKGROUP per block. LANES = 1: lane 0 decodes as above. LANES = 4: the four rANS states live in four lanes - every round each lane decodes the symbol of its state,
+// the lanes count the bytes their renormalisation takes (0, 1 or 2), a prefix over the four lanes gives each its place in the shared byte stream (the order the
+// sequential decoder reads them in: state 0 first), and the stream pointer moves on by the sum. Order 1 writes four quarters of the output, one per lane; what is left
+// behind the quarters belongs to state 3 alone.
+template <int LANES> __global__ __launch_bounds__(64) void cram_rans_lds_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
+                                                                             const uint8_t* __restrict__ syms, uint8_t* __restrict__ out, unsigned int* __restrict__ status)
+{
+	__shared__ uint16_t sC[65 * 64]; __shared__ uint8_t sSym[64]; __shared__ int sK0;
+	const int j = (int)blockIdx.x, lane = (int)threadIdx.x;
+	if (j >= n_jobs) return;
+	const CramQualPlan::Job jb = jobs[j];
+	const int ns = (int)jb.nsym, row = ns + 1, rows = jb.order ? ns : 1;
+	if (jb.in_len < 16 || ns < 1 || ns > 64) { if (lane == 0) atomicOr(status, 1u); return; }
+	for (int x = lane; x < rows * row; x += 64) sC[x] = tabs[jb.tab_off + x];
+	if (lane < ns) sSym[lane] = syms[jb.sym_off + lane];
+	if (lane == 0) sK0 = syms[jb.sym_off + 64];   // the row of context 0
+	__syncthreads();
+	if (lane >= LANES) return;
+	const uint8_t* p = in + jb.in_off; const uint8_t* const end = p + jb.in_len;
+	uint8_t* const o = out + jb.out_off; const uint32_t n = jb.n_out;
+	bool bad = false;
+	auto sym_of = [&](uint32_t x, const uint16_t* C, uint32_t& v) -> int {   // the symbol index of state x in row C; v: the state behind it, before renormalisation
+		const uint32_t m = x & 0xfffu; int k = 0;
+		while (k + 1 < ns && (uint32_t)C[k + 1] <= m) ++k;
+		const uint32_t c0 = C[k], f = (uint32_t)C[k + 1] - c0;
+		if (f == 0 || m < c0 || m >= (uint32_t)C[k + 1]) { bad = true; v = x; return 0; }
+		v = f * (x >> 12) + m - c0;
+		return k;
+	};
+	if (LANES == 1)
+	{
+		uint32_t R[4];
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) { R[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); p += 4; }
+		auto renorm = [&](uint32_t v) { while (v < (1u << 23)) { if (p >= end) { bad = true; break; } v = (v << 8) | *p++; } return v; };
+		if (jb.order == 0)
+		{
+			for (uint32_t i = 0; i < n && !bad; i += 4)
+			{
+				#pragma unroll
+				for (int k = 0; k < 4; ++k) if (i + (uint32_t)k < n && !bad) { uint32_t v; const int s = sym_of(R[k], sC, v); R[k] = renorm(v); o[i + (uint32_t)k] = sSym[s]; }
+			}
+		}
+		else
+		{
+			const uint32_t q = n >> 2; uint32_t idx[4] = {0, q, 2 * q, 3 * q}; const int k0 = sK0; int pk[4] = {k0, k0, k0, k0};
+			if (k0 >= ns) bad = true;
+			for (uint32_t i = 0; i < q && !bad; ++i)
+			{
+				#pragma unroll
+				for (int k = 0; k < 4; ++k) if (!bad) { uint32_t v; const int s = sym_of(R[k], sC + pk[k] * row, v); R[k] = renorm(v); o[idx[k]++] = sSym[s]; pk[k] = s; }
+			}
+			while (idx[3] < n && !bad) { uint32_t v; const int s = sym_of(R[3], sC + pk[3] * row, v); R[3] = renorm(v); o[idx[3]++] = sSym[s]; pk[3] = s; }
+		}
+	}
+	else
+	{
+		uint32_t x = (uint32_t)p[4 * lane] | ((uint32_t)p[4 * lane + 1] << 8) | ((uint32_t)p[4 * lane + 2] << 16) | ((uint32_t)p[4 * lane + 3] << 24);
+		p += 16;   // (every lane tracks the shared stream pointer)
+		// one round: the lane's symbol (when it has one), then the renormalisation bytes in the order of the states
+		auto round = [&](bool active, const uint16_t* C) -> int {
+			uint32_t v = x; int s = 0, cnt = 0;
+			if (active) { s = sym_of(x, C, v); uint32_t t = v; while (t < (1u << 23) && cnt < 3) { t <<= 8; ++cnt; } }
+			const int c0 = __shfl(cnt, 0), c1 = __shfl(cnt, 1), c2 = __shfl(cnt, 2), c3 = __shfl(cnt, 3);
+			const int my = lane == 0 ? 0 : lane == 1 ? c0 : lane == 2 ? c0 + c1 : c0 + c1 + c2;
+			if (p + c0 + c1 + c2 + c3 > end) bad = true;
+			else for (int b = 0; b < cnt; ++b) v = (v << 8) | p[my + b];
+			p += c0 + c1 + c2 + c3;
+			if (active) x = v;
+			return s;
+		};
+		if (jb.order == 0)
+		{
+			for (uint32_t i = 0; i < n; i += 4)
+			{
+				const bool act = i + (uint32_t)lane < n;
+				const int s = round(act, sC);
+				if (act && !bad) o[i + (uint32_t)lane] = sSym[s];
+				if (__any(bad)) break;
+			}
+		}
+		else
+		{
+			const uint32_t q = n >> 2; uint32_t idx = (uint32_t)lane * q; int pk = sK0;
+			if (pk >= ns) bad = true;
+			for (uint32_t i = 0; i < q; ++i)
+			{
+				const int s = round(!bad, sC + pk * row);
+				if (!bad) { o[idx++] = sSym[s]; pk = s; }
+				if (__any(bad)) break;
+			}
+			if (lane == 3 && !bad)   // what the quarters leave over: state 3 alone, bytes one after the other
+				while (idx < n)
+				{
+					uint32_t v; const int s = sym_of(x, sC + pk * row, v);
+					while (v < (1u << 23)) { if (p >= end) { bad = true; break; } v = (v << 8) | *p++; }
+					if (bad) break;
+					x = v; o[idx++] = sSym[s]; pk = s;
+				}
+		}
+	}
+	if (bad) atomicOr(status, 2u);
+}
+
 __global__ __launch_bounds__(256) void cram_patch_kernel(const CramQualPlan::Patch* __restrict__ P, int64_t n, const uint8_t* __restrict__ qs, uint64_t qs_bytes, uint8_t* __restrict__ image, uint64_t image_bytes,
                                                          unsigned int* __restrict__ status)
 {
@@ -96,7 +201,11 @@ double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, ui
 	unsigned int* d_status = nullptr; HIPCHK(hipMalloc((void**)&d_status, sizeof(unsigned int))); HIPCHK(hipMemsetAsync(d_status, 0, sizeof(unsigned int), s));
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HIPCHK(hipEventRecord(e0, s));
-	hipLaunchKernelGGL(cram_rans_kernel, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status); KCHECK();
+	int kind = 4; if (const char* e = getenv("NGSQC_CRAM_RANS_KERNEL")) kind = atoi(e);   // 4: states in four lanes, tables in LDS (default); 1: one lane, tables in LDS; 0: one lane per block, tables in global memory
+	if (kind == 4) hipLaunchKernelGGL(cram_rans_lds_kernel<4>, dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	else if (kind == 1) hipLaunchKernelGGL(cram_rans_lds_kernel<1>, dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	else hipLaunchKernelGGL(cram_rans_kernel, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	KCHECK();
 	if (!plan.patches.empty())
 	{
 		hipLaunchKernelGGL(cram_patch_kernel, dim3((unsigned)((plan.patches.size() + 255) / 256)), dim3(256), 0, s, d_patch, (int64_t)plan.patches.size(), d_out, (uint64_t)plan.out_bytes, d_image, (uint64_t)image_bytes, d_status); KCHECK();
