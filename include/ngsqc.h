@@ -234,7 +234,8 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 /* ---- CRAM 3.0 input. The reference opens CRAM through the same BamReader (htslib; BamReader.cpp:482-492) with the reference genome the caller names
  * (hts_set_fai_filename). Here every ngsqc_open* entry point takes a CRAM 3.0 file: its container layer (containers, slices, blocks with CRC-32, gzip and rANS
  * 4x8 blocks, the encodings, read features, mate chains, the slices' reference MD5) is decoded on the HOST into BAM records, which reach the device as a BAM image
- * whose BGZF members hold stored blocks - the device path (K1's stored-block copy, CRC, record index, walk, depth, counters) is the BAM path. Index-driven
+ * whose BGZF members hold stored blocks - the device path (K1's stored-block copy, record index, walk, depth, counters) is the BAM path. The quality arrays
+ * (rANS blocks) of a whole-file handle are decoded on the device into that image (cram_dev.hip; NGSQC_CRAM_DEVICE_QUALS=0: on the host). Index-driven
  * requests on a CRAM (ngsqc_open_regions) decode only the slices whose headers overlap a region - what the .crai names, read from the slice headers themselves;
  * ngsqc_open_head the first two slices; ngsqc_open_range the whole file. ngsqc_set_reference names the genome (FASTA with .fai; NULL / "": none; NGSQC_REFERENCE is the
  * fallback) for files that need one (preservation key RR); without it: NGSQC_E_IO "Error while setting reference genome ...", a genome that does not match a
