@@ -970,6 +970,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		if (const char* et = getenv("NGSQC_CRAM_THREADS")) nthreads = std::max(1, atoi(et));
 		nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(jobs.size(), 1));
 		std::atomic<size_t> next(0); std::mutex err_mu; std::exception_ptr first_err;
+		std::atomic<long long> us_blocks(0), us_records(0);   // (summed over the workers: NGSQC_TIMING)
+		auto now_us = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 		auto work = [&] {
 			for (;;)
 			{
@@ -980,9 +982,11 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 				{
 					SliceJob& j = jobs[i]; Cur bc(d, n, j.blocks_at);
 					std::vector<Blk> bl((size_t)j.sh.n_blocks);
+					const long long tb0 = now_us();
 					for (Blk& b : bl) read_block(bc, b, defer ? j.ch->qs_only_id : -1);
 					auto on_host = [&](Blk& b) { rans_decode(b.raw, b.raw_n, b.own); if (b.own.size() != b.n) throw CramError("CRAM block inflates to another size than its header says"); b.p = b.own.data(); b.lazy = false; };
 					for (Blk& b : bl) if (b.lazy) { if (rans_plan(b.raw, b.raw_n, (uint64_t)(b.raw - d), b.n, j.qjob, j.qtabs, j.qsyms)) j.has_q = true; else on_host(b); }
+					const long long tb1 = now_us(); us_blocks += tb1 - tb0;
 					try { decode_slice(*j.ch, j.sh, bl, env, j.out, j.has_q ? &j.patches : nullptr); }
 					catch (NeedHostQuals&)
 					{
@@ -991,6 +995,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 						j.has_q = false; j.out.clear(); j.patches.clear();
 						decode_slice(*j.ch, j.sh, bl, env, j.out, nullptr);
 					}
+					us_records += now_us() - tb1;
 				}
 				catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!first_err) first_err = std::current_exception(); return; }
 			}
@@ -1027,8 +1032,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out);
 		}
 		if (getenv("NGSQC_TIMING"))
-			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms; quality blocks left to the device: %zu (%llu bytes)\n",
-			        jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode, n_q, defer ? (unsigned long long)defer->out_bytes : 0ull);
+			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms; quality blocks left to the device: %zu (%llu bytes); summed over the threads: CRC + block codecs %.1f ms, records %.1f ms\n",
+			        jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode, n_q, defer ? (unsigned long long)defer->out_bytes : 0ull, (double)us_blocks.load() / 1e3, (double)us_records.load() / 1e3);
 	}
 	catch (CramError& e) { throw FormatError("Could not read next alignment in BAM/CRAM file " + path + " (" + e.what() + ")"); }
 }
