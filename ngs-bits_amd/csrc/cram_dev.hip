@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64) void cram_rans_kernel(const uint8_t* __restrict
 // the lanes count the bytes their renormalisation takes (0, 1 or 2), a prefix over the four lanes gives each its place in the shared byte stream (the order the
 // sequential decoder reads them in: state 0 first), and the stream pointer moves on by the sum. Order 1 writes four quarters of the output, one per lane; what is left
 // behind the quarters belongs to state 3 alone.
-template <int LANES> __global__ __launch_bounds__(64) void cram_rans_lds_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
+// BISECT: the symbol of a state by bisection over the cumulative row (6 LDS reads for 64 symbols) instead of the scan from the front (these files have ~40 qualities).
+template <int LANES, bool BISECT> __global__ __launch_bounds__(64) void cram_rans_lds_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
                                                                              const uint8_t* __restrict__ syms, uint8_t* __restrict__ out, unsigned int* __restrict__ status)
 {
 	__shared__ uint16_t sC[65 * 64]; __shared__ uint8_t sSym[64]; __shared__ int sK0;
@@ -82,7 +83,13 @@ template <int LANES> __global__ __launch_bounds__(64) void cram_rans_lds_kernel(
 	bool bad = false;
 	auto sym_of = [&](uint32_t x, const uint16_t* C, uint32_t& v) -> int {   // the symbol index of state x in row C; v: the state behind it, before renormalisation
 		const uint32_t m = x & 0xfffu; int k = 0;
-		while (k + 1 < ns && (uint32_t)C[k + 1] <= m) ++k;
+		if (BISECT)
+		{
+			// the LAST k with C[k] <= m: behind it C[k + 1] > m, so that symbol has a frequency (symbols without one repeat the value of their successor)
+			int hi = ns;
+			while (hi - k > 1) { const int mid = (k + hi) >> 1; if ((uint32_t)C[mid] <= m) k = mid; else hi = mid; }
+		}
+		else while (k + 1 < ns && (uint32_t)C[k + 1] <= m) ++k;
 		const uint32_t c0 = C[k], f = (uint32_t)C[k + 1] - c0;
 		if (f == 0 || m < c0 || m >= (uint32_t)C[k + 1]) { bad = true; v = x; return 0; }
 		v = f * (x >> 12) + m - c0;
@@ -202,8 +209,9 @@ double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, ui
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HIPCHK(hipEventRecord(e0, s));
 	int kind = 4; if (const char* e = getenv("NGSQC_CRAM_RANS_KERNEL")) kind = atoi(e);   // 4: states in four lanes, tables in LDS (default); 1: one lane, tables in LDS; 0: one lane per block, tables in global memory
-	if (kind == 4) hipLaunchKernelGGL(cram_rans_lds_kernel<4>, dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
-	else if (kind == 1) hipLaunchKernelGGL(cram_rans_lds_kernel<1>, dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	if (kind == 5) hipLaunchKernelGGL((cram_rans_lds_kernel<4, true>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);   // 5: as 4, the symbol by bisection
+	else if (kind == 4) hipLaunchKernelGGL((cram_rans_lds_kernel<4, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	else if (kind == 1) hipLaunchKernelGGL((cram_rans_lds_kernel<1, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
 	else hipLaunchKernelGGL(cram_rans_kernel, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
 	KCHECK();
 	if (!plan.patches.empty())
