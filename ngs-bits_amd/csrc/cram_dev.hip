@@ -208,7 +208,7 @@ double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, ui
 	unsigned int* d_status = nullptr; HIPCHK(hipMalloc((void**)&d_status, sizeof(unsigned int))); HIPCHK(hipMemsetAsync(d_status, 0, sizeof(unsigned int), s));
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HIPCHK(hipEventRecord(e0, s));
-	int kind = 4; if (const char* e = getenv("NGSQC_CRAM_RANS_KERNEL")) kind = atoi(e);   // 4: states in four lanes, tables in LDS (default); 1: one lane, tables in LDS; 0: one lane per block, tables in global memory
+	int kind = 5; if (const char* e = getenv("NGSQC_CRAM_RANS_KERNEL")) kind = atoi(e);   // 5 (default): states in four lanes, tables in LDS, symbol by bisection; 4: the same with a scan from the front; 1: one lane, tables in LDS; 0: one lane per block, tables in global memory
 	if (kind == 5) hipLaunchKernelGGL((cram_rans_lds_kernel<4, true>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);   // 5: as 4, the symbol by bisection
 	else if (kind == 4) hipLaunchKernelGGL((cram_rans_lds_kernel<4, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
 	else if (kind == 1) hipLaunchKernelGGL((cram_rans_lds_kernel<1, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
