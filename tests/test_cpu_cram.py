@@ -250,3 +250,20 @@ def test_device_quality_plan_replayed(case, twins, tmp_path, monkeypatch):
     assert got == want
     if case == "twin_plain": assert n_jobs == 0 and n_patches == 0        # raw quality blocks: nothing to decode
     else: assert n_jobs >= 1 and n_patches > 500 and bam_stream(blank)[0] != want
+
+
+def test_empty_cram_and_missing_eof_container(twins, tmp_path):
+    twin = twins["MappingQC_in2.bam"]
+    # a file without records: header container + EOF container
+    empty_bam = str(tmp_path / "empty.bam"); cram_twin.write_bam(empty_bam, twin["text"], twin["refs"], [])
+    cram = str(tmp_path / "empty.cram"); out = str(tmp_path / "o.bam")
+    CE.encode(empty_bam, cram, twin["genome"])
+    ngsqc.cram_to_bam(cram, out)
+    text, refs, recs = split_bam(bam_stream(out)[0])
+    assert text.decode() == twin["text"] and refs == twin["refs"] and recs == []
+    # the EOF container cut off (a file that was still being written): htslib warns and reads what is there
+    full = str(tmp_path / "full.cram"); CE.encode(twin["bam"], full, twin["genome"], rr=False)
+    d = open(full, "rb").read(); assert d[-38:] == CE.eof_container()
+    cut = str(tmp_path / "noeof.cram"); open(cut, "wb").write(d[:-38])
+    ngsqc.cram_to_bam(cut, out)
+    assert split_bam(bam_stream(out)[0])[2] == twin["records"]
