@@ -330,7 +330,7 @@ bool scan_bgzf_threads(const uint8_t* file, size_t n, int T, std::vector<BlockDe
 void scan_bgzf(const uint8_t* file, size_t n, std::vector<BlockDesc>& blocks, std::vector<uint32_t>& crc, int64_t& total, std::vector<uint64_t>* file_off = nullptr, int threads = 0, bool* in_pieces = nullptr)
 {
 	if (in_pieces) *in_pieces = false;
-	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+	if (n >= 4 && memcmp(file, "CRAM", 4) == 0) throw std::domain_error("a CRAM file has no BGZF members: ngsqc_open / ngsqc_open_memory decode it (cram.hip)");
 	if (threads <= 0) { threads = 8; if (const char* e = getenv("NGSQC_WALK_THREADS")) threads = std::min(64, std::max(1, atoi(e))); }   // (round 4: on by default - the first job races the copy, tests/test_gpu_tools.py)
 	if (threads > 1 && n >= ((size_t)threads << 20) && scan_bgzf_threads(file, n, threads, blocks, crc, total, file_off)) { if (in_pieces) *in_pieces = true; return; }
 	blocks.clear(); crc.clear(); if (file_off) file_off->clear();
@@ -705,7 +705,7 @@ void open_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, in
 	if (h->up)
 	{
 		// a path: the copy starts before anything else looks at the file (the BGZF member walk below runs beside it; the header read waits for the first pieces only)
-		if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+		if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("a CRAM file has no BGZF members: ngsqc_open / ngsqc_open_memory decode it (cram.hip)");
 		dbg_stamp("open: start");
 		init_device(h, device);
 		dbg_stamp("open: device and streams ready");
@@ -1716,7 +1716,7 @@ struct RangeRequest { bool by_name = false; uint64_t voff[2] = {0, 0}; const ngs
 
 void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int device, const RangeRequest& rq)
 {
-	if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("CRAM input is not supported by the HIP path");
+	if (n >= 4 && memcmp(bytes, "CRAM", 4) == 0) throw std::domain_error("a CRAM file has no BGZF members: ngsqc_open / ngsqc_open_memory decode it (cram.hip)");
 	init_device(h, device);
 	Timer t(h->stream); t.start();
 	// ---- header: members from the start of the file, more of them until the header is complete ----
