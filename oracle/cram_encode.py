@@ -287,7 +287,7 @@ def huffman_lengths(values):
     return syms, [depth[s] for s in syms]
 
 
-def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None):
+def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False):
     """genome: {contig name: bytes, upper case}. rr = False writes every base into the file ('b' features: no genome needed to read it). multi_ref packs several
     references into one slice (RI series, absolute positions). embed_ref stores the slice's reference stretch in the file. variety = False: raw EXTERNAL only."""
     text, refs, recs = read_bam(bam_path)
@@ -305,7 +305,7 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
     counter = 0; crai = []
     for g in groups:
         at = len(out)
-        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, methods); counter += len(g)
+        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, methods, qual_features); counter += len(g)
         out += c; crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (line[0], line[1], line[2], at, line[3], line[4]))
     out += eof_container()
     open(out_path, "wb").write(bytes(out))
@@ -314,7 +314,7 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
     with gzip.open(out_path + ".crai", "wb") as f: f.write("".join(crai).encode())
 
 
-def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods=None):
+def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods=None, qual_features=False):
     ref_ids = sorted({r["ref_id"] for r in g})
     slice_ref = ref_ids[0] if len(ref_ids) == 1 and not multi_ref else -2
     mapped = [r for r in g if r["ref_id"] >= 0 and r["pos"] >= 1]
@@ -358,6 +358,7 @@ def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety
     for i, r in enumerate(g):
         cf[i] &= 0xff
         if len(r["seq"]) == 0: cf[i] |= CD.CF_NO_SEQ
+        elif qual_features and i % 5 == 2 and not r["flag"] & 4 and len(r["seq"]) > 30: pass     # (a lossy-quality record: single qualities as features below, no array)
         elif r["qual"] != b"\xff" * len(r["qual"]): cf[i] |= CD.CF_QUAL_ARRAY
     E["CF"] = ("HUFFMAN",) + tuple(huffman_lengths(cf)) if variety else ext("CF")
     # ---- tags ----
@@ -422,6 +423,9 @@ def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety
                 elif op == "N": feats.append(("N", rp + 1, k)); gp += k
                 elif op == "H": feats.append(("H", rp + 1, k))
                 elif op == "P": feats.append(("P", rp + 1, k))
+            if qual_features and not cf[i] & CD.CF_QUAL_ARRAY and not cf[i] & CD.CF_NO_SEQ and len(seq) > 30:
+                feats += [("Q", 3, r["qual"][2]), ("q", 10, r["qual"][9:17]), ("Q", len(seq), r["qual"][-1])]
+                feats.sort(key=lambda f: (f[1], 0 if f[0] in "Qq" else 1))
             W.put_int("FN", len(feats)); last = 0
             for code, fp, v in feats:
                 W.put_byte("FC", ord(code)); W.put_int("FP", fp - last); last = fp
@@ -431,6 +435,8 @@ def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety
                 elif code == "S": W.put_array("SC", v)
                 elif code == "i": W.put_byte("BA", v)
                 elif code == "b": W.put_array("BB", v)
+                elif code == "Q": W.put_byte("QS", v)
+                elif code == "q": W.put_array("QQ", v)
                 elif code == "D": W.put_int("DL", v)
                 elif code == "N": W.put_int("RS", v)
                 elif code == "H": W.put_int("HC", v)

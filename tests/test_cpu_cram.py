@@ -267,3 +267,25 @@ def test_empty_cram_and_missing_eof_container(twins, tmp_path):
     cut = str(tmp_path / "noeof.cram"); open(cut, "wb").write(d[:-38])
     ngsqc.cram_to_bam(cut, out)
     assert split_bam(bam_stream(out)[0])[2] == twin["records"]
+
+
+def test_lossy_quality_records_fall_back_to_the_host(twins, tmp_path, monkeypatch):
+    """records without a quality array whose qualities come as features (Q: one, q: a stretch; the rest stays 0xff - lossy-quality CRAMs): the product equals the oracle;
+    such a record reads SINGLE bytes out of the QS block, so a slice that holds one keeps its block on the host (no job in the device plan) and still gives the full records"""
+    twin = twins["MappingQC_in2.bam"]; cram = str(tmp_path / "lossy.cram"); out = str(tmp_path / "o.bam"); blank = str(tmp_path / "b.bam"); plan = str(tmp_path / "p.bin")
+    CE.encode(twin["bam"], cram, twin["genome"], qual_features=True, slice_records=700)
+    f = CD.read_cram(cram, cram_twin.ref_fetch_of(twin)); rgs = CD.read_groups(f.header)
+    want = [CD.to_bam_record(r, rgs) for r in f.records]
+    lossy = [r for r in f.records if not r.cf & CD.CF_QUAL_ARRAY and any(c in "Qq" for c, _, _ in r.features)]
+    assert len(lossy) > 100 and all(r.qual[2] != 0xff and r.qual[4] == 0xff and r.qual[9:17] != b"\\xff" * 8 for r in lossy)
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        ngsqc.cram_to_bam(cram, out)
+        monkeypatch.setenv("NGSQC_CRAM_PLAN_DUMP", plan); ngsqc.cram_to_bam(cram, blank); monkeypatch.delenv("NGSQC_CRAM_PLAN_DUMP")
+    finally:
+        ngsqc.set_reference(None)
+    assert split_bam(bam_stream(out)[0])[2] == want
+    got, n_jobs, n_patches = _replay_plan(open(cram, "rb").read(), plan, bam_stream(blank)[0])
+    assert split_bam(got)[2] == want
+    n_slices = sum(len(ss) for _, ss, _ in f.containers)
+    assert n_jobs < n_slices          # slices with such records are not in the plan
