@@ -552,7 +552,7 @@ struct Dec
 
 enum { BAM_FPAIRED = 1, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FMREVERSE = 32, BAM_FREAD1 = 64 };
 enum { CF_QUAL_ARRAY = 1, CF_DETACHED = 2, CF_MATE_DOWNSTREAM = 4, CF_NO_SEQ = 8 };
-struct Feature { char code; int32_t pos; int32_t v = 0; uint8_t q = 0; std::vector<uint8_t> bytes; };
+struct Feature { char code; int32_t pos; int32_t v = 0; uint8_t q = 0; uint32_t boff = 0, blen = 0; };   // boff / blen: the feature's bytes in the record's scratch buffer
 struct RecInfo { uint32_t bf = 0, cf = 0; int32_t ref_id = -1, pos = 0, end = 0, mate_line = -1, mf = 0, ns = -1, np = 0, ts = 0; int32_t mate_ref = -1, mate_pos = 0; int64_t tlen = 0; bool tlen_set = false; size_t off = 0; };
 
 struct DecodeEnv
@@ -627,7 +627,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 
 	const size_t nrec = (size_t)sh.n_records;
 	std::vector<RecInfo> recs(nrec);
-	std::vector<uint8_t> name, seq, qual, tmp, tagbytes; std::vector<Feature> feats; std::vector<uint32_t> cigar;
+	std::vector<uint8_t> name, seq, qual, tmp, tagbytes, fbytes; std::vector<Feature> feats; std::vector<uint32_t> cigar;
 	const Enc &eBF = ch.series("BF"), &eCF = ch.series("CF"), &eRL = ch.series("RL"), &eAP = ch.series("AP"), &eRG = ch.series("RG"), &eTL = ch.series("TL");
 	struct Lazy   // the other series: looked up once, an error only when a record needs one the header does not define
 	{
@@ -695,7 +695,8 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		{
 			const int32_t fn = D.integer(sFN.get());
 			if (fn < 0 || fn > 2 * rl + 64) throw CramError("feature count out of range");
-			feats.clear(); feats.resize((size_t)fn); int32_t fpos = 0;
+			feats.clear(); feats.resize((size_t)fn); fbytes.clear(); int32_t fpos = 0;
+			auto take = [&](const Enc& e, Feature& f) { D.array(e, tmp); f.boff = (uint32_t)fbytes.size(); f.blen = (uint32_t)tmp.size(); fbytes.insert(fbytes.end(), tmp.begin(), tmp.end()); };
 			for (Feature& f : feats)
 			{
 				f.code = (char)D.byte(sFC.get()); fpos += D.integer(sFP.get()); f.pos = fpos;
@@ -703,15 +704,15 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 				{
 				case 'B': f.v = D.byte(sBA.get()); f.q = D.byte(sQS.get()); break;
 				case 'X': f.v = D.byte(sBS.get()); break;
-				case 'I': D.array(sIN.get(), f.bytes); break;
-				case 'S': D.array(sSC.get(), f.bytes); break;
+				case 'I': take(sIN.get(), f); break;
+				case 'S': take(sSC.get(), f); break;
 				case 'H': f.v = D.integer(sHC.get()); break;
 				case 'P': f.v = D.integer(sPD.get()); break;
 				case 'D': f.v = D.integer(sDL.get()); break;
 				case 'N': f.v = D.integer(sRS.get()); break;
 				case 'i': f.v = D.byte(sBA.get()); break;
-				case 'b': D.array(sBB.get(), f.bytes); break;
-				case 'q': D.array(sQQ.get(), f.bytes); break;
+				case 'b': take(sBB.get(), f); break;
+				case 'q': take(sQQ.get(), f); break;
 				case 'Q': f.q = D.byte(sQS.get()); break;
 				default: throw CramError("unknown CRAM read feature code " + std::to_string((int)(uint8_t)f.code));
 				}
@@ -730,7 +731,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 			{
 				const int64_t at = (int64_t)f.pos - 1;
 				if (f.code == 'Q') { span_ok(at, 1); if (!qarr) qual[(size_t)at] = f.q; continue; }
-				if (f.code == 'q') { span_ok(at, f.bytes.size()); if (!qarr) memcpy(qual.data() + at, f.bytes.data(), f.bytes.size()); continue; }
+				if (f.code == 'q') { span_ok(at, f.blen); if (!qarr && f.blen) memcpy(qual.data() + at, fbytes.data() + f.boff, f.blen); continue; }
 				if (at < read_pos) throw CramError("CRAM read features are not ordered");
 				span_ok(at, 0);
 				match_to(at);
@@ -744,10 +745,10 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 					const int ri = rb == 'A' ? 0 : rb == 'C' ? 1 : rb == 'G' ? 2 : rb == 'T' ? 3 : 4;
 					seq[(size_t)at] = (uint8_t)ch.subst[ri][f.v & 3]; add_op(0, 1); ++ref_pos; ++read_pos; break;
 				}
-				case 'I': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(1, (int64_t)f.bytes.size()); read_pos += (int64_t)f.bytes.size(); break;
+				case 'I': span_ok(at, f.blen); if (f.blen) memcpy(seq.data() + at, fbytes.data() + f.boff, f.blen); add_op(1, (int64_t)f.blen); read_pos += (int64_t)f.blen; break;
 				case 'i': span_ok(at, 1); seq[(size_t)at] = (uint8_t)f.v; add_op(1, 1); ++read_pos; break;
-				case 'S': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(4, (int64_t)f.bytes.size()); read_pos += (int64_t)f.bytes.size(); break;
-				case 'b': span_ok(at, f.bytes.size()); memcpy(seq.data() + at, f.bytes.data(), f.bytes.size()); add_op(0, (int64_t)f.bytes.size()); ref_pos += (int64_t)f.bytes.size(); read_pos += (int64_t)f.bytes.size(); break;
+				case 'S': span_ok(at, f.blen); if (f.blen) memcpy(seq.data() + at, fbytes.data() + f.boff, f.blen); add_op(4, (int64_t)f.blen); read_pos += (int64_t)f.blen; break;
+				case 'b': span_ok(at, f.blen); if (f.blen) memcpy(seq.data() + at, fbytes.data() + f.boff, f.blen); add_op(0, (int64_t)f.blen); ref_pos += (int64_t)f.blen; read_pos += (int64_t)f.blen; break;
 				case 'D': add_op(2, f.v); ref_pos += f.v; break;
 				case 'N': add_op(3, f.v); ref_pos += f.v; break;
 				case 'H': add_op(5, f.v); break;
