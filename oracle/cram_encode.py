@@ -287,7 +287,7 @@ def huffman_lengths(values):
     return syms, [depth[s] for s in syms]
 
 
-def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False):
+def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False, slices_per_container=1):
     """genome: {contig name: bytes, upper case}. rr = False writes every base into the file ('b' features: no genome needed to read it). multi_ref packs several
     references into one slice (RI series, absolute positions). embed_ref stores the slice's reference stretch in the file. variety = False: raw EXTERNAL only."""
     text, refs, recs = read_bam(bam_path)
@@ -303,10 +303,10 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
         cur.append(r)
     if cur: groups.append(cur)
     counter = 0; crai = []
-    for g in groups:
-        at = len(out)
-        c, line = encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, methods, qual_features); counter += len(g)
-        out += c; crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (line[0], line[1], line[2], at, line[3], line[4]))
+    for k in range(0, len(groups), max(1, slices_per_container)):
+        gs = groups[k:k + max(1, slices_per_container)]; at = len(out)
+        c, line = encode_container(gs, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, methods, qual_features); counter += sum(len(g) for g in gs)
+        out += c; crai.append("%d\t%d\t%d\t%d\t%d\t%d\n" % (line[0], line[1], line[2], at, line[3], line[4]))   # (the container's first slice)
     out += eof_container()
     open(out_path, "wb").write(bytes(out))
     # the index `samtools index` writes for a CRAM (.crai: gzip text - reference, start, span, container offset, slice offset in the container, slice size)
@@ -315,166 +315,183 @@ def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_r
 
 
 def encode_slice(g, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods=None, qual_features=False):
-    ref_ids = sorted({r["ref_id"] for r in g})
-    slice_ref = ref_ids[0] if len(ref_ids) == 1 and not multi_ref else -2
-    mapped = [r for r in g if r["ref_id"] >= 0 and r["pos"] >= 1]
-    if slice_ref >= 0:
-        start = min(r["pos"] for r in g); span = max(ref_end(r) for r in g) - start + 1
-    else: start = span = 0
-    ap_delta = slice_ref != -2
-    # ---- series encodings of this slice's container ----
+    return encode_container([g], refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods, qual_features)
+
+
+def encode_container(gs, refs, rgs, genome, rr, multi_ref, chains, embed_ref, variety, counter, block_methods=None, qual_features=False):
+    """one container of len(gs) slices: ONE compression header (preservation map, encodings, tag dictionary) for all of them, a landmark per slice"""
+    # ---- per slice: reference, span, read groups, mate chains, CRAM flags ----
+    P = []
+    for g in gs:
+        ref_ids = sorted({r["ref_id"] for r in g})
+        slice_ref = ref_ids[0] if len(ref_ids) == 1 and not multi_ref else -2
+        if slice_ref >= 0:
+            start = min(r["pos"] for r in g); span = max(ref_end(r) for r in g) - start + 1
+        else: start = span = 0
+        rg_of = []
+        for r in g:
+            t = r["tags"]; rg = -1
+            if t and t[-1][0] == b"RG" and t[-1][1] == ord("Z") and t[-1][2][:-1].decode() in rgs: rg = rgs.index(t[-1][2][:-1].decode())
+            rg_of.append(rg)
+        n = len(g); link = [None] * n; cf = [0] * n
+        if chains:   # chains where the decoder's rules give back the BAM's fields
+            open_by_name = {}
+            for i, r in enumerate(g):
+                j = open_by_name.pop(r["name"], None)
+                if j is None:
+                    if r["flag"] & 1: open_by_name[r["name"]] = i
+                    continue
+                if chain_reproduces(g[j], g[i]): link[j] = i; cf[j] |= CD.CF_MATE_DOWNSTREAM; cf[i] |= 0x100   # (0x100: marks the last member; not written)
+        for i, r in enumerate(g):
+            if cf[i] & (CD.CF_MATE_DOWNSTREAM | 0x100): continue
+            plain = not r["flag"] & 1 and r["mate_ref"] == -1 and r["mate_pos"] == 0 and r["tlen"] == 0 and not r["flag"] & 0x28
+            if not plain: cf[i] |= CD.CF_DETACHED
+        for i, r in enumerate(g):
+            cf[i] &= 0xff
+            if len(r["seq"]) == 0: cf[i] |= CD.CF_NO_SEQ
+            elif qual_features and i % 5 == 2 and not r["flag"] & 4 and len(r["seq"]) > 30: pass     # (a lossy-quality record: single qualities as features below, no array)
+            elif r["qual"] != b"\xff" * len(r["qual"]): cf[i] |= CD.CF_QUAL_ARRAY
+        P.append(dict(g=g, ref=slice_ref, start=start, span=span, rg_of=rg_of, link=link, cf=cf))
+    ap_delta = all(p["ref"] != -2 for p in P)      # (the AP flag of the preservation map holds for the whole container)
+    # ---- series encodings of the container ----
     ids = {}
     def ext(key):
         ids.setdefault(key, len(ids) + 1); return ("EXTERNAL", ids[key])
     E = {k: ext(k) for k in ("BF", "RL", "AP", "NP", "TS", "NF", "TL", "FP", "BS", "BA", "QS", "RI", "MF", "NS", "HC", "PD", "RS", "FC")}
     E["RN"] = ("BYTE_ARRAY_STOP", 0, ext("RN")[1]); E["IN"] = ("BYTE_ARRAY_STOP", 0, ext("IN")[1]); E["SC"] = ("BYTE_ARRAY_STOP", 0, ext("SC")[1])
     E["BB"] = ("BYTE_ARRAY_LEN", ext("BBl"), ext("BBv")); E["QQ"] = ("BYTE_ARRAY_LEN", ext("QQl"), ext("QQv"))
-    # per-record values known up front decide the core codecs
-    rg_of = []
-    for r in g:
-        t = r["tags"]; rg = -1
-        if t and t[-1][0] == b"RG" and t[-1][1] == ord("Z") and t[-1][2][:-1].decode() in rgs: rg = rgs.index(t[-1][2][:-1].decode())
-        rg_of.append(rg)
+    all_rg = [x for p in P for x in p["rg_of"]]; all_cf = [x for p in P for x in p["cf"]]
     if variety:
-        E["RG"] = ("HUFFMAN",) + tuple(huffman_lengths(rg_of))
+        E["RG"] = ("HUFFMAN",) + tuple(huffman_lengths(all_rg))
         E["MQ"] = ("BETA", 0, 8); E["FN"] = ("GAMMA", 1); E["DL"] = ("SUBEXP", 0, 2)
+        E["CF"] = ("HUFFMAN",) + tuple(huffman_lengths(all_cf))
     else:
-        E["RG"] = ext("RG"); E["MQ"] = ext("MQ"); E["FN"] = ext("FN"); E["DL"] = ext("DL")
-    # ---- mates: chains where the decoder's rules give back the BAM's fields ----
-    n = len(g); link = [None] * n; cf = [0] * n
-    if chains:
-        open_by_name = {}
-        for i, r in enumerate(g):
-            j = open_by_name.pop(r["name"], None)
-            if j is None:
-                if r["flag"] & 1: open_by_name[r["name"]] = i
-                continue
-            a, b = g[j], g[i]
-            if chain_reproduces(a, b): link[j] = i; cf[j] |= CD.CF_MATE_DOWNSTREAM; cf[i] |= 0x100   # (0x100: marks the last member; not written)
-    for i, r in enumerate(g):
-        if cf[i] & (CD.CF_MATE_DOWNSTREAM | 0x100): continue
-        plain = not r["flag"] & 1 and r["mate_ref"] == -1 and r["mate_pos"] == 0 and r["tlen"] == 0 and not r["flag"] & 0x28
-        if not plain: cf[i] |= CD.CF_DETACHED
-    for i, r in enumerate(g):
-        cf[i] &= 0xff
-        if len(r["seq"]) == 0: cf[i] |= CD.CF_NO_SEQ
-        elif qual_features and i % 5 == 2 and not r["flag"] & 4 and len(r["seq"]) > 30: pass     # (a lossy-quality record: single qualities as features below, no array)
-        elif r["qual"] != b"\xff" * len(r["qual"]): cf[i] |= CD.CF_QUAL_ARRAY
-    E["CF"] = ("HUFFMAN",) + tuple(huffman_lengths(cf)) if variety else ext("CF")
+        E["RG"] = ext("RG"); E["MQ"] = ext("MQ"); E["FN"] = ext("FN"); E["DL"] = ext("DL"); E["CF"] = ext("CF")
     # ---- tags ----
-    TD = []; tl_of = []; tag_enc = {}
-    for r, rg in zip(g, rg_of):
-        tags = r["tags"][:-1] if rg >= 0 else r["tags"]
-        line = tuple((t, typ) for t, typ, _ in tags)
-        if line not in TD: TD.append(line)
-        tl_of.append(TD.index(line))
-        for t, typ, _ in tags:
-            key = (t[0] << 16) | (t[1] << 8) | typ
-            if key not in tag_enc: tag_enc[key] = ("BYTE_ARRAY_LEN", ext("tl%d" % key), ext("tv%d" % key))
-    # ---- records ----
-    W = SliceWriter(E); prev = start; bases = 0
+    TD = []; tag_enc = {}
+    for p in P:
+        p["tl_of"] = []
+        for r, rg in zip(p["g"], p["rg_of"]):
+            tags = r["tags"][:-1] if rg >= 0 else r["tags"]
+            line = tuple((t, typ) for t, typ, _ in tags)
+            if line not in TD: TD.append(line)
+            p["tl_of"].append(TD.index(line))
+            for t, typ, _ in tags:
+                key = (t[0] << 16) | (t[1] << 8) | typ
+                if key not in tag_enc: tag_enc[key] = ("BYTE_ARRAY_LEN", ext("tl%d" % key), ext("tv%d" % key))
     sm = SUBST_DEFAULT
     subst_code = {}
     for ri, rb in enumerate(BASES):
         others = [b for b in BASES if b != rb]
         for k, b in enumerate(others): subst_code[(rb, b)] = (sm[ri] >> (6 - 2 * k)) & 3
-    embedded = None
-    if embed_ref and slice_ref >= 0 and rr: embedded = genome[refs[slice_ref][0]][start - 1:start - 1 + span]
 
     def ref_base(r, p0):
-        if not rr: return None
         seq = genome[refs[r["ref_id"]][0]]
         return chr(seq[p0]) if 0 <= p0 < len(seq) else "N"
-    for i, r in enumerate(g):
-        mapped_rec = not r["flag"] & 4
-        rl = len(r["seq"]) if len(r["seq"]) else sum(k for op, k in r["cigar"] if op in "MIS=X")
-        W.put_int("BF", r["flag"]); W.put_int("CF", cf[i])
-        if slice_ref == -2: W.put_int("RI", r["ref_id"])
-        W.put_int("RL", rl)
-        if ap_delta: W.put_int("AP", r["pos"] - prev); prev = r["pos"]
-        else: W.put_int("AP", r["pos"])
-        W.put_int("RG", rg_of[i]); W.put_array("RN", r["name"])
-        if cf[i] & CD.CF_DETACHED:
-            W.put_int("MF", (1 if r["flag"] & 0x20 else 0) | (2 if r["flag"] & 0x8 else 0))
-            W.put_int("NS", r["mate_ref"]); W.put_int("NP", r["mate_pos"]); W.put_int("TS", r["tlen"])
-        elif cf[i] & CD.CF_MATE_DOWNSTREAM: W.put_int("NF", link[i] - i - 1)
-        W.put_int("TL", tl_of[i])
-        for t, typ, v in (r["tags"][:-1] if rg_of[i] >= 0 else r["tags"]):
-            W.put_array(None, v, tag_enc[(t[0] << 16) | (t[1] << 8) | typ])
-        bases += rl
-        if mapped_rec:
-            feats = []; rp = 0; gp = r["pos"] - 1; seq = r["seq"]
-            for op, k in r["cigar"]:
-                if op in "M=X":
-                    if not rr:
-                        if len(seq): feats.append(("b", rp + 1, seq[rp:rp + k]))
-                    elif len(seq):
-                        for x in range(k):
-                            b = chr(seq[rp + x]); rb = ref_base(r, gp + x)
-                            if rb not in BASES: rb = "N"
-                            if b == rb: continue
-                            if b in BASES: feats.append(("X", rp + x + 1, subst_code[(rb, b)]))
-                            else: feats.append(("B", rp + x + 1, (seq[rp + x], r["qual"][rp + x])))
-                    rp += k; gp += k
-                elif op == "I":
-                    feats.append(("I", rp + 1, seq[rp:rp + k]) if k > 1 or not variety else ("i", rp + 1, seq[rp])); rp += k
-                elif op == "S": feats.append(("S", rp + 1, seq[rp:rp + k])); rp += k
-                elif op == "D": feats.append(("D", rp + 1, k)); gp += k
-                elif op == "N": feats.append(("N", rp + 1, k)); gp += k
-                elif op == "H": feats.append(("H", rp + 1, k))
-                elif op == "P": feats.append(("P", rp + 1, k))
-            if qual_features and not cf[i] & CD.CF_QUAL_ARRAY and not cf[i] & CD.CF_NO_SEQ and len(seq) > 30:
-                feats += [("Q", 3, r["qual"][2]), ("q", 10, r["qual"][9:17]), ("Q", len(seq), r["qual"][-1])]
-                feats.sort(key=lambda f: (f[1], 0 if f[0] in "Qq" else 1))
-            W.put_int("FN", len(feats)); last = 0
-            for code, fp, v in feats:
-                W.put_byte("FC", ord(code)); W.put_int("FP", fp - last); last = fp
-                if code == "B": W.put_byte("BA", v[0]); W.put_byte("QS", v[1])
-                elif code == "X": W.put_byte("BS", v)
-                elif code == "I": W.put_array("IN", v)
-                elif code == "S": W.put_array("SC", v)
-                elif code == "i": W.put_byte("BA", v)
-                elif code == "b": W.put_array("BB", v)
-                elif code == "Q": W.put_byte("QS", v)
-                elif code == "q": W.put_array("QQ", v)
-                elif code == "D": W.put_int("DL", v)
-                elif code == "N": W.put_int("RS", v)
-                elif code == "H": W.put_int("HC", v)
-                elif code == "P": W.put_int("PD", v)
-            W.put_int("MQ", r["mapq"])
-            if cf[i] & CD.CF_QUAL_ARRAY: W.put_bytes("QS", r["qual"])
-        else:
-            if not cf[i] & CD.CF_NO_SEQ: W.put_bytes("BA", r["seq"])
-            if cf[i] & CD.CF_QUAL_ARRAY: W.put_bytes("QS", r["qual"])
     # ---- compression header ----
     pres = b"RN\x01" + b"AP" + bytes([1 if ap_delta else 0]) + b"RR" + bytes([1 if rr else 0]) + b"SM" + sm
     td = b"".join(b"".join(t + bytes([typ]) for t, typ in line) + b"\0" for line in TD)
     pres += b"TD" + itf8(len(td)) + td
     pres = itf8(5) + pres
-    used = {k: e for k, e in E.items()}
-    dsm = itf8(len(used)) + b"".join(k.encode() + enc_bytes(e) for k, e in used.items())
+    dsm = itf8(len(E)) + b"".join(k.encode() + enc_bytes(e) for k, e in E.items())
     tgm = itf8(len(tag_enc)) + b"".join(itf8(k) + enc_bytes(e) for k, e in tag_enc.items())
     ch = itf8(len(pres)) + pres + itf8(len(dsm)) + dsm + itf8(len(tgm)) + tgm
     ch_block = block(0, 1, 0, ch)
-    # ---- blocks ----
-    ext_blocks = []; content_ids = []
-    methods = block_methods or ([0, 1, 4, 41] if variety else [0])
-    for k, (cid, data) in enumerate(sorted(W.ext.items())):
-        m = methods[k % len(methods)]
-        if cid == ids.get("QS") and variety and not block_methods: m = 41
-        if m in (4, 41) and len(data) > 400000: m = 1
-        ext_blocks.append(block(m, 4, cid, bytes(data))); content_ids.append(cid)
-    emb_id = -1
-    if embedded is not None:
-        emb_id = max(content_ids + [0]) + 1; ext_blocks.append(block(1, 4, emb_id, bytes(embedded))); content_ids.append(emb_id)
-    core = block(0, 5, 0, W.core())
-    md5 = b"\0" * 16
-    if slice_ref >= 0 and rr:
-        seq = genome[refs[slice_ref][0]]; md5 = hashlib.md5(bytes(seq[start - 1:start - 1 + span])).digest()
-    sh = itf8(slice_ref) + itf8(start) + itf8(span) + itf8(len(g)) + ltf8(counter) + itf8(1 + len(ext_blocks)) + array_itf8(content_ids) + itf8(emb_id) + md5
-    sh_block = block(0, 2, 0, sh)
-    blocks = [ch_block, sh_block, core] + ext_blocks
-    return container(slice_ref, start, span, len(g), counter, bases, blocks, [len(ch_block)]), (slice_ref, start, span, len(ch_block), sum(len(b) for b in blocks[1:]))
+    blocks = [ch_block]; landmarks = []; total_bases = 0; at = len(ch_block); first_slice_size = 0; rec_counter = counter
+    # ---- slices ----
+    for p in P:
+        g, slice_ref, start, span, rg_of, link, cf, tl_of = p["g"], p["ref"], p["start"], p["span"], p["rg_of"], p["link"], p["cf"], p["tl_of"]
+        W = SliceWriter(E); prev = start; bases = 0
+        embedded = None
+        if embed_ref and slice_ref >= 0 and rr: embedded = genome[refs[slice_ref][0]][start - 1:start - 1 + span]
+        for i, r in enumerate(g):
+            mapped_rec = not r["flag"] & 4
+            rl = len(r["seq"]) if len(r["seq"]) else sum(k for op, k in r["cigar"] if op in "MIS=X")
+            W.put_int("BF", r["flag"]); W.put_int("CF", cf[i])
+            if slice_ref == -2: W.put_int("RI", r["ref_id"])
+            W.put_int("RL", rl)
+            if ap_delta: W.put_int("AP", r["pos"] - prev); prev = r["pos"]
+            else: W.put_int("AP", r["pos"])
+            W.put_int("RG", rg_of[i]); W.put_array("RN", r["name"])
+            if cf[i] & CD.CF_DETACHED:
+                W.put_int("MF", (1 if r["flag"] & 0x20 else 0) | (2 if r["flag"] & 0x8 else 0))
+                W.put_int("NS", r["mate_ref"]); W.put_int("NP", r["mate_pos"]); W.put_int("TS", r["tlen"])
+            elif cf[i] & CD.CF_MATE_DOWNSTREAM: W.put_int("NF", link[i] - i - 1)
+            W.put_int("TL", tl_of[i])
+            for t, typ, v in (r["tags"][:-1] if rg_of[i] >= 0 else r["tags"]):
+                W.put_array(None, v, tag_enc[(t[0] << 16) | (t[1] << 8) | typ])
+            bases += rl
+            if mapped_rec:
+                feats = []; rp = 0; gp = r["pos"] - 1; seq = r["seq"]
+                for op, k in r["cigar"]:
+                    if op in "M=X":
+                        if not rr:
+                            if len(seq): feats.append(("b", rp + 1, seq[rp:rp + k]))
+                        elif len(seq):
+                            for x in range(k):
+                                b = chr(seq[rp + x]); rb = ref_base(r, gp + x)
+                                if rb not in BASES: rb = "N"
+                                if b == rb: continue
+                                if b in BASES: feats.append(("X", rp + x + 1, subst_code[(rb, b)]))
+                                else: feats.append(("B", rp + x + 1, (seq[rp + x], r["qual"][rp + x])))
+                        rp += k; gp += k
+                    elif op == "I":
+                        feats.append(("I", rp + 1, seq[rp:rp + k]) if k > 1 or not variety else ("i", rp + 1, seq[rp])); rp += k
+                    elif op == "S": feats.append(("S", rp + 1, seq[rp:rp + k])); rp += k
+                    elif op == "D": feats.append(("D", rp + 1, k)); gp += k
+                    elif op == "N": feats.append(("N", rp + 1, k)); gp += k
+                    elif op == "H": feats.append(("H", rp + 1, k))
+                    elif op == "P": feats.append(("P", rp + 1, k))
+                if qual_features and not cf[i] & CD.CF_QUAL_ARRAY and not cf[i] & CD.CF_NO_SEQ and len(seq) > 30:
+                    feats += [("Q", 3, r["qual"][2]), ("q", 10, r["qual"][9:17]), ("Q", len(seq), r["qual"][-1])]
+                    feats.sort(key=lambda f: (f[1], 0 if f[0] in "Qq" else 1))
+                W.put_int("FN", len(feats)); last = 0
+                for code, fp, v in feats:
+                    W.put_byte("FC", ord(code)); W.put_int("FP", fp - last); last = fp
+                    if code == "B": W.put_byte("BA", v[0]); W.put_byte("QS", v[1])
+                    elif code == "X": W.put_byte("BS", v)
+                    elif code == "I": W.put_array("IN", v)
+                    elif code == "S": W.put_array("SC", v)
+                    elif code == "i": W.put_byte("BA", v)
+                    elif code == "b": W.put_array("BB", v)
+                    elif code == "Q": W.put_byte("QS", v)
+                    elif code == "q": W.put_array("QQ", v)
+                    elif code == "D": W.put_int("DL", v)
+                    elif code == "N": W.put_int("RS", v)
+                    elif code == "H": W.put_int("HC", v)
+                    elif code == "P": W.put_int("PD", v)
+                W.put_int("MQ", r["mapq"])
+                if cf[i] & CD.CF_QUAL_ARRAY: W.put_bytes("QS", r["qual"])
+            else:
+                if not cf[i] & CD.CF_NO_SEQ: W.put_bytes("BA", r["seq"])
+                if cf[i] & CD.CF_QUAL_ARRAY: W.put_bytes("QS", r["qual"])
+        # ---- the slice's blocks ----
+        ext_blocks = []; content_ids = []
+        methods = block_methods or ([0, 1, 4, 41] if variety else [0])
+        for k, (cid, data) in enumerate(sorted(W.ext.items())):
+            m = methods[k % len(methods)]
+            if cid == ids.get("QS") and variety and not block_methods: m = 41
+            if m in (4, 41) and len(data) > 400000: m = 1
+            ext_blocks.append(block(m, 4, cid, bytes(data))); content_ids.append(cid)
+        emb_id = -1
+        if embedded is not None:
+            emb_id = max(content_ids + [0]) + 1; ext_blocks.append(block(1, 4, emb_id, bytes(embedded))); content_ids.append(emb_id)
+        core = block(0, 5, 0, W.core())
+        md5 = b"\0" * 16
+        if slice_ref >= 0 and rr:
+            seq = genome[refs[slice_ref][0]]; md5 = hashlib.md5(bytes(seq[start - 1:start - 1 + span])).digest()
+        sh = itf8(slice_ref) + itf8(start) + itf8(span) + itf8(len(g)) + ltf8(rec_counter) + itf8(1 + len(ext_blocks)) + array_itf8(content_ids) + itf8(emb_id) + md5
+        sblocks = [block(0, 2, 0, sh), core] + ext_blocks
+        landmarks.append(at); size = sum(len(b) for b in sblocks); at += size
+        if not first_slice_size: first_slice_size = size
+        blocks += sblocks; total_bases += bases; rec_counter += len(g)
+    crefs = {p["ref"] for p in P}
+    if len(crefs) == 1 and -2 not in crefs and next(iter(crefs)) >= 0:
+        cref = next(iter(crefs)); cstart = min(p["start"] for p in P); cspan = max(p["start"] + p["span"] for p in P) - cstart
+    elif crefs == {-1}: cref, cstart, cspan = -1, 0, 0
+    else: cref, cstart, cspan = -2, 0, 0
+    n_rec = sum(len(p["g"]) for p in P)
+    return container(cref, cstart, cspan, n_rec, counter, total_bases, blocks, landmarks), (P[0]["ref"], P[0]["start"], P[0]["span"], len(ch_block), first_slice_size)
 
 
 def chain_reproduces(a, b):

@@ -142,7 +142,8 @@ import cram_encode as CE  # noqa: E402
 import cram_twin  # noqa: E402
 
 VARIANTS = {"default": {}, "no_genome_needed": dict(rr=False), "multi_reference_slices": dict(multi_ref=True, slice_records=700), "embedded_reference": dict(embed_ref=True),
-            "plain_external": dict(variety=False, chains=False), "small_slices": dict(slice_records=150), "bzip2_and_lzma_blocks": dict(methods=[2, 3, 1])}
+            "plain_external": dict(variety=False, chains=False), "small_slices": dict(slice_records=150), "bzip2_and_lzma_blocks": dict(methods=[2, 3, 1]),
+            "containers_of_three_slices": dict(slices_per_container=3, slice_records=300), "containers_of_mixed_slices": dict(slices_per_container=4, slice_records=250, multi_ref=True)}
 
 
 def test_eof_container_equals_the_fixtures():
