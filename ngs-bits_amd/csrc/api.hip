@@ -1845,7 +1845,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 			// the first records: the first two slices; a virtual-offset range means nothing in a CRAM: the whole file
 			CramSelect sel;
 			if (range && range->by_name) for (int64_t i = 0; i < range->n_regions; ++i) sel.regions.push_back(CramSelect::Region{range->regions[i].chr ? range->regions[i].chr : "", range->regions[i].start, range->regions[i].end});
-			if (range && range->head_members > 0) sel.max_slices = std::max<int64_t>(2, range->head_members / 64);   // (a caller that asks for a longer head gets more slices)
+			if (range && range->head_members > 0) sel.max_slices = std::max<int64_t>(2, range->head_members / 4);   // (a slice holds ~10 000 records, a BGZF member ~250: every longer head BamReader::info asks for - x4 each time - brings more slices)
 			// the quality arrays (rANS blocks, about half of the records' bytes) stay compressed and are decoded on the device into the uploaded image (cram_dev.hip):
 			// whole-file handles only (a shard uploads a part of the image); NGSQC_CRAM_DEVICE_QUALS=0 keeps them on the host
 			const char* eq = getenv("NGSQC_CRAM_DEVICE_QUALS");
