@@ -1142,6 +1142,7 @@ static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file,
 	const char* es = getenv("NGSQC_INDEX_SELECT");
 	if ((es && atoi(es) == 0) || bed_file.count() < 2 || bed_file.count() > 4096 || getenv("NGSQC_SHARDS")) return false;
 	if (!hasBamIndex(bam_file)) return false;
+	if (bam_file.size() > 5 && bam_file.compare(bam_file.size() - 5, 5, ".cram") == 0) return false;   // (a CRAM: the library picks the slices of the regions itself)
 	std::vector<ngsqc_region> lines; int n_ref = 0;
 	{
 		BamReader head(bam_file, ref_file, BamReader::Head{1});   // (chromosome numbering of this BAM: the header members only)
