@@ -839,6 +839,26 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 	}
 }
 
+// fn(i) for i in [0, n) on up to `threads` host threads (exceptions: the first one is rethrown)
+template <class F> void parallel_for(size_t n, int threads, F fn)
+{
+	threads = (int)std::min<size_t>((size_t)std::max(threads, 1), std::max<size_t>(n, 1));
+	if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+	std::atomic<size_t> next(0); std::mutex mu; std::exception_ptr err;
+	auto work = [&] { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) return; try { fn(i); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); return; } } };
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+	work();
+	for (auto& t : pool) t.join();
+	if (err) std::rethrow_exception(err);
+}
+int host_threads()
+{
+	int nt = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+	if (const char* et = getenv("NGSQC_CRAM_THREADS")) nt = std::max(1, atoi(et));
+	return nt;
+}
+
 struct SliceJob
 {
 	const CompHdr* ch = nullptr; SliceHdr sh; size_t blocks_at = 0; std::vector<uint8_t> out;
@@ -967,9 +987,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		}
 		const double t_parse = since();
 		// ---- slices in parallel ----
-		int nthreads = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-		if (const char* et = getenv("NGSQC_CRAM_THREADS")) nthreads = std::max(1, atoi(et));
-		nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(jobs.size(), 1));
+		const int nthreads = (int)std::min<size_t>((size_t)host_threads(), std::max<size_t>(jobs.size(), 1));
 		std::atomic<size_t> next(0); std::mutex err_mu; std::exception_ptr first_err;
 		std::atomic<long long> us_blocks(0), us_records(0);   // (summed over the workers: NGSQC_TIMING)
 		auto now_us = [] { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1019,18 +1037,21 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			add32(stream, (uint32_t)ref_names[i].size() + 1); stream.insert(stream.end(), ref_names[i].begin(), ref_names[i].end()); stream.push_back(0);
 			add32(stream, (uint32_t)ref_lens[i]);
 		}
-		size_t n_q = 0;
-		for (SliceJob& j : jobs)
+		size_t n_q = 0; uint64_t at = stream.size(); std::vector<uint64_t> base_of(jobs.size());
+		for (size_t ji = 0; ji < jobs.size(); ++ji) { base_of[ji] = at; at += jobs[ji].out.size(); }
+		stream.resize((size_t)at);
+		parallel_for(jobs.size(), nthreads, [&](size_t ji) { SliceJob& j = jobs[ji]; if (!j.out.empty()) memcpy(stream.data() + base_of[ji], j.out.data(), j.out.size()); std::vector<uint8_t>().swap(j.out); });
+		for (size_t ji = 0; ji < jobs.size(); ++ji)
 		{
+			SliceJob& j = jobs[ji];
 			if (j.has_q && defer)
 			{
-				const uint64_t base = stream.size();
+				const uint64_t base = base_of[ji];
 				CramQualPlan::Job q = j.qjob; q.out_off = defer->out_bytes; q.tab_off = (uint32_t)defer->tabs.size(); q.sym_off = (uint32_t)defer->syms.size();
 				defer->jobs.push_back(q); defer->tabs.insert(defer->tabs.end(), j.qtabs.begin(), j.qtabs.end()); defer->syms.insert(defer->syms.end(), j.qsyms.begin(), j.qsyms.end());
 				for (CramQualPlan::Patch pt : j.patches) { pt.dst += base; pt.src += q.out_off; defer->patches.push_back(pt); }
 				defer->out_bytes += q.n_out; ++n_q;
 			}
-			stream.insert(stream.end(), j.out.begin(), j.out.end()); std::vector<uint8_t>().swap(j.out);
 		}
 		if (getenv("NGSQC_TIMING"))
 			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms; quality blocks left to the device: %zu (%llu bytes); summed over the threads: CRC + block codecs %.1f ms, records %.1f ms\n",
@@ -1054,21 +1075,20 @@ int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std:
 // the stream in BGZF members with STORED deflate blocks (RFC 1951 3.2.4) and the EOF member: what K1's stored-block path copies on the device
 void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image)
 {
+	// member m holds stream bytes [m * 65280, ...): 18 bytes of header, 5 of the stored block, the bytes, CRC-32 and size - every member at a known place, filled in parallel
 	const size_t piece = 0xff00, nm = (stream.size() + piece - 1) / piece;
-	image.clear(); image.reserve(stream.size() + (nm + 1) * 31 + 28);
-	auto member = [&](const uint8_t* p, size_t n) {
+	image.assign(stream.size() + nm * 31 + 28, 0);
+	parallel_for(nm, host_threads(), [&](size_t m) {
+		const uint8_t* p = stream.data() + m * piece; const size_t n = std::min(piece, stream.size() - m * piece);
+		uint8_t* o = image.data() + m * (piece + 31);
 		const uint32_t bsize = (uint32_t)(n + 5 + 25);
-		const uint8_t h[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8)};
-		image.insert(image.end(), h, h + 18);
-		const uint8_t sb[5] = {1, (uint8_t)(n & 255), (uint8_t)(n >> 8), (uint8_t)(~n & 255), (uint8_t)((~n >> 8) & 255)};
-		image.insert(image.end(), sb, sb + 5);
-		image.insert(image.end(), p, p + n);
-		uint8_t none = 0; const uint32_t crc = crc_of(n ? p : &none, n);
-		add32(image, crc); add32(image, (uint32_t)n);
-	};
-	for (size_t o = 0; o < stream.size(); o += piece) member(stream.data() + o, std::min(piece, stream.size() - o));
+		const uint8_t h[23] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8), 1, (uint8_t)(n & 255), (uint8_t)(n >> 8), (uint8_t)(~n & 255), (uint8_t)((~n >> 8) & 255)};
+		memcpy(o, h, 23); memcpy(o + 23, p, n);
+		const uint32_t crc = crc_of(p, n), isize = (uint32_t)n;
+		memcpy(o + 23 + n, &crc, 4); memcpy(o + 27 + n, &isize, 4);
+	});
 	static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	image.insert(image.end(), eof, eof + 28);
+	memcpy(image.data() + image.size() - 28, eof, 28);
 }
 
 } // namespace ngsqc
