@@ -1840,7 +1840,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		const bool from_cram = is_cram((const uint8_t*)bytes, n);
 		if (from_cram)
 		{
-			std::vector<uint8_t> stream; std::string err;
+			std::string err;
 			// regions: the slices whose headers overlap them (what the .crai of `samtools index` would name; the slice headers themselves are read instead);
 			// the first records: the first two slices; a virtual-offset range means nothing in a CRAM: the whole file
 			CramSelect sel;
@@ -1851,12 +1851,11 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 			const char* eq = getenv("NGSQC_CRAM_DEVICE_QUALS");
 			const bool dev_quals = n_shards == 1 && (!eq || atoi(eq) != 0);
 			cram_src = (const uint8_t*)bytes;
-			const int crc = cram_to_bam_stream((const uint8_t*)bytes, n, h->path, stream, err, &sel, dev_quals ? &qplan : nullptr);
+			const int crc = cram_to_bam_image((const uint8_t*)bytes, n, h->path, cram_image, err, &sel, dev_quals ? &qplan : nullptr);
 			if (crc == NGSQC_E_FORMAT) throw FormatError(err);
 			if (crc == NGSQC_E_IO) throw IoError(err);
 			if (crc == NGSQC_E_UNSUPPORTED) throw std::domain_error(err);
 			if (crc != NGSQC_OK) throw std::runtime_error(err);
-			bgzf_store(stream, cram_image);
 			bytes = cram_image.data(); n = cram_image.size(); h->from_cram = true;
 			range = nullptr;   // (regions, a record range, the first records: the whole file holds them)
 		}
@@ -2159,14 +2158,14 @@ int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_n
 	{
 		std::ifstream f(cram_path, std::ios::binary);
 		if (!f) { g_open_error = std::string("Could not open BAM/CRAM file ") + cram_path; return NGSQC_E_IO; }
-		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()), stream, image; std::string err;
+		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()), image; std::string err;
 		if (!ngsqc::is_cram(d.data(), d.size())) { g_open_error = std::string("not a CRAM file: ") + cram_path; return NGSQC_E_FORMAT; }
 		ngsqc::CramSelect sel;
 		for (int64_t i = 0; i < n_regions; ++i) sel.regions.push_back(ngsqc::CramSelect::Region{regions[i].chr ? regions[i].chr : "", regions[i].start, regions[i].end});
 		// NGSQC_CRAM_PLAN_DUMP=<file> (tests): the records with the quality arrays left blank, as the device path uploads them, and the plan of the quality blocks in <file>
 		// (counts, then the arrays of CramQualPlan) - tests/test_cpu_cram.py replays the device kernels of cram_dev.hip on it
 		const char* dump = getenv("NGSQC_CRAM_PLAN_DUMP"); ngsqc::CramQualPlan plan;
-		const int rc = ngsqc::cram_to_bam_stream(d.data(), d.size(), cram_path, stream, err, &sel, dump ? &plan : nullptr);
+		const int rc = ngsqc::cram_to_bam_image(d.data(), d.size(), cram_path, image, err, &sel, dump ? &plan : nullptr);
 		if (rc != NGSQC_OK) { g_open_error = err; return rc; }
 		if (dump)
 		{
@@ -2176,7 +2175,6 @@ int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_n
 			pf.write((const char*)hd, sizeof hd); pf.write((const char*)plan.jobs.data(), (std::streamsize)(plan.jobs.size() * 40)); pf.write((const char*)plan.tabs.data(), (std::streamsize)(plan.tabs.size() * 2));
 			pf.write((const char*)plan.syms.data(), (std::streamsize)plan.syms.size()); pf.write((const char*)plan.patches.data(), (std::streamsize)(plan.patches.size() * 24));
 		}
-		ngsqc::bgzf_store(stream, image);
 		std::ofstream o(bam_path, std::ios::binary | std::ios::trunc);
 		if (o) o.write((const char*)image.data(), (std::streamsize)image.size());
 		o.close();

@@ -56,10 +56,10 @@ struct CramQualPlan
 	std::vector<Job> jobs; std::vector<uint16_t> tabs; std::vector<uint8_t> syms; std::vector<Patch> patches; uint64_t out_bytes = 0;
 	// tabs: per job (order 0: one row; order 1: nsym rows, row = index of the previous symbol) of nsym + 1 cumulative frequencies; syms: per job 64 symbols + 256 bytes "byte -> index"
 };
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel = nullptr, CramQualPlan* defer = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
+// the CRAM as a BAM IMAGE: header + records in BGZF members of 65 280 bytes with stored blocks (+ the EOF member), which the BAM path takes like any other BAM
+int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, std::string& err, const CramSelect* sel = nullptr, CramQualPlan* defer = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
 // decodes the plan's blocks on the device and writes the qualities into the BAM image (stored BGZF members of 65 280 bytes, as bgzf_store lays them out) at d_image; returns the kernel time in ms
 double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, uint8_t* d_image, size_t image_bytes, hipStream_t s);
-void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image);
 
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 

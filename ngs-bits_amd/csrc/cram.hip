@@ -879,8 +879,11 @@ bool is_cram(const uint8_t* d, size_t n) { return n >= 4 && memcmp(d, "CRAM", 4)
 
 namespace {
 // the whole CRAM as an uncompressed BAM stream ("BAM\1", header, records in file order). Throws FormatError / IoError / std::domain_error.
-void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, const CramSelect* sel, CramQualPlan* defer)
+void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, std::vector<uint8_t>& image);
+
+void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, const CramSelect* sel, CramQualPlan* defer)
 {
+	std::vector<uint8_t> stream;   // (the BAM header only: the records stay in the slices' buffers until they are framed)
 	try
 	{
 		const auto t0 = std::chrono::steady_clock::now();
@@ -1029,7 +1032,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		size_t total = 12 + text.size();
 		for (size_t i = 0; i < ref_names.size(); ++i) total += 9 + ref_names[i].size();
 		for (const SliceJob& j : jobs) total += j.out.size();
-		stream.clear(); stream.reserve(total);
+		(void)total;
 		stream.insert(stream.end(), {'B', 'A', 'M', 1}); add32(stream, (uint32_t)text.size()); stream.insert(stream.end(), text.begin(), text.end());
 		add32(stream, (uint32_t)ref_names.size());
 		for (size_t i = 0; i < ref_names.size(); ++i)
@@ -1038,9 +1041,11 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			add32(stream, (uint32_t)ref_lens[i]);
 		}
 		size_t n_q = 0; uint64_t at = stream.size(); std::vector<uint64_t> base_of(jobs.size());
-		for (size_t ji = 0; ji < jobs.size(); ++ji) { base_of[ji] = at; at += jobs[ji].out.size(); }
-		stream.resize((size_t)at);
-		parallel_for(jobs.size(), nthreads, [&](size_t ji) { SliceJob& j = jobs[ji]; if (!j.out.empty()) memcpy(stream.data() + base_of[ji], j.out.data(), j.out.size()); std::vector<uint8_t>().swap(j.out); });
+		std::vector<std::pair<const uint8_t*, size_t>> pieces; pieces.emplace_back(stream.data(), stream.size());
+		for (size_t ji = 0; ji < jobs.size(); ++ji) { base_of[ji] = at; at += jobs[ji].out.size(); pieces.emplace_back(jobs[ji].out.data(), jobs[ji].out.size()); }
+		const size_t stream_bytes = (size_t)at;
+		bgzf_store_pieces(pieces, image);   // (header + the slices' records, cut into stored BGZF members - in parallel, straight out of the slices' buffers)
+		for (SliceJob& j : jobs) std::vector<uint8_t>().swap(j.out);
 		for (size_t ji = 0; ji < jobs.size(); ++ji)
 		{
 			SliceJob& j = jobs[ji];
@@ -1055,17 +1060,17 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		}
 		if (getenv("NGSQC_TIMING"))
 			fprintf(stderr, "[ngsqc] cram: %zu slices on %d host threads: structure %.1f ms, blocks + records %.1f ms, BAM stream of %zu bytes %.1f ms; quality blocks left to the device: %zu (%llu bytes); summed over the threads: CRC + block codecs %.1f ms, records %.1f ms\n",
-			        jobs.size(), nthreads, t_parse, t_decode - t_parse, stream.size(), since() - t_decode, n_q, defer ? (unsigned long long)defer->out_bytes : 0ull, (double)us_blocks.load() / 1e3, (double)us_records.load() / 1e3);
+			        jobs.size(), nthreads, t_parse, t_decode - t_parse, stream_bytes, since() - t_decode, n_q, defer ? (unsigned long long)defer->out_bytes : 0ull, (double)us_blocks.load() / 1e3, (double)us_records.load() / 1e3);
 	}
 	catch (CramError& e) { throw FormatError("Could not read next alignment in BAM/CRAM file " + path + " (" + e.what() + ")"); }
 }
 } // namespace
 
 // NGSQC_OK or NGSQC_E_FORMAT / NGSQC_E_IO / NGSQC_E_UNSUPPORTED / NGSQC_E_DEVICE with the message in err
-int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& stream, std::string& err, const CramSelect* sel, CramQualPlan* defer)
+int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, std::string& err, const CramSelect* sel, CramQualPlan* defer)
 {
 	if (defer) *defer = CramQualPlan();
-	try { cram_to_bam_stream_impl(d, n, path, stream, sel, defer); return NGSQC_OK; }
+	try { cram_to_bam_stream_impl(d, n, path, image, sel, defer); return NGSQC_OK; }
 	catch (FormatError& e) { err = e.what(); return NGSQC_E_FORMAT; }
 	catch (IoError& e) { err = e.what(); return NGSQC_E_IO; }
 	catch (std::domain_error& e) { err = e.what(); return NGSQC_E_UNSUPPORTED; }
@@ -1073,22 +1078,34 @@ int cram_to_bam_stream(const uint8_t* d, size_t n, const std::string& path, std:
 }
 
 // the stream in BGZF members with STORED deflate blocks (RFC 1951 3.2.4) and the EOF member: what K1's stored-block path copies on the device
-void bgzf_store(const std::vector<uint8_t>& stream, std::vector<uint8_t>& image)
+namespace {
+// the concatenation of the pieces in BGZF members with STORED deflate blocks (RFC 1951 3.2.4) and the EOF member: what K1's stored-block path copies on the device.
+// Member m holds stream bytes [m * 65280, ...): 18 bytes of header, 5 of the stored block, the bytes, CRC-32 and size - every member at a known place, filled in parallel.
+void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, std::vector<uint8_t>& image)
 {
-	// member m holds stream bytes [m * 65280, ...): 18 bytes of header, 5 of the stored block, the bytes, CRC-32 and size - every member at a known place, filled in parallel
-	const size_t piece = 0xff00, nm = (stream.size() + piece - 1) / piece;
-	image.assign(stream.size() + nm * 31 + 28, 0);
+	std::vector<uint64_t> start(pieces.size() + 1, 0);
+	for (size_t i = 0; i < pieces.size(); ++i) start[i + 1] = start[i] + pieces[i].second;
+	const uint64_t total = start.back(); const size_t piece = 0xff00, nm = (size_t)((total + piece - 1) / piece);
+	image.assign((size_t)total + nm * 31 + 28, 0);
 	parallel_for(nm, host_threads(), [&](size_t m) {
-		const uint8_t* p = stream.data() + m * piece; const size_t n = std::min(piece, stream.size() - m * piece);
+		const uint64_t s0 = (uint64_t)m * piece; const size_t n = (size_t)std::min<uint64_t>(piece, total - s0);
 		uint8_t* o = image.data() + m * (piece + 31);
 		const uint32_t bsize = (uint32_t)(n + 5 + 25);
 		const uint8_t h[23] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8), 1, (uint8_t)(n & 255), (uint8_t)(n >> 8), (uint8_t)(~n & 255), (uint8_t)((~n >> 8) & 255)};
-		memcpy(o, h, 23); memcpy(o + 23, p, n);
-		const uint32_t crc = crc_of(p, n), isize = (uint32_t)n;
+		memcpy(o, h, 23);
+		size_t pi = (size_t)(std::upper_bound(start.begin(), start.end(), s0) - start.begin()) - 1, done = 0;   // the piece that holds stream byte s0
+		while (done < n)
+		{
+			while (pieces[pi].second == 0 || s0 + done >= start[pi + 1]) ++pi;
+			const uint64_t in = s0 + done - start[pi]; const size_t k = (size_t)std::min<uint64_t>(n - done, pieces[pi].second - in);
+			memcpy(o + 23 + done, pieces[pi].first + in, k); done += k;
+		}
+		const uint32_t crc = crc_of(o + 23, n), isize = (uint32_t)n;
 		memcpy(o + 23 + n, &crc, 4); memcpy(o + 27 + n, &isize, 4);
 	});
 	static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	memcpy(image.data() + image.size() - 28, eof, 28);
 }
+} // namespace
 
 } // namespace ngsqc
