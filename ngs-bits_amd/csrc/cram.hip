@@ -854,7 +854,7 @@ template <class F> void parallel_for(size_t n, int threads, F fn)
 }
 int host_threads()
 {
-	int nt = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+	int nt = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
 	if (const char* et = getenv("NGSQC_CRAM_THREADS")) nt = std::max(1, atoi(et));
 	return nt;
 }
