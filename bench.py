@@ -175,10 +175,19 @@ def main():
         if box[0] is None:
             okc.zero_()
         else:
-            try:
-                comm = ngsqc.Comm(rank, world, box[0], device=local_rank)
-            except Exception as e:
-                comm_note = f"ngsqc_comm_init failed on rank {rank}: {e}"[:200]; okc.zero_()
+            # (in a thread with a deadline: a communicator that does not come up must not hang the bench - the ranks then agree on torch.distributed below)
+            import threading
+            res = {}
+            def _make():
+                try:
+                    res["comm"] = ngsqc.Comm(rank, world, box[0], device=local_rank)
+                except Exception as e:
+                    res["err"] = e
+            th = threading.Thread(target=_make, daemon=True); th.start(); th.join(float(os.environ.get("NGSQC_BENCH_COMM_TIMEOUT", "180")))
+            if "comm" in res:
+                comm = res["comm"]
+            else:
+                comm_note = (f"ngsqc_comm_init failed on rank {rank}: {res['err']}" if "err" in res else f"ngsqc_comm_init did not return on rank {rank} within its deadline")[:200]; okc.zero_()
         dist.all_reduce(okc, op=dist.ReduceOp.MIN)
         if int(okc.item()) == 0:
             if comm is not None:
