@@ -1836,7 +1836,7 @@ int open_impl(ngsqc_handle** out, const char* path, const void* bytes, size_t n,
 		if (!bytes && n) throw ArgError("null BAM buffer");
 		// CRAM 3.0 (BamReader.cpp:482-492): the container layer is decoded on the host (cram.hip) into a BAM stream in stored BGZF members; from here on the file is a BAM
 		// image in memory. Index-driven requests (a .crai names slices, not BGZF members) fall back to the whole file: a superset of what a region needs.
-		std::vector<uint8_t> cram_image; CramQualPlan qplan; const uint8_t* cram_src = nullptr;
+		ByteImage cram_image; CramQualPlan qplan; const uint8_t* cram_src = nullptr;
 		const bool from_cram = is_cram((const uint8_t*)bytes, n);
 		if (from_cram)
 		{
@@ -2158,7 +2158,7 @@ int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_n
 	{
 		std::ifstream f(cram_path, std::ios::binary);
 		if (!f) { g_open_error = std::string("Could not open BAM/CRAM file ") + cram_path; return NGSQC_E_IO; }
-		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()), image; std::string err;
+		std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); ngsqc::ByteImage image; std::string err;
 		if (!ngsqc::is_cram(d.data(), d.size())) { g_open_error = std::string("not a CRAM file: ") + cram_path; return NGSQC_E_FORMAT; }
 		ngsqc::CramSelect sel;
 		for (int64_t i = 0; i < n_regions; ++i) sel.regions.push_back(ngsqc::CramSelect::Region{regions[i].chr ? regions[i].chr : "", regions[i].start, regions[i].end});

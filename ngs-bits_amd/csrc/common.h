@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 #include "../../include/ngsqc.h"
 #include "k1_types.h"
@@ -56,8 +57,17 @@ struct CramQualPlan
 	std::vector<Job> jobs; std::vector<uint16_t> tabs; std::vector<uint8_t> syms; std::vector<Patch> patches; uint64_t out_bytes = 0;
 	// tabs: per job (order 0: one row; order 1: nsym rows, row = index of the previous symbol) of nsym + 1 cumulative frequencies; syms: per job 64 symbols + 256 bytes "byte -> index"
 };
+// a byte buffer that is NOT zeroed when it is made (a BAM image of a WGS CRAM is ~100 GB: the workers that fill it touch its pages, in parallel)
+struct ByteImage
+{
+	std::unique_ptr<uint8_t[]> p; size_t n = 0;
+	void make(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
+	uint8_t* data() { return p.get(); }
+	const uint8_t* data() const { return p.get(); }
+	size_t size() const { return n; }
+};
 // the CRAM as a BAM IMAGE: header + records in BGZF members of 65 280 bytes with stored blocks (+ the EOF member), which the BAM path takes like any other BAM
-int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, std::string& err, const CramSelect* sel = nullptr, CramQualPlan* defer = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
+int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, ByteImage& image, std::string& err, const CramSelect* sel = nullptr, CramQualPlan* defer = nullptr);   // NGSQC_OK or an NGSQC_E_* code with err
 // decodes the plan's blocks on the device and writes the qualities into the BAM image (stored BGZF members of 65 280 bytes, as bgzf_store lays them out) at d_image; returns the kernel time in ms
 double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, uint8_t* d_image, size_t image_bytes, hipStream_t s);
 

@@ -879,9 +879,9 @@ bool is_cram(const uint8_t* d, size_t n) { return n >= 4 && memcmp(d, "CRAM", 4)
 
 namespace {
 // the whole CRAM as an uncompressed BAM stream ("BAM\1", header, records in file order). Throws FormatError / IoError / std::domain_error.
-void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, std::vector<uint8_t>& image);
+void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, ByteImage& image);
 
-void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, const CramSelect* sel, CramQualPlan* defer)
+void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path, ByteImage& image, const CramSelect* sel, CramQualPlan* defer)
 {
 	std::vector<uint8_t> stream;   // (the BAM header only: the records stay in the slices' buffers until they are framed)
 	try
@@ -1067,7 +1067,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 } // namespace
 
 // NGSQC_OK or NGSQC_E_FORMAT / NGSQC_E_IO / NGSQC_E_UNSUPPORTED / NGSQC_E_DEVICE with the message in err
-int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, std::vector<uint8_t>& image, std::string& err, const CramSelect* sel, CramQualPlan* defer)
+int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, ByteImage& image, std::string& err, const CramSelect* sel, CramQualPlan* defer)
 {
 	if (defer) *defer = CramQualPlan();
 	try { cram_to_bam_stream_impl(d, n, path, image, sel, defer); return NGSQC_OK; }
@@ -1081,12 +1081,12 @@ int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, std::
 namespace {
 // the concatenation of the pieces in BGZF members with STORED deflate blocks (RFC 1951 3.2.4) and the EOF member: what K1's stored-block path copies on the device.
 // Member m holds stream bytes [m * 65280, ...): 18 bytes of header, 5 of the stored block, the bytes, CRC-32 and size - every member at a known place, filled in parallel.
-void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, std::vector<uint8_t>& image)
+void bgzf_store_pieces(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, ByteImage& image)
 {
 	std::vector<uint64_t> start(pieces.size() + 1, 0);
 	for (size_t i = 0; i < pieces.size(); ++i) start[i + 1] = start[i] + pieces[i].second;
 	const uint64_t total = start.back(); const size_t piece = 0xff00, nm = (size_t)((total + piece - 1) / piece);
-	image.assign((size_t)total + nm * 31 + 28, 0);
+	image.make((size_t)total + nm * 31 + 28);
 	parallel_for(nm, host_threads(), [&](size_t m) {
 		const uint64_t s0 = (uint64_t)m * piece; const size_t n = (size_t)std::min<uint64_t>(piece, total - s0);
 		uint8_t* o = image.data() + m * (piece + 31);
