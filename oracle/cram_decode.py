@@ -10,7 +10,8 @@ restated here:
 PARITY PINNING: partial. The reference holds four CRAM 3.0 files and no BAM twin of them; its own CRAM tests (src/cppNGS-TEST/BamReader_Test.cpp:400-560) need
 the hg38 genome, which is not in the tree. Pinned here (tests/test_oracle_cram.py): every CRC of the fixtures, the record counts of containers against
 slices, and the known answers of those tests that do not depend on the genome - name, position, end, CIGAR, qualities, mapping quality, insert size, mate
-position, tags MC / AS of the first properly paired read, the CIGARs of the first two mapped reads and of the last read. BASES that come from the reference
+position, tags MC / AS of the first properly paired read, the CIGARs of the first two mapped reads and of the last read, the depths of the eight getPileup calls, the
+allele split of the heterozygous SNPs (reads with a substitution feature at the site) and the insertion / deletion counts of the four indel pileups. BASES that come from the reference
 genome cannot be checked on the fixtures (only those stored in features: soft clips, insertions, explicit bases).
 Record by record, pure Python: fixture-sized inputs only.
 """

@@ -100,6 +100,36 @@ def test_pileup_depths(cram_test):
     assert _pileup(cram_test, "chr5", 80864777)[0] == 16
 
 
+def _indels(f, chrom, pos, window):
+    """the indel part of BamReader::getPileup (BamReader.cpp:870-877) with BamAlignment::extractIndelsByCIGAR (:376-438): (insertions, deletions) of the reads that
+    overlap pos and pass the pileup's filters, within +- window of pos"""
+    tid = [n for n, _ in CD.ref_names(f.header)].index(chrom); ins = dele = 0
+    for r in f.records:
+        if r.ref_id != tid or r.bf & (0x100 | 0x800 | 0x400 | 4) or not r.bf & 2 or r.mapq < 1: continue
+        if not (r.pos <= pos <= r.end): continue
+        g = r.pos
+        for op, n in r.cigar:
+            if op in "M=X": g += n
+            elif op == "I":
+                if pos - window <= g <= pos + window: ins += 1
+            elif op == "D":
+                if pos - window <= g <= pos + window: dele += 1
+                g += n
+            elif op == "N": g += n
+            if g > pos + window: break
+    return ins, dele
+
+
+def test_pileup_indels(cram_test):
+    """CramSupport_getPileup, the indel counts: positions of I and D inside the CIGARs that the decoder builds from the read features of hundreds of reads"""
+    assert _indels(cram_test, "chr3", 10052522, 1) == (10, 4)           # indels().count() == 14: 10 with '+', 4 with '-'
+    assert _indels(cram_test, "chr2", 47806751, 1) == (12, 14)          # 26, 14 with '-'
+    assert _indels(cram_test, "chr6", 130827751, 3) == (298, 27)        # 325
+    assert _indels(cram_test, "chr5", 80864777, 4) == (0, 6)            # 6, all deletions
+    for chrom, pos in (("chr1", 27355990), ("chr1", 27359572), ("chr1", 27360975), ("chr1", 27363868)):
+        assert _indels(cram_test, chrom, pos, 1) == (0, 0)
+
+
 @pytest.mark.parametrize("name,n_records,rr", [("SampleIdentity_in_wes.cram", 17534, True), ("SampleIdentity_in_rna.cram", 10528, False)])
 def test_other_fixtures_decode(name, n_records, rr):
     f = CD.read_cram(os.path.join(GI, name))
