@@ -988,6 +988,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 			}
 			env.genome = &genome;
 		}
+		// (the plan of the device quality decoder holds 24 bytes per record: above 10^8 records - 2.4 GB - the blocks stay on the host until the plan has a per-block form)
+		{ int64_t n_records = 0; for (const SliceJob& j : jobs) n_records += j.sh.n_records; if (n_records > 100000000ll) defer = nullptr; }
 		const double t_parse = since();
 		// ---- slices in parallel ----
 		const int nthreads = (int)std::min<size_t>((size_t)host_threads(), std::max<size_t>(jobs.size(), 1));
