@@ -87,11 +87,12 @@ void rans_read_freqs(Cur& c, RansTable& t)
 	}
 	if (acc < 4096) memset(t.L + acc, 0, 4096 - acc);
 }
-void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out)
+void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out, size_t expect)   // expect: the decoded size the block header names (the stream's own size field must agree BEFORE anything is decoded)
 {
 	if (n < 9) throw CramError("truncated rANS block");
 	const int order = d[0];
 	const uint32_t n_out = (uint32_t)d[5] | ((uint32_t)d[6] << 8) | ((uint32_t)d[7] << 16) | ((uint32_t)d[8] << 24);
+	if ((size_t)n_out != expect) throw CramError("rANS block of another size than its block header says");
 	out.assign(n_out, 0);
 	if (!n_out) return;
 	Cur c(d, n, 9);
@@ -234,7 +235,7 @@ void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1)   // lazy_cid: an externa
 		if (rc != Z_STREAM_END || got != (size_t)rsize) throw CramError("gzip block of the CRAM file does not inflate");
 		b.p = b.own.data(); b.n = b.own.size();
 	}
-	else if (b.method == 4) { rans_decode(raw, (size_t)csize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
+	else if (b.method == 4) { rans_decode(raw, (size_t)csize, b.own, (size_t)rsize); b.p = b.own.data(); b.n = b.own.size(); }
 	else if (b.method == 2) { bz2_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
 	else if (b.method == 3) { lzma_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
 	else throw std::domain_error("CRAM 3.1 block codec " + std::to_string(b.method) + " is not supported by the HIP path");
@@ -545,7 +546,7 @@ struct Dec
 			if (q >= c.n) throw CramError("CRAM byte array without its stop byte");
 			out.assign(c.d + c.p, c.d + q); c.p = q + 1; return;
 		}
-		if (e.kind == E_BYTE_ARRAY_LEN) { const int32_t k = integer(*e.e1); if (k < 0) throw CramError("negative byte array length"); bytes_n(*e.e2, (size_t)k, out); return; }
+		if (e.kind == E_BYTE_ARRAY_LEN) { const int32_t k = integer(*e.e1); if (k < 0 || k > (1 << 28)) throw CramError("byte array length out of range"); bytes_n(*e.e2, (size_t)k, out); return; }
 		throw CramError("CRAM encoding " + std::to_string(e.kind) + " cannot give a byte array");
 	}
 };
@@ -1008,7 +1009,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 					std::vector<Blk> bl((size_t)j.sh.n_blocks);
 					const long long tb0 = now_us();
 					for (Blk& b : bl) read_block(bc, b, defer ? j.ch->qs_only_id : -1);
-					auto on_host = [&](Blk& b) { rans_decode(b.raw, b.raw_n, b.own); if (b.own.size() != b.n) throw CramError("CRAM block inflates to another size than its header says"); b.p = b.own.data(); b.lazy = false; };
+					auto on_host = [&](Blk& b) { rans_decode(b.raw, b.raw_n, b.own, b.n); if (b.own.size() != b.n) throw CramError("CRAM block inflates to another size than its header says"); b.p = b.own.data(); b.lazy = false; };
 					for (Blk& b : bl) if (b.lazy) { if (rans_plan(b.raw, b.raw_n, (uint64_t)(b.raw - d), b.n, j.qjob, j.qtabs, j.qsyms)) j.has_q = true; else on_host(b); }
 					const long long tb1 = now_us(); us_blocks += tb1 - tb0;
 					try { decode_slice(*j.ch, j.sh, bl, env, j.out, j.has_q ? &j.patches : nullptr); }
