@@ -49,7 +49,7 @@ bool load_bai(const std::string& path, Bai& out)
 	size_t o = 4; const size_t n = d.size();
 	auto need = [&](size_t k) { if (o + k > n) throw std::runtime_error("truncated BAI index " + path); };
 	need(4); const int32_t n_ref = (int32_t)r32(&d[o]); o += 4;
-	if (n_ref < 0) return false;
+	if (n_ref < 0 || (size_t)n_ref > (n - o) / 8) return false;   // (every reference takes at least its two counts)
 	out = Bai(); out.refs.resize((size_t)n_ref);
 	for (int32_t r = 0; r < n_ref; ++r)
 	{
@@ -117,7 +117,7 @@ bool load_csi(const std::string& path, Bai& out)
 	if (min_shift < 0 || min_shift > 31 || depth < 0 || depth > 10 || min_shift + 3 * depth > 62 || l_aux < 0) return false;   // (bin numbers are 32 bit: depth <= 10)
 	need((size_t)l_aux); o += (size_t)l_aux;
 	need(4); const int32_t n_ref = (int32_t)r32(&d[o]); o += 4;
-	if (n_ref < 0) return false;
+	if (n_ref < 0 || (size_t)n_ref > (n - o) / 4) return false;   // (every reference takes at least its bin count)
 	out = Bai(); out.csi = true; out.min_shift = min_shift; out.depth = depth; out.refs.resize((size_t)n_ref);
 	for (int32_t r = 0; r < n_ref; ++r)
 	{
@@ -135,17 +135,6 @@ bool load_csi(const std::string& path, Bai& out)
 	return true;
 }
 
-// bins that may hold records overlapping [beg, end) (0-based, half open): SAM spec 5.3 reg2bins, hts.c reg2bins for any (min_shift, depth)
-void reg2bins(int64_t beg, int64_t end, int min_shift, int depth, std::vector<uint32_t>& bins)
-{
-	--end;
-	int s = min_shift + 3 * depth; uint32_t t = 0;
-	for (int l = 0; l <= depth; ++l)
-	{
-		for (int64_t k = (int64_t)t + (beg >> s); k <= (int64_t)t + (end >> s); ++k) bins.push_back((uint32_t)k);
-		s -= 3; t += 1u << (3 * l);
-	}
-}
 const IdxBin* find_bin(const BaiRef& R, uint32_t bin)
 {
 	auto it = std::lower_bound(R.bins.begin(), R.bins.end(), bin, [](const IdxBin& a, uint32_t b) { return a.bin < b; });
@@ -190,14 +179,16 @@ static bool region_range(const Bai& bai, const ngsqc_region& g, int32_t n_ref, u
 		min_off = hit ? hit->loff : 0;
 	}
 	else if (!R.ioffset.empty()) { const size_t w = (size_t)(beg >> shift); min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back(); }
-	std::vector<uint32_t> bins; reg2bins(beg, end, shift, depth, bins);
-	std::sort(bins.begin(), bins.end());
+	// (the bins of the INDEX are tested against the region - the interval of a bin follows from its number - instead of listing the region's bins as reg2bins does:
+	// an index with a tiny min_shift would make that list as long as the region)
 	const uint32_t n_bins = n_bins_of(depth);
 	rb = ~0ull; re = 0; uint64_t stop = ~0ull; bool any = false;
 	for (const IdxBin& bc : R.bins)
 	{
 		if (bc.bin >= n_bins) continue;   // (n_bins + 1: the metadata pseudo-bin)
-		if (std::binary_search(bins.begin(), bins.end(), bc.bin))
+		const int l = bin_level(bc.bin);
+		const int64_t bin_start = (int64_t)(bc.bin - bin_first(l)) << (shift + 3 * (depth - l)), bin_size = 1ll << (shift + 3 * (depth - l));
+		if (bin_start < end && bin_start + bin_size > beg)
 		{
 			for (const BaiChunk& c : bc.chunks)
 				if (c.end > min_off) { rb = std::min(rb, c.beg); re = std::max(re, c.end); any = true; }
@@ -206,8 +197,6 @@ static bool region_range(const Bai& bai, const ngsqc_region& g, int32_t n_ref, u
 		// A bin whose interval starts at or behind the region's end holds only records that start there, so its first chunk starts at such a record. The file is
 		// sorted by start: every record that overlaps the region lies in front of that record - where the iterator of the reference stops, too (hts_itr_next:
 		// "beg >= iter->end"). Without this bound the range runs to the last chunk of the region's super-bins.
-		const int l = bin_level(bc.bin);
-		const int64_t bin_start = (int64_t)(bc.bin - bin_first(l)) << (shift + 3 * (depth - l));
 		if (bin_start >= end) for (const BaiChunk& c : bc.chunks) stop = std::min(stop, c.beg);
 	}
 	if (!any) return false;
