@@ -423,7 +423,8 @@ public:
 		while (std::getline(fai, line))
 		{
 			std::istringstream is(line); Entry e; std::string name;
-			if (!(is >> name >> e.len >> e.offset >> e.line_bases >> e.line_bytes) || e.line_bases <= 0 || e.line_bytes < e.line_bases) { err = "damaged index " + fasta + ".fai"; return false; }
+			if (!(is >> name >> e.len >> e.offset >> e.line_bases >> e.line_bytes) || e.len < 0 || e.offset < 0 || e.line_bases <= 0 || e.line_bytes < e.line_bases || e.line_bytes > e.line_bases + 2)
+			{ err = "damaged index " + fasta + ".fai"; return false; }
 			idx_[name] = e;
 		}
 		fd_ = ::open(fasta.c_str(), O_RDONLY);
@@ -450,7 +451,7 @@ public:
 		while (got < e.len)
 		{
 			const int64_t k = std::min<int64_t>(e.line_bases, e.len - got);
-			if (o + (size_t)k > n_) throw CramError("reference genome is shorter than its index says");
+			if (o > n_ || (size_t)k > n_ - o) throw CramError("reference genome is shorter than its index says");
 			for (int64_t i = 0; i < k; ++i) { uint8_t ch = map_[o + (size_t)i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32); (*s)[(size_t)(got + i)] = (char)ch; }
 			got += k; o += (size_t)e.line_bytes;
 		}
