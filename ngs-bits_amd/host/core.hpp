@@ -18,6 +18,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <climits>
+#include <cerrno>
 #include <unordered_map>
 #include <vector>
 
@@ -161,9 +163,16 @@ public:
 			if (line[0] == '#' || line.rfind("track ", 0) == 0 || line.rfind("browser ", 0) == 0 || line.rfind("Chromosome\tStart\tEnd", 0) == 0) { headers_.push_back(line); continue; }
 			std::vector<std::string> f = split(line, '\t');
 			if (f.size() < 3) NB_THROW(FileParseException, "BED file line with less than three fields found: '" + trimmed(line) + "'");
-			char* e1; char* e2; long s = strtol(f[1].c_str(), &e1, 10); long e = strtol(f[2].c_str(), &e2, 10);
-			if (f[1].empty() || *e1) NB_THROW(FileParseException, "BED file line with invalid starts position found: '" + trimmed(line) + "'");
-			if (f[2].empty() || *e2) NB_THROW(FileParseException, "BED file line with invalid end position found: '" + trimmed(line) + "'");
+			// QByteArray::toInt(&ok) (BedFile.cpp:157-160): base 10, white space around the number ignored, not ok outside the range of int
+			auto to_int = [](const std::string& t, long& v) -> bool {
+				char* e = nullptr; errno = 0; v = strtol(t.c_str(), &e, 10);
+				if (e == t.c_str() || errno == ERANGE || v < INT_MIN || v > INT_MAX) return false;
+				while (*e == ' ' || *e == '\t' || *e == '\n' || *e == '\v' || *e == '\f' || *e == '\r') ++e;
+				return *e == 0;
+			};
+			long s = 0, e = 0;
+			if (!to_int(f[1], s)) NB_THROW(FileParseException, "BED file line with invalid starts position found: '" + trimmed(line) + "'");
+			if (!to_int(f[2], e)) NB_THROW(FileParseException, "BED file line with invalid end position found: '" + trimmed(line) + "'");
 			std::vector<std::string> annos; if (read_annotations) annos.assign(f.begin() + 3, f.end());
 			append(BedLine(Chromosome(f[0]), (int)s + 1, (int)e, annos));
 		}

@@ -73,10 +73,10 @@ def bed_regions(bed_path, refs, merge_mode):
     err = C.create_string_buffer(512)
     n = L.ngsbits_bed_regions(os.fsencode(bed_path), names, len(refs), merge_mode, None, 0, err, 512)
     if n < 0:
-        raise RuntimeError(err.value.decode())
+        raise RuntimeError(err.value.decode("utf-8", "replace"))
     out = np.zeros((max(n, 1), 3), dtype=np.int32)
     if L.ngsbits_bed_regions(os.fsencode(bed_path), names, len(refs), merge_mode, out.ctypes.data, n, err, 512) != n:
-        raise RuntimeError(err.value.decode())
+        raise RuntimeError(err.value.decode("utf-8", "replace"))
     return [(int(a), int(b), int(c)) for a, b, c in out[:n]], [[] for _ in range(n)]
 
 

@@ -185,3 +185,19 @@ def test_region_tables_of_the_host_layer_equal_the_oracle(mode):
         assert got == exp, (bed, mode)
         n += len(got)
     assert n > 1000
+
+
+def test_bed_positions_parse_like_qbytearray_toint(tmp_path):
+    """BedFile::load (src/cppNGS/BedFile.cpp:155-160) converts with QByteArray::toInt(&ok): base 10, white space around the number is ignored, a value outside the range of
+    int is NOT ok - the line is refused ("BED file line with invalid ... position found"), never wrapped"""
+    import hostprep as H
+    refs = [("chr1", 1), ("chr2", 1)]
+    p = str(tmp_path / "a.bed")
+    open(p, "w").write("chr1\t 100\t200 \nchr2\t+5\t7\r\n")
+    assert H.bed_regions(p, refs, 0)[0] == [(0, 101, 200), (1, 6, 7)]
+    for bad, what in (("chr1\t2147483648\t5\n", "starts"), ("chr1\t5\t-2147483649\n", "end"), ("chr1\t5\t99999999999999999999\n", "end"), ("chr1\t1e3\t5\n", "starts"),
+                      ("chr1\t0x10\t50\n", "starts"), ("chr1\t\t5\n", "starts"), ("chr1\t5\t6x\n", "end")):
+        open(p, "w").write("chr2\t1\t2\n" + bad)
+        with pytest.raises(RuntimeError) as e:
+            H.bed_regions(p, refs, 0)
+        assert "invalid %s position" % what in str(e.value), (bad, str(e.value))
