@@ -300,6 +300,8 @@ public:
 			++n; std::vector<std::string> fl = split(line, '\t');
 			if (fl.size() != 5) NB_THROW(FileParseException, "Malformed FASTA index line " + std::to_string(n) + " in file '" + fasta_file + ".fai'!");
 			idx_[Chromosome(fl[0]).num()] = Entry{atoi(fl[1].c_str()), atoll(fl[2].c_str()), atoi(fl[3].c_str())};
+			const Entry& en = idx_[Chromosome(fl[0]).num()];
+			if (en.length < 0 || en.offset < 0 || en.line_blen <= 0) NB_THROW(FileParseException, "Malformed FASTA index line " + std::to_string(n) + " in file '" + fasta_file + ".fai'!");   // (a line length of 0 would divide by zero in seq())
 		}
 		if (idx_.empty()) NB_THROW(FileParseException, "Empty FAI file for " + fasta_file + "'!");
 	}
