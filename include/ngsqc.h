@@ -346,6 +346,10 @@ typedef struct ngsqc_timings {
 	double job_wall_ms;               /* host wall time of the last ngsqc_run_job (setup, all tiles, result copies) */
 	int64_t members_second_chance;    /* members whose launch ran out of token pages and that were inflated again with the worst-case pool (since the handle was opened) */
 	int64_t members_third_chance;     /* ... and again with the bound that holds for every valid member (members of thousands of DEFLATE blocks) */
+	/* record index (round 5): how the tiles of the last decode found their record chains */
+	int64_t tiles_chain_on_device;    /* tiles whose chain passed the check on the device (every walker's exit = the next walker's start): no host verification */
+	int64_t tiles_scan_fused;         /* ... of which the job's mapping / depth scan rode the chain walk (one read of every record's first line) */
+	int64_t walkers_per_member;       /* walkers per BGZF member of the last tile's fast path (NGSQC_WALKERS) */
 } ngsqc_timings;
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
 

@@ -51,7 +51,8 @@ class Timings(C.Structure):
                 ("inflated_bytes", C.c_int64), ("n_records", C.c_int64), ("scan_kernel_ms", C.c_double), ("depth_kernel_ms", C.c_double), ("inflate_huff_ms", C.c_double), ("inflate_lz77_ms", C.c_double),
                 ("inflate_huff_launches", C.c_int64), ("n_tiles", C.c_int64), ("members_inflated", C.c_int64), ("depth_scan_ms", C.c_double),
                 ("pileup_ms", C.c_double), ("reads_ms", C.c_double), ("job_wall_ms", C.c_double),
-                ("members_second_chance", C.c_int64), ("members_third_chance", C.c_int64)]
+                ("members_second_chance", C.c_int64), ("members_third_chance", C.c_int64),
+                ("tiles_chain_on_device", C.c_int64), ("tiles_scan_fused", C.c_int64), ("walkers_per_member", C.c_int64)]
 
 
 class JobDesc(C.Structure):

@@ -168,8 +168,7 @@ struct ngsqc_handle
 	static constexpr int MAX_TILE_BUFS = 4;
 	int k1_slots = K1_SLOTS_DEFAULT;
 	DevBuf<uint8_t> buf[MAX_TILE_BUFS]; int nbuf = 2;
-	// the record chain of every member of a tile as the CRC pass of K1 found it (crc.hip), per tile buffer: K2 adopts it for htslib-style tiles
-	struct Prewalk { DevBuf<int32_t> start; DevBuf<uint32_t> cnt, exit; DevBuf<uint16_t> rel; } pw[MAX_TILE_BUFS]; bool prewalk = false; int64_t max_tile_members = 0;  // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
+	int64_t max_tile_members = 0;   // tile buffers (tile t lives in buf[t % nbuf]): [pfx carried bytes right-aligned][members][64]
 	std::vector<hipEvent_t> ev_chunk;                  // 4 per chunk: p1 start/end, p2 start/end
 	std::vector<hipEvent_t> ev_tile;                   // 2 per tile: K1 done (status on the host), consumed
 	PinBuf<BlockStatus> p_status; PinBuf<int32_t> p_start; PinBuf<int64_t> p_next; PinBuf<unsigned long long> p_small;
@@ -217,12 +216,13 @@ struct ngsqc_handle
 	// htslib file (the general K2 path takes over); fused_tile = the tile whose records that scan has already seen
 	struct FusedScan   // what K2 needs of such a scan (ScanState)
 	{
-		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int64_t scan_limit) = 0;
+		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t scan_limit) = 0;
 		virtual unsigned long long* fused_long_count() = 0;   // device address of the deferred-record count
 		virtual double fused_elapsed_ms() = 0;                // duration of the last fused_launch (waits for it)
 		virtual ~FusedScan() = default;
 	};
 	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
+	bool k2_plain = false;   // a tile of the running stream did not pass the chain check on the device: the later tiles walk whole members, as the general path needs them
 	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last raw-read QC pass
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
 	Partial* partial = nullptr;
@@ -897,16 +897,6 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	for (int i = 0; i < std::min(nt, h->nbuf); ++i) h->buf[i].ensure((size_t)(h->pfx + h->max_tile_bytes) + 64);
 	dbg_stamp("layout: tile buffers allocated");
 	h->max_tile_members = 0; for (auto& tl : h->tiles) h->max_tile_members = std::max(h->max_tile_members, tl.second);
-	// NGSQC_PREWALK=1: the CRC pass of K1 also follows every member's record chain, so that K2 only has to adopt it (K2 + scan of a 96 M-read shard
-	// 9.2 -> 6.6 ms un-pipelined). Off by default: the chain walk triples the life of the CRC waves, which then hold the wave slots phase 2 needs -
-	// the whole job got 9 % slower (measured, 6 tiles), and the job is what the tools wait for.
-	{ const char* e = getenv("NGSQC_PREWALK"); h->prewalk = h->verify_crc && e && atoi(e) != 0; }
-	if (h->prewalk)
-		for (int i = 0; i < std::min(nt, h->nbuf); ++i)
-		{
-			auto& w = h->pw[i]; const size_t m = (size_t)h->max_tile_members;
-			w.start.ensure(m); w.cnt.ensure(m); w.exit.ensure(m); w.rel.ensure(m * K2_REL_STRIDE);
-		}
 	h->p_status.ensure((size_t)nb);
 	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
 	while ((int)h->ev_tile.size() < 2 * nt) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_tile.push_back(e); }
@@ -968,14 +958,7 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 		if (h->verify_crc)   // htslib checks every member's CRC32 (bgzf.c); a mismatch fails the read
 		{
 			if (crc_stream != h->s_p2) HIPCHK(hipStreamWaitEvent(crc_stream, e4[3], 0));
-			CrcWalk cw; 
-			if (h->prewalk)
-			{
-				auto& w = h->pw[t % h->nbuf];
-				cw.start = w.start.p; cw.cnt = w.cnt.p; cw.exit = w.exit.p; cw.rel = w.rel.p; cw.member0 = c0 - h->tiles[(size_t)t].first;
-				cw.exp0 = t == 0 ? std::max<int64_t>(h->first_rec, 0) - (int64_t)h->blocks[(size_t)h->tiles[0].first].upos : 0;   // (the first tile starts behind the BAM header)
-			}
-			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream, h->prewalk ? &cw : nullptr);
+			launch_crc32(h->d_kdesc.p + c0, cn, out_base, h->d_crc.p + c0, h->d_status.p + c0, crc_stream);
 		}
 	};
 	for (int64_t c = cA; c < cB; ++c) { launch_p1(c); launch_p2(c); }
@@ -1022,80 +1005,81 @@ void index_tile(ngsqc_handle* h, int t)
 	const int64_t total = prefix + (u_hi - u_lo);
 	const uint8_t* base = h->buf[t % h->nbuf].p + h->pfx - prefix;
 	const BlockDesc* d_desc = h->d_kdesc.p + first;
-	const int64_t ne = nm + 1;   // entry 0 = the carried prefix
-	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };
+	// entries: entry 0 = the carried prefix, then the members - on the fast path each cut into 2^ksh pieces with a walker of its own (common.h entry_range;
+	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 4); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
+	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
+	int ksh = 2; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
+	if (anchor_by_guess || h->k2_plain) ksh = 0;
+	const int64_t ne0 = nm + 1;
+	int64_t ne = (nm << ksh) + 1;
+	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };   // (whole members: the general path)
 	auto e_sz = [&](int64_t e) -> int64_t { return e == 0 ? prefix : (int64_t)h->blocks[(size_t)(first + e - 1)].usize; };
 	Timer tmr(h->stream); tmr.start();
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
-	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	// (with slack: a later tile has one entry more - its carried prefix - and regrowing means hipFree, which waits for all queued K1 work)
-	h->d_start.ensure_slack((size_t)ne); h->d_cnt.ensure_slack((size_t)ne + 1); h->d_next.ensure_slack((size_t)ne + 1); h->d_base.ensure_slack((size_t)ne + 1); h->d_bad.ensure(2);
-	h->d_scan_tmp.ensure_slack(scan_tmp_bytes(ne) + 64); h->d_rel.ensure_slack((size_t)ne * K2_REL_STRIDE);
+	h->d_start.ensure_slack((size_t)ne); h->d_cnt.ensure_slack((size_t)ne + 1); h->d_next.ensure_slack((size_t)ne + 1); h->d_base.ensure_slack((size_t)ne + 1); h->d_bad.ensure(4);   // d_bad: {corrupt records, chain violations} + the offset of a record cut by the tile end (int64, -1: none)
+	h->d_scan_tmp.ensure_slack(scan_tmp_bytes(ne) + 64); h->d_rel.ensure_slack((size_t)(ne0 + 1) * K2_REL_STRIDE + 64);
 	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
-	// ---- fast path: htslib-style members (a record starts at every member's first byte, none straddles). One round trip: guess + walk every
-	// member's chain, check the pattern on the device, scan the counts; the host reads back {violations, corrupt records, n_rec} only ----
-	launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
-	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-	// K2's chain walk was done by the CRC pass of K1 while the members' bytes were in the caches: adopted when it describes this tile (htslib-style layout)
+	// ---- fast path: one round trip. Guess the first record of every entry, walk every entry's chain, check on the device that every walker's exit is the
+	// next walker's start (index_chain_kernel: exact), scan the counts; the host reads back {violations, corrupt records, n_rec} only. An htslib-written
+	// file passes (a record starts at every member's first byte, none straddles members or tiles) ----
+	launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, h->d_start.p, h->stream);
+	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_bad.p + 2, 0xff, sizeof(long long), h->stream));
 	h->fused_tile = -1;
-	bool adopted = false; const uint16_t* rel_src = h->d_rel.p;
-	if (h->prewalk && !anchor_by_guess && prefix == 0 && h->fuse_ok)
-	{
-		auto& w = h->pw[t % h->nbuf];
-		CrcWalk cw; cw.start = w.start.p; cw.cnt = w.cnt.p; cw.exit = w.exit.p; cw.rel = w.rel.p;
-		launch_index_adopt(d_desc, ne, exp0, cw, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->stream);
-		adopted = true; rel_src = w.rel.p - K2_REL_STRIDE;   // (entry e = member e - 1 of the tile)
-	}
-	// otherwise the job's first scan consumer rides K2's own walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
-	const bool try_fuse = !adopted && h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
+	// the job's first scan consumer rides K2's walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
+	const bool try_fuse = h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
 	const int64_t fuse_limit = h->shard_own_members >= 0 ? prefix + (h->shard_limit - u_lo) : INT64_MAX;   // a shard only scans the records that start in front of its limit
 	if (try_fuse)
 	{
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(total / 160, 1024));   // deferred (long-CIGAR) records of the tile: an estimate, checked below
-		launch_index_guess(base, total, d_desc, ne, prefix, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
-		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, fuse_limit);
+		launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
+		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, ksh, fuse_limit);
 	}
-	else if (!adopted) launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
-	if (!adopted) launch_index_aligned(d_desc, ne, prefix, exp0, h->d_start.p, h->d_next.p, h->d_bad.p + 1, h->stream);
+	else launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	launch_index_chain(d_desc, ne, prefix, ksh, exp0, total, h->d_start.p, h->d_next.p, h->d_bad.p + 1, (long long*)(h->d_bad.p + 2), h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
-	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = n_rec
-	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipMemcpyAsync(sm + 1, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = record cut by the tile end, [2] = deferred records of the riding scan, [3] = n_rec
+	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(sm + 3, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	sm[2] = 0; if (try_fuse) HIPCHK(hipMemcpyAsync(sm + 2, h->fuse->fused_long_count(), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	const uint32_t n_corrupt = ((const uint32_t*)sm)[0], n_viol = ((const uint32_t*)sm)[1];
 	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
-	if (adopted && !aligned)
-	{
-		// not an htslib-style tile: K2 walks it itself (and the later tiles of this file too)
-		h->fuse_ok = false; rel_src = h->d_rel.p;
-		launch_index_init(d_desc, ne, prefix, exp0, anchor_by_guess, h->d_start.p, h->stream);
-		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-		launch_index_count(base, total, d_desc, ne, prefix, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
-	}
 	if (try_fuse)
 	{
 		if (aligned && n_corrupt == 0 && sm[2] <= (unsigned long long)h->d_long.n) h->fused_tile = t;
 		else if (!aligned || n_corrupt == 0)
 		{
-			// not an htslib-style tile (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual.
-			// This includes a tile whose guessed chains ran into something that looks like a corrupt record (a false start guess in an unaligned layout): the
+			// the chain did not check out (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual.
+			// This includes a tile whose guessed chains ran into something that looks like a corrupt record (a false start guess): the
 			// general path below repairs the chain, so the walk's contributions must go whatever it met (only aligned && corrupt throws, below)
-			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, fuse_limit);
+			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, ksh, fuse_limit);
 			if (!aligned) h->fuse_ok = false; else h->d_long.ensure_slack((size_t)sm[2]);
 		}
 	}
 	if (aligned)
 	{
 		if (n_corrupt) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
+		straddle = (int64_t)sm[1]; h->tm.tiles_chain_on_device++; if (h->fused_tile == t) h->tm.tiles_scan_fused++;
+		h->tm.walkers_per_member = 1ll << ksh;
+		if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 		chain_exit = std::max(total, exp0);   // (exp0 > total: the first record of the file starts in a later tile)
 	}
 	else
 	{
-	// ---- general path: records cut by member borders, carried records, shards that guess their first record ----
+	// ---- general path: records cut by tile borders, false guesses, shards that guess their first record. Whole members (ksh = 0): the host verifies that every
+	// member's exit lands on the next member's start and repairs the first mismatch, round by round ----
+	if (!anchor_by_guess) h->k2_plain = true;
+	if (ksh != 0)
+	{
+		ksh = 0; ne = ne0;
+		launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, h->d_start.p, h->stream);
+		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
+		launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	}
 	h->p_start.ensure((size_t)ne + 64); h->p_next.ensure((size_t)ne + 64);
 	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
 	bool first_round = true;
@@ -1104,7 +1088,7 @@ void index_tile(ngsqc_handle* h, int t)
 		if (!first_round)
 		{
 			HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
-			launch_index_count(base, total, d_desc, ne, prefix, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+			launch_index_count(base, total, d_desc, ne, prefix, 0, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 		}
 		first_round = false;
 		HIPCHK(hipMemcpyAsync(start + from, h->d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1147,12 +1131,12 @@ void index_tile(ngsqc_handle* h, int t)
 		from = mismatch;
 	}
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
-	HIPCHK(hipMemcpyAsync(sm + 1, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(sm + 3, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	}
-	int64_t n_rec = (int64_t)sm[1];
+	int64_t n_rec = (int64_t)sm[3];
 	h->d_recoff.ensure_slack((size_t)std::max<int64_t>(n_rec, 1));
-	launch_index_write(base, total, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_base.p, rel_src, h->d_recoff.p, h->stream);
+	launch_index_write(base, total, d_desc, ne, prefix, ksh, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
 	{
@@ -1201,7 +1185,7 @@ TileCtx resident_ctx(ngsqc_handle* h)
 void reset_decode_timings(ngsqc_handle* h)
 {
 	h->tm.inflate_ms = 0; h->tm.index_ms = 0; h->tm.inflate_launches = 0; h->tm.n_records = 0; h->tm.inflate_huff_ms = 0; h->tm.inflate_lz77_ms = 0;
-	h->tm.inflate_huff_launches = 0; h->tm.members_inflated = 0;
+	h->tm.inflate_huff_launches = 0; h->tm.members_inflated = 0; h->tm.tiles_chain_on_device = 0; h->tm.tiles_scan_fused = 0;
 }
 
 void sync_all(ngsqc_handle* h)
@@ -1220,7 +1204,7 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	if (nt == 0) { h->decoded = true; h->n_rec = 0; return; }
 	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(resident_ctx(h)); return; }
 	reset_decode_timings(h);
-	h->decoded = false; h->cur_tile = -1; h->k1_enq = 0;
+	h->decoded = false; h->cur_tile = -1; h->k1_enq = 0; h->k2_plain = false;
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
 	const char* pe = getenv("NGSQC_PIPELINE"); const bool pipelined = !pe || atoi(pe) != 0;   // 0: K1 of a tile starts only when the previous tile is consumed (stage attribution)
 	HIPCHK(hipMemsetAsync(h->d_work.p, 0, (size_t)h->nch * sizeof(unsigned long long), h->stream));
@@ -1362,7 +1346,7 @@ struct ScanState : ngsqc_handle::FusedScan
 		kernel_ms = 0; stage_ms = 0; launches = 0;
 	}
 	// the scan of a tile inside K2's chain walk (index_tile); sgn = -1 takes the tile's contributions back
-	void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int64_t scan_limit) override
+	void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t scan_limit) override
 	{
 		sp.scan_limit = scan_limit; sp.infl = infl; sp.total = total; sp.recoff = nullptr; sp.n_rec = 0; sp.ord_base = 0;
 		sp.long_list = h->d_long.p; sp.long_cap = (int64_t)h->d_long.n; sp.entry_base = nullptr; sp.sgn = sgn; sp.tile_slots = 1;
@@ -1375,7 +1359,7 @@ struct ScanState : ngsqc_handle::FusedScan
 		}
 		if (!ftk) ftk.reset(new Timer(h->stream));
 		ftk->start();
-		launch_walk_scan(sp, d_desc, ne, prefix, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
+		launch_walk_scan(sp, d_desc, ne, prefix, ksh, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
 		ftk->mark(); launches++;
 		sp.sgn = 1; sp.scan_limit = INT64_MAX;
 	}
@@ -1418,8 +1402,8 @@ struct ScanState : ngsqc_handle::FusedScan
 			// (entry, k) names -> ordinals in the file: index in the tile = first record of the entry (the scanned counts) + k
 			auto ordinal = [&](unsigned long long name) -> unsigned long long {
 				int64_t b0 = 0;
-				HIPCHK(hipMemcpyAsync(&b0, h->d_base.p + (name >> 20), sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
-				return (unsigned long long)(c.ord_base + b0 + (int64_t)(name & 0xfffffull));
+				HIPCHK(hipMemcpyAsync(&b0, h->d_base.p + (name >> NAME_SHIFT), sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+				return (unsigned long long)(c.ord_base + b0 + (int64_t)(name & ((1ull << NAME_SHIFT) - 1)));
 			};
 			if (s[1]) s[1] = (s[1] & ~0xFFFFFFFFFFull) | (0xFFFFFFFFFFull - ordinal(0xFFFFFFFFFFull - (s[1] & 0xFFFFFFFFFFull)));
 			if (s[2] != ~0ull) s[2] = ordinal(s[2]);

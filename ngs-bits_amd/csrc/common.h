@@ -12,7 +12,9 @@
 
 namespace ngsqc {
 
-constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the member) kept per member for K2's write pass
+constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the entry) kept per BGZF member for K2's write pass: an entry of a member cut into 2^ksh pieces owns K2_REL_STRIDE >> ksh of them
+constexpr int K2_MAX_KSH = 3;        // a member is walked by up to 8 threads (round 5: several walkers per member, see entry_range)
+constexpr int NAME_SHIFT = 12;       // a record of a tile scanned by the chain walk is named (entry << NAME_SHIFT | k): a 64 KiB member holds at most 65536 / 36 records
 
 // ---- K1 ----
 // two-phase K1 (k1_kernels.h / inflate.hip): lane-per-member Huffman -> token groups in pages of a pool, then wave-per-member LZ77 resolve
@@ -74,20 +76,15 @@ double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, ui
 void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC
-// The CRC pass can also follow each member's BAM record chain while the member's bytes are in the caches (what K2's chain walk does, for tiles laid out
-// like an htslib file): per member of the tile the assumed first-record offset, the record count, the chain exit (member-relative; WALK_BROKEN: a
-// record cut by the member end, WALK_CORRUPT: a record bam_read1 would refuse) and the member-relative record offsets (K2_REL_STRIDE per member).
-constexpr uint32_t WALK_BROKEN = 0xfffffff0u, WALK_CORRUPT = 0xfffffff1u;
-struct CrcWalk { int32_t* start = nullptr; uint32_t* cnt = nullptr; uint32_t* exit = nullptr; uint16_t* rel = nullptr; int64_t member0 = 0, exp0 = 0; };   // member0: tile index of blocks[0]; exp0: tile-local offset of the tile's first record
-void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s, const CrcWalk* walk = nullptr);
-void launch_index_adopt(const BlockDesc* d_blocks, int64_t n_entries, int64_t exp0, const CrcWalk& w, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad_viol, hipStream_t s);
+void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);
 
 // ---- K2 ----
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
+// (n_entries = members << ksh, + 1 for the carried prefix; every array is indexed by entry)
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s);
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s);
-void launch_index_aligned(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, hipStream_t s);
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s);
+void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle /* -1 before the launch */, hipStream_t s);
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,
                         const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s);
 void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
 void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
@@ -131,7 +128,7 @@ struct ScanParams
 	unsigned long long* gc_tab;    // [101][GC_NMAX]
 	double* gc_over;               // [101]
 	int64_t* long_list; int64_t long_cap;
-	// the scan fused into K2's chain walk (launch_walk_scan): records are named (entry << 20 | k) until the counts are scanned (entry_base != null: the
+	// the scan fused into K2's chain walk (launch_walk_scan): records are named (entry << NAME_SHIFT | k) until the counts are scanned (entry_base != null: the
 	// long list holds such names); sgn = -1 takes a tile's contributions back (a tile that turned out not to be laid out like an htslib file)
 	// the site pileup of the job riding the same walk: records whose span holds a known site leave their offset in list (list == nullptr: no pileup rides)
 	struct Pile { const int32_t* site_pos = nullptr; const int32_t* tid_first = nullptr; const int32_t* tid_last = nullptr; const int32_t* bucket = nullptr; const int64_t* tid_bucket0 = nullptr;
@@ -141,8 +138,8 @@ struct ScanParams
 
 void launch_scan(const ScanParams& p, hipStream_t s);
 // K2's chain walk (what launch_index_count does) with the scan of every record the walk passes: one read of a record's first line instead of two
-void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
-void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s);
 void launch_prefix_capture(const ScanParams& p, int64_t n, uint32_t* d_head, hipStream_t s);
@@ -175,12 +172,22 @@ void launch_line_runs(bool write, const int32_t* d_depth, const int64_t* d_slot,
 
 #ifdef __HIPCC__
 namespace ngsqc {
-// Entries of a tile: entry 0 is the pseudo member that covers the bytes carried over from the previous tile ([0, prefix)),
-// entry e >= 1 is member e - 1 of the tile's (static) descriptor table, whose upos is relative to the tile's first member.
-__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int64_t& lo, int64_t& hi)
+// Entries of a tile: entry 0 is the pseudo member that covers the bytes carried over from the previous tile ([0, prefix)); the entries behind it are the
+// tile's members (static descriptor table, upos relative to the tile's first member), each cut into 2^ksh pieces of equal size: entry e >= 1 is piece
+// (e - 1) & (2^ksh - 1) of member (e - 1) >> ksh. Round 5: the chain walk is a dependent chain of sparse line fetches (one 128-byte line per record, ~190
+// records per member) - with one thread per member a tile kept 1.9 waves per SIMD busy and 77 % of their cycles waited for memory. A piece in the middle
+// of a member does not know where its first record starts: the guess kernel finds the first plausible record header (index.hip), every piece's walker runs
+// to the end of its piece, and the chain is accepted only if every walker's exit IS the next walker's start (index_chain_kernel) - by induction from the
+// tile's known first record every start then lies on the true chain; anything else takes the general path.
+__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int ksh, int64_t& lo, int64_t& hi)
 {
 	if (e == 0) { lo = 0; hi = prefix; }
-	else { const BlockDesc bd = blocks[e - 1]; lo = prefix + (int64_t)bd.upos; hi = lo + bd.usize; }
+	else
+	{
+		const int64_t idx = e - 1; const BlockDesc bd = blocks[idx >> ksh]; const int64_t j = idx & ((1ll << ksh) - 1);
+		const int64_t mlo = prefix + (int64_t)bd.upos;
+		lo = mlo + (((int64_t)bd.usize * j) >> ksh); hi = mlo + (((int64_t)bd.usize * (j + 1)) >> ksh);
+	}
 }
 // what htslib's bam_read1 checks before it accepts a record (the reference then throws "Could not read next alignment",
 // src/cppNGS/BamReader.h:389-392): the variable-length fields must fit the record. Kernels behind K2 trust these fields.

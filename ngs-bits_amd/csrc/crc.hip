@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)   // a * b mo
 }
 
 __global__ __launch_bounds__(256) void crc32_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, const uint8_t* __restrict__ out_base,
-                                                    const uint32_t* __restrict__ expected, BlockStatus* __restrict__ status, const uint32_t* __restrict__ tabs, const CrcWalk walk)
+                                                    const uint32_t* __restrict__ expected, BlockStatus* __restrict__ status, const uint32_t* __restrict__ tabs)
 {
 	__shared__ uint32_t T[2048];   // [0,1024) slice-by-4 tables T3..T0 order by byte position, [1024,2048) "skip 4032 zero bytes" tables
 	for (int i = threadIdx.x; i < 2048; i += 256) T[i] = tabs[i];
@@ -83,34 +83,6 @@ __global__ __launch_bounds__(256) void crc32_kernel(const BlockDesc* __restrict_
 		{
 			const uint32_t crc = v ^ tabs[TAB_INIT + n] ^ 0xFFFFFFFFu;
 			if (crc != expected[b]) status[b].error = K1_ERR_CRC;
-		}
-		// ---- the member's BAM record chain, while its bytes are still in the caches (K2's chain walk otherwise fetches a third of the tile again) ----
-		// Wave-uniform: the wave follows block_size from record to record as if the member started with a record (an htslib-written file), never reads
-		// behind the member, and keeps the member-relative record offsets. K2 adopts the result when every member's chain starts where the tile's chain
-		// says and ends exactly at the member's end; any other layout takes K2's own walk.
-		if (walk.cnt)
-		{
-			const int64_t m = walk.member0 + b;                     // member index inside the tile
-			const int64_t lo = (int64_t)bd.upos, hi = lo + n;       // tile-local (nothing carried in front of the tile)
-			const int32_t s0 = hi <= walk.exp0 ? -1 : (lo < walk.exp0 ? (int32_t)(walk.exp0 - lo) : 0);
-			uint32_t o = s0 < 0 ? (uint32_t)n : (uint32_t)s0, k = 0, ex = 0; uint32_t myrel = 0;
-			while (o < (uint32_t)n)
-			{
-				if (o + 36u > (uint32_t)n) { ex = WALK_BROKEN; break; }                      // a record header cut by the member end: not this layout
-				uint32_t bs; __builtin_memcpy(&bs, p + o, 4); bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
-				if (bs < 32u) { ex = WALK_CORRUPT; break; }
-				if ((uint64_t)o + 4u + bs > (uint64_t)n) { ex = WALK_BROKEN; break; }         // the record ends behind the member
-				uint32_t f[3]; __builtin_memcpy(f, p + o + 12, 12);
-				const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[0]), w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[1]);
-				const int32_t l_seq = __builtin_amdgcn_readfirstlane((int)f[2]);
-				if (!record_fields_fit(w & 0xffu, w2 & 0xffffu, l_seq, bs)) { ex = WALK_CORRUPT; break; }
-				if ((k & 63u) == (uint32_t)lane) myrel = o;
-				++k;
-				if ((k & 63u) == 0 && k <= (uint32_t)K2_REL_STRIDE) walk.rel[m * K2_REL_STRIDE + (k - 64u) + (uint32_t)lane] = (uint16_t)myrel;
-				o += 4u + bs;
-			}
-			if ((k & 63u) != 0 && k <= (uint32_t)K2_REL_STRIDE && (uint32_t)lane < (k & 63u)) walk.rel[m * K2_REL_STRIDE + (k & ~63u) + (uint32_t)lane] = (uint16_t)myrel;
-			if (lane == 0) { walk.start[m] = s0; walk.cnt[m] = k; walk.exit[m] = ex ? ex : o; }
 		}
 	}
 }
@@ -168,12 +140,12 @@ const uint32_t* device_tables()
 }
 } // namespace
 
-void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s, const CrcWalk* walk)
+void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
 	const uint32_t* tabs = device_tables();
 	const int64_t wgs = (n_blocks + 3) / 4;
-	hipLaunchKernelGGL(crc32_kernel, dim3((int)(wgs < 32768 ? wgs : 32768)), dim3(256), 0, s, d_blocks, n_blocks, d_out, d_expected, d_status, tabs, walk ? *walk : CrcWalk{}); KCHECK();
+	hipLaunchKernelGGL(crc32_kernel, dim3((int)(wgs < 32768 ? wgs : 32768)), dim3(256), 0, s, d_blocks, n_blocks, d_out, d_expected, d_status, tabs); KCHECK();
 }
 
 } // namespace ngsqc

@@ -38,12 +38,26 @@ __device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total
 	if (r[36 + l_name - 1] != 0) return false; // qname is NUL-terminated
 	return true;
 }
+// a plausible header whose two successors (as far as they lie inside the tile) are plausible too
+__device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
+{
+	if (!plausible(infl, total, o, n_ref)) return false;
+	for (int k = 0; k < 2; ++k)
+	{
+		o += 4 + (int64_t)ld32u(infl + o);       // (plausible: the record ends inside the tile)
+		if (o + 36 > total) return true;          // the tile ends here, or inside the next header: nothing more to check
+		const uint32_t bs = ld32u(infl + o);
+		if (o + 4 + (int64_t)bs > total) return bs >= 32 && bs <= (1u << 28);   // a record cut by the tile end (plausible() refuses it for that alone)
+		if (!plausible(infl, total, o, n_ref)) return false;
+	}
+	return true;
+}
 
-// Guessing the first record of a member, one WAVE per member: 64 consecutive offsets are tested per step (two coalesced
-// 4-byte loads reject almost every offset before the full plausibility check), so a member that lies inside one long record
-// (ONT: most members) costs 1 k steps instead of a 65 k-step scalar scan per thread. Members whose start is already known
-// (>= 0 or -1) are skipped; a member without any plausible start gets -1.
-__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t from,
+// Guessing the first record of an entry, one WAVE per entry: a lane takes 16 bytes and tests the four offsets inside its first dword (block_size and refID
+// of each candidate are funnel shifts of the loaded words: 256 offsets per step, two rejected almost always before the full plausibility check), so an entry
+// that lies inside one long record (ONT: most members) costs 256 steps, and the piece of a short-read member (its first record starts ~170 bytes in) one.
+// Entries whose start is already known (>= 0 or -1) are skipped; an entry without any plausible start gets -1.
+__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t from,
                                                           int32_t* start, int32_t n_ref)
 {
 	const int lane = threadIdx.x & 63;
@@ -51,38 +65,40 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 	for (int64_t b = from + wave; b < n_blocks; b += n_waves)
 	{
 		if (start[b] != -2) continue;
-		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 		int32_t found = -1;
-		for (int64_t base = lo; base < hi; base += 64)
+		for (int64_t base = lo; base < hi; base += 256)
 		{
-			const int64_t o = base + lane;
-			bool ok = false;
-			if (o < hi && o + 36 <= total)
+			const int64_t o0 = base + 4 * lane;
+			uint32_t w[4] = {0u, 0u, 0u, 0u};
+			if (o0 + 16 <= total) __builtin_memcpy(w, infl + o0, 16);
+			else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[k] = ld32u(infl + o0 + 4 * k);
+			uint32_t cand = 0;   // bit t: offset o0 + t passes the cheap test
+			#pragma unroll
+			for (int t = 0; t < 4; ++t)
 			{
-				const uint32_t bs = ld32u(infl + o); const int32_t tid = (int32_t)ld32u(infl + o + 4);
-				ok = bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref;
+				const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[1], w[0], 8u * t) : w[0];
+				const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[2], w[1], 8u * t) : w[1]);
+				if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
 			}
-			if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
-			if (ok)
-			{
-				ok = plausible(infl, total, o, n_ref);
-				if (ok) { const int64_t o2 = o + 4 + ld32u(infl + o); if (o2 < total && !plausible(infl, total, o2, n_ref)) ok = false; }   // chain one more record
-			}
-			const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
-			if (m) { found = (int32_t)(base + __builtin_ctzll(m) - lo); break; }
+			if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) continue;
+			int32_t mine = -1;
+			if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
+			const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
+			if (m) { const int l = __builtin_ctzll(m); found = (int32_t)(base + 4 * l + __builtin_amdgcn_readlane(mine, l) - lo); break; }
 		}
 		if (lane == 0) start[b] = found;
 	}
 }
 
-// start[b]: >=0 first-record offset inside member b; -1 none (a longer record covers the whole member); -2 guess.
-__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t from,
+// start[b]: >=0 first-record offset inside entry b; -1 none (a longer record covers the whole entry); -2 guess.
+__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                    uint32_t* __restrict__ bad, int32_t n_ref, uint16_t* __restrict__ rel)
 {
 	int64_t b = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 	int32_t s = start[b];
 	if (s == -2)
 	{
@@ -99,6 +115,7 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 	if (s < 0) { cnt[b] = 0; next_abs[b] = -1; return; }
 	// next_abs: >= 0 chain exit; -2 corrupt record; <= -10 a record starts at o = -(next_abs + 10) but extends past the end
 	// of the resident tile (it is carried into the next tile, not counted here)
+	const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
 	int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
 	while (o < hi)
 	{
@@ -107,7 +124,7 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 		if (bs < 32) { res = -2; stop = true; break; }
 		if (o + 4 + (int64_t)bs > total) { res = -(o + 10); stop = true; break; }
 		if (!record_fields_fit(infl + o, bs)) { res = -2; stop = true; break; }
-		if (n < (uint32_t)K2_REL_STRIDE) rel[b * K2_REL_STRIDE + n] = (uint16_t)(o - lo);   // (entry 0, the carried prefix, may exceed 16 bits: it is always walked again)
+		if (n < stride) rel[b * stride + n] = (uint16_t)(o - lo);   // (entry 0, the carried prefix, may exceed 16 bits: it is always walked again)
 		++n; o += 4 + (int64_t)bs;
 	}
 	cnt[b] = n; next_abs[b] = stop ? res : o;
@@ -115,74 +132,61 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 }
 
 // start[] of every entry from what the host knows before K2: the tile-local offset exp0 of the first record (start = -2: guess)
-__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t exp0, int guess_all, int32_t* __restrict__ start)
+__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int guess_all, int32_t* __restrict__ start)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 	start[b] = guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
 }
 
-// The common case of an htslib-written BAM: a record starts at the first byte of every member and no record straddles members. Then
-// every member's chain must start at 0 (at exp0 inside the member that holds it, nowhere in front of it) and leave the member exactly at
-// its end - which makes the chain consistent by construction, and the host can skip its sequential verification of the exits.
-// viol counts the entries that do not fit the pattern (any non-zero count sends the tile to the general path).
-__global__ void index_aligned_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int64_t exp0,
-                                     const int32_t* __restrict__ start, const int64_t* __restrict__ next_abs, uint32_t* __restrict__ viol)
+// The exact check of the walked chain on the device. Entries in front of the tile's first record (hi <= exp0) hold nothing; the entry that holds exp0 starts
+// there; every other start is a GUESS. The chain is right iff every walker leaves its entry exactly at the start of the next entry that has one, every entry
+// without a start lies wholly in front of that exit, and the last walker leaves the tile exactly at its end - or meets a record that the tile end cuts (it is
+// carried into the next tile: *straddle = its offset) with no start behind it. By induction from exp0 every start then lies on the true chain, and the host
+// skips its sequential verification; viol counts the entries that do not fit (any: the tile takes the general path). For an htslib-written file (a record
+// starts at every member's first byte, none straddles) and ksh = 0 this is round 3's "aligned" test.
+__global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int64_t total,
+                                   const int32_t* __restrict__ start, const int64_t* __restrict__ next_abs, uint32_t* __restrict__ viol, long long* __restrict__ straddle)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool bad = false;
 	if (b < n_blocks)
 	{
-		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
-		const int32_t want = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : 0);
-		bad = start[b] != want || (want >= 0 && next_abs[b] != hi);
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+		const int32_t s = start[b];
+		if (hi <= exp0) bad = s != -1;
+		else if (lo <= exp0) bad = s != (int32_t)(exp0 - lo);
+		if (!bad && s >= 0)
+		{
+			const int64_t nx = next_abs[b];
+			if (nx == -2) bad = false;   // (a corrupt record: counted by the walk itself, the host throws)
+			else if (nx < 0)
+			{
+				// a record cut by the tile end: the rest of the tile belongs to it
+				for (int64_t e = b + 1; e < n_blocks && !bad; ++e) bad = start[e] >= 0;
+				if (!bad) *straddle = -(nx + 10);
+			}
+			else
+			{
+				int64_t e = b + 1;
+				for (; e < n_blocks && start[e] < 0; ++e) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, l2, h2); if (h2 > nx) { bad = true; break; } }
+				if (!bad)
+				{
+					if (e < n_blocks) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, l2, h2); bad = nx != l2 + start[e]; }
+					else bad = nx != total;
+				}
+			}
+		}
 	}
 	const unsigned long long m = __ballot(bad);
 	if ((threadIdx.x & 63) == 0 && m) atomicAdd(viol, (uint32_t)__popcll(m));
 }
 
-// K2's chain walk done by the CRC pass of K1 (crc.hip): adopt it when it describes this tile - every member's chain starts where the tile's chain says
-// (offset 0; exp0 inside the member that holds it; no record in front of it) and leaves the member exactly at its end. bad_viol[0] counts records
-// bam_read1 would refuse, bad_viol[1] the members that do not fit (any: K2 walks the tile itself).
-__global__ void index_adopt_kernel(const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t exp0, const CrcWalk w,
-                                   int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs, uint32_t* __restrict__ bad_viol)
-{
-	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool viol = false, corrupt = false;
-	if (e < n_entries)
-	{
-		if (e == 0) { start[0] = -1; cnt[0] = 0; next_abs[0] = -1; }   // (nothing is carried in front of such a tile)
-		else
-		{
-			int64_t lo, hi; entry_range(blocks, e, 0, lo, hi);
-			const int32_t want = hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : 0);
-			const int64_t m = e - 1;
-			start[e] = want;
-			if (w.start[m] != want) viol = true;
-			else if (want < 0) { cnt[e] = 0; next_abs[e] = -1; }
-			else
-			{
-				const uint32_t ex = w.exit[m];
-				corrupt = ex == WALK_CORRUPT;
-				viol = ex == WALK_BROKEN || (!corrupt && lo + (int64_t)ex != hi);
-				cnt[e] = w.cnt[m]; next_abs[e] = corrupt ? -2 : lo + (int64_t)ex;
-			}
-		}
-	}
-	const unsigned long long mv = __ballot(viol), mc = __ballot(corrupt);
-	if ((threadIdx.x & 63) == 0) { if (mc) atomicAdd(bad_viol, (uint32_t)__popcll(mc)); if (mv) atomicAdd(bad_viol + 1, (uint32_t)__popcll(mv)); }
-}
-void launch_index_adopt(const BlockDesc* d_blocks, int64_t n_entries, int64_t exp0, const CrcWalk& w, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad_viol, hipStream_t s)
-{
-	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_adopt_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, exp0, w, d_start, d_cnt, d_next_abs, d_bad_viol); KCHECK();
-}
-
-// Record offsets of every entry, ONE WAVE PER ENTRY: the member-relative offsets that the count pass stored are expanded with coalesced loads
+// Record offsets of every entry, ONE WAVE PER ENTRY: the entry-relative offsets that the count pass stored are expanded with coalesced loads
 // and stores (the chain is not walked a second time: that would read a third of the inflated tile again). Entry 0 (the carried prefix, offsets
-// may exceed 16 bits) and members with more than K2_REL_STRIDE records walk their chain on lane 0.
-__global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix,
+// may exceed 16 bits) and entries with more records than their share of K2_REL_STRIDE walk their chain on lane 0.
+__global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh,
                                                           const int32_t* __restrict__ start, const uint32_t* __restrict__ cnt, const int64_t* __restrict__ base,
                                                           const uint16_t* __restrict__ rel, int64_t* __restrict__ recoff)
 {
@@ -192,11 +196,12 @@ __global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restr
 	const int32_t s = start[b];
 	if (s < 0) return;
 	const uint32_t n = cnt[b];
-	int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+	const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 	const int64_t k0 = base[b];
-	if (b != 0 && n <= (uint32_t)K2_REL_STRIDE)
+	if (b != 0 && n <= stride)
 	{
-		for (uint32_t k = lane; k < n; k += 64) recoff[k0 + k] = lo + rel[b * K2_REL_STRIDE + k];
+		for (uint32_t k = lane; k < n; k += 64) recoff[k0 + k] = lo + rel[b * stride + k];
 		return;
 	}
 	if (lane != 0) return;
@@ -268,43 +273,43 @@ __global__ void scan_tile_apply(const TIn* __restrict__ in, int64_t n, const int
 
 size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE; return (size_t)(tiles + 2) * sizeof(int64_t); }
 
-// entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = member e - 1 of d_blocks); arrays are indexed by entry
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start,
+// entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = piece (e - 1) & (2^ksh - 1) of member (e - 1) >> ksh of d_blocks); arrays are indexed by entry
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref, s);   // (the count kernel keeps its scalar guess loop only as a fallback)
+	launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref, s);   // (the count kernel keeps its scalar guess loop only as a fallback)
 	int grid = (int)((n + 63) / 64);
-	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
+	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
 }
 
 // resolve the guessed first-record offsets (start == -2) wave-cooperatively
-void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s)
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
 	const int64_t wg = (n + 3) / 4;
-	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 16 ? wg : 256 * 16)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, from, d_start, n_ref); KCHECK();
+	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref); KCHECK();
 }
 
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, exp0, guess_all ? 1 : 0, d_start); KCHECK();
+	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, guess_all ? 1 : 0, d_start); KCHECK();
 }
-void launch_index_aligned(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int64_t exp0, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, hipStream_t s)
+void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_aligned_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, exp0, d_start, d_next, d_viol); KCHECK();
+	hipLaunchKernelGGL(index_chain_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, total, d_start, d_next, d_viol, d_straddle); KCHECK();
 }
 
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,
                         const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s)
 {
 	if (n_entries <= 0) return;
 	int grid = (int)((n_entries + 3) / 4);   // one wave per entry
-	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, d_start, d_cnt, d_base, d_rel, d_recoff); KCHECK();
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_base, d_rel, d_recoff); KCHECK();
 }
 
 // exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).

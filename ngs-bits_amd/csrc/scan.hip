@@ -23,7 +23,10 @@ __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { uint16_t v; __built
 // per-lane partial sums (A_* in common.h), reduced per wave at the end of the kernel: one atomic per wave and counter
 struct Acc
 {
-	long long v[A_COUNT]; int max_len; unsigned long long best_key; unsigned long long first_paired;
+	// v: sums that an adversarial record can make large (lengths, clipped bases, overlaps); n: plain counts (and insert sizes below 1000) - a thread of one launch
+	// sees far fewer than 2^22 records, so 32 bits hold them (round 5: nine VGPRs less in the walk). A slot is kept in ONE of the two; the other stays zero and
+	// costs nothing (the compiler drops it)
+	long long v[A_COUNT]; uint32_t n[A_COUNT]; int max_len; unsigned long long best_key; unsigned long long first_paired;
 	// A thread meets its records in ascending position (a member's record chain; a strided range of a sorted file), so the answer of the last region search holds for
 	// the next records too: lower_region(start1) == rc_idx for every start1 in (rc_lo, rc_hi] on reference rc_tid. Likewise the next known site of the pileup
 	// candidates. Round 4: the walk spends its time in the address unit (every lane its own line, ~15 load instructions per record) - these two caches take the
@@ -39,6 +42,24 @@ struct RecView
 	const uint8_t* cigar; uint32_t n_cigar;  // effective CIGAR (may be the CG tag payload)
 };
 
+// the fixed part of a record as the chain walk keeps it one record ahead: block_size, refID, pos, (l_read_name | mapq | bin), (n_cigar_op | flag), l_seq, tlen
+struct Hdr { uint32_t bs, tid, pos, w, w2, l_seq, isize; };
+__device__ __forceinline__ Hdr load_hdr(const uint8_t* p)
+{
+	Hdr h; uint32_t a[4], b[2];
+	__builtin_memcpy(a, p, 16); __builtin_memcpy(b, p + 16, 8);
+	h.bs = a[0]; h.tid = a[1]; h.pos = a[2]; h.w = a[3]; h.w2 = b[0]; h.l_seq = b[1]; h.isize = ld32(p + 32);
+	return h;
+}
+__device__ __forceinline__ RecView make_rec(const uint8_t* infl, int64_t off, const Hdr& h)
+{
+	RecView r; const uint8_t* p = infl + off;
+	r.bs = h.bs; r.core = p + 4; r.tid = (int32_t)h.tid; r.pos = (int32_t)h.pos;
+	r.l_name = h.w & 0xff; r.mapq = (h.w >> 8) & 0xff; r.n_cigar_raw = h.w2 & 0xffff; r.flag = h.w2 >> 16;
+	r.l_seq = (int32_t)h.l_seq; r.isize = (int32_t)h.isize;
+	r.cigar = p + 36 + r.l_name; r.n_cigar = r.n_cigar_raw;
+	return r;
+}
 __device__ __forceinline__ RecView load_rec(const uint8_t* infl, int64_t off)
 {
 	RecView r; const uint8_t* p = infl + off;
@@ -190,8 +211,8 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 	// chrY/chrX read counts: index query chr:[1,len] returns tid==t && pos < len && endpos > 0, minus secondary/supplementary
 	if (!secondary && !supp)
 	{
-		if (r.tid == p.tid_x && r.pos < p.len_x && r.pos + rlen > 0) a.v[A_READS_X]++;
-		if (r.tid == p.tid_y && r.pos < p.len_y && r.pos + rlen > 0) a.v[A_READS_Y]++;
+		if (r.tid == p.tid_x && r.pos < p.len_x && r.pos + rlen > 0) a.n[A_READS_X]++;
+		if (r.tid == p.tid_y && r.pos < p.len_y && r.pos + rlen > 0) a.n[A_READS_Y]++;
 	}
 
 	// indexed ROI pass of mapping_wgs (Statistics.cpp:1154-1182), fused: per (read, overlapped region) pair
@@ -222,7 +243,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 	}
 
 	if (secondary || supp) return;
-	a.v[A_TOTAL]++;
+	a.n[A_TOTAL]++;
 	if (paired && (unsigned long long)ord < a.first_paired) a.first_paired = (unsigned long long)ord;
 	a.v[A_SUM_LEN] += length;
 	if (length > a.max_len) a.max_len = length;
@@ -234,7 +255,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 
 	if (!unmapped)
 	{
-		a.v[A_MAPPED]++;
+		a.n[A_MAPPED]++;
 		a.v[A_BASES_MAPPED] += length;
 		a.v[A_CLIPPED] += clip;
 		if (MODE == NGSQC_MODE_ROI)
@@ -247,13 +268,13 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 					int n0 = lower_region(p.reg_end, first, last, start1 - 250);
 					if (n0 < last && p.reg_start[n0] <= end1 + 250)
 					{
-						a.v[A_NEAR]++;
+						a.n[A_NEAR]++;
 						int i0 = lower_region(p.reg_end, n0, last, start1);
 						if (i0 < last && p.reg_start[i0] <= end1)
 						{
-							a.v[A_ONTARGET]++;
+							a.n[A_ONTARGET]++;
 							int dp = aux_tagi(r, 'D', 'P');
-							if (dp != 0) { int bin = min(dp, 4); bin = bin < 1 ? 0 : bin - 1; a.v[A_DD0 + bin]++; }
+							if (dp != 0) { int bin = min(dp, 4); bin = bin < 1 ? 0 : bin - 1; a.n[A_DD0 + bin]++; }
 							if (!dup && (int)r.mapq >= p.min_mapq)
 							{
 								int dpi = min(max(dp, 0), 4);
@@ -285,7 +306,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		{
 			if (tid_ok && p.tid_nonspecial[r.tid])
 			{
-				a.v[A_ONTARGET]++;
+				a.n[A_ONTARGET]++;
 				if (!dup && (int)r.mapq >= p.min_mapq) a.v[A_USABLE] += length; // "no overlap" share is resolved with first_paired_idx afterwards
 			}
 		}
@@ -293,19 +314,19 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 
 	if (paired && proper)
 	{
-		a.v[A_PP]++;
+		a.n[A_PP]++;
 		if (!spliced)
 		{
 			int insert_size = abs(r.isize);
 			if (insert_size < 1000)
 			{
-				a.v[A_INS_CNT]++; a.v[A_INS_SUM] += insert_size;
+				a.n[A_INS_CNT]++; a.n[A_INS_SUM] += (uint32_t)insert_size;
 				atomicAdd(&lds_hist[insert_size], 1u);
 				if (MODE != NGSQC_MODE_ROI && read1 && !dup && (int)r.mapq >= p.min_mapq && 2 * length > insert_size) a.v[A_NO_OVERLAP] -= (2 * length) - insert_size;
 			}
 		}
 	}
-	if (dup) a.v[A_DUP]++;
+	if (dup) a.n[A_DUP]++;
 }
 
 __device__ __forceinline__ long long wave_sum(long long v)
@@ -317,7 +338,7 @@ __device__ __forceinline__ long long wave_sum(long long v)
 __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 {
 	const int lane = threadIdx.x & 63;
-	for (int i = 0; i < A_COUNT; ++i) { long long s = wave_sum(a.v[i]); if (lane == 0 && s) atomicAdd(&p.counters[i], (unsigned long long)(p.sgn * s)); }
+	for (int i = 0; i < A_COUNT; ++i) { long long s = wave_sum(a.v[i] + (long long)a.n[i]); if (lane == 0 && s) atomicAdd(&p.counters[i], (unsigned long long)(p.sgn * s)); }
 	int m = a.max_len; unsigned long long bk = a.best_key, fp = a.first_paired;
 	for (int o = 32; o > 0; o >>= 1)
 	{
@@ -335,22 +356,32 @@ __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) if (lds_hist[i]) atomicAdd(&p.counters[A_HIST0 + i], (unsigned long long)(p.sgn * (long long)lds_hist[i]));
 }
 
-// CIGAR sums of a short record + classify; false: the record goes to the wave-per-record kernel (long CIGAR, possible CG:B,I tag)
+// CIGAR sums of a short record + classify; false: the record goes to the wave-per-record kernel (long CIGAR, possible CG:B,I tag).
+// The first four operations come with ONE 16-byte load (97 % of the short reads of a WGS have at most three; the bytes behind a shorter CIGAR are the
+// record's own sequence, and the tile buffers end with 64 spare bytes): the walk waits for one round trip instead of one per operation.
 template <int MODE>
 __device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist, long long* ref_len_out = nullptr)
 {
-	bool defer = r.n_cigar_raw > (uint32_t)LONG_CIGAR;
-	if (!defer && r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
-	{
-		uint32_t c0 = ld32(r.cigar);
-		if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq) defer = true; // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
-	}
-	if (defer) return false;
+	if (r.n_cigar_raw > (uint32_t)LONG_CIGAR) return false;
+	uint32_t c4[4] = {0u, 0u, 0u, 0u};
+	if (r.n_cigar_raw > 0) __builtin_memcpy(c4, r.cigar, 16);
+	if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0 && (c4[0] & 15u) == 4 && (int32_t)(c4[0] >> 4) == r.l_seq) return false;   // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
 	long long ref_len = 0, clip = 0; bool spliced = false;
-	for (uint32_t k = 0; k < r.n_cigar; ++k)
+	#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k)
+	{
+		if (k < r.n_cigar)
+		{
+			const uint32_t c = c4[k], op = c & 15u, len = c >> 4;
+			if ((0x18Du >> op) & 1u) ref_len += len;            // M,D,N,=,X  (bits 0,2,3,7,8)
+			else if (op == 4 || op == 5) clip += len;
+			if (op == 3) spliced = true;
+		}
+	}
+	for (uint32_t k = 4; k < r.n_cigar; ++k)
 	{
 		uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
-		if ((0x18Du >> op) & 1u) ref_len += len;            // M,D,N,=,X  (bits 0,2,3,7,8)
+		if ((0x18Du >> op) & 1u) ref_len += len;
 		else if (op == 4 || op == 5) clip += len;
 		if (op == 3) spliced = true;
 	}
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p)
 	__shared__ uint32_t lds_hist[1000];
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
-	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
 	const long long stride = (long long)gridDim.x * blockDim.x;
 	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < p.n_rec; li += stride)
 	{
@@ -418,14 +449,14 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 	__shared__ uint32_t lds_hist[1000];
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
-	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
 	const int lane = threadIdx.x & 63;
 	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
 	for (long long w = wave; w < n_long; w += n_waves)
 	{
 		long long li = p.long_list[w]; long long ord;
-		if (p.entry_base) { ord = li; li = p.entry_base[li >> 20] + (li & 0xfffff); }   // a tile scanned by the chain walk: records are compared by their (entry, k) names
+		if (p.entry_base) { ord = li; li = p.entry_base[li >> NAME_SHIFT] + (li & ((1ll << NAME_SHIFT) - 1)); }   // a tile scanned by the chain walk: records are compared by their (entry, k) names
 		else ord = p.ord_base + li;
 		RecView r = load_rec(p.infl, p.recoff[li]);
 		// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries
@@ -506,44 +537,57 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 }
 
 // ---- the scan fused into K2's chain walk ----
-// What index_count_kernel does (one thread per entry walks the entry's record chain, validates every record like bam_read1, keeps the member-relative
+// What index_count_kernel does (one thread per entry walks the entry's record chain, validates every record like bam_read1, keeps the entry-relative
 // offsets) - and every record the walk passes is scanned right there: the walk has the record's first line in its hands, the separate scan kernel would
-// fetch it a second time (a third of the inflated tile per pass). A record is named (entry << 20 | k) until the counts are scanned; the order-dependent
+// fetch it a second time (a third of the inflated tile per pass). A record is named (entry << NAME_SHIFT | k) until the counts are scanned; the order-dependent
 // results (first longest read, first paired read) are kept per tile in that form (A_TILE_KEY / A_TILE_PAIRED), the host turns them into ordinals.
-// Only for tiles laid out like an htslib file (a record starts every member): the launch happens before that is known, sgn = -1 takes it back.
-template <int MODE>
-__global__ __launch_bounds__(64, 3) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix,
+// The launch happens before the chain is known to be right (index_chain_kernel): sgn = -1 takes a tile's contributions back - the same walks from the same
+// starts, so whatever a false start guess made a walker add is subtracted again.
+// Round 5: (a) an entry is a PIECE of a member (common.h entry_range): four walkers per member instead of one, a quarter of the dependent chain each and four
+// times the lines in flight; (b) the fixed 36 bytes of the NEXT record are requested before this record is processed (round 3/4 asked for its block_size only
+// and then waited for the fields): one round trip per record is the CIGAR's, the header's is hidden behind the scan of the record in front; (c) the offsets go
+// out as 16-byte stores of eight (round 4: a 2-byte store per record and lane - 64 partial sectors per instruction, 32.6 bytes of HBM writes per record).
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix, int ksh,
                                                         const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
 	__shared__ uint32_t lds_hist[1000];
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
-	Acc a; for (int i = 0; i < A_COUNT; ++i) a.v[i] = 0; a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
+	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b < n_entries)
 	{
-		int64_t lo, hi; entry_range(blocks, b, prefix, lo, hi);
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 		const int32_t s = start[b];   // (the guess kernel ran: >= 0 or -1)
 		if (s < 0) { cnt[b] = 0; next_abs[b] = -1; }
 		else
 		{
-			// the next record's block_size is requested before this record is processed: its line arrives while the scan works
+			const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
+			uint64_t* const rel8 = (uint64_t*)(rel + b * stride);   // (16-byte aligned: stride is a multiple of 8)
+			uint64_t pk_lo = 0, pk_hi = 0;                           // the last eight offsets, oldest in the low bits
 			int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
-			uint32_t bs = o < hi && o + 4 <= p.total ? ld32(p.infl + o) : 0u;
+			Hdr nx; nx.bs = 0; nx.tid = nx.pos = nx.w = nx.w2 = nx.l_seq = nx.isize = 0;
+			if (o < hi) { if (o + 36 <= p.total) nx = load_hdr(p.infl + o); else if (o + 4 <= p.total) nx.bs = ld32(p.infl + o); }
 			while (o < hi)
 			{
+				const uint32_t bs = nx.bs;
 				if (o + 4 > p.total) { res = -(o + 10); stop = true; break; }
 				if (bs < 32) { res = -2; stop = true; break; }
 				if (o + 4 + (int64_t)bs > p.total) { res = -(o + 10); stop = true; break; }
 				const int64_t o_next = o + 4 + (int64_t)bs;
-				RecView r = load_rec(p.infl, o);
-				const uint32_t bs_next = o_next < hi && o_next + 4 <= p.total ? ld32(p.infl + o_next) : 0u;
+				RecView r = make_rec(p.infl, o, nx);   // (bs >= 32 and the record ends inside the tile: all 36 bytes were loaded)
+				if (o_next < hi) { if (o_next + 36 <= p.total) nx = load_hdr(p.infl + o_next); else { nx.bs = o_next + 4 <= p.total ? ld32(p.infl + o_next) : 0u; } }
 				if (!record_fields_fit(r.l_name, r.n_cigar_raw, r.l_seq, r.bs)) { res = -2; stop = true; break; }
-				if (n < (uint32_t)K2_REL_STRIDE) rel[b * K2_REL_STRIDE + n] = (uint16_t)(o - lo);
+				if (n < stride)
+				{
+					pk_lo = (pk_lo >> 16) | (pk_hi << 48); pk_hi = (pk_hi >> 16) | ((uint64_t)(uint16_t)(o - lo) << 48);
+					if ((n & 7u) == 7u) { rel8[(n >> 3) * 2] = pk_lo; rel8[(n >> 3) * 2 + 1] = pk_hi; }
+				}
 				if (o < p.scan_limit)
 				{
-					const long long name = (long long)((b << 20) | (int64_t)n);
+					const long long name = (long long)((b << NAME_SHIFT) | (int64_t)n);
 					long long ref_len = 0;
 					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len);
 					if (!scanned && p.sgn > 0)
@@ -553,7 +597,13 @@ __global__ __launch_bounds__(64, 3) void walk_scan_kernel(const ScanParams p, co
 					}
 					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a);
 				}
-				++n; o = o_next; bs = bs_next;
+				++n; o = o_next;
+			}
+			if ((n & 7u) != 0 && n < stride)
+			{
+				// the last, partial group of eight: moved down to the low bits
+				for (uint32_t k = n & 7u; k < 8u; ++k) { pk_lo = (pk_lo >> 16) | (pk_hi << 48); pk_hi >>= 16; }
+				rel8[(n >> 3) * 2] = pk_lo; rel8[(n >> 3) * 2 + 1] = pk_hi;
 			}
 			cnt[b] = n; next_abs[b] = stop ? res : o;
 			if (stop && res == -2) atomicAdd(bad, 1u);
@@ -562,19 +612,27 @@ __global__ __launch_bounds__(64, 3) void walk_scan_kernel(const ScanParams p, co
 	flush(p, a, lds_hist);
 }
 
-void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
+template <int WAVES>
+static void launch_walk_scan_w(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
 {
-	if (n_entries <= 0) return;
 	const int grid = (int)((n_entries + 63) / 64);
 	switch (p.mode)
 	{
-		case NGSQC_MODE_ROI: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_ROI>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case NGSQC_MODE_NOROI: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_NOROI>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case NGSQC_MODE_WGS: hipLaunchKernelGGL(walk_scan_kernel<NGSQC_MODE_WGS>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case MODE_COUNT: hipLaunchKernelGGL(walk_scan_kernel<MODE_COUNT>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		default: hipLaunchKernelGGL(walk_scan_kernel<3>, dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_ROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_ROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_NOROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_NOROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_WGS: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_WGS, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case MODE_COUNT: hipLaunchKernelGGL((walk_scan_kernel<MODE_COUNT, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		default: hipLaunchKernelGGL((walk_scan_kernel<3, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
 	}
 	KCHECK();
+}
+// NGSQC_WALK_WAVES = 3 / 4: the register budget the walk is compiled for (waves per SIMD: 170 / 128 VGPRs)
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
+{
+	if (n_entries <= 0) return;
+	int waves = 3; if (const char* e = getenv("NGSQC_WALK_WAVES")) waves = atoi(e);
+	if (waves >= 4) launch_walk_scan_w<4>(p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
+	else launch_walk_scan_w<3>(p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
 }
 
 // ---- order-dependent fix-ups on a record prefix ----

@@ -147,20 +147,24 @@ def test_fused_job_equals_single_purpose_calls(tmp_path, monkeypatch, tile_membe
 
 @pytest.mark.parametrize("aligned,tile_members", [(True, 0), (True, 9), (False, 9)])
 def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
-    """Three ways to the record index give the same job result: the scan riding K2's chain walk (default), the chain walk inside K1's CRC pass
-    (NGSQC_PREWALK=1, adopted by K2 for htslib-style tiles, refused for members that cut records) and the plain K2 + scan (both switched off)."""
+    """Every way to the record index gives the same job result: the scan riding K2's chain walk with four walkers per BGZF member (default), with one, two
+    and eight (NGSQC_WALKERS; pieces of a member whose first record is guessed, the chain checked on the device), compiled for four waves per SIMD
+    (NGSQC_WALK_WAVES=4) and the plain K2 + scan (NGSQC_NO_FUSED_SCAN=1)."""
     p = str(tmp_path / "k2.bam")
     G.write(p, n_reads=50000, seed=77, aligned=aligned)
     if tile_members:
         monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
     res = []
-    for env in ({}, {"NGSQC_PREWALK": "1"}, {"NGSQC_NO_FUSED_SCAN": "1"}):
+    for env in ({}, {"NGSQC_WALKERS": "1"}, {"NGSQC_WALKERS": "2"}, {"NGSQC_WALKERS": "8"}, {"NGSQC_WALK_WAVES": "4"}, {"NGSQC_NO_FUSED_SCAN": "1"}, {"NGSQC_NO_FUSED_SCAN": "1", "NGSQC_WALKERS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = ngsqc.Handle(path=p)
         regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
         out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=H.known_sites(h.refs))
         res.append((out["counters"].copy(), out["site_counts"].copy(), h.depth(int(out["counters"][26])).copy()))
+        tm = h.timings()
+        if aligned and "NGSQC_NO_FUSED_SCAN" not in env:   # an htslib-style file: every tile's chain is checked on the device and scanned by the walk itself
+            assert tm["tiles_chain_on_device"] == tm["n_tiles"] == tm["tiles_scan_fused"] and tm["walkers_per_member"] == int(env.get("NGSQC_WALKERS", 4)), tm
         h.close()
         for k in env:
             monkeypatch.delenv(k)
