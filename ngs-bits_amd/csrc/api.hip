@@ -1723,8 +1723,7 @@ void open_range_common(ngsqc_handle* h, const uint8_t* bytes, size_t n, int devi
 		for (int64_t i = 0; i < rq.n_regions; ++i)
 		{
 			const std::string want = rq.regions[i].chr ? rq.regions[i].chr : "";
-			auto norm = [](std::string c) { if (c.size() > 3 && (c.compare(0, 3, "chr") == 0 || c.compare(0, 3, "CHR") == 0)) c = c.substr(3); if (c == "M") c = "MT"; for (auto& ch : c) ch = (char)toupper((unsigned char)ch); return c; };   // (Chromosome::normalizedStringRepresentation)
-			for (size_t r = 0; r < h->ref_names.size(); ++r) if (h->ref_names[r] == want || norm(h->ref_names[r]) == norm(want)) { regs.push_back(ngsqc_region{(int32_t)r, rq.regions[i].start, rq.regions[i].end}); break; }
+			for (size_t r = 0; r < h->ref_names.size(); ++r) if (h->ref_names[r] == want || chr_norm(h->ref_names[r]) == chr_norm(want)) { regs.push_back(ngsqc_region{(int32_t)r, rq.regions[i].start, rq.regions[i].end}); break; }
 		}
 		if (!bai_range(h->path, regs.data(), (int64_t)regs.size(), (int32_t)h->ref_names.size(), beg, end, found))
 			throw IoError("Could not load index of BAM/CRAM file " + h->path);   // BamReader.cpp:742-746

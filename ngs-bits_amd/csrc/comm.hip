@@ -29,7 +29,7 @@ Rccl& rccl()
 	static Rccl r; static std::once_flag once;
 	std::call_once(once, [] {
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.so) break; }
-		if (!r.so) { r.err = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+		if (!r.so) { const char* e = dlerror(); r.err = std::string("librccl could not be loaded: ") + (e ? e : "?"); return; }   // (dlerror() clears the message: one call)
 		auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
 		r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId"); r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
 		r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy"); r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <cctype>
 #include <memory>
 #include <vector>
 #include "../../include/ngsqc.h"
@@ -43,6 +44,16 @@ struct BaiRunV { uint64_t voff; int32_t tid; uint32_t bin; int32_t pos; uint32_t
 // reads without a reference. Returns an error text ("" = written).
 std::string bai_assemble(const std::string& out_path, int32_t n_ref, uint64_t offset0, uint64_t final_off, const std::vector<BaiRunV>& runs, const std::vector<uint64_t>& lidx,
                          const std::vector<int64_t>& first, const std::vector<int64_t>& counts, bool csi = false, int min_shift = 14, int depth = 5);
+
+// A chromosome name as the reference compares it (Chromosome::normalizedStringRepresentation, src/cppNGS/Chromosome.cpp:133-190): "chr" / "CHR" dropped, M -> MT,
+// upper case. Every place that turns a region's name into a reference id of the file uses this one (BAM index queries and CRAM slice selection: ADVICE r04)
+inline std::string chr_norm(std::string c)
+{
+	if (c.size() > 3 && (c.compare(0, 3, "chr") == 0 || c.compare(0, 3, "CHR") == 0)) c = c.substr(3);
+	if (c == "M") c = "MT";
+	for (auto& ch : c) ch = (char)toupper((unsigned char)ch);
+	return c;
+}
 
 // CRAM 3.0 input (cram.hip; host only): the file as a BAM stream / as a BGZF image with stored blocks that the BAM path takes like any other BAM
 bool is_cram(const uint8_t* d, size_t n);

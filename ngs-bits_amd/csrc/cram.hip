@@ -12,6 +12,8 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -437,31 +439,58 @@ public:
 	~RefGenome() { if (map_) munmap(const_cast<uint8_t*>(map_), n_); if (fd_ >= 0) ::close(fd_); }
 	bool has(const std::string& name) const { return idx_.count(name) != 0; }
 	int64_t length(const std::string& name) const { auto it = idx_.find(name); return it == idx_.end() ? -1 : it->second.len; }
-	// the whole contig, upper case (loaded on first use; slices of one contig share it)
+	// the whole contig, upper case (loaded on first use; slices of one contig share it). The cache keeps the four contigs used last (evicting the
+	// smallest NAME threw chr10..chr22 out on every load once chr7..chr9 were in); a contig is read OUTSIDE the lock - workers of other contigs do not wait for it,
+	// workers of the same contig wait for the one that loads it
 	std::shared_ptr<const std::string> contig(const std::string& name)
 	{
-		std::lock_guard<std::mutex> g(mu_);
-		auto c = cache_.find(name);
-		if (c != cache_.end()) return c->second;
+		std::unique_lock<std::mutex> g(mu_);
+		while (true)
+		{
+			auto c = cache_.find(name);
+			if (c != cache_.end()) { c->second.used = ++tick_; return c->second.seq; }
+			if (!loading_.count(name)) break;
+			cv_.wait(g);
+		}
 		auto it = idx_.find(name);
 		if (it == idx_.end()) return nullptr;
-		const Entry& e = it->second;
-		auto s = std::make_shared<std::string>(); s->resize((size_t)e.len);
-		int64_t got = 0; size_t o = (size_t)e.offset;
-		while (got < e.len)
+		const Entry e = it->second;
+		loading_.insert(name);
+		g.unlock();
+		std::shared_ptr<std::string> s; std::string err;
+		try
 		{
-			const int64_t k = std::min<int64_t>(e.line_bases, e.len - got);
-			if (o > n_ || (size_t)k > n_ - o) throw CramError("reference genome is shorter than its index says");
-			for (int64_t i = 0; i < k; ++i) { uint8_t ch = map_[o + (size_t)i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32); (*s)[(size_t)(got + i)] = (char)ch; }
-			got += k; o += (size_t)e.line_bytes;
+			s = std::make_shared<std::string>(); s->resize((size_t)e.len);
+			int64_t got = 0; size_t o = (size_t)e.offset;
+			while (got < e.len)
+			{
+				const int64_t k = std::min<int64_t>(e.line_bases, e.len - got);
+				if (o > n_ || (size_t)k > n_ - o) throw CramError("reference genome is shorter than its index says");
+				for (int64_t i = 0; i < k; ++i) { uint8_t ch = map_[o + (size_t)i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32); (*s)[(size_t)(got + i)] = (char)ch; }
+				got += k; o += (size_t)e.line_bytes;
+			}
 		}
-		if (cache_.size() >= 4) cache_.erase(cache_.begin());   // (a sorted file walks the contigs one after the other)
-		cache_[name] = s;
+		catch (const std::exception& ex) { err = ex.what(); s.reset(); }
+		g.lock();
+		loading_.erase(name);
+		if (s)
+		{
+			while (cache_.size() >= 4)
+			{
+				auto old = cache_.begin();
+				for (auto c = cache_.begin(); c != cache_.end(); ++c) if (c->second.used < old->second.used) old = c;
+				cache_.erase(old);
+			}
+			cache_[name] = Cached{s, ++tick_};
+		}
+		cv_.notify_all();
+		if (!s) throw CramError(err);
 		return s;
 	}
 private:
 	struct Entry { int64_t len = 0, offset = 0, line_bases = 0, line_bytes = 0; };
-	std::map<std::string, Entry> idx_; std::map<std::string, std::shared_ptr<const std::string>> cache_; std::mutex mu_;
+	struct Cached { std::shared_ptr<const std::string> seq; uint64_t used = 0; };
+	std::map<std::string, Entry> idx_; std::map<std::string, Cached> cache_; std::set<std::string> loading_; std::mutex mu_; std::condition_variable cv_; uint64_t tick_ = 0;
 	int fd_ = -1; const uint8_t* map_ = nullptr; size_t n_ = 0;
 };
 
@@ -777,10 +806,19 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		out.push_back((uint8_t)(name.size() + 1)); out.push_back((uint8_t)mapq);
 		const int64_t pos0 = (int64_t)r.pos - 1, end0 = cigar.empty() ? pos0 + 1 : (int64_t)r.end;
 		add16(out, pos0 < 0 ? 4680u : reg2bin14(pos0, end0));
-		add16(out, (uint32_t)cigar.size()); add16(out, r.bf); add32(out, (uint32_t)l_seq);
+		// more than 65535 operations do not fit n_cigar_op: the BAM convention (SAM spec 4.2.2, htslib bam_write1) - a placeholder <l_seq>S<reference length>N and
+		// the operations in a CG:B,I tag behind the record's other tags, which every reader of the image (K2 / K3, like htslib's bam_tag2cigar) puts back
+		const bool cg = cigar.size() > 65535;
+		add16(out, cg ? 2u : (uint32_t)cigar.size()); add16(out, r.bf); add32(out, (uint32_t)l_seq);
 		add32(out, 0xffffffffu); add32(out, 0xffffffffu); add32(out, 0);   // next_refID, next_pos, tlen
 		out.insert(out.end(), name.begin(), name.end()); out.push_back(0);
-		for (uint32_t c : cigar) add32(out, c);
+		if (cg)
+		{
+			const int64_t ref_len = end0 - pos0;
+			if (l_seq >= (1u << 28) || ref_len < 0 || ref_len >= (1ll << 28)) throw CramError("a read with more than 65535 CIGAR operations is too long for the BAM placeholder CIGAR");
+			add32(out, ((uint32_t)l_seq << 4) | 4u); add32(out, ((uint32_t)ref_len << 4) | 3u);
+		}
+		else for (uint32_t c : cigar) add32(out, c);
 		const size_t sq = out.size(); out.resize(sq + (l_seq + 1) / 2, 0);
 		for (size_t x = 0; x < l_seq; ++x) out[sq + (x >> 1)] |= (uint8_t)(nt16[seq[x]] << ((x & 1) ? 0 : 4));
 		if (D.took) { if (patches && l_seq) patches->push_back(CramQualPlan::Patch{(uint64_t)out.size(), D.last_src, (uint32_t)l_seq, 0u}); D.took = false; }
@@ -790,6 +828,11 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		{
 			const std::string& id = (*env.rg_ids)[(size_t)rg];
 			out.push_back('R'); out.push_back('G'); out.push_back('Z'); out.insert(out.end(), id.begin(), id.end()); out.push_back(0);
+		}
+		if (cg)
+		{
+			out.push_back('C'); out.push_back('G'); out.push_back('B'); out.push_back('I'); add32(out, (uint32_t)cigar.size());
+			for (uint32_t c : cigar) add32(out, c);
 		}
 		put32(out, r.off, (uint32_t)(out.size() - r.off - 4));
 	}
@@ -934,9 +977,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		if (sel) for (const CramSelect::Region& g : sel->regions)
 		{
 			int32_t tid = -1;
-			auto bare = [](const std::string& x) { return x.compare(0, 3, "chr") == 0 ? x.substr(3) : x; };
 			for (size_t i = 0; i < ref_names.size() && tid < 0; ++i) if (ref_names[i] == g.chr) tid = (int32_t)i;
-			for (size_t i = 0; i < ref_names.size() && tid < 0; ++i) if (bare(ref_names[i]) == bare(g.chr)) tid = (int32_t)i;
+			for (size_t i = 0; i < ref_names.size() && tid < 0; ++i) if (chr_norm(ref_names[i]) == chr_norm(g.chr)) tid = (int32_t)i;   // (the same rule as the BAM index path, api.hip open_range_common)
 			if (tid >= 0) want.push_back(ngsqc_region{tid, g.start, g.end});
 		}
 		const bool by_region = sel && !sel->regions.empty(); size_t n_seen = 0;
@@ -969,6 +1011,8 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 				if (keep) jobs.push_back(std::move(j));
 			}
 			c.p = end;
+			// a head request (BamReader::info re-opens with a head four times as long each round) has what it asked for: the rest of the file is not walked
+			if (sel && sel->max_slices > 0 && n_seen >= (size_t)sel->max_slices && !by_region) break;
 		}
 		(void)eof;   // (htslib warns about a missing EOF container and goes on)
 		// ---- the genome ----

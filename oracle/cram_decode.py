@@ -527,7 +527,13 @@ def to_bam_record(r, rgs):
     end0 = r.end if r.cigar else pos0 + 1
     bin_ = reg2bin(pos0, end0) if r.ref_id >= 0 or pos0 >= 0 else 4680
     if pos0 < 0: bin_ = 4680
-    body = struct.pack("<iiBBHHHiiii", r.ref_id, pos0, len(name), r.mapq, bin_, len(r.cigar), r.bf, l_seq, r.mate_ref, r.mate_pos - 1, r.tlen) + name + cig + bytes(packed) + qual[:l_seq] + tags
+    n_cig = len(r.cigar)
+    if n_cig > 65535:
+        # SAM spec 4.2.2 / htslib bam_write1: n_cigar_op is 16 bits - the record carries the placeholder <l_seq>S<reference length>N and its operations in a
+        # CG:B,I tag behind all other tags (readers put them back: htslib bam_tag2cigar, oracle/bamio.hpp, K2 / K3)
+        tags += b"CGBI" + struct.pack("<i", n_cig) + cig
+        cig = struct.pack("<II", l_seq << 4 | 4, (end0 - pos0) << 4 | 3); n_cig = 2
+    body = struct.pack("<iiBBHHHiiii", r.ref_id, pos0, len(name), r.mapq, bin_, n_cig, r.bf, l_seq, r.mate_ref, r.mate_pos - 1, r.tlen) + name + cig + bytes(packed) + qual[:l_seq] + tags
     return struct.pack("<i", len(body)) + body
 
 

@@ -175,7 +175,17 @@ def parse_record(raw):
     packed = raw[o:o + (l_seq + 1) // 2]; o += (l_seq + 1) // 2
     seq = bytes(b"=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if not i & 1 else 0)) & 15] for i in range(l_seq))
     qual = raw[o:o + l_seq]; o += l_seq
-    return dict(raw=raw, ref_id=ref_id, pos=pos0 + 1, mapq=mapq, flag=flag, mate_ref=mref, mate_pos=mpos0 + 1, tlen=tlen, name=name, cigar=cigar, seq=seq, qual=qual, tags=split_tags(raw[o:]))
+    tags = split_tags(raw[o:])
+    # htslib bam_tag2cigar (sam_read1 of a BAM): a placeholder CIGAR <l_seq>S... with a CG:B,I tag of at least as many operations stands for a CIGAR of more
+    # than 65535 operations - the reader puts it back and drops the tag; the CRAM then holds the real operations as read features
+    if n_cig and ref_id >= 0 and pos0 >= 0 and cigar[0] == ("S", l_seq):
+        cg = [t for t in tags if t[0] == b"CG" and t[1] == ord("B") and t[2][:1] == b"I"]
+        if cg:
+            n = struct.unpack_from("<i", cg[0][2], 1)[0]
+            if n_cig <= n < 1 << 29:
+                cigar = [(CD.CIGAR_OPS[c & 15], c >> 4) for c in struct.unpack_from("<%dI" % n, cg[0][2], 5)]
+                tags = [t for t in tags if t is not cg[0]]
+    return dict(raw=raw, ref_id=ref_id, pos=pos0 + 1, mapq=mapq, flag=flag, mate_ref=mref, mate_pos=mpos0 + 1, tlen=tlen, name=name, cigar=cigar, seq=seq, qual=qual, tags=tags)
 
 
 def split_tags(aux):

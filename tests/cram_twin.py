@@ -100,3 +100,30 @@ def make_twin(src_bam, out_dir, window=250_000, seed=1, max_records=None):
 def ref_fetch_of(twin):
     names = [n for n, _ in twin["refs"]]
     return lambda ref_id, p0, n: twin["genome"][names[ref_id]][p0:p0 + n]
+
+
+def long_cigar_bam(path, n_groups=17500, seed=5):
+    """A small coordinate-sorted BAM on one 200 kb contig with ordinary reads around ONE read of 4 * n_groups CIGAR operations (2M 1I 2M 1D, repeated): more
+    than 65535 do not fit n_cigar_op, so the record carries the BAM convention - the placeholder <l_seq>S<reference length>N and a CG:B,I tag behind its other
+    tags (SAM spec 4.2.2). -> the raw records"""
+    rng = random.Random(seed)
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrL\tLN:200000\n@PG\tID:x\tPN:x\n"
+    refs = [("chrL", 200000)]
+
+    def rec(name, pos0, ops, flag=0, mapq=60, tags=b"NMC\x03"):
+        l_seq = sum(k for op, k in ops if op in "MIS=X"); ref_len = sum(k for op, k in ops if op in "MDN=X")
+        seq = bytes(rng.choice(b"ACGT") for _ in range(l_seq)); qual = bytes(rng.choice((2, 12, 23, 37)) for _ in range(l_seq))
+        code = {c: i for i, c in enumerate(b"=ACMGRSVTWYHKDBN")}; packed = bytearray((l_seq + 1) // 2)
+        for i, ch in enumerate(seq): packed[i >> 1] |= code[ch] << 4 if not i & 1 else code[ch]
+        cig = b"".join(struct.pack("<I", k << 4 | "MIDNSHP=X".index(op)) for op, k in ops); n_cig = len(ops)
+        if n_cig > 65535:
+            tags = tags + b"CGBI" + struct.pack("<i", n_cig) + cig
+            cig = struct.pack("<II", l_seq << 4 | 4, ref_len << 4 | 3); n_cig = 2
+        nm = name + b"\0"
+        body = struct.pack("<iiBBHHHiiii", 0, pos0, len(nm), mapq, CD.reg2bin(pos0, pos0 + max(ref_len, 1)), n_cig, flag, l_seq, -1, -1, 0) + nm + cig + bytes(packed) + qual + tags
+        return struct.pack("<i", len(body)) + body
+    raws = [rec(b"short%04d" % i, 100 + 37 * i, [("M", 150)]) for i in range(40)]
+    raws.append(rec(b"long_cigar", 1700, [("S", 7)] + [("M", 2), ("I", 1), ("M", 2), ("D", 1)] * n_groups + [("S", 5)], flag=16))
+    raws += [rec(b"after%04d" % i, 1800 + 911 * i, [("M", 100), ("D", 2), ("M", 50)]) for i in range(100)]
+    write_bam(path, text, refs, raws)
+    return raws

@@ -119,6 +119,30 @@ def test_cram_of_a_bam_gives_back_the_bam(twins, src, variant, tmp_path, monkeyp
         assert got == want, (i, got[:48].hex(), want[:48].hex())
 
 
+def test_read_with_more_than_65535_cigar_operations(tmp_path, monkeypatch):
+    """n_cigar_op is 16 bits. A CRAM read of 70 002 operations comes back as the BAM convention (placeholder <l_seq>S<ref_len>N + CG:B,I behind the
+    other tags) - the record of the BAM the CRAM was written from, byte for byte, from the product and from the oracle."""
+    d = str(tmp_path); src = os.path.join(d, "long.bam")
+    cram_twin.long_cigar_bam(src)
+    twin = cram_twin.make_twin(src, os.path.join(d, "twin"))
+    long_raw = [r for r in twin["records"] if b"long_cigar\0" in r[:64]]
+    assert len(long_raw) == 1 and struct.unpack_from("<H", long_raw[0], 16)[0] == 2 and b"CGBI" in long_raw[0]
+    parsed = CE.parse_record(long_raw[0])
+    assert len(parsed["cigar"]) == 70002 and all(t[0] != b"CG" for t in parsed["tags"])          # the encoder sees the real operations, like htslib's reader
+    cram = os.path.join(d, "long.cram"); out = os.path.join(d, "back.bam")
+    CE.encode(twin["bam"], cram, twin["genome"])
+    monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False)
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        ngsqc.cram_to_bam(cram, out)
+    finally:
+        ngsqc.set_reference(None)
+    _, _, recs = split_bam(bam_stream(out)[0])
+    assert recs == twin["records"]
+    f = CD.read_cram(cram, cram_twin.ref_fetch_of(twin)); rgs = CD.read_groups(f.header)
+    assert [CD.to_bam_record(r, rgs) for r in f.records] == twin["records"]
+
+
 def test_genome_errors(twins, tmp_path, monkeypatch):
     twin = twins["MappingQC_in2.bam"]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "o.bam")
     CE.encode(twin["bam"], cram, twin["genome"])
@@ -174,7 +198,8 @@ def test_region_selection_decodes_only_the_overlapping_slices(twins, tmp_path):
         used = sorted({r["ref_id"] for r in parsed if r["ref_id"] >= 0 and not r["flag"] & 4})
         t = used[len(used) // 2]; on_t = [r for r in parsed if r["ref_id"] == t]
         mid = on_t[len(on_t) // 2]["pos"]; region = (names[t], mid, mid + 150)
-        for chrom in (region[0], region[0][3:] if region[0].startswith("chr") else "chr" + region[0]):   # with and without "chr"
+        bare = region[0][3:] if region[0].startswith("chr") else region[0]
+        for chrom in (region[0], bare if region[0].startswith("chr") else "chr" + bare, "CHR" + bare.upper(), bare.lower()):   # the reference's Chromosome rule: "chr" / "CHR" dropped, upper case (as the BAM index path)
             ngsqc.cram_to_bam(cram, out, regions=[(chrom, region[1], region[2])])
             _, _, recs = split_bam(bam_stream(out)[0])
             want = [r["raw"] for r in parsed if r["ref_id"] == t and r["pos"] <= region[2] and CE.ref_end(r) >= region[1]]

@@ -156,6 +156,54 @@ def test_regions_on_a_cram_decode_only_their_slices(twin, tmp_path):
         ngsqc.set_reference(None)
 
 
+def test_region_names_resolve_like_the_bam_index_path(twin, tmp_path):
+    """ADVICE r04: a BED that says CHR1 / 1 / chr1 for the file's chr1 must select the same CRAM slices as it selects BAM members (Chromosome::normalizedStringRepresentation:
+    "chr" / "CHR" dropped, upper case) - before, only a lower-case "chr" was stripped for a CRAM and such a region silently read as depth 0"""
+    cram = str(tmp_path / "small_slices.cram"); CE.encode(twin["bam"], cram, twin["genome"], slice_records=300)
+    name, ln = max(twin["refs"], key=lambda x: x[1]); tid = [n for n, _ in twin["refs"]].index(name)
+    bare = name[3:] if name.lower().startswith("chr") else name
+    regs = [(tid, ln // 2, ln // 2 + 200)]; n = 201
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        whole = ngsqc.Handle(path=twin["bam"]); whole.scan_depth(regs, min_mapq=1); want = whole.depth(n).copy(); whole.close()
+        assert want.sum() > 0
+        for spelled in (name, bare, "CHR" + bare.upper(), "chr" + bare.lower()):
+            for path in (cram, twin["bam"]):
+                part = ngsqc.Handle(path=path, regions=[(spelled, regs[0][1], regs[0][2])])
+                try:
+                    part.scan_depth(regs, min_mapq=1)
+                    assert np.array_equal(part.depth(n), want), (spelled, path)
+                finally:
+                    part.close()
+    finally:
+        ngsqc.set_reference(None)
+
+
+def test_read_with_more_than_65535_cigar_operations(tmp_path):
+    """a CRAM read of 70 002 CIGAR operations reaches the device as the BAM convention (placeholder CIGAR + CG:B,I tag), which K2 / K3 put back like
+    htslib's bam_tag2cigar: the handle on the CRAM gives the inflated stream, counters and depth of the handle on the BAM the CRAM was written from"""
+    d = str(tmp_path); src = os.path.join(d, "long.bam")
+    cram_twin.long_cigar_bam(src)
+    t = cram_twin.make_twin(src, os.path.join(d, "twin"))
+    cram = os.path.join(d, "long.cram"); CE.encode(t["bam"], cram, t["genome"])
+    ngsqc.set_reference(t["fasta"])
+    try:
+        a = ngsqc.Handle(path=cram); b = ngsqc.Handle(path=t["bam"])
+        try:
+            assert a.n_records == b.n_records == 141
+            assert np.array_equal(a.inflated(), b.inflated())
+            ca, _ = _mapping(a); cb, _ = _mapping(b)
+            assert np.array_equal(ca, cb) and int(ca[9]) >= 12                       # bases_clipped: the 7S + 5S of the long read were seen through the CG tag
+            regs = [(0, 1, 120000)]
+            a.scan_depth(regs, min_mapq=1); b.scan_depth(regs, min_mapq=1)
+            da = a.depth(120000)
+            assert np.array_equal(da, b.depth(120000)) and int(da[60000]) == 1        # the long read alone covers 1 708 .. 89 207
+        finally:
+            a.close(); b.close()
+    finally:
+        ngsqc.set_reference(None)
+
+
 def test_baminfo_and_readcount_on_a_cram(twin, tmp_path):
     """BamInfo names the container version (BamReader.cpp:603-617: "CRAM 3.0") and finds mapper / paired-end from the first slices; BedReadCount counts like on the BAM"""
     rows = {}

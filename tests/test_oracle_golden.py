@@ -132,6 +132,25 @@ def test_low_coverage_known_answers(tmp_path):  # Statistics_Test.cpp:691-712
             assert O.low_high_coverage(_bam(f), str(bed), 20, 1, tool_merge=0, random_access=ra)["out_bases"] == 0
 
 
+def test_lowhigh_hand_vectors(tmp_path):
+    """rows a10 / a11 (BedLowCoverage / BedHighCoverage, `-min_baseq`): every reference vector needs the missing panel.bam, so the oracle is pinned on vectors
+    written out BY HAND from the reference's lines (tests/hand_vectors.py: the '=' / 'X' quirk of BamAlignment::qualities, D / N stay covered, I / S advance the
+    read index, 300 -> 254 in the sweep only, names joined by the input merge and made unique by the output merge, two runs in one line)"""
+    import hand_vectors as HV
+    bam = str(tmp_path / "hand.bam"); HV.write_bam(bam, HV.READS)
+    ob = O.Bam(bam)
+    assert ob.count == len(HV.READS) == 312
+    for case, c in HV.CASES.items():
+        bed = str(tmp_path / (case + ".bed")); HV.write_bed(bed, case)
+        for ra in (True, False):
+            r = O.low_high_coverage(ob, bed, c["cutoff"], 1, c["min_baseq"], is_high=c["is_high"], random_access=ra, tool_merge=1)
+            assert r["bed"].splitlines() == HV.expected(case, ra), (case, ra)
+            assert r["depth"].tolist() == (c["depth"] if ra else [min(d, 254) for d in c["depth"]]), (case, ra)   # (the sweep's unsigned char stops at 254)
+            assert r["roi_bases"] == len(c["depth"])
+            r = O.low_high_coverage(ob, bed, c["cutoff"], 1, c["min_baseq"], is_high=c["is_high"], random_access=ra, tool_merge=0)
+            assert r["bed"].splitlines() == HV.expected(case, ra, function_level=True), (case, ra, "function level")
+
+
 def test_yx_longread_and_sry(tmp_path):  # Statistics_Test.cpp:811-820, 850-854
     r = O.mapping(_bam("Statistics_longread.bam"), O.MODE_NOROI)
     assert r["reads_x"] == 214 and r["reads_y"] == 0
