@@ -129,6 +129,126 @@ def prefix_image(image, target_bytes):
     return out
 
 
+
+def scan_roofline(tm):
+    """t_scan = K2-K6 on resident inflated data (an un-pipelined step's HIP-event stage times do not overlap)"""
+    t_scan = tm["index_ms"] + tm["scan_ms"] + tm["finalize_ms"]
+    b = int(tm["scan_algorithmic_bytes"])
+    gbs = b / max(t_scan, 1e-9) / 1e6
+    return {"stage": "K2-K6 on resident inflated data, un-pipelined step", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes": b, "t_scan_ms": round(t_scan, 4),
+            "scan_kernel_only": {"frac": round(b / max(tm["scan_kernel_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 5), "ms": round(tm["scan_kernel_ms"], 4)}}
+
+
+def timed_steps(step, h, steps):
+    """one warm-up, `steps` timed whole-job steps (compressed image resident, every step from the compressed bytes), one extra un-pipelined step for the stage times"""
+    import torch
+    step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    tm = h.timings()
+    os.environ["NGSQC_PIPELINE"] = "0"
+    try:
+        step(); serial = h.timings()
+    finally:
+        del os.environ["NGSQC_PIPELINE"]
+    n_rec = int(tm["n_records"])
+    return res, {"value": round(n_rec * steps / el / 1e6, 3), "unit": "Mreads/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "reads_per_step": n_rec,
+                 "members_inflated_per_step": int(tm["members_inflated"]), "tiles": int(tm["n_tiles"]), "tiles_scan_fused": int(tm["tiles_scan_fused"]),
+                 "walkers_per_member": int(tm["walkers_per_member"]), "roofline_scan": scan_roofline(serial)}
+
+
+def coverage_tool_leg(ngsqc, H, O, h, image, refs, tool, min_baseq, steps, args, device):
+    """configs[2]: BedCoverage / BedLowCoverage over the SAME resident 30x image as the headline step (exome-shaped BED, 200 000 intervals,
+    ~38 Mb; BedCoverage on the unmerged variant with 10 % overlapping lines; BedLowCoverage -cutoff 20 with and without -min_baseq 20). Reference:
+    WorkerAverageCoverage.cpp:86-173, WorkerLowOrHighCoverage.cpp:141-252."""
+    tag = tool + (f"_baseq{min_baseq}" if min_baseq else "")
+    bed_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_exome_{args.seed}_{tag}.bed")
+    n_lines = synthetic_exome_bed(bed_path, refs, args.seed, overlapping=(tool == "bedcoverage"))
+    union, _ = H.bed_regions(bed_path, refs, 2); lines, _ = H.bed_regions(bed_path, refs, 0)
+    union_c = ngsqc.capi._regions_array(np.array(union, dtype=np.int32)); lines_c = ngsqc.capi._regions_array(np.array(lines, dtype=np.int32))
+
+    def step():
+        h.drop_decoded()
+        if tool == "bedcoverage":
+            h.scan_depth(union_c, min_mapq=1, n_regions=len(union))
+            return h.region_sums(lines_c, n_lines=len(lines))
+        h.scan_depth(union_c, min_mapq=1, min_baseq=min_baseq, n_regions=len(union))
+        return h.lowhigh_runs(lines_c, 20, is_high=False, saturate254=True, n_lines=len(lines), as_array=True)
+    _, out = timed_steps(step, h, steps)
+    out["workload"] = ({"bedcoverage": "BedCoverage: depth scan over the merged exome regions + per-line sums (unmerged BED, 10 % overlapping lines)",
+                        "bedlowcoverage": f"BedLowCoverage -cutoff 20{' -min_baseq ' + str(min_baseq) if min_baseq else ''}: depth scan + low-coverage runs, sweep saturation"}[tool]
+                       + f"; exome BED of {n_lines} lines, {int(sum(e - s + 1 for _, s, e in union))} merged bases; the full resident image, every step from the compressed bytes")
+    if not args.no_cpu_baseline:
+        # the oracle's restatement of the tool (1 thread) on the first records of the same BAM; the same sample through the GPU path is the parity check
+        samp = prefix_image(image, min(int(image.size), args.cpu_sample_reads * BYTES_PER_READ_COMPRESSED))
+        sp = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ngsqc_bench_sample_{args.seed}_{tag}.bam")
+        samp.tofile(sp)
+        try:
+            t1 = time.time()
+            ob = O.Bam(sp)                                  # (sequential inflate + record framing of the sample: part of the CPU tool's work)
+            t_load = time.time() - t1
+            hs = ngsqc.Handle(data=samp, device=device)
+            t1 = time.time()
+            if tool == "bedcoverage":
+                cov, _, _ = O.avg_coverage(ob, bed_path, merge_bed=False, min_mapq=1, random_access=False)
+                secs = time.time() - t1 + t_load
+                hs.scan_depth(union, min_mapq=1); ok = bool(np.array_equal(hs.region_sums(lines), cov))
+            else:
+                exp = O.low_high_coverage(ob, bed_path, 20, 1, min_baseq, is_high=False, random_access=False, tool_merge=1)
+                secs = time.time() - t1 + t_load
+                hs.scan_depth(union, min_mapq=1, min_baseq=min_baseq)
+                ok = bool(np.array_equal(np.minimum(hs.depth(exp["roi_bases"]), 254), np.minimum(exp["depth"], 254)))
+            hs.close()
+            out["cpu_baseline"] = {"value": round(ob.count / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ob.count} records of the same BAM: sequential inflate + record framing + the oracle's restatement of the tool's sweep, 1 thread, {secs:.1f} s"}
+            out["counters_match_gpu"] = ok
+            out["counters_match_note"] = "per-line depth sums (BedCoverage) / per-base depth of the whole exome BED (BedLowCoverage) of the sample, GPU vs oracle, bit-exact"
+        finally:
+            os.remove(sp)
+    os.remove(bed_path)
+    return tag, out
+
+
+def ont_leg(ngsqc, G, H, O, args, device, steps):
+    """configs[4]: MappingQC -wgs (fused job incl. contamination pileup) on a shard of the 40x ONT file: 400 k of ~8e6 reads (N50 ~20 kb, ~1 CIGAR op per 12 bp, CG-tag
+    records) - the long-read generator is the limit of the shard's size, not the GPU. Reference: Statistics.cpp:1068-1182 over BamReader::cigarData (long CIGAR / CG tag)."""
+    reads = int(os.environ.get("NGSQC_BENCH_ONT_READS", "400000"))
+    gen_kw = dict(seed=args.seed, mode=1, depth=40.0, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=0)
+    t0 = time.time(); image = G.generate(reads, threads=2 * G.effective_cpus(), **gen_kw); gen_s = time.time() - t0
+    h = ngsqc.Handle(data=image, device=device)
+    refs = h.refs
+    omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
+    tx, ty = H.xy_tids(refs); regs, _ = H.bed_regions(omim, refs, 3); sites_arr = H.known_sites(refs)
+    mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs))
+
+    def step():
+        h.drop_decoded()
+        return h.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, True))["counters"]
+    _, out = timed_steps(step, h, steps)
+    tm = h.timings()
+    out["workload"] = (f"MappingQC -wgs as one fused job on a SHARD of configs[4]: {out['reads_per_step']} of ~8e6 reads of the 40x ONT-like BAM (N50 ~20 kb, ~1 CIGAR op per 12 bp, "
+                       f"CG-tag records), {int(tm['compressed_bytes'])} compressed / {int(tm['inflated_bytes'])} inflated bytes; compressed image resident, every step from the compressed bytes")
+    out["gbases_per_s"] = round(out["value"] * 1e6 * (int(tm["inflated_bytes"]) / max(out["reads_per_step"], 1)) / 1.72 / 1e9, 2)   # (~1.72 inflated bytes per base: 4-bit SEQ + QUAL + CIGAR share)
+    out["generate_s"] = round(gen_s, 1)
+    h.close()
+    if not args.no_cpu_baseline:
+        c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, min(150_000, reads))
+        out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 5), "unit": "Mreads/s", "cores": 1, "kind": "port",
+                               "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop, {secs:.1f} s"}
+        # long reads span BGZF members, so the file cannot be cut into per-thread member ranges for an all-cores parity pass: parity of the generator's data is
+        # checked on a small BAM of the same generator (all counters of the GPU job vs the sequential oracle, bit-exact)
+        small = G.generate(20_000, **dict(gen_kw, threads=0))
+        hs = ngsqc.Handle(data=small, device=device)
+        got = hs.run_job(mapping=mp)["counters"]; hs.close()
+        c_small, _, _ = O.baseline_wgs_stream(small, omim, 1, -1)
+        out["counters_match_gpu"] = bool(all(int(got[i]) == int(c_small[i]) for i in range(len(got)) if i not in (27, 28)))
+        out["counters_match_note"] = "a 20 000-read BAM of the same generator and seed: all counters of the GPU job vs the sequential oracle, bit-exact"
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -558,8 +678,25 @@ def main():
             out["cpu_baseline"] = {"value": round(ob.count / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
                                    "sample": f"first {ob.count} records of the same BAM: sequential inflate + record framing + the oracle's restatement of the tool's sweep, 1 thread, {secs:.1f} s", "counters_match_gpu": ok,
                                    "counters_match_note": "per-line depth sums (BedCoverage) / per-base depth of the whole exome BED (BedLowCoverage) of the sample, GPU vs oracle, bit-exact"}
+    # ---- the other named configs of BASELINE.json in the SAME line: configs[2] = BedCoverage / BedLowCoverage over the resident 30x image,
+    # configs[4] = the ONT shard (behind the headline handle: it needs the HBM) ----
+    want_extra = rank == 0 and world == 1 and tool == "mappingqc" and not args.ont and not args.single_bam and os.environ.get("NGSQC_BENCH_NO_TOOLS") is None
+    if want_extra:
+        import oracle_lib as O
+        out["tools"] = {}
+        for tl, bq in (("bedcoverage", 0), ("bedlowcoverage", 0), ("bedlowcoverage", 20)):
+            try:
+                tag, leg = coverage_tool_leg(ngsqc, H, O, h, image, refs, tl, bq, max(3, min(args.steps, 5)), args, local_rank)
+                out["tools"][tag] = leg
+            except Exception as e:   # never let an extra leg break the bench line
+                out["tools"][tl + (f"_baseq{bq}" if bq else "")] = {"error": str(e)[:300]}
     n_members_file = int(h.n_blocks) if not args.single_bam else None
     h.close()
+    if want_extra and os.environ.get("NGSQC_BENCH_NO_ONT") is None:
+        try:
+            out["ont"] = ont_leg(ngsqc, G, H, O, args, local_rank, 3)
+        except Exception as e:
+            out["ont"] = {"error": str(e)[:300]}
     if args.single_bam and rank == 0 and tool == "mappingqc" and image is not None:
         # parity of the sharded path: the unsharded job on this rank's GPU over the whole BAM (all 1032 counters and the depth histogram)
         try:

@@ -118,6 +118,29 @@ struct Timer
 	double elapsed() { HIPCHK(hipEventSynchronize(b)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); return ms; }
 };
 
+// HIP-event intervals on a stream whose durations are only read after the tile loop (round 5: a Timer::stop() is a host wait - eight of them per tile kept the
+// device idle between the kernels of a tile). begin() / end() record; resolve() adds every interval to the sums it was opened for.
+struct EvLog
+{
+	struct Iv { hipEvent_t a, b; double* sum[2]; };
+	std::vector<hipEvent_t> pool; size_t used = 0; std::vector<Iv> open;
+	hipEvent_t get() { if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); } return pool[used++]; }
+	size_t begin(hipStream_t s, double* sum0, double* sum1 = nullptr) { Iv iv{get(), get(), {sum0, sum1}}; HIPCHK(hipEventRecord(iv.a, s)); open.push_back(iv); return open.size() - 1; }
+	void end(size_t id, hipStream_t s) { HIPCHK(hipEventRecord(open[id].b, s)); }
+	void resolve()
+	{
+		for (Iv& iv : open)
+		{
+			float ms = 0;
+			if (hipEventSynchronize(iv.b) == hipSuccess && hipEventElapsedTime(&ms, iv.a, iv.b) == hipSuccess) { for (double* q : iv.sum) if (q) *q += ms; }
+			else (void)hipGetLastError();
+		}
+		open.clear(); used = 0;
+	}
+	void discard() { open.clear(); used = 0; (void)hipGetLastError(); }
+	~EvLog() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
 double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -214,11 +237,17 @@ struct ngsqc_handle
 	std::thread plan_thread; std::string plan_err;   // plan_layout in the background of ngsqc_open (device buffers of the tile stream: allocation overlaps the H2D)
 	// the scan that rides K2's chain walk (launch_walk_scan): set by the job for its first scan consumer; fuse_ok turns false when a tile is not laid out like an
 	// htslib file (the general K2 path takes over); fused_tile = the tile whose records that scan has already seen
+	EvLog ev_store; EvLog* evlog = &ev_store;   // stage times of the running tile stream (resolved at its end)
+	// what the host learns about a tile in ONE wait (round 5; p_rb, pinned): [0 .. A_HIST0) the device accumulators of the riding scan after its walk (deferred-record
+	// count, the tile's longest / first paired record, totals), [RB_CAND] the site pileup's candidates
+	PinBuf<unsigned long long> p_rb; static constexpr int RB_CAND = 64, RB_TOTAL = 72;
+	// record offsets of the resident tile are expanded on demand (ensure_recoff): a job whose consumers all ride the chain walk never reads them
+	bool lazy_recoff = false; int recoff_tile = -1;
+	struct RecoffArgs { const uint8_t* base = nullptr; int64_t total = 0; const BlockDesc* desc = nullptr; int64_t ne = 0, prefix = 0, n_rec = 0; int ksh = 0; int tile = -1; } rw;
 	struct FusedScan   // what K2 needs of such a scan (ScanState)
 	{
 		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t scan_limit) = 0;
-		virtual unsigned long long* fused_long_count() = 0;   // device address of the deferred-record count
-		virtual double fused_elapsed_ms() = 0;                // duration of the last fused_launch (waits for it)
+		virtual void fused_readback(ngsqc_handle* h) = 0;     // enqueues the copy of its accumulators (and of what rides with it) into h->p_rb
 		virtual ~FusedScan() = default;
 	};
 	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
@@ -900,7 +929,7 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	h->p_status.ensure((size_t)nb);
 	while ((int64_t)h->ev_chunk.size() < 4 * h->nch) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev_chunk.push_back(e); }
 	while ((int)h->ev_tile.size() < 2 * nt) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_tile.push_back(e); }
-	h->p_small.ensure(64);
+	h->p_small.ensure(64); h->p_rb.ensure((size_t)ngsqc_handle::RB_TOTAL);
 	HIPCHK(hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
 	h->tm.n_tiles = nt;
 	if (h->stream_img && early_pass) { stream_pass_begin(h); h->up->pass_fresh = true; }   // (ngsqc_open's layout thread: the copy starts now)
@@ -990,6 +1019,21 @@ void finish_k1_tile(ngsqc_handle* h, int t)
 	inflate_sync(h, redo, desc, h->buf[t % h->nbuf].p + h->pfx);
 }
 
+// d_recoff of the tile that index_tile has just indexed (K2's write pass: the entry-relative offsets kept by the walk, expanded with coalesced stores)
+const int64_t* ensure_recoff(ngsqc_handle* h)
+{
+	const ngsqc_handle::RecoffArgs& a = h->rw;
+	if (h->recoff_tile != a.tile || a.tile < 0)
+	{
+		h->d_recoff.ensure_slack((size_t)std::max<int64_t>(a.n_rec, 1));
+		size_t iv = h->evlog->begin(h->stream, &h->tm.index_ms);
+		launch_index_write(a.base, a.total, a.desc, a.ne, a.prefix, a.ksh, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
+		h->evlog->end(iv, h->stream);
+		h->recoff_tile = a.tile;
+	}
+	return h->d_recoff.p;
+}
+
 // K2 for tile t (its members are in buf[t % nbuf] behind the prefix area; carry_len bytes of the previous tile's straddling
 // record have been copied right in front of them). Tile-local coordinates: byte 0 = first carried byte.
 void index_tile(ngsqc_handle* h, int t)
@@ -1014,7 +1058,7 @@ void index_tile(ngsqc_handle* h, int t)
 	int64_t ne = (nm << ksh) + 1;
 	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };   // (whole members: the general path)
 	auto e_sz = [&](int64_t e) -> int64_t { return e == 0 ? prefix : (int64_t)h->blocks[(size_t)(first + e - 1)].usize; };
-	Timer tmr(h->stream); tmr.start();
+	EvLog& ev = *h->evlog; size_t iv = ev.begin(h->stream, &h->tm.index_ms);   // (the riding scan's kernel is booked as scan time: the interval is cut around it)
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
@@ -1026,7 +1070,8 @@ void index_tile(ngsqc_handle* h, int t)
 	// ---- fast path: one round trip. Guess the first record of every entry, walk every entry's chain, check on the device that every walker's exit is the
 	// next walker's start (index_chain_kernel: exact), scan the counts; the host reads back {violations, corrupt records, n_rec} only. An htslib-written
 	// file passes (a record starts at every member's first byte, none straddles members or tiles) ----
-	launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, h->d_start.p, h->stream);
+	const bool assume0 = !anchor_by_guess && !h->k2_plain && !getenv("NGSQC_K2_GUESS_ALL");   // (a file that has looked like an htslib file so far: its members start with a record)
+	launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, assume0, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_bad.p + 2, 0xff, sizeof(long long), h->stream));
 	h->fused_tile = -1;
 	// the job's first scan consumer rides K2's walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
@@ -1035,8 +1080,10 @@ void index_tile(ngsqc_handle* h, int t)
 	if (try_fuse)
 	{
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(total / 160, 1024));   // deferred (long-CIGAR) records of the tile: an estimate, checked below
-		launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
+		if (!assume0 || ksh) launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
+		ev.end(iv, h->stream);
 		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, ksh, fuse_limit);
+		iv = ev.begin(h->stream, &h->tm.index_ms);
 	}
 	else launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 	launch_index_chain(d_desc, ne, prefix, ksh, exp0, total, h->d_start.p, h->d_next.p, h->d_bad.p + 1, (long long*)(h->d_bad.p + 2), h->stream);
@@ -1044,8 +1091,9 @@ void index_tile(ngsqc_handle* h, int t)
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = record cut by the tile end, [2] = deferred records of the riding scan, [3] = n_rec
 	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipMemcpyAsync(sm + 3, h->d_base.p + ne, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-	sm[2] = 0; if (try_fuse) HIPCHK(hipMemcpyAsync(sm + 2, h->fuse->fused_long_count(), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	sm[2] = 0; if (try_fuse) h->fuse->fused_readback(h);   // (what the riding scan's consumers need of this tile comes with the same wait)
 	HIPCHK(hipStreamSynchronize(h->stream));
+	if (try_fuse) sm[2] = h->p_rb.p[A_LONG_COUNT];
 	const uint32_t n_corrupt = ((const uint32_t*)sm)[0], n_viol = ((const uint32_t*)sm)[1];
 	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
 	if (try_fuse)
@@ -1056,7 +1104,9 @@ void index_tile(ngsqc_handle* h, int t)
 			// the chain did not check out (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual.
 			// This includes a tile whose guessed chains ran into something that looks like a corrupt record (a false start guess): the
 			// general path below repairs the chain, so the walk's contributions must go whatever it met (only aligned && corrupt throws, below)
+			ev.end(iv, h->stream);
 			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, ksh, fuse_limit);
+			iv = ev.begin(h->stream, &h->tm.index_ms);
 			if (!aligned) h->fuse_ok = false; else h->d_long.ensure_slack((size_t)sm[2]);
 		}
 	}
@@ -1073,10 +1123,10 @@ void index_tile(ngsqc_handle* h, int t)
 	// ---- general path: records cut by tile borders, false guesses, shards that guess their first record. Whole members (ksh = 0): the host verifies that every
 	// member's exit lands on the next member's start and repairs the first mismatch, round by round ----
 	if (!anchor_by_guess) h->k2_plain = true;
-	if (ksh != 0)
+	if (ksh != 0 || assume0)
 	{
 		ksh = 0; ne = ne0;
-		launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, h->d_start.p, h->stream);
+		launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, false, h->d_start.p, h->stream);
 		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
 		launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 	}
@@ -1135,8 +1185,11 @@ void index_tile(ngsqc_handle* h, int t)
 	HIPCHK(hipStreamSynchronize(h->stream));
 	}
 	int64_t n_rec = (int64_t)sm[3];
-	h->d_recoff.ensure_slack((size_t)std::max<int64_t>(n_rec, 1));
-	launch_index_write(base, total, d_desc, ne, prefix, ksh, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
+	// the record offsets: expanded now, or - a job whose consumers all ride the walk - only if somebody asks (ensure_recoff)
+	h->rw = ngsqc_handle::RecoffArgs{base, total, d_desc, ne, prefix, n_rec, ksh, t}; h->recoff_tile = -1;
+	ev.end(iv, h->stream);
+	if (!h->lazy_recoff || h->fused_tile != t || h->shard_own_members >= 0) ensure_recoff(h);
+	iv = ev.begin(h->stream, &h->tm.index_ms);
 	if (t == 0 && h->shard_own_members >= 0) h->shard_first_abs = (found_start && (n_rec > 0 || straddle >= 0)) ? h->shard_u_base + u_lo + (exp0 - prefix) : -1;
 	if (h->shard_own_members >= 0)
 	{
@@ -1165,7 +1218,7 @@ void index_tile(ngsqc_handle* h, int t)
 			}
 		}
 	}
-	{ const double el = tmr.stop(); h->tm.index_ms += h->fused_tile == t ? std::max(0.0, el - h->fuse->fused_elapsed_ms()) : el; }   // (the riding scan is booked as scan time)
+	ev.end(iv, h->stream);
 	// ---- publish tile state ----
 	h->cur_tile = t; h->tile_prefix = prefix; h->tile_total = total; h->tile_u_lo = u_lo; h->tile_ord_base = h->next_ord_base;
 	h->n_rec = n_rec; h->tm.n_records += n_rec;
@@ -1179,7 +1232,7 @@ void index_tile(ngsqc_handle* h, int t)
 TileCtx resident_ctx(ngsqc_handle* h)
 {
 	const int nt = (int)h->tiles.size(); const int t = h->cur_tile;
-	return TileCtx{h->buf[t % h->nbuf].p + h->pfx - h->tile_prefix, h->tile_total, h->d_recoff.p, h->n_rec, h->tile_ord_base, t, t == nt - 1};
+	return TileCtx{h->buf[t % h->nbuf].p + h->pfx - h->tile_prefix, h->tile_total, h->recoff_tile == t ? h->d_recoff.p : nullptr /* not expanded: ensure_recoff */, h->n_rec, h->tile_ord_base, t, t == nt - 1};
 }
 
 void reset_decode_timings(ngsqc_handle* h)
@@ -1202,7 +1255,11 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	dbg_stamp("tile stream: layout ready");
 	const int nt = (int)h->tiles.size();
 	if (nt == 0) { h->decoded = true; h->n_rec = 0; return; }
-	if (nt == 1 && h->decoded && h->cur_tile == 0) { f(resident_ctx(h)); return; }
+	if (nt == 1 && h->decoded && h->cur_tile == 0)
+	{
+		try { f(resident_ctx(h)); } catch (...) { h->evlog->discard(); throw; }
+		h->evlog->resolve(); return;
+	}
 	reset_decode_timings(h);
 	h->decoded = false; h->cur_tile = -1; h->k1_enq = 0; h->k2_plain = false;
 	const bool dbg = getenv("NGSQC_DEBUG") != nullptr;
@@ -1241,7 +1298,8 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 			if (!pipelined && t + 1 < nt) { HIPCHK(hipStreamSynchronize(h->stream)); enqueue_k1_tile(h, t + 1); }
 		}
 	}
-	catch (...) { if (h->stream_img) stream_pass_end(h); sync_all(h); h->decoded = false; h->cur_tile = -1; throw; }
+	catch (...) { if (h->stream_img) stream_pass_end(h); sync_all(h); h->evlog->discard(); h->decoded = false; h->cur_tile = -1; throw; }
+	h->evlog->resolve();   // (index / scan / pileup stage times: HIP-event intervals that nobody waited for inside the loop)
 	if (h->stream_img)
 	{
 		// a tile stream that stopped early (a shard's last tile, a consumer that had enough) leaves copies nobody waits for: the pass ends here
@@ -1357,56 +1415,75 @@ struct ScanState : ngsqc_handle::FusedScan
 			HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
 			HIPCHK(hipMemcpyAsync(d_counters.p + A_TILE_KEY, s, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));   // A_TILE_KEY, A_TILE_PAIRED
 		}
-		if (!ftk) ftk.reset(new Timer(h->stream));
-		ftk->start();
+		const size_t iv = h->evlog->begin(h->stream, &kernel_ms, &stage_ms);   // (the walk + scan kernel: booked as scan time, not under K2)
 		launch_walk_scan(sp, d_desc, ne, prefix, ksh, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
-		ftk->mark(); launches++;
+		h->evlog->end(iv, h->stream); launches++;
 		sp.sgn = 1; sp.scan_limit = INT64_MAX;
 	}
-	unsigned long long* fused_long_count() override { return d_counters.p + A_LONG_COUNT; }
-	double fused_elapsed_ms() override { fused_ms = ftk ? ftk->elapsed() : 0; return fused_ms; }
-	std::unique_ptr<Timer> ftk; double fused_ms = 0;
+	// round 5: everything the host needs of a tile scanned by the walk arrives with K2's own wait (index_tile) - one copy of the accumulators' head
+	void fused_readback(ngsqc_handle* h) override
+	{
+		HIPCHK(hipMemcpyAsync(h->p_rb.p, d_counters.p, (size_t)A_HIST0 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		h->p_rb.p[ngsqc_handle::RB_CAND] = 0;
+		if (sp.pile.list) HIPCHK(hipMemcpyAsync(h->p_rb.p + ngsqc_handle::RB_CAND, sp.pile.count, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+	}
 
 	void tile(ngsqc_handle* h, const TileCtx& c)
 	{
 		const bool fused = h->fuse == this && h->fused_tile == c.tile;   // K2's chain walk has scanned the tile's records already
 		if (!fused) h->d_long.ensure_slack((size_t)std::max<int64_t>(c.n_rec, 1));   // (fused: the list holds the walk's deferred records - growing it would drop them; index_tile checked that they fit)
-		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
+		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff /* null: not expanded yet (ensure_recoff) */; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
 		sp.long_list = h->d_long.p; sp.long_cap = fused ? (int64_t)h->d_long.n : c.n_rec; sp.sgn = 1;
 		sp.entry_base = fused ? h->d_base.p : nullptr; sp.tile_slots = fused ? 1 : 0;
-		Timer t(h->stream); t.start();
-		Timer tk(h->stream);
+		EvLog& ev = *h->evlog;
+		const size_t ivs = ev.begin(h->stream, &stage_ms);
+		unsigned long long s[16] = {0};
+		auto readback = [&]() {
+			unsigned long long* q = h->p_small.p;
+			HIPCHK(hipMemcpyAsync(q + 0, d_counters.p + A_LONG_COUNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(q + 1, d_counters.p + (fused ? A_TILE_KEY : A_FIRST_MAX_KEY), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(q + 2, d_counters.p + (fused ? A_TILE_PAIRED : A_FIRST_PAIRED), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(q + 3, d_counters.p + A_TOTAL, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipMemcpyAsync(q + 4, d_counters.p + A_USABLE, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+			for (int i = 0; i < 5; ++i) s[i] = q[i];
+		};
 		if (!fused)
 		{
 			// per-tile slots: long-record count, (longest read, first ordinal) key
 			HIPCHK(hipMemsetAsync(d_counters.p + A_LONG_COUNT, 0, sizeof(unsigned long long), h->stream));
 			HIPCHK(hipMemsetAsync(d_counters.p + A_FIRST_MAX_KEY, 0, sizeof(unsigned long long), h->stream));
-			tk.start();
+			const size_t ivk = ev.begin(h->stream, &kernel_ms);
 			launch_scan(sp, h->stream);
-			kernel_ms += tk.stop(); launches++;
+			ev.end(ivk, h->stream); launches++;
+			readback();
 		}
-		else { kernel_ms += fused_ms; stage_ms += fused_ms; }   // (the walk + scan kernel of index_tile: booked here, not under K2)
-		unsigned long long* s = h->p_small.p;
-		auto readback = [&]() {
-			HIPCHK(hipMemcpyAsync(s + 0, d_counters.p + A_LONG_COUNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 1, d_counters.p + (fused ? A_TILE_KEY : A_FIRST_MAX_KEY), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 2, d_counters.p + (fused ? A_TILE_PAIRED : A_FIRST_PAIRED), sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 3, d_counters.p + A_TOTAL, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipMemcpyAsync(s + 4, d_counters.p + A_USABLE, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-		};
-		readback();
-		if (s[0]) { tk.start(); launch_scan_long(sp, (int64_t)s[0], h->stream); kernel_ms += tk.stop(); launches++; readback(); }
+		else
+		{
+			// (index_tile's wait brought the accumulators as the walk left them)
+			const unsigned long long* rb = h->p_rb.p;
+			s[0] = rb[A_LONG_COUNT]; s[1] = rb[A_TILE_KEY]; s[2] = rb[A_TILE_PAIRED]; s[3] = rb[A_TOTAL]; s[4] = rb[A_USABLE];
+		}
+		if (s[0])
+		{
+			sp.recoff = ensure_recoff(h);   // (deferred records are found through the record offsets)
+			const size_t ivk = ev.begin(h->stream, &kernel_ms);
+			launch_scan_long(sp, (int64_t)s[0], h->stream);
+			ev.end(ivk, h->stream); launches++;
+			readback();
+		}
 		if (fused)
 		{
-			// (entry, k) names -> ordinals in the file: index in the tile = first record of the entry (the scanned counts) + k
+			// (entry, k) names -> ordinals in the file: index in the tile = first record of the entry (the scanned counts) + k. Only a tile that holds a longer read
+			// than every tile before it, or the file's first paired read, asks (the first tile of a file)
 			auto ordinal = [&](unsigned long long name) -> unsigned long long {
 				int64_t b0 = 0;
 				HIPCHK(hipMemcpyAsync(&b0, h->d_base.p + (name >> NAME_SHIFT), sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
 				return (unsigned long long)(c.ord_base + b0 + (int64_t)(name & ((1ull << NAME_SHIFT) - 1)));
 			};
-			if (s[1]) s[1] = (s[1] & ~0xFFFFFFFFFFull) | (0xFFFFFFFFFFull - ordinal(0xFFFFFFFFFFull - (s[1] & 0xFFFFFFFFFFull)));
-			if (s[2] != ~0ull) s[2] = ordinal(s[2]);
+			// a key orders by (length, earlier record): a tile whose longest read is not longer than an earlier tile's never wins - its record is not asked for
+			if (s[1]) s[1] = (s[1] >> 40) > (best_key >> 40) ? (s[1] & ~0xFFFFFFFFFFull) | (0xFFFFFFFFFFull - ordinal(0xFFFFFFFFFFull - (s[1] & 0xFFFFFFFFFFull))) : (s[1] & ~0xFFFFFFFFFFull);
+			if (s[2] != ~0ull) s[2] = first_paired == ~0ull ? ordinal(s[2]) : first_paired;   // (a later tile's first paired read lies behind the file's first)
 		}
 		const unsigned long long key = s[1], fp = s[2], total = s[3], usable = s[4];
 		if (key > best_key) best_key = key;   // keys order by (length, earlier ordinal): the maximum over tiles is the BAM's first longest read
@@ -1422,14 +1499,16 @@ struct ScanState : ngsqc_handle::FusedScan
 			unsigned long long fix[3] = {0, 0, 0};
 			if (lf > 0 || lp > 0)
 			{
-				s[12] = 0; s[13] = 0; s[14] = (unsigned long long)run_max; s[15] = 0;   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
-				HIPCHK(hipMemcpyAsync(d_counters.p + A_FIX_TRIM, s + 12, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+				sp.recoff = ensure_recoff(h);
+				unsigned long long* q = h->p_small.p;
+				q[12] = 0; q[13] = 0; q[14] = (unsigned long long)run_max; q[15] = 0;   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
+				HIPCHK(hipMemcpyAsync(d_counters.p + A_FIX_TRIM, q + 12, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 				launch_prefix_fix(sp, lf, lp, nullptr, h->stream);
-				HIPCHK(hipMemcpyAsync(s + 8, d_counters.p + A_FIX_TRIM, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-				HIPCHK(hipMemcpyAsync(s + 9, d_counters.p + A_FIX_LEN, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-				HIPCHK(hipMemcpyAsync(s + 10, d_counters.p + A_FIX_CNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipMemcpyAsync(q + 8, d_counters.p + A_FIX_TRIM, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipMemcpyAsync(q + 9, d_counters.p + A_FIX_LEN, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipMemcpyAsync(q + 10, d_counters.p + A_FIX_CNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 				HIPCHK(hipStreamSynchronize(h->stream));
-				fix[0] = s[8]; fix[1] = s[9]; fix[2] = s[10];
+				fix[0] = q[8]; fix[1] = q[9]; fix[2] = q[10];
 			}
 			if (need_trim) { sum_runmax += (long long)fix[0] + (n_counted - (long long)fix[2]) * tile_max; run_max = tile_max; }
 			else sum_runmax += n_counted * run_max;
@@ -1440,7 +1519,7 @@ struct ScanState : ngsqc_handle::FusedScan
 			}
 			prev_total = total; prev_usable = usable;
 		}
-		stage_ms += t.stop();
+		ev.end(ivs, h->stream);
 	}
 	void end(ngsqc_handle* h)
 	{
@@ -1517,23 +1596,17 @@ struct PileupState
 	void tile(ngsqc_handle* h, const TileCtx& c)
 	{
 		if (n_sites == 0) return;
-		Timer t(h->stream); t.start();
-		unsigned long long* s = h->p_small.p + 16;
-		// the tile's candidates when the riding scan saw this tile (and its list held them all), else every record of the tile
-		const int64_t* offs = c.recoff; int64_t n = c.n_rec;
-		if (rider && h->fuse == rider && h->fused_tile == c.tile)
-		{
-			HIPCHK(hipMemcpyAsync(s, d_ncand.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-			if ((int64_t)*s <= CAND_CAP) { offs = d_cand.p; n = (int64_t)*s; ++tiles_from_list; }
-		}
+		const size_t iv = h->evlog->begin(h->stream, &stage_ms);
+		// the tile's candidates when the riding scan saw this tile (and its list held them all: the count came with index_tile's wait), else every record of the tile
+		const int64_t* offs = nullptr; int64_t n = c.n_rec;
+		if (rider && h->fuse == rider && h->fused_tile == c.tile && (int64_t)h->p_rb.p[ngsqc_handle::RB_CAND] <= CAND_CAP) { offs = d_cand.p; n = (int64_t)h->p_rb.p[ngsqc_handle::RB_CAND]; ++tiles_from_list; }
+		if (!offs) offs = ensure_recoff(h);
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(n, 1));
 		HIPCHK(hipMemsetAsync(d_nlong.p, 0, sizeof(unsigned long long), h->stream));
 		launch_pileup(c.infl, offs, n, n_ref, d_pos.p, d_tf.p, d_tl.p, d_bucket.p, d_tb0.p, min_mapq, min_baseq, include_npp, d_cnt.p, h->d_long.p, d_nlong.p, h->stream);
-		HIPCHK(hipMemcpyAsync(s, d_nlong.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		if (*s) launch_pileup_long(c.infl, offs, h->d_long.p, (int64_t)*s, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream);
-		stage_ms += t.stop();
+		// records with long CIGARs: a wave each; how many there are stays on the device (no wait between the two kernels)
+		launch_pileup_long(c.infl, offs, h->d_long.p, d_nlong.p, n, d_pos.p, d_tl.p, d_bucket.p, d_tb0.p, min_baseq, d_cnt.p, h->stream);
+		h->evlog->end(iv, h->stream);
 	}
 	void end(ngsqc_handle* h, int64_t* counts)
 	{
@@ -2010,6 +2083,10 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
 	const double w1 = wall_ms();
 	FuseGuard fg(h, do_map ? &map.scan : (do_depth && j->depth->min_baseq <= 0 ? &dscan : nullptr));
+	// the record offsets of a tile are only expanded when a consumer reads them: the mapping scan rides the chain walk (deferred long-CIGAR records and the
+	// order-dependent fix-ups ask for them), the site pileup works on the walk's candidate list; the extra depth scan and the raw-read QC read every record
+	struct LazyGuard { ngsqc_handle* h; ~LazyGuard() { h->lazy_recoff = false; } } lg{h};
+	h->lazy_recoff = do_map && !part && !do_depth && !do_reads && !getenv("NGSQC_EAGER_RECOFF");
 	stream_tiles(h, [&](const TileCtx& c) {
 		if (do_map) map.scan.tile(h, c);
 		if (part && c.ord_base == 0 && c.n_rec > 0)

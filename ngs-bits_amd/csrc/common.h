@@ -93,7 +93,7 @@ void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_
 // (n_entries = members << ksh, + 1 for the carried prefix; every array is indexed by entry)
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s);
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s);
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, bool assume0 /* members start with a record: no guess for their first piece */, int32_t* d_start, hipStream_t s);
 void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle /* -1 before the launch */, hipStream_t s);
 void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,
                         const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s);
@@ -160,7 +160,7 @@ constexpr int PILEUP_BUCKET_SHIFT = 16;   // 64 kb position buckets per referenc
 void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, int n_ref, const int32_t* site_pos, const int32_t* tid_first, const int32_t* tid_last,
                    const int32_t* bucket, const int64_t* tid_bucket0, int min_mapq, int min_baseq, int include_npp, uint32_t* counts,
                    int64_t* long_list, unsigned long long* long_count, hipStream_t s);
-void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, int64_t n_long, const int32_t* site_pos, const int32_t* tid_last,
+void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, const unsigned long long* d_n_long /* count on the device */, int64_t n_long_max, const int32_t* site_pos, const int32_t* tid_last,
                         const int32_t* bucket, const int64_t* tid_bucket0, int min_baseq, uint32_t* counts, hipStream_t s);
 
 // ---- raw-read QC pass (reads.hip): StatisticsReads::update(BamAlignment) ----

@@ -77,8 +77,10 @@ __device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64
 {
 	if (!plausible(infl, total, o, n_ref)) return false;
 	{
+		// (only a header that claims more than 1 KiB of optional fields: the false ones claim megabytes, and a short-read record's 50 bytes are not worth ten round trips)
 		const uint8_t* r = infl + o; const uint32_t bs = ld32u(r), l_name = r[12], n_cigar = ld32u(r + 16) & 0xffffu, l_seq = ld32u(r + 20);
-		if (!aux_parses(r + 36 + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq, r + 4 + bs)) return false;
+		const uint8_t* aux = r + 36 + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+		if (r + 4 + bs - aux > 1024 && !aux_parses(aux, r + 4 + bs)) return false;
 	}
 	for (int k = 0; k < 2; ++k)
 	{
@@ -169,13 +171,16 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 	if (stop && res == -2) atomicAdd(bad, 1u);
 }
 
-// start[] of every entry from what the host knows before K2: the tile-local offset exp0 of the first record (start = -2: guess)
-__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int guess_all, int32_t* __restrict__ start)
+// start[] of every entry from what the host knows before K2: the tile-local offset exp0 of the first record (start = -2: guess). assume0 (the fast path): a
+// member is taken to start with a record, as htslib writes them - no guess kernel for those entries; if it does not, the walker's predecessor ends elsewhere
+// and the chain check sends the tile to the general path (which guesses).
+__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int guess_all, int assume0, int32_t* __restrict__ start)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
 	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
-	start[b] = guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : -2));
+	const bool first_piece = b > 0 && ((b - 1) & ((1ll << ksh) - 1)) == 0;
+	start[b] = hi <= lo ? -1 : guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : (assume0 && first_piece ? 0 : -2)));   // (an empty entry holds no record start)
 }
 
 // The exact check of the walked chain on the device. Entries in front of the tile's first record (hi <= exp0) hold nothing; the entry that holds exp0 starts
@@ -331,10 +336,10 @@ void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref); KCHECK();
 }
 
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, int32_t* d_start, hipStream_t s)
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, bool assume0, int32_t* d_start, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, guess_all ? 1 : 0, d_start); KCHECK();
+	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, guess_all ? 1 : 0, assume0 ? 1 : 0, d_start); KCHECK();
 }
 void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle, hipStream_t s)
 {

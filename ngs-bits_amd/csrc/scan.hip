@@ -834,13 +834,14 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 // slice of the ops; a wave prefix sum gives each slice its genome / read position, then for every site inside the read each
 // lane looks for the first op of its slice that carries the genome position to or past the site (and for a soft clip that
 // exhausts the read, BamReader.cpp:346-353); the earliest such op of the wave decides, exactly as the sequential walk does.
-__global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, const int64_t* __restrict__ long_list, long long n_long,
+__global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, const int64_t* __restrict__ long_list, const unsigned long long* __restrict__ n_long_dev,
                                                           const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_last,
                                                           const int32_t* __restrict__ bucket, const int64_t* __restrict__ tid_bucket0,
                                                           int min_baseq, uint32_t* __restrict__ counts)
 {
 	const int lane = threadIdx.x & 63;
 	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+	const long long n_long = (long long)*n_long_dev;   // (round 5: the count stays on the device - the host does not wait for pileup_kernel to learn it)
 	for (long long w = wave; w < n_long; w += n_waves)
 	{
 		RecView r = load_rec(infl, recoff[long_list[w]]);      // (passed the read filters in pileup_kernel)
@@ -926,12 +927,12 @@ void launch_pileup(const uint8_t* infl, const int64_t* recoff, int64_t n_rec, in
 	const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 256 * 32);
 	hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, (long long)n_rec, n_ref, site_pos, tid_first, tid_last, bucket, tid_bucket0, min_mapq, min_baseq, include_npp, counts, long_list, long_count); KCHECK();
 }
-void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, int64_t n_long, const int32_t* site_pos, const int32_t* tid_last,
+void launch_pileup_long(const uint8_t* infl, const int64_t* recoff, const int64_t* long_list, const unsigned long long* d_n_long, int64_t n_long_max, const int32_t* site_pos, const int32_t* tid_last,
                         const int32_t* bucket, const int64_t* tid_bucket0, int min_baseq, uint32_t* counts, hipStream_t s)
 {
-	if (n_long <= 0) return;
-	const int grid = (int)std::min<int64_t>((n_long + 3) / 4, 256 * 16);
-	hipLaunchKernelGGL(pileup_long_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, long_list, (long long)n_long, site_pos, tid_last, bucket, tid_bucket0, min_baseq, counts); KCHECK();
+	if (n_long_max <= 0) return;
+	const int grid = (int)std::min<int64_t>((n_long_max + 3) / 4, 256 * 16);   // (sized for the most there can be; the waves stride over what there is)
+	hipLaunchKernelGGL(pileup_long_kernel, dim3(grid), dim3(256), 0, s, infl, recoff, long_list, d_n_long, site_pos, tid_last, bucket, tid_bucket0, min_baseq, counts); KCHECK();
 }
 
 } // namespace ngsqc

@@ -23,7 +23,7 @@ def _bench(*args, timeout=600, env=None):
 
 @pytest.mark.timeout(900)
 def test_bench_line_on_a_small_shard():
-    d = _bench("--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "1000000")
+    d = _bench("--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "1000000", env={"NGSQC_BENCH_ONT_READS": "6000"})
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
@@ -31,6 +31,15 @@ def test_bench_line_on_a_small_shard():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["counters_match_gpu"] is True
     assert d["config"]["members_inflated_per_step"] == d["config"]["bgzf_members"]      # one K1 visit per member for the whole MappingQC step
     assert d["roofline_scan"]["frac"] > 0 and "t_scan_ms" in d["roofline_scan"]
+    # BASELINE.json configs[2] and configs[4] ride in the same line: BedCoverage / BedLowCoverage (with and without -min_baseq 20) over the same
+    # resident image, and the ONT shard - each with its value, scan-stage roofline, CPU baseline and parity of the sample
+    assert set(d["tools"]) == {"bedcoverage", "bedlowcoverage", "bedlowcoverage_baseq20"}
+    for leg in list(d["tools"].values()) + [d["ont"]]:
+        assert "error" not in leg, leg
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["steps"] >= 3 and leg["roofline_scan"]["frac"] > 0
+        assert leg["cpu_baseline"]["kind"] == "port" and leg["counters_match_gpu"] is True
+    assert all(leg["reads_per_step"] == d["config"]["reads_per_gpu_per_step"] for leg in d["tools"].values())
+    assert d["ont"]["reads_per_step"] == 6000 and "SHARD" in d["ont"]["workload"]
 
 
 @pytest.mark.timeout(900)

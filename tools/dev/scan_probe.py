@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--min-baseq", type=int, default=0)
     ap.add_argument("--sets", default="NGSQC_WALKERS=1;NGSQC_WALKERS=2;NGSQC_WALKERS=4;NGSQC_WALKERS=8;NGSQC_WALKERS=4,NGSQC_WALK_WAVES=4;NGSQC_WALKERS=8,NGSQC_WALK_WAVES=4")
     ap.add_argument("--pipelined", action="store_true", help="also time pipelined steps (job wall)")
+    ap.add_argument("--no-default", action="store_true", help="only the settings of --sets")
+    ap.add_argument("--image-cache", default=None, help="keep the generated BAM in this file (profiling: several runs of one command)")
     args = ap.parse_args()
     ngsqc = importlib.import_module("ngs-bits_amd")
     import bamgen_lib as G
@@ -31,7 +33,12 @@ def main():
     import bench as B
 
     t0 = time.time()
-    image = G.generate(args.reads, seed=20260821, mode=1 if args.ont else 0, depth=40.0 if args.ont else 30.0, level=6, aligned=True)
+    if args.image_cache and os.path.exists(args.image_cache):
+        image = np.fromfile(args.image_cache, dtype=np.uint8)
+    else:
+        image = G.generate(args.reads, seed=20260821, mode=1 if args.ont else 0, depth=40.0 if args.ont else 30.0, level=6, aligned=True)
+        if args.image_cache:
+            image.tofile(args.image_cache)
     print(f"[probe] generated {args.reads} reads, {image.size / 1e9:.2f} GB in {time.time() - t0:.1f} s", flush=True)
     h = ngsqc.Handle(data=image, device=0)
     refs = h.refs
@@ -65,7 +72,7 @@ def main():
             return np.frombuffer(bytes(r), dtype=np.uint8).copy()
 
     ref = None
-    for spec in [""] + [x for x in args.sets.split(";") if x]:
+    for spec in ([] if args.no_default else [""]) + [x for x in args.sets.split(";") if x]:
         env = dict(kv.split("=") for kv in spec.split(",") if kv)
         for k, v in env.items():
             os.environ[k] = v
