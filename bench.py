@@ -251,6 +251,12 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
 
 def main():
     args = parse_args()
+    t_main = time.time(); marks = []   # (phase, seconds since start): the run's wall-time budget, printed to stderr and kept in the line ("budget")
+
+    def mark(what):
+        marks.append((what, round(time.time() - t_main, 1)))
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"[bench] t+{marks[-1][1]:.1f} s {what}", file=sys.stderr, flush=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -392,10 +398,12 @@ def main():
         if args.image_cache:
             image.tofile(args.image_cache)
     gen_s = time.time() - t0
+    mark("image ready (generated / shared)")
     # H2D of the compressed image (of this rank's member range with --single-bam): not in the timed region, reported as end_to_end
     t0 = time.time()
     h = ngsqc.Handle(data=image, device=local_rank, shard=(rank, world)) if args.single_bam else ngsqc.Handle(data=image, device=local_rank)
     open_s = time.time() - t0
+    mark("handle open (compressed image in HBM)")
     h2d_ms = h.timings()["h2d_ms"]
     if world > 1:
         dist.barrier()
@@ -472,6 +480,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    mark("warm-up + timed steps done")
     if world > 1:
         et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
@@ -690,6 +699,7 @@ def main():
                 out["tools"][tag] = leg
             except Exception as e:   # never let an extra leg break the bench line
                 out["tools"][tl + (f"_baseq{bq}" if bq else "")] = {"error": str(e)[:300]}
+    mark("stage / roofline / cpu-baseline / tool legs done")
     n_members_file = int(h.n_blocks) if not args.single_bam else None
     h.close()
     if want_extra and os.environ.get("NGSQC_BENCH_NO_ONT") is None:
@@ -810,6 +820,8 @@ def main():
                                 os.remove(f_)
             except Exception as e:
                 out["end_to_end"]["e2e_error"] = str(e)[:300]
+        mark("all legs done")
+        out["budget"] = {"note": "wall time of this run by phase (seconds since the start of main on rank 0); the driver allows 1800 s", "phases": marks, "total_s": marks[-1][1]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

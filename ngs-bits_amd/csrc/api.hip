@@ -1050,9 +1050,9 @@ void index_tile(ngsqc_handle* h, int t)
 	const uint8_t* base = h->buf[t % h->nbuf].p + h->pfx - prefix;
 	const BlockDesc* d_desc = h->d_kdesc.p + first;
 	// entries: entry 0 = the carried prefix, then the members - on the fast path each cut into 2^ksh pieces with a walker of its own (common.h entry_range;
-	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 4); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
+	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 2: more waves than the chip holds at once buy nothing - profiles/r05_scan_probe.txt); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
-	int ksh = 2; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
+	int ksh = 1; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
 	if (anchor_by_guess || h->k2_plain) ksh = 0;
 	const int64_t ne0 = nm + 1;
 	int64_t ne = (nm << ksh) + 1;
@@ -1080,12 +1080,12 @@ void index_tile(ngsqc_handle* h, int t)
 	if (try_fuse)
 	{
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(total / 160, 1024));   // deferred (long-CIGAR) records of the tile: an estimate, checked below
-		if (!assume0 || ksh) launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);
+		if (!assume0) launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);   // (else: the walkers of the pieces guess for themselves)
 		ev.end(iv, h->stream);
 		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, ksh, fuse_limit);
 		iv = ev.begin(h->stream, &h->tm.index_ms);
 	}
-	else launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+	else launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream, !assume0);
 	launch_index_chain(d_desc, ne, prefix, ksh, exp0, total, h->d_start.p, h->d_next.p, h->d_bad.p + 1, (long long*)(h->d_bad.p + 2), h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = record cut by the tile end, [2] = deferred records of the riding scan, [3] = n_rec
@@ -1257,7 +1257,8 @@ template <class F> void stream_tiles(ngsqc_handle* h, F f)
 	if (nt == 0) { h->decoded = true; h->n_rec = 0; return; }
 	if (nt == 1 && h->decoded && h->cur_tile == 0)
 	{
-		try { f(resident_ctx(h)); } catch (...) { h->evlog->discard(); throw; }
+		// (the tile may have been left by a job whose consumers never asked for the record offsets: this visitor may)
+		try { if (!h->lazy_recoff) ensure_recoff(h); f(resident_ctx(h)); } catch (...) { h->evlog->discard(); throw; }
 		h->evlog->resolve(); return;
 	}
 	reset_decode_timings(h);

@@ -92,7 +92,7 @@ void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_
 // ---- K2 ----
 // (n_entries = members << ksh, + 1 for the carried prefix; every array is indexed by entry)
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
-                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s);
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s, bool wave_guess = true);
 void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, bool assume0 /* members start with a record: no guess for their first piece */, int32_t* d_start, hipStream_t s);
 void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle /* -1 before the launch */, hipStream_t s);
 void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,

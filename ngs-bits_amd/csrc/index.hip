@@ -9,88 +9,15 @@
 //
 // Replaces the sequential record pull of BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-398).
 #include "common.h"
+#include "k2_guess.h"
 
 namespace ngsqc {
-
-__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 // (entry_range and record_fields_fit: common.h, shared with the scan that rides the chain walk)
 __device__ __forceinline__ bool record_fields_fit(const uint8_t* r, uint32_t bs)
 {
 	const uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16);
 	return record_fields_fit(w & 0xff, w2 & 0xffff, (int32_t)ld32u(r + 20), bs);
-}
-
-// cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
-__device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
-{
-	if (o + 36 > total) return false;
-	const uint8_t* r = infl + o;
-	uint32_t bs = ld32u(r);
-	if (bs < 32 || bs > (1u << 28) || o + 4 + (int64_t)bs > total) return false;
-	int32_t tid = (int32_t)ld32u(r + 4), pos = (int32_t)ld32u(r + 8);
-	uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16);
-	int32_t l_seq = (int32_t)ld32u(r + 20), mtid = (int32_t)ld32u(r + 24), mpos = (int32_t)ld32u(r + 28);
-	uint32_t l_name = w & 0xff, n_cigar = w2 & 0xffff;
-	if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_seq < 0 || l_name == 0) return false;
-	uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
-	if (need > bs) return false;
-	if (r[36 + l_name - 1] != 0) return false; // qname is NUL-terminated
-	return true;
-}
-// The optional fields of a record must parse, tag by tag, to exactly the record's end (tag[2] type[1] value: SAM spec 4.2.4). A header check alone is not enough
-// for a guess INSIDE a member (round 5): two bytes in front of a true record on the first reference the length word reads as (true block_size << 16 | 2 bytes of
-// the record in front) - 20 MB - and every field test passes against so large a block_size; with records of ~330 bytes one such leap in 330 lands on a true
-// record, from where the chain looks perfect (measured on the generator's data: 0.24 % of the pieces on chr1). A false header's optional fields do not parse.
-// (Used for guessing only: a record htslib would read but this refuses costs the tile the general path, never a wrong result.)
-__device__ static bool aux_parses(const uint8_t* p, const uint8_t* end)
-{
-	int budget = 4096;   // bytes of text tags looked at (long MM / MD strings: not worth a lane's time - accept)
-	while (p < end)
-	{
-		if (p + 3 > end) return false;
-		const uint8_t type = p[2]; p += 3; size_t sz;
-		switch (type)
-		{
-			case 'A': case 'c': case 'C': sz = 1; break;
-			case 's': case 'S': sz = 2; break;
-			case 'i': case 'I': case 'f': sz = 4; break;
-			case 'd': sz = 8; break;
-			case 'Z': case 'H': { const uint8_t* q = p; while (q < end && *q && --budget > 0) ++q; if (budget <= 0) return true; if (q >= end) return false; sz = (size_t)(q - p) + 1; break; }
-			case 'B':
-			{
-				if (p + 5 > end) return false;
-				const uint8_t st = p[0]; const uint32_t n = ld32u(p + 1);
-				const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
-				if (!es) return false;
-				sz = 5 + es * (size_t)n; break;
-			}
-			default: return false;
-		}
-		if (sz > (size_t)(end - p)) return false;
-		p += sz;
-	}
-	return true;
-}
-// a plausible header whose optional fields parse and whose two successors (as far as they lie inside the tile) are plausible too
-__device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
-{
-	if (!plausible(infl, total, o, n_ref)) return false;
-	{
-		// (only a header that claims more than 1 KiB of optional fields: the false ones claim megabytes, and a short-read record's 50 bytes are not worth ten round trips)
-		const uint8_t* r = infl + o; const uint32_t bs = ld32u(r), l_name = r[12], n_cigar = ld32u(r + 16) & 0xffffu, l_seq = ld32u(r + 20);
-		const uint8_t* aux = r + 36 + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
-		if (r + 4 + bs - aux > 1024 && !aux_parses(aux, r + 4 + bs)) return false;
-	}
-	for (int k = 0; k < 2; ++k)
-	{
-		o += 4 + (int64_t)ld32u(infl + o);       // (plausible: the record ends inside the tile)
-		if (o + 36 > total) return true;          // the tile ends here, or inside the next header: nothing more to check
-		const uint32_t bs = ld32u(infl + o);
-		if (o + 4 + (int64_t)bs > total) return bs >= 32 && bs <= (1u << 28);   // a record cut by the tile end (plausible() refuses it for that alone)
-		if (!plausible(infl, total, o, n_ref)) return false;
-	}
-	return true;
 }
 
 // Guessing the first record of an entry, one WAVE per entry: a lane takes 16 bytes and tests the four offsets inside its first dword (block_size and refID
@@ -107,25 +34,47 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 		if (start[b] != -2) continue;
 		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 		int32_t found = -1;
-		for (int64_t base = lo; base < hi; base += 256)
+		// the first 256 bytes alone (the piece of a short-read member: its first record starts ~170 bytes in), then 1 KiB per step with four loads in flight - an
+		// entry inside one long record (ONT: most members) is scanned at four windows per memory round trip
+		for (int64_t base = lo; base < hi && found < 0;)
 		{
-			const int64_t o0 = base + 4 * lane;
-			uint32_t w[4] = {0u, 0u, 0u, 0u};
-			if (o0 + 16 <= total) __builtin_memcpy(w, infl + o0, 16);
-			else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[k] = ld32u(infl + o0 + 4 * k);
-			uint32_t cand = 0;   // bit t: offset o0 + t passes the cheap test
+			const int nwin = base == lo ? 1 : 4;
+			uint32_t w[4][4];
 			#pragma unroll
-			for (int t = 0; t < 4; ++t)
+			for (int q = 0; q < 4; ++q)
 			{
-				const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[1], w[0], 8u * t) : w[0];
-				const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[2], w[1], 8u * t) : w[1]);
-				if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
+				w[q][0] = w[q][1] = w[q][2] = w[q][3] = 0u;
+				const int64_t o0 = base + 256 * q + 4 * lane;
+				if (q < nwin && o0 < hi + 16)
+				{
+					if (o0 + 16 <= total) __builtin_memcpy(w[q], infl + o0, 16);
+					else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[q][k] = ld32u(infl + o0 + 4 * k);
+				}
 			}
-			if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) continue;
-			int32_t mine = -1;
-			if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
-			const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
-			if (m) { const int l = __builtin_ctzll(m); found = (int32_t)(base + 4 * l + __builtin_amdgcn_readlane(mine, l) - lo); break; }
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				if (q < nwin && found < 0)
+				{
+					const int64_t o0 = base + 256 * q + 4 * lane;
+					uint32_t cand = 0;   // bit t: offset o0 + t passes the cheap test
+					#pragma unroll
+					for (int t = 0; t < 4; ++t)
+					{
+						const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[q][1], w[q][0], 8u * t) : w[q][0];
+						const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[q][2], w[q][1], 8u * t) : w[q][1]);
+						if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
+					}
+					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
+					{
+						int32_t mine = -1;
+						if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
+						const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
+						if (m) { const int l = __builtin_ctzll(m); found = (int32_t)(base + 256 * q + 4 * l + __builtin_amdgcn_readlane(mine, l) - lo); }
+					}
+				}
+			}
+			base += 256 * nwin;
 		}
 		if (lane == 0) start[b] = found;
 	}
@@ -140,18 +89,7 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 	if (b >= n_blocks) return;
 	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
 	int32_t s = start[b];
-	if (s == -2)
-	{
-		s = -1;
-		for (int64_t o = lo; o < hi; ++o)
-		{
-			if (!plausible(infl, total, o, n_ref)) continue;
-			int64_t o2 = o + 4 + ld32u(infl + o);
-			if (o2 < total && !plausible(infl, total, o2, n_ref)) continue; // chain one more record
-			s = (int32_t)(o - lo); break;
-		}
-		start[b] = s;
-	}
+	if (s == -2) { s = lane_guess(infl, total, lo, hi, n_ref); start[b] = s; }   // (not resolved by the guess kernel: the piece of a member on the fast path)
 	if (s < 0) { cnt[b] = 0; next_abs[b] = -1; return; }
 	// next_abs: >= 0 chain exit; -2 corrupt record; <= -10 a record starts at o = -(next_abs + 10) but extends past the end
 	// of the resident tile (it is carried into the next tile, not counted here)
@@ -318,11 +256,13 @@ size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TI
 
 // entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = piece (e - 1) & (2^ksh - 1) of member (e - 1) >> ksh of d_blocks); arrays are indexed by entry
 void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
-                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s)
+                        uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s, bool wave_guess)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref, s);   // (the count kernel keeps its scalar guess loop only as a fallback)
+	// starts still to be guessed: by a wave per entry (entries that may lie inside one long record: 64 KiB to look through), or by each walker for itself (the
+	// pieces of a short-read member: the first record is a few hundred bytes in)
+	if (wave_guess) launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref, s);
 	int grid = (int)((n + 63) / 64);
 	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
 }

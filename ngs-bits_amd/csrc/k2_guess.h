@@ -1,0 +1,105 @@
+// K2's guess of a record start in the middle of the inflated stream (index.hip: the wave-cooperative guess kernel; scan.hip / index.hip: the walkers of the pieces of
+// a member guess their own first record). Guessing is never trusted: the chain check (index_chain_kernel / the host's verification) accepts a tile only if every
+// walker's exit is the next walker's start.
+#pragma once
+#include "common.h"
+
+namespace ngsqc {
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// cheap structural plausibility of a record header at absolute offset o (used for guessing only, never for correctness)
+__device__ __noinline__ static bool plausible(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
+{
+	if (o + 36 > total) return false;
+	const uint8_t* r = infl + o;
+	uint32_t bs = ld32u(r);
+	if (bs < 32 || bs > (1u << 28) || o + 4 + (int64_t)bs > total) return false;
+	int32_t tid = (int32_t)ld32u(r + 4), pos = (int32_t)ld32u(r + 8);
+	uint32_t w = ld32u(r + 12), w2 = ld32u(r + 16);
+	int32_t l_seq = (int32_t)ld32u(r + 20), mtid = (int32_t)ld32u(r + 24), mpos = (int32_t)ld32u(r + 28);
+	uint32_t l_name = w & 0xff, n_cigar = w2 & 0xffff;
+	if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_seq < 0 || l_name == 0) return false;
+	uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+	if (need > bs) return false;
+	if (r[36 + l_name - 1] != 0) return false; // qname is NUL-terminated
+	return true;
+}
+// The optional fields of a record must parse, tag by tag, to exactly the record's end (tag[2] type[1] value: SAM spec 4.2.4). A header check alone is not enough
+// for a guess INSIDE a member (round 5): two bytes in front of a true record on the first reference the length word reads as (true block_size << 16 | 2 bytes of
+// the record in front) - 20 MB - and every field test passes against so large a block_size; with records of ~330 bytes one such leap in 330 lands on a true
+// record, from where the chain looks perfect (measured on the generator's data: 0.24 % of the pieces on chr1). A false header's optional fields do not parse.
+// (Used for guessing only: a record htslib would read but this refuses costs the tile the general path, never a wrong result.)
+__device__ static bool aux_parses(const uint8_t* p, const uint8_t* end)
+{
+	int budget = 4096;   // bytes of text tags looked at (long MM / MD strings: not worth a lane's time - accept)
+	while (p < end)
+	{
+		if (p + 3 > end) return false;
+		const uint8_t type = p[2]; p += 3; size_t sz;
+		switch (type)
+		{
+			case 'A': case 'c': case 'C': sz = 1; break;
+			case 's': case 'S': sz = 2; break;
+			case 'i': case 'I': case 'f': sz = 4; break;
+			case 'd': sz = 8; break;
+			case 'Z': case 'H': { const uint8_t* q = p; while (q < end && *q && --budget > 0) ++q; if (budget <= 0) return true; if (q >= end) return false; sz = (size_t)(q - p) + 1; break; }
+			case 'B':
+			{
+				if (p + 5 > end) return false;
+				const uint8_t st = p[0]; const uint32_t n = ld32u(p + 1);
+				const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+				if (!es) return false;
+				sz = 5 + es * (size_t)n; break;
+			}
+			default: return false;
+		}
+		if (sz > (size_t)(end - p)) return false;
+		p += sz;
+	}
+	return true;
+}
+// a plausible header whose optional fields parse and whose two successors (as far as they lie inside the tile) are plausible too
+__device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64_t o, int32_t n_ref)
+{
+	if (!plausible(infl, total, o, n_ref)) return false;
+	{
+		// (only a header that claims more than 1 KiB of optional fields: the false ones claim megabytes, and a short-read record's 50 bytes are not worth ten round trips)
+		const uint8_t* r = infl + o; const uint32_t bs = ld32u(r), l_name = r[12], n_cigar = ld32u(r + 16) & 0xffffu, l_seq = ld32u(r + 20);
+		const uint8_t* aux = r + 36 + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+		if (r + 4 + bs - aux > 1024 && !aux_parses(aux, r + 4 + bs)) return false;
+	}
+	for (int k = 0; k < 2; ++k)
+	{
+		o += 4 + (int64_t)ld32u(infl + o);       // (plausible: the record ends inside the tile)
+		if (o + 36 > total) return true;          // the tile ends here, or inside the next header: nothing more to check
+		const uint32_t bs = ld32u(infl + o);
+		if (o + 4 + (int64_t)bs > total) return bs >= 32 && bs <= (1u << 28);   // a record cut by the tile end (plausible() refuses it for that alone)
+		if (!plausible(infl, total, o, n_ref)) return false;
+	}
+	return true;
+}
+
+
+// One lane looks for the first record of its piece [lo, hi) by itself (round 5: a walker of the second half of a short-read member finds its first record ~170
+// bytes in - twenty 16-byte loads of three lines that it reads anyway - where the separate guess kernel cost a wave and a dozen dependent round trips per piece,
+// 0.35 ms per tile and walker). Four offsets per load, the same tests as the guess kernel. -1: no record starts in the piece.
+__device__ static int32_t lane_guess(const uint8_t* infl, int64_t total, int64_t lo, int64_t hi, int32_t n_ref)
+{
+	for (int64_t o0 = lo; o0 < hi; o0 += 4)
+	{
+		uint32_t w[4] = {0u, 0u, 0u, 0u};
+		if (o0 + 16 <= total) __builtin_memcpy(w, infl + o0, 16);
+		else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[k] = ld32u(infl + o0 + 4 * k);
+		#pragma unroll
+		for (int t = 0; t < 4; ++t)
+		{
+			const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[1], w[0], 8u * t) : w[0];
+			const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[2], w[1], 8u * t) : w[1]);
+			if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref && plausible_chain(infl, total, o0 + t, n_ref)) return (int32_t)(o0 + t - lo);
+		}
+	}
+	return -1;
+}
+
+} // namespace ngsqc

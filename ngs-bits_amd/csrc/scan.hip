@@ -13,6 +13,7 @@
 // the reference increments the whole reference span [start,end] of a read (RegionDepth::incrementRegion,
 // Statistics.cpp:45-53), which is exactly a prefix sum over these differences. All arithmetic is integer.
 #include "common.h"
+#include "k2_guess.h"
 #include <algorithm>
 
 namespace ngsqc {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 // out as 16-byte stores of eight (round 4: a 2-byte store per record and lane - 64 partial sectors per instruction, 32.6 bytes of HBM writes per record).
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix, int ksh,
-                                                        const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
+                                                        int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
 	__shared__ uint32_t lds_hist[1000];
@@ -560,7 +561,8 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 	if (b < n_entries)
 	{
 		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
-		const int32_t s = start[b];   // (the guess kernel ran: >= 0 or -1)
+		int32_t s = start[b];   // >= 0, -1 (nothing starts here), or -2: a piece in the middle of a member - this walker looks for its first record itself
+		if (s == -2) { s = lane_guess(p.infl, p.total, lo, hi, p.n_ref); if (p.sgn > 0) start[b] = s; }   // (the take-back pass finds the start the first pass left)
 		if (s < 0) { cnt[b] = 0; next_abs[b] = -1; }
 		else
 		{

@@ -58,3 +58,16 @@ def test_bench_two_ranks_on_one_shared_image():
     d = _bench("--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo", "--reads", "2000000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", env={"NGSQC_BENCH_SHARED_IMAGE": "1"})
     assert d["n_gpus"] == 2 and "private copy per rank" in d["data"] and d["collective"]["distinct_inputs"] == 1
     assert d["collective"]["allreduce_matches_gathered_sum_per_rank"] == [True, True]
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_rehearsal():
+    """`bench.py --gpus 8` end to end without eight GPUs - eight ranks (gloo) share this box's one device: rank spawning, ONE generated image shared through
+    /dev/shm and mapped by eight ranks, eight handles, the per-step all-reduce checked against a second channel on every rank, the one-BAM-over-eight-shards leg, the
+    barriers and max-over-ranks timing, the budget of the run. (RCCL itself refuses two ranks on one device; its call sequence is what test_gpu_shard's world-of-one runs.)"""
+    d = _bench("--gpus", "8", "--all-ranks-on-device0", "--backend", "gloo", "--reads", "1500000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", timeout=1100, env={"NGSQC_BENCH_SHARED_IMAGE": "1"})
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["reads_per_gpu_per_step"] == 1500000
+    assert d["collective"]["allreduce_matches_gathered_sum_per_rank"] == [True] * 8 and d["collective"]["distinct_inputs"] == 1
+    sb = d["single_bam"]
+    assert "error" not in sb and sb["scaling"] == "strong" and sb["counters_match_one_gpu_job"] is True and sb["members_inflated_per_step"] >= sb["bgzf_members"]
+    assert d["budget"]["total_s"] > 0 and len(d["budget"]["phases"]) >= 4

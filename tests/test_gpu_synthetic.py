@@ -173,6 +173,22 @@ def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
     assert res[0][0][0] > 0
 
 
+def test_record_offsets_after_a_job_that_never_asked_for_them(tmp_path):
+    """round 5: the fused MappingQC job works on the chain walk's own names and candidate lists - the record offsets of a tile are only expanded when a consumer
+    reads them. A single-tile handle stays resident behind the job; whoever comes next (the BAI writer, a depth scan, the test hook) must still find them."""
+    p = str(tmp_path / "lazy.bam")
+    G.write(p, n_reads=30000, seed=5)
+    h = ngsqc.Handle(path=p)
+    regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs)
+    h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=H.known_sites(h.refs))
+    assert h.timings()["tiles_scan_fused"] == 1
+    assert np.array_equal(h.record_offsets(), O.Bam(p).record_offsets())
+    h.write_bai(str(tmp_path / "lazy.bai"))
+    h2 = ngsqc.Handle(path=p); h2.write_bai(str(tmp_path / "eager.bai")); h2.close()
+    assert open(str(tmp_path / "lazy.bai"), "rb").read() == open(str(tmp_path / "eager.bai"), "rb").read()
+    h.close()
+
+
 def _bgzf_member(payload):
     import struct, zlib
     c = zlib.compressobj(6, zlib.DEFLATED, -15); comp = c.compress(payload) + c.flush()
