@@ -746,12 +746,15 @@ def main():
                 dist.all_reduce(mem)
             hs.close()
             if rank == 0:
-                same = bool(np.array_equal(np.asarray(c_s), np.asarray(result))) and bool(np.array_equal(hist_s, hist))
+                # (N > 1: `result` is the all-reduced vector of the N BAMs of the weak-scaling steps; the one-BAM job to compare with is rank 0's own, before the reduce)
+                ref_c = np.asarray(aux["local_counters"] if world > 1 and "local_counters" in aux else result)
+                same = bool(np.array_equal(np.asarray(c_s), ref_c)) and bool(np.array_equal(hist_s, hist))
+                diff = [] if same else [(int(i), int(np.asarray(c_s)[i]), int(ref_c[i])) for i in np.nonzero(np.asarray(c_s) != ref_c)[0][:12]]
                 strong = {"what": f"ONE 30x BAM over {world} GPU(s): shards by BGZF member range, ngsqc_run_job_partial per shard (mapping_wgs + contamination pileup in one decode), "
                                   "all-gather of the shard summaries, SUM all-reduce of counters, site counts and the int32 difference array",
                           "value": round(int(mem[1].item()) * k2 / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong", "steps": k2, "ms_per_step": round(el / k2 * 1e3, 3),
                           "members_inflated_per_step": int(mem[0].item()), "bgzf_members": n_members_file,
-                          "counters_match_one_gpu_job": same,
+                          "counters_match_one_gpu_job": same, **({} if same else {"mismatch_index_sharded_unsharded": diff, "depth_histogram_matches": bool(np.array_equal(hist_s, hist))}),
                           "note": "all 1032 counters (the order-dependent ones included) and the 600-bin depth histogram against the unsharded job of rank 0; members behind a shard that "
                                   "only complete its last record are inflated by two shards (64 per cut)"}
         except Exception as e:   # never let the extra leg break the bench line

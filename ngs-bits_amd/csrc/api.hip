@@ -243,14 +243,15 @@ struct ngsqc_handle
 	PinBuf<unsigned long long> p_rb; static constexpr int RB_CAND = 64, RB_TOTAL = 72;
 	// record offsets of the resident tile are expanded on demand (ensure_recoff): a job whose consumers all ride the chain walk never reads them
 	bool lazy_recoff = false; int recoff_tile = -1;
-	struct RecoffArgs { const uint8_t* base = nullptr; int64_t total = 0; const BlockDesc* desc = nullptr; int64_t ne = 0, prefix = 0, n_rec = 0; int ksh = 0; int tile = -1; } rw;
+	struct RecoffArgs { const uint8_t* base = nullptr; int64_t total = 0; const BlockDesc* desc = nullptr; int64_t ne = 0, prefix = 0, n_rec = 0, nm = 0; int ksh = 0; int tile = -1; } rw;
 	struct FusedScan   // what K2 needs of such a scan (ScanState)
 	{
-		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t scan_limit) = 0;
+		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t nm, int64_t scan_limit) = 0;
 		virtual void fused_readback(ngsqc_handle* h) = 0;     // enqueues the copy of its accumulators (and of what rides with it) into h->p_rb
 		virtual ~FusedScan() = default;
 	};
 	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
+	bool long_reads = false;   // the file's first record is longer than 8 KiB (index_tile): entries are groups of members, nothing is assumed about member starts
 	bool k2_plain = false;   // a tile of the running stream did not pass the chain check on the device: the later tiles walk whole members, as the general path needs them
 	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last raw-read QC pass
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish
@@ -646,10 +647,14 @@ void stream_pass_begin(ngsqc_handle* h)
 	// address-space lock against the other copiers' faults). The mapping stays.
 	const int fd = u->fd; size_t pmax = 0; for (const auto& P : u->sp) pmax = std::max(pmax, P.bytes);
 	const char* em = getenv("NGSQC_H2D_PREAD"); const bool from_map = fd < 0 || !(em && atoi(em) != 0);
+	// NGSQC_H2D_REGISTER=1 (round 5, measured in profiles/r05_tool_probe.txt): a piece of the mapping is registered with the driver (hipHostRegister, read only) just
+	// before it is sent, so that the DMA engines read the page cache's pages themselves instead of the runtime staging them through its own pinned buffers
+	const char* er = getenv("NGSQC_H2D_REGISTER"); const bool reg = from_map && er && atoi(er) != 0;
 	u->pass_running = true;
 	for (int t = 0; t < T; ++t)
-		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, fd, pmax, from_map] {
+		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, fd, pmax, from_map, reg] {
 			hipStream_t st = nullptr; uint8_t* pin[2] = {nullptr, nullptr}; hipEvent_t pev[2] = {nullptr, nullptr}; long last = -1;
+			void* reg_ptr[2] = {nullptr, nullptr};
 			auto drop_last = [&]() { last = -1; };
 			try
 			{
@@ -677,9 +682,17 @@ void stream_pass_begin(ngsqc_handle* h)
 						HIPCHK(hipEventSynchronize(ev_chunk[4 * prev + 3]));
 					}
 					if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+					if (reg)
+					{
+						if (!pev[k]) HIPCHK(hipEventCreateWithFlags(&pev[k], hipEventDisableTiming));
+						if (reg_ptr[k]) { HIPCHK(hipEventSynchronize(pev[k])); (void)hipHostUnregister(reg_ptr[k]); reg_ptr[k] = nullptr; }
+						const uintptr_t a0 = (uintptr_t)(u->src_base + P.src) & ~(uintptr_t)4095, a1 = ((uintptr_t)(u->src_base + P.src) + P.bytes + 4095) & ~(uintptr_t)4095;
+						if (hipHostRegister((void*)a0, (size_t)(a1 - a0), hipHostRegisterReadOnly) == hipSuccess) reg_ptr[k] = (void*)a0;
+						else (void)hipGetLastError();   // (not registrable: the piece goes through the runtime's staging like any pageable source)
+					}
 					HIPCHK(hipMemcpyAsync(dst + P.dst, from_map ? u->src_base + P.src : pin[k], P.bytes, hipMemcpyHostToDevice, st));
 					HIPCHK(hipEventRecord(u->ev[i], st));
-					if (!from_map) HIPCHK(hipEventRecord(pev[k], st));
+					if (!from_map || reg) HIPCHK(hipEventRecord(pev[k], st));
 					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
 					u->cv.notify_all();
 					last = (long)i;
@@ -688,7 +701,7 @@ void stream_pass_begin(ngsqc_handle* h)
 				drop_last();
 			}
 			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); }
-			for (int k = 0; k < 2; ++k) { if (pin[k]) (void)hipHostFree(pin[k]); if (pev[k]) (void)hipEventDestroy(pev[k]); }
+			for (int k = 0; k < 2; ++k) { if (reg_ptr[k]) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(reg_ptr[k]); } if (pin[k]) (void)hipHostFree(pin[k]); if (pev[k]) (void)hipEventDestroy(pev[k]); }
 			if (st) (void)hipStreamDestroy(st);
 			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
 			u->cv.notify_all();
@@ -1027,7 +1040,7 @@ const int64_t* ensure_recoff(ngsqc_handle* h)
 	{
 		h->d_recoff.ensure_slack((size_t)std::max<int64_t>(a.n_rec, 1));
 		size_t iv = h->evlog->begin(h->stream, &h->tm.index_ms);
-		launch_index_write(a.base, a.total, a.desc, a.ne, a.prefix, a.ksh, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
+		launch_index_write(a.base, a.total, a.desc, a.ne, a.prefix, a.ksh, a.nm, h->d_start.p, h->d_cnt.p, h->d_base.p, h->d_rel.p, h->d_recoff.p, h->stream);
 		h->evlog->end(iv, h->stream);
 		h->recoff_tile = a.tile;
 	}
@@ -1050,18 +1063,33 @@ void index_tile(ngsqc_handle* h, int t)
 	const uint8_t* base = h->buf[t % h->nbuf].p + h->pfx - prefix;
 	const BlockDesc* d_desc = h->d_kdesc.p + first;
 	// entries: entry 0 = the carried prefix, then the members - on the fast path each cut into 2^ksh pieces with a walker of its own (common.h entry_range;
-	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 2: more waves than the chip holds at once buy nothing - profiles/r05_scan_probe.txt); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
+	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 1: a tile of the 30x file is 190 k members = three waves per SIMD already, and more waves than the chip holds buy nothing - profiles/r05_scan_probe.txt); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
-	int ksh = 1; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
-	if (anchor_by_guess || h->k2_plain) ksh = 0;
+	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
+	// long reads (round 5): the file's first record says what kind of file this is - a record of more than 8 KiB means members that mostly lie inside one record.
+	// Then nothing is assumed about member starts, and an entry of the fast path is a group of 16 members (common.h entry_range)
+	if (t == 0)
+	{
+		h->long_reads = false;
+		const char* elr = getenv("NGSQC_LONG_READ_MODE");   // 0 / 1: never / always (tests); unset: by the first record
+		if (elr) h->long_reads = atoi(elr) != 0 && !anchor_by_guess;
+		else if (!anchor_by_guess && exp0 >= 0 && exp0 + 4 <= total)
+		{
+			uint32_t bs0 = 0;
+			HIPCHK(hipMemcpyAsync(&bs0, base + exp0, 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+			h->long_reads = bs0 > 8192;
+		}
+	}
+	int ksh = 0; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
+	if (h->long_reads) { ksh = K2_MIN_KSH; if (const char* e = getenv("NGSQC_GROUP_SHIFT")) ksh = -std::min(8, std::max(0, atoi(e))); }
+	if (anchor_by_guess || (h->k2_plain && !h->long_reads)) ksh = 0;
 	const int64_t ne0 = nm + 1;
-	int64_t ne = (nm << ksh) + 1;
+	int64_t ne = ksh >= 0 ? (nm << ksh) + 1 : ((nm + (1ll << -ksh) - 1) >> -ksh) + 1;
 	auto e_lo = [&](int64_t e) -> int64_t { return e == 0 ? 0 : prefix + ((int64_t)h->blocks[(size_t)(first + e - 1)].upos - u_lo); };   // (whole members: the general path)
 	auto e_sz = [&](int64_t e) -> int64_t { return e == 0 ? prefix : (int64_t)h->blocks[(size_t)(first + e - 1)].usize; };
 	EvLog& ev = *h->evlog; size_t iv = ev.begin(h->stream, &h->tm.index_ms);   // (the riding scan's kernel is booked as scan time: the interval is cut around it)
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
-	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	// (with slack: a later tile has one entry more - its carried prefix - and regrowing means hipFree, which waits for all queued K1 work)
 	h->d_start.ensure_slack((size_t)ne); h->d_cnt.ensure_slack((size_t)ne + 1); h->d_next.ensure_slack((size_t)ne + 1); h->d_base.ensure_slack((size_t)ne + 1); h->d_bad.ensure(4);   // d_bad: {corrupt records, chain violations} + the offset of a record cut by the tile end (int64, -1: none)
 	h->d_scan_tmp.ensure_slack(scan_tmp_bytes(ne) + 64); h->d_rel.ensure_slack((size_t)(ne0 + 1) * K2_REL_STRIDE + 64);
@@ -1070,23 +1098,23 @@ void index_tile(ngsqc_handle* h, int t)
 	// ---- fast path: one round trip. Guess the first record of every entry, walk every entry's chain, check on the device that every walker's exit is the
 	// next walker's start (index_chain_kernel: exact), scan the counts; the host reads back {violations, corrupt records, n_rec} only. An htslib-written
 	// file passes (a record starts at every member's first byte, none straddles members or tiles) ----
-	const bool assume0 = !anchor_by_guess && !h->k2_plain && !getenv("NGSQC_K2_GUESS_ALL");   // (a file that has looked like an htslib file so far: its members start with a record)
-	launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, assume0, h->d_start.p, h->stream);
+	const bool assume0 = !anchor_by_guess && !h->k2_plain && !h->long_reads && !getenv("NGSQC_K2_GUESS_ALL");   // (a file that has looked like an htslib file so far: its members start with a record)
+	launch_index_init(d_desc, ne, prefix, ksh, nm, exp0, anchor_by_guess, assume0, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_bad.p + 2, 0xff, sizeof(long long), h->stream));
 	h->fused_tile = -1;
 	// the job's first scan consumer rides K2's walk when the file has looked like an htslib file so far (one read of every record's first line instead of two)
-	const bool try_fuse = h->fuse && h->fuse_ok && !anchor_by_guess && prefix == 0 && !getenv("NGSQC_NO_FUSED_SCAN");
+	const bool try_fuse = h->fuse && (h->fuse_ok || h->long_reads) && !anchor_by_guess && (prefix == 0 || h->long_reads) && !getenv("NGSQC_NO_FUSED_SCAN");   // (long reads: nearly every tile starts inside a carried record)
 	const int64_t fuse_limit = h->shard_own_members >= 0 ? prefix + (h->shard_limit - u_lo) : INT64_MAX;   // a shard only scans the records that start in front of its limit
 	if (try_fuse)
 	{
 		h->d_long.ensure_slack((size_t)std::max<int64_t>(total / 160, 1024));   // deferred (long-CIGAR) records of the tile: an estimate, checked below
-		if (!assume0) launch_index_guess(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);   // (else: the walkers of the pieces guess for themselves)
+		if (!assume0 || ksh > 0) launch_index_guess(base, total, d_desc, ne, prefix, ksh, nm, 0, h->d_start.p, (int32_t)h->ref_names.size(), h->stream);   // (one walker per member of an htslib-style file: nothing to guess)
 		ev.end(iv, h->stream);
-		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, ksh, fuse_limit);
+		h->fuse->fused_launch(h, base, total, +1, d_desc, ne, prefix, ksh, nm, fuse_limit);
 		iv = ev.begin(h->stream, &h->tm.index_ms);
 	}
-	else launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream, !assume0);
-	launch_index_chain(d_desc, ne, prefix, ksh, exp0, total, h->d_start.p, h->d_next.p, h->d_bad.p + 1, (long long*)(h->d_bad.p + 2), h->stream);
+	else launch_index_count(base, total, d_desc, ne, prefix, ksh, nm, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream, !assume0 || ksh > 0);
+	launch_index_chain(d_desc, ne, prefix, ksh, nm, exp0, total, h->d_start.p, h->d_next.p, h->d_bad.p + 1, (long long*)(h->d_bad.p + 2), h->stream);
 	launch_scan_counts(h->d_cnt.p, ne, h->d_base.p, h->d_scan_tmp.p, h->stream);
 	unsigned long long* sm = h->p_small.p + 32;   // [0] = {corrupt, violations} (2 x u32), [1] = record cut by the tile end, [2] = deferred records of the riding scan, [3] = n_rec
 	HIPCHK(hipMemcpyAsync(sm, h->d_bad.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1105,7 +1133,7 @@ void index_tile(ngsqc_handle* h, int t)
 			// This includes a tile whose guessed chains ran into something that looks like a corrupt record (a false start guess): the
 			// general path below repairs the chain, so the walk's contributions must go whatever it met (only aligned && corrupt throws, below)
 			ev.end(iv, h->stream);
-			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, ksh, fuse_limit);
+			h->fuse->fused_launch(h, base, total, -1, d_desc, ne, prefix, ksh, nm, fuse_limit);
 			iv = ev.begin(h->stream, &h->tm.index_ms);
 			if (!aligned) h->fuse_ok = false; else h->d_long.ensure_slack((size_t)sm[2]);
 		}
@@ -1114,7 +1142,7 @@ void index_tile(ngsqc_handle* h, int t)
 	{
 		if (n_corrupt) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
 		straddle = (int64_t)sm[1]; h->tm.tiles_chain_on_device++; if (h->fused_tile == t) h->tm.tiles_scan_fused++;
-		h->tm.walkers_per_member = 1ll << ksh;
+		h->tm.walkers_per_member = ksh >= 0 ? 1ll << ksh : -(1ll << -ksh);   // (negative: members per walker)
 		if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
 		chain_exit = std::max(total, exp0);   // (exp0 > total: the first record of the file starts in a later tile)
 	}
@@ -1126,9 +1154,9 @@ void index_tile(ngsqc_handle* h, int t)
 	if (ksh != 0 || assume0)
 	{
 		ksh = 0; ne = ne0;
-		launch_index_init(d_desc, ne, prefix, ksh, exp0, anchor_by_guess, false, h->d_start.p, h->stream);
+		launch_index_init(d_desc, ne, prefix, ksh, nm, exp0, anchor_by_guess, false, h->d_start.p, h->stream);
 		HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream));
-		launch_index_count(base, total, d_desc, ne, prefix, ksh, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+		launch_index_count(base, total, d_desc, ne, prefix, ksh, nm, 0, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 	}
 	h->p_start.ensure((size_t)ne + 64); h->p_next.ensure((size_t)ne + 64);
 	int32_t* start = h->p_start.p; int64_t* next = h->p_next.p;
@@ -1138,7 +1166,7 @@ void index_tile(ngsqc_handle* h, int t)
 		if (!first_round)
 		{
 			HIPCHK(hipMemsetAsync(h->d_bad.p, 0, sizeof(uint32_t), h->stream));
-			launch_index_count(base, total, d_desc, ne, prefix, 0, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
+			launch_index_count(base, total, d_desc, ne, prefix, 0, nm, from, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, (int32_t)h->ref_names.size(), h->d_rel.p, h->stream);
 		}
 		first_round = false;
 		HIPCHK(hipMemcpyAsync(start + from, h->d_start.p + from, (size_t)(ne - from) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1186,7 +1214,7 @@ void index_tile(ngsqc_handle* h, int t)
 	}
 	int64_t n_rec = (int64_t)sm[3];
 	// the record offsets: expanded now, or - a job whose consumers all ride the walk - only if somebody asks (ensure_recoff)
-	h->rw = ngsqc_handle::RecoffArgs{base, total, d_desc, ne, prefix, n_rec, ksh, t}; h->recoff_tile = -1;
+	h->rw = ngsqc_handle::RecoffArgs{base, total, d_desc, ne, prefix, n_rec, nm, ksh, t}; h->recoff_tile = -1;
 	ev.end(iv, h->stream);
 	if (!h->lazy_recoff || h->fused_tile != t || h->shard_own_members >= 0) ensure_recoff(h);
 	iv = ev.begin(h->stream, &h->tm.index_ms);
@@ -1405,7 +1433,7 @@ struct ScanState : ngsqc_handle::FusedScan
 		kernel_ms = 0; stage_ms = 0; launches = 0;
 	}
 	// the scan of a tile inside K2's chain walk (index_tile); sgn = -1 takes the tile's contributions back
-	void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t scan_limit) override
+	void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t nm, int64_t scan_limit) override
 	{
 		sp.scan_limit = scan_limit; sp.infl = infl; sp.total = total; sp.recoff = nullptr; sp.n_rec = 0; sp.ord_base = 0;
 		sp.long_list = h->d_long.p; sp.long_cap = (int64_t)h->d_long.n; sp.entry_base = nullptr; sp.sgn = sgn; sp.tile_slots = 1;
@@ -1417,7 +1445,7 @@ struct ScanState : ngsqc_handle::FusedScan
 			HIPCHK(hipMemcpyAsync(d_counters.p + A_TILE_KEY, s, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));   // A_TILE_KEY, A_TILE_PAIRED
 		}
 		const size_t iv = h->evlog->begin(h->stream, &kernel_ms, &stage_ms);   // (the walk + scan kernel: booked as scan time, not under K2)
-		launch_walk_scan(sp, d_desc, ne, prefix, ksh, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
+		launch_walk_scan(sp, d_desc, ne, prefix, ksh, nm, h->d_start.p, h->d_cnt.p, h->d_next.p, h->d_bad.p, h->d_rel.p, h->stream);
 		h->evlog->end(iv, h->stream); launches++;
 		sp.sgn = 1; sp.scan_limit = INT64_MAX;
 	}

@@ -14,7 +14,7 @@
 namespace ngsqc {
 
 constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the entry) kept per BGZF member for K2's write pass: an entry of a member cut into 2^ksh pieces owns K2_REL_STRIDE >> ksh of them
-constexpr int K2_MAX_KSH = 3;        // a member is walked by up to 8 threads (round 5: several walkers per member, see entry_range)
+constexpr int K2_MAX_KSH = 3, K2_MIN_KSH = -4;        // a member is walked by up to 8 threads (round 5: several walkers per member, see entry_range)
 constexpr int NAME_SHIFT = 12;       // a record of a tile scanned by the chain walk is named (entry << NAME_SHIFT | k): a 64 KiB member holds at most 65536 / 36 records
 
 // ---- K1 ----
@@ -91,11 +91,11 @@ void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_
 
 // ---- K2 ----
 // (n_entries = members << ksh, + 1 for the carried prefix; every array is indexed by entry)
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s, bool wave_guess = true);
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, bool assume0 /* members start with a record: no guess for their first piece */, int32_t* d_start, hipStream_t s);
-void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle /* -1 before the launch */, hipStream_t s);
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t exp0, bool guess_all, bool assume0 /* members start with a record: no guess for their first piece */, int32_t* d_start, hipStream_t s);
+void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle /* -1 before the launch */, hipStream_t s);
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, const int32_t* d_start,
                         const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s);
 void launch_scan_counts(const uint32_t* d_cnt, int64_t n, int64_t* d_base, void* d_tmp, hipStream_t s);
 void launch_depth_prefix(int32_t* d_diff, int64_t n_slots, void* d_tmp, hipStream_t s);
@@ -149,8 +149,8 @@ struct ScanParams
 
 void launch_scan(const ScanParams& p, hipStream_t s);
 // K2's chain walk (what launch_index_count does) with the scan of every record the walk passes: one read of a record's first line instead of two
-void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
-void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s);
 void launch_prefix_capture(const ScanParams& p, int64_t n, uint32_t* d_head, hipStream_t s);
@@ -190,16 +190,27 @@ namespace ngsqc {
 // of a member does not know where its first record starts: the guess kernel finds the first plausible record header (index.hip), every piece's walker runs
 // to the end of its piece, and the chain is accepted only if every walker's exit IS the next walker's start (index_chain_kernel) - by induction from the
 // tile's known first record every start then lies on the true chain; anything else takes the general path.
-__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int ksh, int64_t& lo, int64_t& hi)
+// ksh < 0 (long reads, round 5): an entry is a GROUP of 2^-ksh consecutive members (nm = members of the tile): a 20 kb read spans a third of a member, so
+// most members hold no record start at all and a guess per member reads the whole tile once more; a walker per megabyte follows ~35 records and its guess
+// looks through half a record.
+__device__ __forceinline__ void entry_range(const BlockDesc* __restrict__ blocks, int64_t e, int64_t prefix, int ksh, int64_t nm, int64_t& lo, int64_t& hi)
 {
 	if (e == 0) { lo = 0; hi = prefix; }
-	else
+	else if (ksh >= 0)
 	{
 		const int64_t idx = e - 1; const BlockDesc bd = blocks[idx >> ksh]; const int64_t j = idx & ((1ll << ksh) - 1);
 		const int64_t mlo = prefix + (int64_t)bd.upos;
 		lo = mlo + (((int64_t)bd.usize * j) >> ksh); hi = mlo + (((int64_t)bd.usize * (j + 1)) >> ksh);
 	}
+	else
+	{
+		const int64_t m0 = (e - 1) << -ksh, m1 = min(m0 + (1ll << -ksh), nm) - 1;
+		const BlockDesc a = blocks[m0], z = blocks[m1];
+		lo = prefix + (int64_t)a.upos; hi = prefix + (int64_t)z.upos + z.usize;
+	}
 }
+// offsets (u16, relative to the entry) the walk keeps per entry for K2's write pass; 0: none (a group of members is longer than 64 KiB - its chain is walked again)
+__device__ __forceinline__ uint32_t rel_stride(int ksh) { return ksh >= 0 ? (uint32_t)K2_REL_STRIDE >> ksh : 0u; }
 // what htslib's bam_read1 checks before it accepts a record (the reference then throws "Could not read next alignment",
 // src/cppNGS/BamReader.h:389-392): the variable-length fields must fit the record. Kernels behind K2 trust these fields.
 __device__ __forceinline__ bool record_fields_fit(uint32_t l_name, uint32_t n_cigar, int32_t l_seq, uint32_t bs)

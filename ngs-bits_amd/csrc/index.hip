@@ -24,7 +24,7 @@ __device__ __forceinline__ bool record_fields_fit(const uint8_t* r, uint32_t bs)
 // of each candidate are funnel shifts of the loaded words: 256 offsets per step, two rejected almost always before the full plausibility check), so an entry
 // that lies inside one long record (ONT: most members) costs 256 steps, and the piece of a short-read member (its first record starts ~170 bytes in) one.
 // Entries whose start is already known (>= 0 or -1) are skipped; an entry without any plausible start gets -1.
-__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t from,
+__global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
                                                           int32_t* start, int32_t n_ref)
 {
 	const int lane = threadIdx.x & 63;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 	for (int64_t b = from + wave; b < n_blocks; b += n_waves)
 	{
 		if (start[b] != -2) continue;
-		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
 		int32_t found = -1;
 		// the first 256 bytes alone (the piece of a short-read member: its first record starts ~170 bytes in), then 1 KiB per step with four loads in flight - an
 		// entry inside one long record (ONT: most members) is scanned at four windows per memory round trip
@@ -81,19 +81,19 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 }
 
 // start[b]: >=0 first-record offset inside entry b; -1 none (a longer record covers the whole entry); -2 guess.
-__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t from,
+__global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                    uint32_t* __restrict__ bad, int32_t n_ref, uint16_t* __restrict__ rel)
 {
 	int64_t b = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
 	int32_t s = start[b];
-	if (s == -2) { s = lane_guess(infl, total, lo, hi, n_ref); start[b] = s; }   // (not resolved by the guess kernel: the piece of a member on the fast path)
+	if (s == -2) { s = lane_guess(infl, total, lo, hi, n_ref); start[b] = s; }   // (fallback: the guess kernel resolves them wave by wave)
 	if (s < 0) { cnt[b] = 0; next_abs[b] = -1; return; }
 	// next_abs: >= 0 chain exit; -2 corrupt record; <= -10 a record starts at o = -(next_abs + 10) but extends past the end
 	// of the resident tile (it is carried into the next tile, not counted here)
-	const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
+	const uint32_t stride = rel_stride(ksh);
 	int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
 	while (o < hi)
 	{
@@ -112,11 +112,11 @@ __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t tot
 // start[] of every entry from what the host knows before K2: the tile-local offset exp0 of the first record (start = -2: guess). assume0 (the fast path): a
 // member is taken to start with a record, as htslib writes them - no guess kernel for those entries; if it does not, the walker's predecessor ends elsewhere
 // and the chain check sends the tile to the general path (which guesses).
-__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int guess_all, int assume0, int32_t* __restrict__ start)
+__global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t exp0, int guess_all, int assume0, int32_t* __restrict__ start)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
 	const bool first_piece = b > 0 && ((b - 1) & ((1ll << ksh) - 1)) == 0;
 	start[b] = hi <= lo ? -1 : guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : (assume0 && first_piece ? 0 : -2)));   // (an empty entry holds no record start)
 }
@@ -127,14 +127,14 @@ __global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t 
 // carried into the next tile: *straddle = its offset) with no start behind it. By induction from exp0 every start then lies on the true chain, and the host
 // skips its sequential verification; viol counts the entries that do not fit (any: the tile takes the general path). For an htslib-written file (a record
 // starts at every member's first byte, none straddles) and ksh = 0 this is round 3's "aligned" test.
-__global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t exp0, int64_t total,
+__global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t exp0, int64_t total,
                                    const int32_t* __restrict__ start, const int64_t* __restrict__ next_abs, uint32_t* __restrict__ viol, long long* __restrict__ straddle)
 {
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool bad = false;
 	if (b < n_blocks)
 	{
-		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
 		const int32_t s = start[b];
 		if (hi <= exp0) bad = s != -1;
 		else if (lo <= exp0) bad = s != (int32_t)(exp0 - lo);
@@ -142,6 +142,7 @@ __global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t
 		{
 			const int64_t nx = next_abs[b];
 			if (nx == -2) bad = false;   // (a corrupt record: counted by the walk itself, the host throws)
+			else if (nx == -3) bad = true;   // (an entry with more records than a name of the riding scan holds)
 			else if (nx < 0)
 			{
 				// a record cut by the tile end: the rest of the tile belongs to it
@@ -151,10 +152,10 @@ __global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t
 			else
 			{
 				int64_t e = b + 1;
-				for (; e < n_blocks && start[e] < 0; ++e) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, l2, h2); if (h2 > nx) { bad = true; break; } }
+				for (; e < n_blocks && start[e] < 0; ++e) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, nm, l2, h2); if (h2 > nx) { bad = true; break; } }
 				if (!bad)
 				{
-					if (e < n_blocks) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, l2, h2); bad = nx != l2 + start[e]; }
+					if (e < n_blocks) { int64_t l2, h2; entry_range(blocks, e, prefix, ksh, nm, l2, h2); bad = nx != l2 + start[e]; }
 					else bad = nx != total;
 				}
 			}
@@ -167,7 +168,7 @@ __global__ void index_chain_kernel(const BlockDesc* __restrict__ blocks, int64_t
 // Record offsets of every entry, ONE WAVE PER ENTRY: the entry-relative offsets that the count pass stored are expanded with coalesced loads
 // and stores (the chain is not walked a second time: that would read a third of the inflated tile again). Entry 0 (the carried prefix, offsets
 // may exceed 16 bits) and entries with more records than their share of K2_REL_STRIDE walk their chain on lane 0.
-__global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh,
+__global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm,
                                                           const int32_t* __restrict__ start, const uint32_t* __restrict__ cnt, const int64_t* __restrict__ base,
                                                           const uint16_t* __restrict__ rel, int64_t* __restrict__ recoff)
 {
@@ -177,10 +178,10 @@ __global__ __launch_bounds__(256) void index_write_kernel(const uint8_t* __restr
 	const int32_t s = start[b];
 	if (s < 0) return;
 	const uint32_t n = cnt[b];
-	const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
-	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
+	const uint32_t stride = rel_stride(ksh);
+	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
 	const int64_t k0 = base[b];
-	if (b != 0 && n <= stride)
+	if (b != 0 && n <= stride)   // (stride 0: a group of members - walked again)
 	{
 		for (uint32_t k = lane; k < n; k += 64) recoff[k0 + k] = lo + rel[b * stride + k];
 		return;
@@ -255,44 +256,44 @@ __global__ void scan_tile_apply(const TIn* __restrict__ in, int64_t n, const int
 size_t scan_tmp_bytes(int64_t n) { int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE; return (size_t)(tiles + 2) * sizeof(int64_t); }
 
 // entries [from, n_entries) of the tile (entry 0 = carried prefix, entry e = piece (e - 1) & (2^ksh - 1) of member (e - 1) >> ksh of d_blocks); arrays are indexed by entry
-void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start,
+void launch_index_count(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start,
                         uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, int32_t n_ref, uint16_t* d_rel, hipStream_t s, bool wave_guess)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
 	// starts still to be guessed: by a wave per entry (entries that may lie inside one long record: 64 KiB to look through), or by each walker for itself (the
 	// pieces of a short-read member: the first record is a few hundred bytes in)
-	if (wave_guess) launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref, s);
+	if (wave_guess) launch_index_guess(d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref, s);
 	int grid = (int)((n + 63) / 64);
-	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
+	hipLaunchKernelGGL(index_count_kernel, dim3(grid), dim3(64), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, d_cnt, d_next_abs, d_bad, n_ref, d_rel); KCHECK();
 }
 
 // resolve the guessed first-record offsets (start == -2) wave-cooperatively
-void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s)
+void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s)
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
 	const int64_t wg = (n + 3) / 4;
-	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, from, d_start, n_ref); KCHECK();
+	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK();
 }
 
-void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, bool guess_all, bool assume0, int32_t* d_start, hipStream_t s)
+void launch_index_init(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t exp0, bool guess_all, bool assume0, int32_t* d_start, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, guess_all ? 1 : 0, assume0 ? 1 : 0, d_start); KCHECK();
+	hipLaunchKernelGGL(index_init_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, nm, exp0, guess_all ? 1 : 0, assume0 ? 1 : 0, d_start); KCHECK();
 }
-void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle, hipStream_t s)
+void launch_index_chain(const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t exp0, int64_t total, const int32_t* d_start, const int64_t* d_next, uint32_t* d_viol, long long* d_straddle, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	hipLaunchKernelGGL(index_chain_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, exp0, total, d_start, d_next, d_viol, d_straddle); KCHECK();
+	hipLaunchKernelGGL(index_chain_kernel, dim3((int)((n_entries + 255) / 256)), dim3(256), 0, s, d_blocks, n_entries, prefix, ksh, nm, exp0, total, d_start, d_next, d_viol, d_straddle); KCHECK();
 }
 
-void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, const int32_t* d_start,
+void launch_index_write(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, const int32_t* d_start,
                         const uint32_t* d_cnt, const int64_t* d_base, const uint16_t* d_rel, int64_t* d_recoff, hipStream_t s)
 {
 	if (n_entries <= 0) return;
 	int grid = (int)((n_entries + 3) / 4);   // one wave per entry
-	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_base, d_rel, d_recoff); KCHECK();
+	hipLaunchKernelGGL(index_write_kernel, dim3(grid), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_base, d_rel, d_recoff); KCHECK();
 }
 
 // exclusive scan of u32 counts into int64 bases; d_base[n] receives the total. d_tmp needs scan_tmp_bytes(n).

@@ -13,7 +13,6 @@
 // the reference increments the whole reference span [start,end] of a read (RegionDepth::incrementRegion,
 // Statistics.cpp:45-53), which is exactly a prefix sum over these differences. All arithmetic is integer.
 #include "common.h"
-#include "k2_guess.h"
 #include <algorithm>
 
 namespace ngsqc {
@@ -476,13 +475,24 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 				if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; }
 			}
 		}
+		// the CIGAR, four operations per lane and step (16-byte loads: a read of 20 kb has ~1 700 operations = seven steps of the wave; round 4 took one per lane)
 		long long ref_len = 0, clip = 0; int spl = 0;
-		for (uint32_t k = lane; k < r.n_cigar; k += 64)
+		for (uint32_t k0 = 4u * lane; k0 < r.n_cigar; k0 += 256u)
 		{
-			uint32_t c = ld32(r.cigar + 4ull * k); uint32_t op = c & 15u, len = c >> 4;
-			if ((0x18Du >> op) & 1u) ref_len += len;
-			else if (op == 4 || op == 5) clip += len;
-			if (op == 3) spl = 1;
+			uint32_t c4[4] = {0u, 0u, 0u, 0u};
+			if (k0 + 4u <= r.n_cigar) __builtin_memcpy(c4, r.cigar + 4ull * k0, 16);
+			else for (uint32_t j = 0; k0 + j < r.n_cigar; ++j) c4[j] = ld32(r.cigar + 4ull * (k0 + j));
+			#pragma unroll
+			for (uint32_t j = 0; j < 4u; ++j)
+			{
+				if (k0 + j < r.n_cigar)
+				{
+					const uint32_t c = c4[j], op = c & 15u, len = c >> 4;
+					if ((0x18Du >> op) & 1u) ref_len += len;
+					else if (op == 4 || op == 5) clip += len;
+					if (op == 3) spl = 1;
+				}
+			}
 		}
 		ref_len = wave_sum(ref_len); clip = wave_sum(clip); spl = __any(spl);
 		if (MODE == 3 && p.min_baseq > 0)
@@ -549,8 +559,8 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 // and then waited for the fields): one round trip per record is the CIGAR's, the header's is hidden behind the scan of the record in front; (c) the offsets go
 // out as 16-byte stores of eight (round 4: a 2-byte store per record and lane - 64 partial sectors per instruction, 32.6 bytes of HBM writes per record).
 template <int MODE, int WAVES>
-__global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix, int ksh,
-                                                        int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
+__global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm,
+                                                        const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
 	__shared__ uint32_t lds_hist[1000];
@@ -560,13 +570,12 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b < n_entries)
 	{
-		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, lo, hi);
-		int32_t s = start[b];   // >= 0, -1 (nothing starts here), or -2: a piece in the middle of a member - this walker looks for its first record itself
-		if (s == -2) { s = lane_guess(p.infl, p.total, lo, hi, p.n_ref); if (p.sgn > 0) start[b] = s; }   // (the take-back pass finds the start the first pass left)
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
+		const int32_t s = start[b];   // (>= 0, or -1: nothing starts here; the guess kernel has resolved every -2)
 		if (s < 0) { cnt[b] = 0; next_abs[b] = -1; }
 		else
 		{
-			const uint32_t stride = (uint32_t)K2_REL_STRIDE >> ksh;
+			const uint32_t stride = rel_stride(ksh);
 			uint64_t* const rel8 = (uint64_t*)(rel + b * stride);   // (16-byte aligned: stride is a multiple of 8)
 			uint64_t pk_lo = 0, pk_hi = 0;                           // the last eight offsets, oldest in the low bits
 			int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
@@ -582,6 +591,7 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 				RecView r = make_rec(p.infl, o, nx);   // (bs >= 32 and the record ends inside the tile: all 36 bytes were loaded)
 				if (o_next < hi) { if (o_next + 36 <= p.total) nx = load_hdr(p.infl + o_next); else { nx.bs = o_next + 4 <= p.total ? ld32(p.infl + o_next) : 0u; } }
 				if (!record_fields_fit(r.l_name, r.n_cigar_raw, r.l_seq, r.bs)) { res = -2; stop = true; break; }
+				if (n >= (1u << NAME_SHIFT) - 1u) { res = -3; stop = true; break; }   // more records than a name holds (a group of members of a short-read file): not for this path
 				if (n < stride)
 				{
 					pk_lo = (pk_lo >> 16) | (pk_hi << 48); pk_hi = (pk_hi >> 16) | ((uint64_t)(uint16_t)(o - lo) << 48);
@@ -615,26 +625,26 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 }
 
 template <int WAVES>
-static void launch_walk_scan_w(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
+static void launch_walk_scan_w(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
 {
 	const int grid = (int)((n_entries + 63) / 64);
 	switch (p.mode)
 	{
-		case NGSQC_MODE_ROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_ROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case NGSQC_MODE_NOROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_NOROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case NGSQC_MODE_WGS: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_WGS, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		case MODE_COUNT: hipLaunchKernelGGL((walk_scan_kernel<MODE_COUNT, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
-		default: hipLaunchKernelGGL((walk_scan_kernel<3, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_ROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_ROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_NOROI: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_NOROI, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case NGSQC_MODE_WGS: hipLaunchKernelGGL((walk_scan_kernel<NGSQC_MODE_WGS, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		case MODE_COUNT: hipLaunchKernelGGL((walk_scan_kernel<MODE_COUNT, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
+		default: hipLaunchKernelGGL((walk_scan_kernel<3, WAVES>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); break;
 	}
 	KCHECK();
 }
 // NGSQC_WALK_WAVES = 3 / 4: the register budget the walk is compiled for (waves per SIMD: 170 / 128 VGPRs)
-void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
+void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
 {
 	if (n_entries <= 0) return;
 	int waves = 3; if (const char* e = getenv("NGSQC_WALK_WAVES")) waves = atoi(e);
-	if (waves >= 4) launch_walk_scan_w<4>(p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
-	else launch_walk_scan_w<3>(p, d_blocks, n_entries, prefix, ksh, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
+	if (waves >= 4) launch_walk_scan_w<4>(p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
+	else launch_walk_scan_w<3>(p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
 }
 
 // ---- order-dependent fix-ups on a record prefix ----
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, lon
 static int scan_grid(long long n, int per_wg)
 {
 	long long wgs = (n + per_wg - 1) / per_wg;
-	long long cap = 256 * 8;
+	long long cap = per_wg == 4 ? 256 * 64 : 256 * 8;   // (a wave per long record: the records of a tile at once - their CIGAR loads are what hides each other's latency)
 	return (int)(wgs < 1 ? 1 : (wgs < cap ? wgs : cap));
 }
 

@@ -53,8 +53,26 @@ def test_chrX_chrY_counts(tmp_path):
     _check(tmp_path, "xy.bam", None, ngsqc.MODE_NOROI, 0, n_reads=100_000, seed=3, first_contig=22, start_pos=156_000_000, depth=2.0)
 
 
-def test_long_reads_cg_tag(tmp_path):
+@pytest.mark.parametrize("long_mode", [None, "1", "0"])
+def test_long_reads_cg_tag(tmp_path, monkeypatch, long_mode):
+    """long_mode 1: the long-read form of K2's fast path (round 5: an entry is a group of 16 members, every start guessed, tiles that begin inside a carried record
+    ride the walk too) whatever the first record's size; 0: never; None: by the file's first record"""
+    if long_mode is not None:
+        monkeypatch.setenv("NGSQC_LONG_READ_MODE", long_mode)
     _check(tmp_path, "ont.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=1500, seed=4, mode=1, depth=40.0, start_pos=15_900_000)
+    if long_mode == "1":   # the fused job (mapping scan riding the walk + site pileup over its candidates) against the oracle, single tile and 5-member tiles
+        p = str(tmp_path / "ont.bam"); ob = O.Bam(p)
+        for tm_ in (None, "5", "40"):
+            if tm_: monkeypatch.setenv("NGSQC_TILE_MEMBERS", tm_)
+            h = ngsqc.Handle(path=p)
+            regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs); sites = H.known_sites(h.refs)
+            out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=sites, site_params=(1, 13, True))
+            exp = O.mapping(ob, ngsqc.MODE_WGS, OMIM, merge_bed=False)
+            assert all(int(out["counters"][i]) == int(exp.counters[i]) for i in range(len(exp.counters)) if i not in SKIP)
+            assert np.array_equal(out["site_counts"][:, :6], O.site_pileup(ob, sites, 1, 13, True))
+            t = h.timings()
+            assert t["tiles_chain_on_device"] >= t["n_tiles"] - 1 and t["walkers_per_member"] == -16, t   # (a tile may fall back when a guess inside a long record was wrong: exact either way)
+            h.close()
 
 
 def test_roi_mode_exome_like(tmp_path):
@@ -79,13 +97,17 @@ def test_roi_mode_exome_like(tmp_path):
     h.close()
 
 
-@pytest.mark.parametrize("tile_members", [1, 3, 7])
+@pytest.mark.parametrize("tile_members", [1, 3, 7, 33])
 def test_tiled_processing_matches_single_tile(tmp_path, monkeypatch, tile_members):
     """Files larger than HBM are processed in member ranges ("tiles"); records straddling tile borders are carried.
     Tiny tiles on unaligned / long-read inputs exercise every carry path; results must be identical."""
     monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
     _check(tmp_path, "t_unaligned.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=30_000, seed=12, aligned=False, start_pos=15_900_000)
     _check(tmp_path, "t_ont.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=400, seed=13, mode=1, depth=40.0, start_pos=15_900_000)
+    monkeypatch.setenv("NGSQC_LONG_READ_MODE", "1"); monkeypatch.setenv("NGSQC_GROUP_SHIFT", "2")     # groups of four members, tiles that cut groups and records
+    _check(tmp_path, "t_ont.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=400, seed=13, mode=1, depth=40.0, start_pos=15_900_000)
+    _check(tmp_path, "t_unaligned.bam", OMIM, ngsqc.MODE_WGS, 3, n_reads=30_000, seed=12, aligned=False, start_pos=15_900_000)
+    monkeypatch.delenv("NGSQC_LONG_READ_MODE"); monkeypatch.delenv("NGSQC_GROUP_SHIFT")
     _check(tmp_path, "t_noroi.bam", None, ngsqc.MODE_NOROI, 0, n_reads=20_000, seed=14, first_contig=22, start_pos=156_000_000, depth=2.0)
     # inflated stream of a multi-tile file through the test hook
     path = str(tmp_path / "t_unaligned.bam")
@@ -147,7 +169,7 @@ def test_fused_job_equals_single_purpose_calls(tmp_path, monkeypatch, tile_membe
 
 @pytest.mark.parametrize("aligned,tile_members", [(True, 0), (True, 9), (False, 9)])
 def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
-    """Every way to the record index gives the same job result: the scan riding K2's chain walk with four walkers per BGZF member (default), with one, two
+    """Every way to the record index gives the same job result: the scan riding K2's chain walk with one walker per BGZF member (default), with two, four
     and eight (NGSQC_WALKERS; pieces of a member whose first record is guessed, the chain checked on the device), compiled for four waves per SIMD
     (NGSQC_WALK_WAVES=4) and the plain K2 + scan (NGSQC_NO_FUSED_SCAN=1)."""
     p = str(tmp_path / "k2.bam")
@@ -155,7 +177,8 @@ def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
     if tile_members:
         monkeypatch.setenv("NGSQC_TILE_MEMBERS", str(tile_members))
     res = []
-    for env in ({}, {"NGSQC_WALKERS": "1"}, {"NGSQC_WALKERS": "2"}, {"NGSQC_WALKERS": "8"}, {"NGSQC_WALK_WAVES": "4"}, {"NGSQC_NO_FUSED_SCAN": "1"}, {"NGSQC_NO_FUSED_SCAN": "1", "NGSQC_WALKERS": "1"}):
+    for env in ({}, {"NGSQC_WALKERS": "2"}, {"NGSQC_WALKERS": "4"}, {"NGSQC_WALKERS": "8"}, {"NGSQC_WALK_WAVES": "4"}, {"NGSQC_NO_FUSED_SCAN": "1"}, {"NGSQC_NO_FUSED_SCAN": "1", "NGSQC_WALKERS": "4"},
+                {"NGSQC_LONG_READ_MODE": "1"}, {"NGSQC_LONG_READ_MODE": "1", "NGSQC_GROUP_SHIFT": "1"}, {"NGSQC_EAGER_RECOFF": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = ngsqc.Handle(path=p)
@@ -163,8 +186,8 @@ def test_k2_variants_agree(tmp_path, monkeypatch, aligned, tile_members):
         out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=H.known_sites(h.refs))
         res.append((out["counters"].copy(), out["site_counts"].copy(), h.depth(int(out["counters"][26])).copy()))
         tm = h.timings()
-        if aligned and "NGSQC_NO_FUSED_SCAN" not in env:   # an htslib-style file: every tile's chain is checked on the device and scanned by the walk itself
-            assert tm["tiles_chain_on_device"] == tm["n_tiles"] == tm["tiles_scan_fused"] and tm["walkers_per_member"] == int(env.get("NGSQC_WALKERS", 4)), tm
+        if aligned and "NGSQC_NO_FUSED_SCAN" not in env and "NGSQC_LONG_READ_MODE" not in env:   # an htslib-style file: every tile's chain is checked on the device and scanned by the walk itself
+            assert tm["tiles_chain_on_device"] == tm["n_tiles"] == tm["tiles_scan_fused"] and tm["walkers_per_member"] == int(env.get("NGSQC_WALKERS", 1)), tm
         h.close()
         for k in env:
             monkeypatch.delenv(k)
