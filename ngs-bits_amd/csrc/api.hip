@@ -147,7 +147,7 @@ uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 constexpr int K1_CHUNK_WAVES_PER_CU = 6;   // a K1 chunk = this many decoder waves per CU (x 64 members); the launch itself keeps up to P1_WAVES_PER_CU resident
-constexpr int P1_WAVES_PER_CU = 12;       // decoder waves a CU holds (11 KB LDS and <= 128 VGPRs each); NGSQC_P1_WAVES
+constexpr int P1_WAVES_PER_CU = 12;       // decoder waves a CU holds (11 KB LDS and <= 128 VGPRs each; 10 / 14 / 16 measured within 2 %)
 constexpr int K1_SLOTS_DEFAULT = 3;  // token ring: chunk c uses slot c % slots (phase 1 of the next two chunks runs while phase 2 of c reads; a fourth slot measured the same: 865 / 877 vs 890 / 884 Mreads/s on 96 M reads); NGSQC_TOKEN_SLOTS
 constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
 
@@ -385,7 +385,7 @@ void init_device(ngsqc_handle* h, int device)
 	HIPCHK(hipStreamCreateWithFlags(&h->s_p2, hipStreamNonBlocking));
 	HIPCHK(hipStreamCreateWithFlags(&h->s_crc, hipStreamNonBlocking));
 	int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cu = cu;
-	int pw = P1_WAVES_PER_CU; if (const char* e = getenv("NGSQC_P1_WAVES")) pw = std::min(32, std::max(1, atoi(e)));
+	const int pw = P1_WAVES_PER_CU;
 	h->p1_wgs = h->n_cu * pw;
 	k1_read_switches();
 	if (const char* e = getenv("NGSQC_VERIFY_CRC")) h->verify_crc = atoi(e) != 0;
@@ -642,37 +642,28 @@ void stream_pass_begin(ngsqc_handle* h)
 	uint8_t* const dst = h->d_comp.p; const int device = h->device; const int slots = h->comp_slots; hipEvent_t* const ev_chunk = h->ev_chunk.data();
 	// The source of a piece is the mapping of the file (hipMemcpyAsync stages a pageable source through the runtime's pinned buffers). Reading through the mapping
 	// faults in one page-table entry per 4 KB - 15 M of them for a 60 GB file - and tearing them down again costs 0.3 - 0.75 s at close for a 19 GB file. Measured
-	// alternatives on a 19 GB BAM (profiles/r04_tool_probe.txt): NGSQC_H2D_PREAD=1 (pieces read into pinned buffers of the copier threads) 12.5 GB/s with four threads,
+	// alternatives on a 19 GB BAM (profiles/r04_tool_probe.txt; code removed in round 5): pieces read with pread into pinned buffers of the copier threads, 12.5 GB/s with four threads,
 	// 24 GB/s with eight, against 37 GB/s through the mapping; dropping a sent piece's entries with madvise(MADV_DONTNEED) made the job ten times slower (the
 	// address-space lock against the other copiers' faults). The mapping stays.
-	const int fd = u->fd; size_t pmax = 0; for (const auto& P : u->sp) pmax = std::max(pmax, P.bytes);
-	const char* em = getenv("NGSQC_H2D_PREAD"); const bool from_map = fd < 0 || !(em && atoi(em) != 0);
 	// NGSQC_H2D_REGISTER=1 (round 5, measured in profiles/r05_tool_probe.txt): a piece of the mapping is registered with the driver (hipHostRegister, read only) just
 	// before it is sent, so that the DMA engines read the page cache's pages themselves instead of the runtime staging them through its own pinned buffers
-	const char* er = getenv("NGSQC_H2D_REGISTER"); const bool reg = from_map && er && atoi(er) != 0;
+	const char* er = getenv("NGSQC_H2D_REGISTER"); const bool reg = er && atoi(er) != 0;
 	u->pass_running = true;
 	for (int t = 0; t < T; ++t)
-		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, fd, pmax, from_map, reg] {
-			hipStream_t st = nullptr; uint8_t* pin[2] = {nullptr, nullptr}; hipEvent_t pev[2] = {nullptr, nullptr}; long last = -1;
+		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, reg] {
+			hipStream_t st = nullptr; hipEvent_t pev[2] = {nullptr, nullptr}; long last = -1;
 			void* reg_ptr[2] = {nullptr, nullptr};
 			auto drop_last = [&]() { last = -1; };
 			try
 			{
 				HIPCHK(hipSetDevice(device));
 				HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-				if (!from_map) for (int k = 0; k < 2; ++k) { HIPCHK(hipHostMalloc((void**)&pin[k], pmax, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&pev[k], hipEventDisableTiming)); }
 				for (int k = 0;; k ^= 1)
 				{
 					const size_t i = u->next.fetch_add(1);
 					if (i >= u->sp.size() || u->cancel) break;
 					const ngsqc_handle::Upload::SPiece& P = u->sp[i];
 					drop_last();
-					if (!from_map)
-					{
-						HIPCHK(hipEventSynchronize(pev[k]));   // the last DMA out of this buffer is done (an unrecorded event is complete)
-						size_t got = 0;
-						while (got < P.bytes) { const ssize_t r = pread(fd, pin[k] + got, P.bytes - got, (off_t)(P.src + got)); if (r <= 0) throw std::runtime_error("could not read the BAM file"); got += (size_t)r; }
-					}
 					if (P.chunk >= slots)
 					{
 						// the slot still holds chunk P.chunk - slots: wait until its phase 2 (the last reader of the compressed bytes) has been enqueued, then until it is done
@@ -690,9 +681,9 @@ void stream_pass_begin(ngsqc_handle* h)
 						if (hipHostRegister((void*)a0, (size_t)(a1 - a0), hipHostRegisterReadOnly) == hipSuccess) reg_ptr[k] = (void*)a0;
 						else (void)hipGetLastError();   // (not registrable: the piece goes through the runtime's staging like any pageable source)
 					}
-					HIPCHK(hipMemcpyAsync(dst + P.dst, from_map ? u->src_base + P.src : pin[k], P.bytes, hipMemcpyHostToDevice, st));
+					HIPCHK(hipMemcpyAsync(dst + P.dst, u->src_base + P.src, P.bytes, hipMemcpyHostToDevice, st));
 					HIPCHK(hipEventRecord(u->ev[i], st));
-					if (!from_map || reg) HIPCHK(hipEventRecord(pev[k], st));
+					if (reg) HIPCHK(hipEventRecord(pev[k], st));
 					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
 					u->cv.notify_all();
 					last = (long)i;
@@ -701,7 +692,7 @@ void stream_pass_begin(ngsqc_handle* h)
 				drop_last();
 			}
 			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); }
-			for (int k = 0; k < 2; ++k) { if (reg_ptr[k]) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(reg_ptr[k]); } if (pin[k]) (void)hipHostFree(pin[k]); if (pev[k]) (void)hipEventDestroy(pev[k]); }
+			for (int k = 0; k < 2; ++k) { if (reg_ptr[k]) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(reg_ptr[k]); } if (pev[k]) (void)hipEventDestroy(pev[k]); }
 			if (st) (void)hipStreamDestroy(st);
 			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
 			u->cv.notify_all();
@@ -829,7 +820,7 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	h->planned = true;
 	if (nb == 0) return;
 	int64_t div = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_DIV")) div = std::max<int64_t>(1, atoll(e));
-	int64_t mul = 1; if (const char* e = getenv("NGSQC_K1_CHUNK_MUL")) mul = std::max<int64_t>(1, atoll(e));   // chunk = mul decoder rounds (lanes pull several members from the queue)
+	const int64_t mul = 1;
 	// A streamed image is bound by PCIe (60 GB in 1.2 s against 0.57 s of K1), and what a one-shot tool waits for besides the copy is the ALLOCATION of the stream's
 	// buffers (28 GB/s when another process has just given the memory back): half-size chunks and one chunk per tile cut the ring, the token pool and the tile
 	// buffers from 65 GB to 23 GB for the 30x file; the job stays behind the copy
@@ -839,8 +830,8 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	// 930 | 0.46. The job barely cares; the chain walk of the fused scan has one thread per MEMBER, so a tile of 195 k members keeps twice the lines in flight of a 97 k one.
 	int64_t cpt = h->stream_img ? 1 : 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
-	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile). NGSQC_TILE_BUFFERS=2..4.
-	h->nbuf = 3; if (const char* e = getenv("NGSQC_TILE_BUFFERS")) h->nbuf = std::min<int>(ngsqc_handle::MAX_TILE_BUFS, std::max(2, atoi(e)));
+	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile).
+	h->nbuf = 3;
 	bool forced = false;
 	if (const char* e = getenv("NGSQC_TILE_MEMBERS")) { h->chunk = std::max<int64_t>(1, atoll(e)); cpt = 1; forced = true; }
 	else
@@ -964,27 +955,24 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 {
 	const int64_t nb = (int64_t)h->blocks.size();
 	uint8_t* out_base = h->buf[t % h->nbuf].p + h->pfx;
-	const char* se = getenv("NGSQC_K1_SORTED"); const bool sorted_queue = !se || atoi(se) != 0;
-	// CRC of a chunk on its own stream behind the chunk's phase 2, beside phase 2 of the next chunk (NGSQC_CRC_STREAM=0: in line on the phase-2
-	// stream). With the round-3 kernels (2.4 KB LDS and 37 VGPRs per phase-2 wave) the two no longer compete for a CU's LDS: K1 of a
+	// CRC of a chunk on its own stream behind the chunk's phase 2, beside phase 2 of the next chunk. With the round-3 kernels (2.4 KB LDS and 37 VGPRs per phase-2 wave) the two no longer compete for a CU's LDS: K1 of a
 	// 96 M-read shard 100 -> 88 ms.
-	const char* e1s = getenv("NGSQC_P1_STREAMS"); const bool one_p1_stream = e1s && atoi(e1s) == 1;
 	const char* eks = getenv("NGSQC_K1_SERIAL"); const bool k1_serial = eks && atoi(eks) != 0;   // profiling: every K1 kernel in line on ONE stream (isolated per-kernel counters)   // 1: the next chunk's phase 1 starts when the whole previous launch is done
-	const char* ce = getenv("NGSQC_CRC_STREAM"); hipStream_t crc_stream = (!ce || atoi(ce) != 0) ? h->s_crc : h->s_p2;
+	hipStream_t crc_stream = h->s_crc;
 	// (A "phased" schedule - a tile's decoder launches together, then its phase-2 launches alone - was measured in round 4: 876 against 896 Mreads/s on a 96 M-read
 	// shard, profiles/r04_probe_schedule.txt; removed.)
 	const int64_t cA = h->tile_first_chunk[(size_t)t], cB = h->tile_first_chunk[(size_t)t + 1];
 	auto launch_p1 = [&](int64_t c) {
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
-		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[one_p1_stream ? 0 : (c & 1)];
+		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[c & 1];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
 		if (h->stream_img) stream_wait_chunk(h, c, s1);
-		else if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (one_p1_stream ? 0 : (int)(c & 1))); }
+		else if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (int)(c & 1)); }
 		HIPCHK(hipEventRecord(e4[0], s1));
 		uint32_t* const pool = h->d_tok.p + (size_t)(c % h->k1_slots) * (size_t)h->slot_pages * K1_PAGE_WORDS;   // the chunk's slot of the token pool ring
 		launch_huff_tokens(h->d_comp.p, h->d_kdesc.p + c0, cn, h->d_status.p + c0, pool, (uint32_t)h->slot_pages, h->d_pool_ctr.p + c, h->d_tok_first.p + c0, h->d_tok_cnt.p + c0, h->d_work.p + c,
-		                   sorted_queue ? h->d_order.p + c0 : nullptr, h->p1_wgs, s1);
+		                   h->d_order.p + c0, h->p1_wgs, s1);
 		HIPCHK(hipEventRecord(e4[1], s1));
 	};
 	auto launch_p2 = [&](int64_t c) {
@@ -1091,14 +1079,15 @@ void index_tile(ngsqc_handle* h, int t)
 	// a shard behind the file header does not know where its first record starts: every member is guessed and the first
 	// plausible start anchors the chain (checked against the previous shard's chain exit by ngsqc_plan_shard_fix)
 	// (with slack: a later tile has one entry more - its carried prefix - and regrowing means hipFree, which waits for all queued K1 work)
-	h->d_start.ensure_slack((size_t)ne); h->d_cnt.ensure_slack((size_t)ne + 1); h->d_next.ensure_slack((size_t)ne + 1); h->d_base.ensure_slack((size_t)ne + 1); h->d_bad.ensure(4);   // d_bad: {corrupt records, chain violations} + the offset of a record cut by the tile end (int64, -1: none)
-	h->d_scan_tmp.ensure_slack(scan_tmp_bytes(ne) + 64); h->d_rel.ensure_slack((size_t)(ne0 + 1) * K2_REL_STRIDE + 64);
+	const size_t ne_max = (size_t)std::max(ne, ne0);   // (the general path below works on whole members whatever the fast path's entries were)
+	h->d_start.ensure_slack(ne_max); h->d_cnt.ensure_slack(ne_max + 1); h->d_next.ensure_slack(ne_max + 1); h->d_base.ensure_slack(ne_max + 1); h->d_bad.ensure(4);   // d_bad: {corrupt records, chain violations} + the offset of a record cut by the tile end (int64, -1: none)
+	h->d_scan_tmp.ensure_slack(scan_tmp_bytes((int64_t)ne_max) + 64); h->d_rel.ensure_slack((size_t)(ne0 + 1) * K2_REL_STRIDE + 64);
 	int64_t from = 0; int rounds = 0; int64_t straddle = -1; bool found_start = !anchor_by_guess; int64_t chain_exit = total;
 	const bool tail_may_cut_a_record = h->shard_own_members >= 0 && h->shard + 1 < h->n_shards;   // the members behind a shard end anywhere
 	// ---- fast path: one round trip. Guess the first record of every entry, walk every entry's chain, check on the device that every walker's exit is the
 	// next walker's start (index_chain_kernel: exact), scan the counts; the host reads back {violations, corrupt records, n_rec} only. An htslib-written
 	// file passes (a record starts at every member's first byte, none straddles members or tiles) ----
-	const bool assume0 = !anchor_by_guess && !h->k2_plain && !h->long_reads && !getenv("NGSQC_K2_GUESS_ALL");   // (a file that has looked like an htslib file so far: its members start with a record)
+	const bool assume0 = !anchor_by_guess && !h->k2_plain && !h->long_reads;   // (a file that has looked like an htslib file so far: its members start with a record)
 	launch_index_init(d_desc, ne, prefix, ksh, nm, exp0, anchor_by_guess, assume0, h->d_start.p, h->stream);
 	HIPCHK(hipMemsetAsync(h->d_bad.p, 0, 2 * sizeof(uint32_t), h->stream)); HIPCHK(hipMemsetAsync(h->d_bad.p + 2, 0xff, sizeof(long long), h->stream));
 	h->fused_tile = -1;

@@ -84,7 +84,7 @@ int cram_to_bam_image(const uint8_t* d, size_t n, const std::string& path, ByteI
 // decodes the plan's blocks on the device and writes the qualities into the BAM image (stored BGZF members of 65 280 bytes, as bgzf_store lays them out) at d_image; returns the kernel time in ms
 double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, uint8_t* d_image, size_t image_bytes, hipStream_t s);
 
-void k1_read_switches();   // NGSQC_P1_PARK, NGSQC_P1_LDS_PAD, NGSQC_P2_LDS_PAD, NGSQC_P2_WGS (read when a handle is opened)
+void k1_read_switches();   // NGSQC_P1_PARK (read when a handle is opened)
 
 // CRC32 of every inflated member against its BGZF trailer (crc.hip); a mismatch sets status.error = K1_ERR_CRC
 void launch_crc32(const BlockDesc* d_blocks, int64_t n_blocks, const uint8_t* d_out, const uint32_t* d_expected, BlockStatus* d_status, hipStream_t s);

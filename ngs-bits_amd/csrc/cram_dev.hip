@@ -9,62 +9,15 @@
 
 namespace ngsqc {
 namespace {
-__global__ __launch_bounds__(64) void cram_rans_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
-                                                       const uint8_t* __restrict__ syms, uint8_t* __restrict__ out, unsigned int* __restrict__ status)
-{
-	const int j = (int)(blockIdx.x * 64 + threadIdx.x);
-	if (j >= n_jobs) return;
-	const CramQualPlan::Job jb = jobs[j];
-	const uint8_t* p = in + jb.in_off; const uint8_t* const end = p + jb.in_len;
-	const uint8_t* const sym = syms + jb.sym_off; const uint8_t* const lut = sym + 64;
-	const uint16_t* const T = tabs + jb.tab_off; const int ns = (int)jb.nsym, row = ns + 1;
-	uint8_t* const o = out + jb.out_off; const uint32_t n = jb.n_out;
-	if (jb.in_len < 16 || ns < 1 || ns > 64) { atomicOr(status, 1u); return; }
-	uint32_t R[4];
-	#pragma unroll
-	for (int k = 0; k < 4; ++k) { R[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); p += 4; }
-	bool bad = false;
-	// one symbol of state x with the cumulative row C: its index; the state is advanced and renormalised from the shared byte stream
-	auto step = [&](uint32_t& x, const uint16_t* C) -> int {
-		const uint32_t m = x & 0xfffu; int k = 0;
-		while (k + 1 < ns && (uint32_t)C[k + 1] <= m) ++k;
-		const uint32_t c0 = C[k], f = (uint32_t)C[k + 1] - c0;
-		if (f == 0 || m < c0 || m >= (uint32_t)C[k + 1]) { bad = true; return 0; }
-		uint32_t v = f * (x >> 12) + m - c0;
-		while (v < (1u << 23)) { if (p >= end) { bad = true; break; } v = (v << 8) | *p++; }
-		x = v;
-		return k;
-	};
-	if (jb.order == 0)
-	{
-		for (uint32_t i = 0; i < n && !bad; i += 4)
-		{
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) if (i + (uint32_t)k < n && !bad) o[i + (uint32_t)k] = sym[step(R[k], T)];
-		}
-	}
-	else
-	{
-		const uint32_t q = n >> 2; uint32_t idx[4] = {0, q, 2 * q, 3 * q};
-		const int k0 = lut[0]; int pk[4] = {k0, k0, k0, k0};
-		if (k0 >= ns) bad = true;
-		for (uint32_t i = 0; i < q && !bad; ++i)
-		{
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) if (!bad) { const int s = step(R[k], T + pk[k] * row); o[idx[k]++] = sym[s]; pk[k] = s; }
-		}
-		while (idx[3] < n && !bad) { const int s = step(R[3], T + pk[3] * row); o[idx[3]++] = sym[s]; pk[3] = s; }
-	}
-	if (bad) atomicOr(status, 2u);
-}
-
-// The same with the job's tables in LDS (a search step is an LDS read instead of a dependent global load: the first kernel spent ~5 us per symbol on those) and one
-// WORKGROUP per block. LANES = 1: lane 0 decodes as above. LANES = 4: the four rANS states live in four lanes - every round each lane decodes the symbol of its state,
+// One WORKGROUP per block, the job's tables in LDS (a search step is an LDS read, not a dependent global load). The four rANS states live in four lanes - every round
+// each lane decodes the symbol of its state,
 // the lanes count the bytes their renormalisation takes (0, 1 or 2), a prefix over the four lanes gives each its place in the shared byte stream (the order the
 // sequential decoder reads them in: state 0 first), and the stream pointer moves on by the sum. Order 1 writes four quarters of the output, one per lane; what is left
 // behind the quarters belongs to state 3 alone.
-// BISECT: the symbol of a state by bisection over the cumulative row (6 LDS reads for 64 symbols) instead of the scan from the front (these files have ~40 qualities).
-template <int LANES, bool BISECT> __global__ __launch_bounds__(64) void cram_rans_lds_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
+// The symbol of a state by bisection over the cumulative row (6 LDS reads for 64 symbols). (Round 4 went through four versions - one lane per block with the
+// tables in global memory, one lane with the tables in LDS, four lanes with a scan from the front: 800 -> 480 -> 150 -> 38 ms for the test twin's largest block,
+// profiles/r04_cram_device_quals.txt; only the last one is kept.)
+__global__ __launch_bounds__(64) void cram_rans_lds_kernel(const uint8_t* __restrict__ in, const CramQualPlan::Job* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ tabs,
                                                                              const uint8_t* __restrict__ syms, uint8_t* __restrict__ out, unsigned int* __restrict__ status)
 {
 	__shared__ uint16_t sC[65 * 64]; __shared__ uint8_t sSym[64]; __shared__ int sK0;
@@ -77,51 +30,20 @@ template <int LANES, bool BISECT> __global__ __launch_bounds__(64) void cram_ran
 	if (lane < ns) sSym[lane] = syms[jb.sym_off + lane];
 	if (lane == 0) sK0 = syms[jb.sym_off + 64];   // the row of context 0
 	__syncthreads();
-	if (lane >= LANES) return;
+	if (lane >= 4) return;
 	const uint8_t* p = in + jb.in_off; const uint8_t* const end = p + jb.in_len;
 	uint8_t* const o = out + jb.out_off; const uint32_t n = jb.n_out;
 	bool bad = false;
 	auto sym_of = [&](uint32_t x, const uint16_t* C, uint32_t& v) -> int {   // the symbol index of state x in row C; v: the state behind it, before renormalisation
 		const uint32_t m = x & 0xfffu; int k = 0;
-		if (BISECT)
-		{
-			// the LAST k with C[k] <= m: behind it C[k + 1] > m, so that symbol has a frequency (symbols without one repeat the value of their successor)
-			int hi = ns;
-			while (hi - k > 1) { const int mid = (k + hi) >> 1; if ((uint32_t)C[mid] <= m) k = mid; else hi = mid; }
-		}
-		else while (k + 1 < ns && (uint32_t)C[k + 1] <= m) ++k;
+		// the LAST k with C[k] <= m: behind it C[k + 1] > m, so that symbol has a frequency (symbols without one repeat the value of their successor)
+		int hi = ns;
+		while (hi - k > 1) { const int mid = (k + hi) >> 1; if ((uint32_t)C[mid] <= m) k = mid; else hi = mid; }
 		const uint32_t c0 = C[k], f = (uint32_t)C[k + 1] - c0;
 		if (f == 0 || m < c0 || m >= (uint32_t)C[k + 1]) { bad = true; v = x; return 0; }
 		v = f * (x >> 12) + m - c0;
 		return k;
 	};
-	if (LANES == 1)
-	{
-		uint32_t R[4];
-		#pragma unroll
-		for (int k = 0; k < 4; ++k) { R[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); p += 4; }
-		auto renorm = [&](uint32_t v) { while (v < (1u << 23)) { if (p >= end) { bad = true; break; } v = (v << 8) | *p++; } return v; };
-		if (jb.order == 0)
-		{
-			for (uint32_t i = 0; i < n && !bad; i += 4)
-			{
-				#pragma unroll
-				for (int k = 0; k < 4; ++k) if (i + (uint32_t)k < n && !bad) { uint32_t v; const int s = sym_of(R[k], sC, v); R[k] = renorm(v); o[i + (uint32_t)k] = sSym[s]; }
-			}
-		}
-		else
-		{
-			const uint32_t q = n >> 2; uint32_t idx[4] = {0, q, 2 * q, 3 * q}; const int k0 = sK0; int pk[4] = {k0, k0, k0, k0};
-			if (k0 >= ns) bad = true;
-			for (uint32_t i = 0; i < q && !bad; ++i)
-			{
-				#pragma unroll
-				for (int k = 0; k < 4; ++k) if (!bad) { uint32_t v; const int s = sym_of(R[k], sC + pk[k] * row, v); R[k] = renorm(v); o[idx[k]++] = sSym[s]; pk[k] = s; }
-			}
-			while (idx[3] < n && !bad) { uint32_t v; const int s = sym_of(R[3], sC + pk[3] * row, v); R[3] = renorm(v); o[idx[3]++] = sSym[s]; pk[3] = s; }
-		}
-	}
-	else
 	{
 		uint32_t x = (uint32_t)p[4 * lane] | ((uint32_t)p[4 * lane + 1] << 8) | ((uint32_t)p[4 * lane + 2] << 16) | ((uint32_t)p[4 * lane + 3] << 24);
 		p += 16;   // (every lane tracks the shared stream pointer)
@@ -208,11 +130,7 @@ double cram_device_quals(const uint8_t* cram_image, const CramQualPlan& plan, ui
 	unsigned int* d_status = nullptr; HIPCHK(hipMalloc((void**)&d_status, sizeof(unsigned int))); HIPCHK(hipMemsetAsync(d_status, 0, sizeof(unsigned int), s));
 	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 	HIPCHK(hipEventRecord(e0, s));
-	int kind = 5; if (const char* e = getenv("NGSQC_CRAM_RANS_KERNEL")) kind = atoi(e);   // 5 (default): states in four lanes, tables in LDS, symbol by bisection; 4: the same with a scan from the front; 1: one lane, tables in LDS; 0: one lane per block, tables in global memory
-	if (kind == 5) hipLaunchKernelGGL((cram_rans_lds_kernel<4, true>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);   // 5: as 4, the symbol by bisection
-	else if (kind == 4) hipLaunchKernelGGL((cram_rans_lds_kernel<4, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
-	else if (kind == 1) hipLaunchKernelGGL((cram_rans_lds_kernel<1, false>), dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
-	else hipLaunchKernelGGL(cram_rans_kernel, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
+	hipLaunchKernelGGL(cram_rans_lds_kernel, dim3((unsigned)jobs.size()), dim3(64), 0, s, d_in, d_jobs, (int)jobs.size(), d_tabs, d_syms, d_out, d_status);
 	KCHECK();
 	if (!plan.patches.empty())
 	{

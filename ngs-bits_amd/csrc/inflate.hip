@@ -7,16 +7,14 @@
 
 namespace ngsqc {
 
-// measurement switches of the K1 launches, read when a handle is opened (not per launch)
-static struct { int park_hi = 32, p1_pad = 0, p2_pad = 0, p1_prio = 0; int64_t p2_cap = (int64_t)1 << 20; } g_sw;
+// NGSQC_P1_PARK (tests: the slow section entered by few / many waiting lanes), read when a handle is opened. (Round 5: the other schedule switches of rounds 3-4 -
+// decoder priority, LDS padding of either phase, a capped phase-2 grid - all measured within +-2 % of the defaults, profiles/r04_probe_schedule.txt - are gone.)
+static struct { int park_hi = 32, p1_occ = 4; } g_sw;
 void k1_read_switches()
 {
 	const char* e;
 	g_sw.park_hi = (e = getenv("NGSQC_P1_PARK")) ? atoi(e) : 32;                       // lanes that wait for the slow section before the wave enters it
-	g_sw.p1_prio = (e = getenv("NGSQC_P1_PRIO")) ? std::min(3, std::max(0, atoi(e))) : 0;   // s_setprio of the decoder waves
-	g_sw.p1_pad = (e = getenv("NGSQC_P1_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per decoder workgroup = fewer decoder waves per CU
-	g_sw.p2_pad = (e = getenv("NGSQC_P2_LDS_PAD")) ? std::max(0, atoi(e)) : 0;           // extra LDS per phase-2 workgroup = fewer phase-2 waves beside the decoder waves
-	g_sw.p2_cap = (e = getenv("NGSQC_P2_WGS")) ? std::max<int64_t>(1, atoll(e)) : (int64_t)1 << 20;   // caps the phase-2 grid: the waves then stride over the members
+	g_sw.p1_occ = (e = getenv("NGSQC_P1_OCC")) ? atoi(e) : 4;                          // register budget of the decoder: 4 waves per SIMD (128 VGPRs, 156 bytes of scratch) or 3 (166 VGPRs, none); a CU holds 12 decoder waves either way
 }
 
 void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_t n_blocks, BlockStatus* d_status,
@@ -27,7 +25,8 @@ void launch_huff_tokens(const uint8_t* d_comp, const BlockDesc* d_blocks, int64_
 	// d_work: the launch's member queue head, d_pool_ctr: pages taken from the launch's token pool (both zeroed by the caller). One-wave workgroups.
 	const int64_t wgs = (n_blocks + 63) / 64;
 	const int grid1 = (int)(wgs < max_wgs ? wgs : max_wgs);
-	hipLaunchKernelGGL(k1::huff_tokens_kernel, dim3(grid1), dim3(64), g_sw.p1_pad, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, (g_sw.park_hi & 255) | (g_sw.p1_prio << 8));
+	if (g_sw.p1_occ == 3) hipLaunchKernelGGL(k1::huff_tokens_kernel<3>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, g_sw.park_hi & 255);
+	else hipLaunchKernelGGL(k1::huff_tokens_kernel<4>, dim3(grid1), dim3(64), 0, s, d_comp, d_blocks, n_blocks, d_pool, pool_pages, d_pool_ctr, d_tok_first, d_tok_count, d_status, d_work, d_order, g_sw.park_hi & 255);
 	KCHECK();
 }
 
@@ -35,9 +34,9 @@ void launch_lz77_resolve(const BlockDesc* d_blocks, int64_t n_blocks, uint8_t* d
                          const uint32_t* d_pool, const uint32_t* d_tok_first, const uint32_t* d_tok_count, const uint8_t* d_comp, hipStream_t s)
 {
 	if (n_blocks <= 0) return;
-	// one member per one-wave workgroup, handed out by the dispatcher (NGSQC_P2_WGS caps the grid: the waves then stride over the members)
-	const int grid2 = (int)(n_blocks < g_sw.p2_cap ? n_blocks : g_sw.p2_cap);
-	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), g_sw.p2_pad, s, d_pool, d_tok_first, d_tok_count, d_blocks, n_blocks, d_out, d_status, d_comp); KCHECK();
+	// one member per one-wave workgroup, handed out by the dispatcher (the waves stride over the members of a grid that is capped)
+	const int grid2 = (int)std::min<int64_t>(n_blocks, (int64_t)1 << 20);
+	hipLaunchKernelGGL(k1::lz77_groups_kernel, dim3(grid2), dim3(64), 0, s, d_pool, d_tok_first, d_tok_count, d_blocks, n_blocks, d_out, d_status, d_comp); KCHECK();
 }
 
 } // namespace ngsqc

@@ -120,7 +120,7 @@ struct CodeShape
 	K1_DEV bool ok() const { return !over && (left == 0 || lmax <= 1); }
 };
 
-K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+template <int OCC = P1_WAVES_PER_SIMD> K1_KERNEL_OCC(64, OCC) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                       uint32_t* __restrict__ pool, uint32_t pool_pages, uint32_t* __restrict__ pool_ctr,
                                       uint32_t* __restrict__ tok_first, uint32_t* __restrict__ tok_count,
                                       BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)

@@ -33,6 +33,7 @@ struct Acc
 	// region-table and site-table loads out of the common record.
 	int rc_tid = -2, rc_lo = 0, rc_hi = 0, rc_idx = 0, rc_last = 0, rc_start = 0;
 	int pc_tid = -2, pc_lo = 0, pc_next = 0;
+	int ns_tid = -2; bool ns_val = false;   // tid_nonspecial[ns_tid] (round 5: one dependent load per record less - a walker changes reference a few times per file)
 };
 
 struct RecView
@@ -304,7 +305,8 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		}
 		else
 		{
-			if (tid_ok && p.tid_nonspecial[r.tid])
+			if (tid_ok && a.ns_tid != r.tid) { a.ns_tid = r.tid; a.ns_val = p.tid_nonspecial[r.tid] != 0; }
+			if (tid_ok && a.ns_val)
 			{
 				a.n[A_ONTARGET]++;
 				if (!dup && (int)r.mapq >= p.min_mapq) a.v[A_USABLE] += length; // "no overlap" share is resolved with first_paired_idx afterwards
@@ -359,12 +361,23 @@ __device__ static void flush(const ScanParams& p, Acc& a, uint32_t* lds_hist)
 // CIGAR sums of a short record + classify; false: the record goes to the wave-per-record kernel (long CIGAR, possible CG:B,I tag).
 // The first four operations come with ONE 16-byte load (97 % of the short reads of a WGS have at most three; the bytes behind a shorter CIGAR are the
 // record's own sequence, and the tile buffers end with 64 spare bytes): the walk waits for one round trip instead of one per operation.
+// The first four CIGAR operations of a record whose fields fit, WITHOUT a branch: a divergent if / else around the loads made the compiler wait for them at the
+// join (s_waitcnt vmcnt(0) in front of the next record's header request). Operation 0 is a 4-byte load; operations 1-3 a 12-byte load whose address, for a
+// record of one operation (93 % of a WGS), is the record's own header - bytes that are in the cache already - instead of 12 more bytes that cross into the next
+// 64-byte sector four times as often as the first four.
+__device__ __forceinline__ void load_cigar4(const RecView& r, uint32_t (&c4)[4])
+{
+	const bool any = r.n_cigar_raw >= 1 && r.n_cigar_raw <= (uint32_t)LONG_CIGAR, many = any && r.n_cigar_raw > 1;
+	const uint8_t* p0 = any ? r.cigar : r.core; const uint8_t* p1 = many ? r.cigar + 4 : r.core;
+	uint32_t a = ld32(p0), b[3]; __builtin_memcpy(b, p1, 12);
+	c4[0] = any ? a : 0u; c4[1] = many ? b[0] : 0u; c4[2] = many ? b[1] : 0u; c4[3] = many ? b[2] : 0u;
+}
 template <int MODE>
-__device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist, long long* ref_len_out = nullptr)
+__device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, long long ord, Acc& a, uint32_t* lds_hist, long long* ref_len_out = nullptr, const uint32_t* c4_in = nullptr)
 {
 	if (r.n_cigar_raw > (uint32_t)LONG_CIGAR) return false;
-	uint32_t c4[4] = {0u, 0u, 0u, 0u};
-	if (r.n_cigar_raw > 0) __builtin_memcpy(c4, r.cigar, 16);
+	uint32_t c4[4];
+	if (c4_in) { c4[0] = c4_in[0]; c4[1] = c4_in[1]; c4[2] = c4_in[2]; c4[3] = c4_in[3]; } else load_cigar4(r, c4);
 	if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0 && (c4[0] & 15u) == 4 && (int32_t)(c4[0] >> 4) == r.l_seq) return false;   // possible CG:B,I long CIGAR (htslib bam_tag2cigar)
 	long long ref_len = 0, clip = 0; bool spliced = false;
 	#pragma unroll
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 			uint64_t pk_lo = 0, pk_hi = 0;                           // the last eight offsets, oldest in the low bits
 			int64_t o = lo + s; uint32_t n = 0; int64_t res = 0; bool stop = false;
 			Hdr nx; nx.bs = 0; nx.tid = nx.pos = nx.w = nx.w2 = nx.l_seq = nx.isize = 0;
-			if (o < hi) { if (o + 36 <= p.total) nx = load_hdr(p.infl + o); else if (o + 4 <= p.total) nx.bs = ld32(p.infl + o); }
+			if (o < hi) nx = load_hdr(p.infl + o);
 			while (o < hi)
 			{
 				const uint32_t bs = nx.bs;
@@ -589,8 +602,15 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 				if (o + 4 + (int64_t)bs > p.total) { res = -(o + 10); stop = true; break; }
 				const int64_t o_next = o + 4 + (int64_t)bs;
 				RecView r = make_rec(p.infl, o, nx);   // (bs >= 32 and the record ends inside the tile: all 36 bytes were loaded)
-				if (o_next < hi) { if (o_next + 36 <= p.total) nx = load_hdr(p.infl + o_next); else { nx.bs = o_next + 4 <= p.total ? ld32(p.infl + o_next) : 0u; } }
 				if (!record_fields_fit(r.l_name, r.n_cigar_raw, r.l_seq, r.bs)) { res = -2; stop = true; break; }
+				// this record's CIGAR is requested BEFORE the next record's header: loads return in order as far as s_waitcnt vmcnt can tell, so the other way round
+				// the wait for the CIGAR (a line that is mostly here already) was a wait for the next header too - an HBM miss per record that nothing overlapped
+				uint32_t c4[4]; load_cigar4(r, c4);
+				// (unconditional - the last record of the entry asks for its own header again - so that the compiler knows three loads follow the CIGAR's and waits for the
+				// CIGAR with s_waitcnt vmcnt(3). o_next < total: the 36 bytes lie inside the tile buffer, which ends with 64 spare bytes; what lies behind total is never used)
+				__builtin_amdgcn_sched_barrier(0);   // (the scheduler must not move the header's loads in front of the CIGAR's: see above)
+				nx = load_hdr(p.infl + (o_next < hi ? o_next : o));
+				__builtin_amdgcn_sched_barrier(0);
 				if (n >= (1u << NAME_SHIFT) - 1u) { res = -3; stop = true; break; }   // more records than a name holds (a group of members of a short-read file): not for this path
 				if (n < stride)
 				{
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 				{
 					const long long name = (long long)((b << NAME_SHIFT) | (int64_t)n);
 					long long ref_len = 0;
-					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len);
+					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len, c4);
 					if (!scanned && p.sgn > 0)
 					{
 						unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
@@ -707,7 +727,7 @@ __global__ __launch_bounds__(256) void prefix_fix_kernel(const ScanParams p, lon
 static int scan_grid(long long n, int per_wg)
 {
 	long long wgs = (n + per_wg - 1) / per_wg;
-	long long cap = per_wg == 4 ? 256 * 64 : 256 * 8;   // (a wave per long record: the records of a tile at once - their CIGAR loads are what hides each other's latency)
+	long long cap = 256 * 8;   // (more workgroups were tried for the wave-per-record kernels in round 5: every wave ends with atomics on the same counters - 150 k waves took 1.5 ms longer than 8 k)
 	return (int)(wgs < 1 ? 1 : (wgs < cap ? wgs : cap));
 }
 

@@ -65,11 +65,12 @@ def test_long_reads_cg_tag(tmp_path, monkeypatch, long_mode):
         for tm_ in (None, "5", "40"):
             if tm_: monkeypatch.setenv("NGSQC_TILE_MEMBERS", tm_)
             h = ngsqc.Handle(path=p)
-            regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs); sites = H.known_sites(h.refs)
+            regs, _ = H.bed_regions(OMIM, h.refs, 3); tx, ty = H.xy_tids(h.refs); sites = [(0, p_) for p_ in range(15_900_500, 17_500_000, 4999)]
             out = h.run_job(mapping=dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs)), sites=sites, site_params=(1, 13, True))
             exp = O.mapping(ob, ngsqc.MODE_WGS, OMIM, merge_bed=False)
             assert all(int(out["counters"][i]) == int(exp.counters[i]) for i in range(len(exp.counters)) if i not in SKIP)
-            assert np.array_equal(out["site_counts"][:, :6], O.site_pileup(ob, sites, 1, 13, True))
+            exp_sites = O.site_pileup(ob, sites, 1, 13, True)
+            assert np.array_equal(out["site_counts"][:, :6], exp_sites) and int(exp_sites.sum()) > 100
             t = h.timings()
             assert t["tiles_chain_on_device"] >= t["n_tiles"] - 1 and t["walkers_per_member"] == -16, t   # (a tile may fall back when a guess inside a long record was wrong: exact either way)
             h.close()
