@@ -563,7 +563,7 @@ def main():
                        "parallelism": (f"one BAM sharded over {world} GPU(s) by BGZF member range, 1 process/GPU; all-gather of shard summaries, "
                                        "SUM all-reduce of counters and of the int32 difference array (RCCL)") if args.single_bam
                                       else f"{world} BAM(s), one per GPU, 1 process/GPU, RCCL all-reduce of the counter vectors"},
-            "roofline": {"kernel": dom[0], "bound": "hbm", "limited_by": "instruction issue (VALU / LDS), not HBM: see profiles/r04_sq_counters.txt", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": dom[0], "bound": "hbm", "limited_by": "instruction issue (VALU / LDS), not HBM: see profiles/r05_sq_counters.txt", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(dom[1]),
                          "avg_launch_ms": round(dom[2], 4), "launches_per_step": k1_launches, "sum_launches_ms": round(dom[2] * k1_launches, 3),
                          "isolated": iso is not None,
@@ -603,7 +603,7 @@ def main():
             per = {}
             settings_ok = False
             want = "k1_format=r04-word-per-trip tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
-            for ln in open(os.path.join(ROOT, "profiles", "r04_hbm_traffic_pmc.txt")):
+            for ln in open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_pmc.txt")):
                 if ln.startswith("# settings: "):
                     settings_ok = want in ln   # (the per-member figures only describe launches of the same kernels under the same schedule)
                 if not settings_ok:
@@ -617,7 +617,7 @@ def main():
                 fb, wb = per[(kname, "FETCH_SIZE")] * members_per_launch, per[(kname, "WRITE_SIZE")] * members_per_launch
                 out["roofline"]["traffic"] = int(fb + wb)
                 out["roofline"]["traffic_pmc"] = {"fetch_bytes_raw": int(fb), "write_bytes_raw": int(wb), "members_per_launch": int(members_per_launch),
-                                                  "source": "profiles/r04_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
+                                                  "source": "profiles/r05_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
                                                   "ratio_to_algorithmic": round((fb + wb) / max(dom[1], 1), 2),
                                                   "note": "raw FETCH_SIZE / WRITE_SIZE x 1024 B (no x2: the K1 accesses are 16-byte pieces of 64 different member streams per "
                                                           "instruction, between the guide's narrow and wide regimes)"}
@@ -626,7 +626,7 @@ def main():
                 if keys:
                     tot = sum(per[k] for k in keys) * n_rec
                     out["roofline_scan"]["traffic"] = int(tot)
-                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r04_hbm_traffic_pmc.txt) x the records of the step; the "
+                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r05_hbm_traffic_pmc.txt) x the records of the step; the "
                                                             "kernels gather one or two 128-byte lines per record, so the guide's x2 for wide streams does not apply")
         except OSError:
             pass

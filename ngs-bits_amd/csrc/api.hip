@@ -645,20 +645,18 @@ void stream_pass_begin(ngsqc_handle* h)
 	// alternatives on a 19 GB BAM (profiles/r04_tool_probe.txt; code removed in round 5): pieces read with pread into pinned buffers of the copier threads, 12.5 GB/s with four threads,
 	// 24 GB/s with eight, against 37 GB/s through the mapping; dropping a sent piece's entries with madvise(MADV_DONTNEED) made the job ten times slower (the
 	// address-space lock against the other copiers' faults). The mapping stays.
-	// NGSQC_H2D_REGISTER=1 (round 5, measured in profiles/r05_tool_probe.txt): a piece of the mapping is registered with the driver (hipHostRegister, read only) just
-	// before it is sent, so that the DMA engines read the page cache's pages themselves instead of the runtime staging them through its own pinned buffers
-	const char* er = getenv("NGSQC_H2D_REGISTER"); const bool reg = er && atoi(er) != 0;
+	// (Round 5, profiles/r05_tool_probe.txt: registering each piece of the mapping with hipHostRegister(read only) just before it is sent - so that the DMA engines
+	// read the page cache's pages themselves - made the job of a 9.4 GB BAM 0.32 -> 1.40 s, eight copier threads instead of four 1.06 s: neither is kept.)
 	u->pass_running = true;
 	for (int t = 0; t < T; ++t)
-		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk, reg] {
-			hipStream_t st = nullptr; hipEvent_t pev[2] = {nullptr, nullptr}; long last = -1;
-			void* reg_ptr[2] = {nullptr, nullptr};
+		u->th.emplace_back([u, dst, device, delay_us, slots, ev_chunk] {
+			hipStream_t st = nullptr; long last = -1;
 			auto drop_last = [&]() { last = -1; };
 			try
 			{
 				HIPCHK(hipSetDevice(device));
 				HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-				for (int k = 0;; k ^= 1)
+				for (;;)
 				{
 					const size_t i = u->next.fetch_add(1);
 					if (i >= u->sp.size() || u->cancel) break;
@@ -673,17 +671,8 @@ void stream_pass_begin(ngsqc_handle* h)
 						HIPCHK(hipEventSynchronize(ev_chunk[4 * prev + 3]));
 					}
 					if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
-					if (reg)
-					{
-						if (!pev[k]) HIPCHK(hipEventCreateWithFlags(&pev[k], hipEventDisableTiming));
-						if (reg_ptr[k]) { HIPCHK(hipEventSynchronize(pev[k])); (void)hipHostUnregister(reg_ptr[k]); reg_ptr[k] = nullptr; }
-						const uintptr_t a0 = (uintptr_t)(u->src_base + P.src) & ~(uintptr_t)4095, a1 = ((uintptr_t)(u->src_base + P.src) + P.bytes + 4095) & ~(uintptr_t)4095;
-						if (hipHostRegister((void*)a0, (size_t)(a1 - a0), hipHostRegisterReadOnly) == hipSuccess) reg_ptr[k] = (void*)a0;
-						else (void)hipGetLastError();   // (not registrable: the piece goes through the runtime's staging like any pageable source)
-					}
 					HIPCHK(hipMemcpyAsync(dst + P.dst, u->src_base + P.src, P.bytes, hipMemcpyHostToDevice, st));
 					HIPCHK(hipEventRecord(u->ev[i], st));
-					if (reg) HIPCHK(hipEventRecord(pev[k], st));
 					{ std::lock_guard<std::mutex> g(u->mu); u->recorded[i] = 1; }
 					u->cv.notify_all();
 					last = (long)i;
@@ -692,7 +681,6 @@ void stream_pass_begin(ngsqc_handle* h)
 				drop_last();
 			}
 			catch (std::exception& e) { std::lock_guard<std::mutex> g(u->mu); if (u->err.empty()) u->err = e.what(); }
-			for (int k = 0; k < 2; ++k) { if (reg_ptr[k]) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(reg_ptr[k]); } if (pev[k]) (void)hipEventDestroy(pev[k]); }
 			if (st) (void)hipStreamDestroy(st);
 			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
 			u->cv.notify_all();

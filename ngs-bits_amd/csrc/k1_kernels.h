@@ -45,7 +45,7 @@ constexpr int P1_W_DSYM = 34;     // the distance symbols in code order, one byt
 constexpr int P1_LANE_W = 42;
 constexpr int P1_RING_SLOTS = 8;
 constexpr int P1_TRIPS = 4;             // trips between two service blocks = the four words of a token group (one word per trip)
-constexpr int P1_WAVES_PER_SIMD = 4;   // register budget of the decoder: 128 VGPRs
+constexpr int P1_WAVES_PER_SIMD = 4;   // register budget of the decoder: 128 VGPRs and 156 bytes of scratch (round 5 measured the budget of 3 - 166 VGPRs, no scratch - in the job: 45.9 against 46.1 ms per 48 M reads, no difference)
 constexpr int P1_TAB_W = 128;     // per workgroup: base | extra bits << 16 of the symbols 256..287 (words 0..31) and the distance symbols (words 32..63); the rest is padding (an index byte of a damaged stream may point behind the tables)
 constexpr int P1_LDS_W = P1_LANE_W * 64 + P1_TAB_W;   // 11 264 B per one-wave workgroup
 
@@ -120,7 +120,7 @@ struct CodeShape
 	K1_DEV bool ok() const { return !over && (left == 0 || lmax <= 1); }
 };
 
-template <int OCC = P1_WAVES_PER_SIMD> K1_KERNEL_OCC(64, OCC) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
+K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __restrict__ comp, const BlockDesc* __restrict__ blocks, int64_t n_blocks,
                                       uint32_t* __restrict__ pool, uint32_t pool_pages, uint32_t* __restrict__ pool_ctr,
                                       uint32_t* __restrict__ tok_first, uint32_t* __restrict__ tok_count,
                                       BlockStatus* __restrict__ status, unsigned long long* __restrict__ work_counter, const uint32_t* __restrict__ order, int park_hi)
