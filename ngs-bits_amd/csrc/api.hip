@@ -1390,7 +1390,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 // tile's records in front of that read (prefix_fix_kernel) - normally a handful of records of the first tile.
 struct ScanState : ngsqc_handle::FusedScan
 {
-	ScanParams sp{}; DevBuf<unsigned long long> d_counters;
+	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<uint32_t> d_fix;   // d_fix: scratch of the parallel order-dependent fix-up
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
 	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
 	// running state of the in-pass fix
@@ -1509,7 +1509,8 @@ struct ScanState : ngsqc_handle::FusedScan
 				unsigned long long* q = h->p_small.p;
 				q[12] = 0; q[13] = 0; q[14] = (unsigned long long)run_max; q[15] = 0;   // A_FIX_TRIM, A_FIX_LEN, A_FIX_CARRY, A_FIX_CNT
 				HIPCHK(hipMemcpyAsync(d_counters.p + A_FIX_TRIM, q + 12, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-				launch_prefix_fix(sp, lf, lp, nullptr, h->stream);
+				d_fix.ensure_slack(prefix_fix_scratch_words(std::max(lf, lp)) + 1);
+				launch_prefix_fix(sp, lf, lp, nullptr, h->stream, d_fix.p);
 				HIPCHK(hipMemcpyAsync(q + 8, d_counters.p + A_FIX_TRIM, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 				HIPCHK(hipMemcpyAsync(q + 9, d_counters.p + A_FIX_LEN, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 				HIPCHK(hipMemcpyAsync(q + 10, d_counters.p + A_FIX_CNT, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));

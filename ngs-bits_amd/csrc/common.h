@@ -152,7 +152,9 @@ void launch_scan(const ScanParams& p, hipStream_t s);
 void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
 void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
-void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s);
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s,
+                       uint32_t* d_scratch = nullptr /* prefix_fix_scratch_words(max(upto_max, upto_paired)) words: the parallel form; null: one workgroup */);
+size_t prefix_fix_scratch_words(int64_t upto);
 void launch_prefix_capture(const ScanParams& p, int64_t n, uint32_t* d_head, hipStream_t s);
 
 // site pileup (BamReader::getPileup SNP counts for a table of sites; counts = u32[n_sites][8])

@@ -10,6 +10,7 @@
 // Replaces the sequential record pull of BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-398).
 #include "common.h"
 #include "k2_guess.h"
+#include <algorithm>
 
 namespace ngsqc {
 
@@ -77,6 +78,62 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 			base += 256 * nwin;
 		}
 		if (lane == 0) start[b] = found;
+	}
+}
+
+// The same search for entries that may lie inside ONE long record (long reads, round 5): sixteen waves per entry, each looking through its own sixteenth of the
+// entry for the first plausible record and stopping there; the entry's start is the find of the lowest wave that has one. A group of 16 members inside a 500 kb
+// read is then sixteen parallel scans of 64 KiB instead of one of 500 KiB (1.6 ms per tile of the ONT-like bench shard: the longest record set the kernel's time).
+__global__ __launch_bounds__(1024) void index_guess_wide_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
+                                                                int32_t* start, int32_t n_ref)
+{
+	__shared__ int32_t hit[16];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int64_t b = from + blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		if (start[b] != -2) continue;   // (uniform for the block)
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
+		const int64_t part = (((hi - lo) + 15) / 16 + 255) & ~255ll;
+		const int64_t wlo = lo + wave * part, whi = min(hi, wlo + part);
+		int32_t found = -1;
+		for (int64_t base = wlo; base < whi && found < 0; base += 1024)
+		{
+			uint32_t w[4][4];
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				w[q][0] = w[q][1] = w[q][2] = w[q][3] = 0u;
+				const int64_t o0 = base + 256 * q + 4 * lane;
+				if (o0 < whi + 16) { if (o0 + 16 <= total) __builtin_memcpy(w[q], infl + o0, 16); else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[q][k] = ld32u(infl + o0 + 4 * k); }
+			}
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				if (found < 0)
+				{
+					const int64_t o0 = base + 256 * q + 4 * lane;
+					uint32_t cand = 0;
+					#pragma unroll
+					for (int t = 0; t < 4; ++t)
+					{
+						const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[q][1], w[q][0], 8u * t) : w[q][0];
+						const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[q][2], w[q][1], 8u * t) : w[q][1]);
+						if (o0 + t < whi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
+					}
+					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
+					{
+						int32_t mine = -1;
+						if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
+						const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
+						if (m) { const int l = __builtin_ctzll(m); found = (int32_t)(base + 256 * q + 4 * l + __builtin_amdgcn_readlane(mine, l) - lo); }
+					}
+				}
+			}
+		}
+		if (lane == 0) hit[wave] = found;
+		__syncthreads();
+		if (threadIdx.x == 0) { int32_t f = -1; for (int k = 0; k < 16 && f < 0; ++k) f = hit[k]; start[b] = f; }
+		__syncthreads();
 	}
 }
 
@@ -273,6 +330,7 @@ void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
+	if (ksh < 0) { hipLaunchKernelGGL(index_guess_wide_kernel, dim3((int)std::min<int64_t>(n, 256 * 8)), dim3(1024), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK(); return; }   // (groups of members: long reads)
 	const int64_t wg = (n + 3) / 4;
 	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK();
 }

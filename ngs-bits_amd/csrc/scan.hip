@@ -761,10 +761,86 @@ void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s)
 	KCHECK();
 }
 
-void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head, hipStream_t s)
+// ---- the same fix-up in parallel (round 5: the single workgroup above took 1.1 ms for the 150 k records in front of an ONT tile's longest read). Three launches:
+// head words + the longest counted read of every block of 1024 records; the running maximum in front of every block (one workgroup over the block maxima, seeded
+// with A_FIX_CARRY, which then moves on to the overall maximum); per block the running maximum of every record from that seed and the three sums. ----
+constexpr int PF_T = 256, PF_ITEMS = 4, PF_BLK = PF_T * PF_ITEMS;
+__global__ __launch_bounds__(PF_T) void prefix_fix_max_kernel(const ScanParams p, long long upto, const uint32_t* __restrict__ head, uint32_t* __restrict__ words, int32_t* __restrict__ block_max)
+{
+	__shared__ int sh[PF_T];
+	const long long base = (long long)blockIdx.x * PF_BLK + (long long)threadIdx.x * PF_ITEMS;
+	int m = 0;
+	#pragma unroll
+	for (int i = 0; i < PF_ITEMS; ++i)
+	{
+		const long long ord = base + i;
+		if (ord < upto) { const uint32_t w = head ? head[ord] : head_word(p, ord); words[ord] = w; if ((w >> 30) & 1u) m = max(m, (int)(w & 0x3fffffffu)); }
+	}
+	sh[threadIdx.x] = m; __syncthreads();
+	for (int d = PF_T / 2; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + d]); __syncthreads(); }
+	if (threadIdx.x == 0) block_max[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void prefix_fix_seed_kernel(const ScanParams p, int32_t* block_max, long long n_blocks)   // block_max[b] -> maximum in front of block b (carry included)
+{
+	__shared__ int sh[256]; __shared__ int carry;
+	if (threadIdx.x == 0) carry = (int)p.counters[A_FIX_CARRY];
+	__syncthreads();
+	for (long long base = 0; base < n_blocks; base += 256)
+	{
+		const long long j = base + threadIdx.x;
+		const int v = j < n_blocks ? block_max[j] : 0;
+		sh[threadIdx.x] = v; __syncthreads();
+		for (int d = 1; d < 256; d <<= 1) { const int t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] = max(sh[threadIdx.x], t); __syncthreads(); }
+		const int incl = max(carry, sh[threadIdx.x]);
+		const int excl = threadIdx.x ? max(carry, sh[threadIdx.x - 1]) : carry;
+		if (j < n_blocks) block_max[j] = excl;
+		__syncthreads();
+		if (threadIdx.x == 255) carry = incl;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) p.counters[A_FIX_CARRY] = (unsigned long long)carry;
+}
+__global__ __launch_bounds__(PF_T) void prefix_fix_sum_kernel(const ScanParams p, long long upto_max, long long upto_paired, const uint32_t* __restrict__ words, const int32_t* __restrict__ block_seed)
+{
+	__shared__ int sh[PF_T];
+	const long long upto = upto_max > upto_paired ? upto_max : upto_paired;
+	const long long base = (long long)blockIdx.x * PF_BLK + (long long)threadIdx.x * PF_ITEMS;
+	uint32_t w[PF_ITEMS]; int m = 0;
+	#pragma unroll
+	for (int i = 0; i < PF_ITEMS; ++i) { const long long ord = base + i; w[i] = ord < upto ? words[ord] : 0u; if ((w[i] >> 30) & 1u) m = max(m, (int)(w[i] & 0x3fffffffu)); }
+	sh[threadIdx.x] = m; __syncthreads();
+	for (int d = 1; d < PF_T; d <<= 1) { const int t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] = max(sh[threadIdx.x], t); __syncthreads(); }
+	int run = max(block_seed[blockIdx.x], threadIdx.x ? sh[threadIdx.x - 1] : 0);   // the running maximum in front of this thread's first record
+	long long s_trim = 0, s_len = 0, s_cnt = 0;
+	#pragma unroll
+	for (int i = 0; i < PF_ITEMS; ++i)
+	{
+		const long long ord = base + i;
+		const bool counted = (w[i] >> 30) & 1u, passing = w[i] >> 31; const int len = (int)(w[i] & 0x3fffffffu);
+		if (counted) run = max(run, len);
+		if (counted && ord < upto_max) { s_trim += run; ++s_cnt; }
+		if (passing && ord < upto_paired) s_len += len;
+	}
+	s_trim = wave_sum(s_trim); s_len = wave_sum(s_len); s_cnt = wave_sum(s_cnt);
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (s_trim) atomicAdd(&p.counters[A_FIX_TRIM], (unsigned long long)s_trim);
+		if (s_len) atomicAdd(&p.counters[A_FIX_LEN], (unsigned long long)s_len);
+		if (s_cnt) atomicAdd(&p.counters[A_FIX_CNT], (unsigned long long)s_cnt);
+	}
+}
+size_t prefix_fix_scratch_words(int64_t upto) { return upto > 4096 ? (size_t)upto + (size_t)((upto + PF_BLK - 1) / PF_BLK) + 64 : 0; }
+
+void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head, hipStream_t s, uint32_t* d_scratch)
 {
 	if (upto_max <= 0 && upto_paired <= 0) return;
-	hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, d_head); KCHECK();
+	const int64_t upto = std::max(upto_max, upto_paired);
+	if (!d_scratch || upto <= 4096) { hipLaunchKernelGGL(prefix_fix_kernel, dim3(1), dim3(256), 0, s, p, (long long)upto_max, (long long)upto_paired, d_head); KCHECK(); return; }
+	const int64_t nb = (upto + PF_BLK - 1) / PF_BLK;
+	uint32_t* words = d_scratch; int32_t* bmax = (int32_t*)(d_scratch + upto);
+	hipLaunchKernelGGL(prefix_fix_max_kernel, dim3((int)nb), dim3(PF_T), 0, s, p, (long long)upto, d_head, words, bmax); KCHECK();
+	hipLaunchKernelGGL(prefix_fix_seed_kernel, dim3(1), dim3(256), 0, s, p, bmax, (long long)nb); KCHECK();
+	hipLaunchKernelGGL(prefix_fix_sum_kernel, dim3((int)nb), dim3(PF_T), 0, s, p, (long long)upto_max, (long long)upto_paired, words, bmax); KCHECK();
 }
 void launch_prefix_capture(const ScanParams& p, int64_t n, uint32_t* d_head, hipStream_t s)
 {
@@ -862,10 +938,13 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t* __restrict__
 	}
 }
 
-// Records with long CIGARs (ONT: ~1 op per 12 bp, thousands of ops): ONE WAVE PER RECORD. Every lane owns a contiguous
-// slice of the ops; a wave prefix sum gives each slice its genome / read position, then for every site inside the read each
-// lane looks for the first op of its slice that carries the genome position to or past the site (and for a soft clip that
-// exhausts the read, BamReader.cpp:346-353); the earliest such op of the wave decides, exactly as the sequential walk does.
+// Records with long CIGARs (ONT: ~1 op per 12 bp, thousands of ops): ONE WAVE PER RECORD, the CIGAR streamed in file order (round 5; rounds 2-4 gave every lane a
+// contiguous slice of the operations to walk by itself: a 500 kb read of 40 000 operations was 2 x 625 dependent loads per lane, and one such record set the
+// kernel's time - 5.8 ms per tile of the ONT-like shard). Pass 1: the reference length (four operations per lane and step, 16-byte loads) gives the span and with it
+// the known sites inside the read - none for four reads in five. Pass 2: 64 operations per step, one per lane, coalesced; a wave prefix sum gives every operation
+// the genome / read position behind it; the sites are met in ascending order, each at the first operation that carries the genome position to or past it, exactly
+// where the sequential walk stops (BamReader.cpp:307-374): a deletion counts as deletion, a skip as nothing, anything else gives the base; a soft clip that
+// exhausts the read in front of that operation ends the walk for this and every later site (:346-353). The stream ends behind the last site of the span.
 __global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restrict__ infl, const int64_t* __restrict__ recoff, const int64_t* __restrict__ long_list, const unsigned long long* __restrict__ n_long_dev,
                                                           const int32_t* __restrict__ site_pos, const int32_t* __restrict__ tid_last,
                                                           const int32_t* __restrict__ bucket, const int64_t* __restrict__ tid_bucket0,
@@ -897,56 +976,68 @@ __global__ __launch_bounds__(256) void pileup_long_kernel(const uint8_t* __restr
 			for (uint32_t k = lane; k < r.n_cigar_raw; k += 64) { const uint32_t op = ld32(r.core + 32 + r.l_name + 4ull * k) & 15u; other |= (op != 1u && op != 4u) ? 1u : 0u; }
 			if (__builtin_amdgcn_ballot_w64(other != 0) == 0) continue;   // insertion / soft-clip only: the reference skips the read (BamReader.cpp:845)
 		}
-		const uint32_t per = (r.n_cigar + 63) / 64, k0 = min((uint32_t)lane * per, r.n_cigar), k1 = min(k0 + per, r.n_cigar);
-		long long s_ref = 0, s_read = 0;
-		for (uint32_t k = k0; k < k1; ++k)
+		// ---- pass 1: the reference length ----
+		long long ref_len = 0;
+		for (uint32_t k0 = 4u * lane; k0 < r.n_cigar; k0 += 256u)
 		{
-			const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u; const long long len = c >> 4;
-			if ((0x18Du >> op) & 1u) s_ref += len;
-			if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) s_read += len;
+			uint32_t c4[4] = {0u, 0u, 0u, 0u};
+			if (k0 + 4u <= r.n_cigar) __builtin_memcpy(c4, r.cigar + 4ull * k0, 16);
+			else for (uint32_t j = 0; k0 + j < r.n_cigar; ++j) c4[j] = ld32(r.cigar + 4ull * (k0 + j));
+			#pragma unroll
+			for (uint32_t j = 0; j < 4u; ++j) if (k0 + j < r.n_cigar && ((0x18Du >> (c4[j] & 15u)) & 1u)) ref_len += c4[j] >> 4;
 		}
-		long long p_ref = s_ref, p_read = s_read;   // inclusive wave scan -> exclusive prefix
-		#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const long long a = __shfl_up(p_ref, o), b = __shfl_up(p_read, o); if (lane >= o) { p_ref += a; p_read += b; } }
-		long long ref_len = __shfl(p_ref, 63); if (ref_len == 0) ref_len = 1;
-		p_ref -= s_ref; p_read -= s_read;
+		ref_len = wave_sum(ref_len);
+		const bool no_ref_ops = ref_len == 0;
+		if (ref_len == 0) ref_len = 1;   // bam_endpos
 		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
 		const int last = tid_last[r.tid];
 		const int64_t b0 = tid_bucket0[r.tid], nbk = tid_bucket0[r.tid + 1] - b0;
 		int64_t bi = start1 > 0 ? (int64_t)(start1 >> PILEUP_BUCKET_SHIFT) : 0; if (bi >= nbk) bi = nbk - 1;
-		int a = bucket[b0 + bi];
-		while (a < last && site_pos[a] < start1) ++a;
-		for (int i = a; i < last && site_pos[i] <= end1; ++i)
+		int cur = bucket[b0 + bi];
+		while (cur < last && site_pos[cur] < start1) ++cur;
+		int site_end = cur; while (site_end < last && site_pos[site_end] <= end1) ++site_end;
+		if (cur >= site_end) continue;
+		if (no_ref_ops) { if (lane == 0) for (int i = cur; i < site_end; ++i) atomicAdd(&counts[8ull * i + 7], 1u); continue; }   // "Could not find position": no operation ever reaches it
+		// ---- pass 2: the operations in order ----
+		long long g_base = r.pos, rp_base = 0; bool s_seen = false;   // genome position (0-based start - 1 + consumed = 1-based position of the last consumed base) and read position behind the chunks so far
+		for (uint32_t k0 = 0; k0 < r.n_cigar && cur < site_end && !s_seen; k0 += 64u)
 		{
-			const int pos = site_pos[i];
-			long long g = r.pos + p_ref, rp = p_read;
-			uint32_t hit_k = 0xffffffffu, hit_op = 0, s_k = 0xffffffffu; long long hit_g = 0, hit_rp = 0;
-			for (uint32_t k = k0; k < k1; ++k)
-			{
-				const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u; const long long len = c >> 4;
-				if ((0x18Du >> op) & 1u) g += len;
-				if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) rp += len;
-				if (op == 4 && rp >= r.l_seq && s_k == 0xffffffffu) s_k = k;
-				if (((0x18Du >> op) & 1u) && g >= pos && hit_k == 0xffffffffu) { hit_k = k; hit_op = op; hit_g = g; hit_rp = rp; }
-			}
-			uint32_t first_hit = hit_k, first_s = s_k;
+			const uint32_t k = k0 + (uint32_t)lane;
+			uint32_t op = 15u; long long len = 0;
+			if (k < r.n_cigar) { const uint32_t c = ld32(r.cigar + 4ull * k); op = c & 15u; len = c >> 4; }
+			const bool ref_op = (0x18Du >> op) & 1u, read_op = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+			long long g = ref_op ? len : 0, rp = read_op ? len : 0;
 			#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) { first_hit = min(first_hit, (uint32_t)__shfl_xor((int)first_hit, o)); first_s = min(first_s, (uint32_t)__shfl_xor((int)first_s, o)); }
-			if (first_hit == 0xffffffffu) { if (lane == 0) atomicAdd(&counts[8ull * i + 7], 1u); continue; }   // "Could not find position"
-			if (first_s < first_hit) continue;                                                                  // '~'
-			if (hit_k == first_hit)   // exactly one lane
+			for (int o = 1; o < 64; o <<= 1) { const long long a = __shfl_up(g, o), b = __shfl_up(rp, o); if (lane >= o) { g += a; rp += b; } }
+			g += g_base; rp += rp_base;   // positions BEHIND this lane's operation
+			const uint64_t m_s = __builtin_amdgcn_ballot_w64(op == 4u && rp >= (long long)r.l_seq);   // soft clips that exhaust the read
+			while (cur < site_end)
 			{
-				if (hit_op == 2) atomicAdd(&counts[8ull * i + 5], 1u);                                          // deleted base, quality 255
-				else if (hit_op != 3)
+				const int pos = site_pos[cur];
+				const uint64_t m_hit = __builtin_amdgcn_ballot_w64(ref_op && g >= (long long)pos);
+				if (!m_hit) break;                                   // this site lies behind the chunk
+				const int l = __builtin_ctzll(m_hit);
+				if (m_s & ((1ull << l) - 1ull)) { s_seen = true; break; }   // the walk ended at a soft clip in front of the operation
+				if (lane == l)
 				{
-					const long long ap = hit_rp - (hit_g + 1 - pos);
-					if (ap < 0 || ap >= r.l_seq) { atomicAdd(&counts[8ull * i + 7], 1u); continue; }   // CIGAR longer than SEQ
-					const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
-					const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15, q = rec_qual(r)[ap];
-					const int base = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
-					if (q >= min_baseq) atomicAdd(&counts[8ull * i + base], 1u);
+					if (op == 2u) atomicAdd(&counts[8ull * cur + 5], 1u);                                            // deleted base, quality 255
+					else if (op != 3u)
+					{
+						const long long ap = rp - (g + 1 - pos);
+						if (ap < 0 || ap >= r.l_seq) atomicAdd(&counts[8ull * cur + 7], 1u);   // CIGAR longer than SEQ
+						else
+						{
+							const uint8_t* seq = r.core + 32 + r.l_name + 4ull * r.n_cigar_raw;
+							const int nib = (seq[ap >> 1] >> ((~ap & 1) << 2)) & 15, q = rec_qual(r)[ap];
+							const int base = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : 6;
+							if (q >= min_baseq) atomicAdd(&counts[8ull * cur + base], 1u);
+						}
+					}
 				}
+				++cur;
 			}
+			if (m_s) s_seen = true;   // (a later site's operation lies behind it)
+			g_base = __shfl(g, 63); rp_base = __shfl(rp, 63);
 		}
 	}
 }
