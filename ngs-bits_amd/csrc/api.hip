@@ -240,7 +240,7 @@ struct ngsqc_handle
 	EvLog ev_store; EvLog* evlog = &ev_store;   // stage times of the running tile stream (resolved at its end)
 	// what the host learns about a tile in ONE wait (round 5; p_rb, pinned): [0 .. A_HIST0) the device accumulators of the riding scan after its walk (deferred-record
 	// count, the tile's longest / first paired record, totals), [RB_CAND] the site pileup's candidates
-	PinBuf<unsigned long long> p_rb; static constexpr int RB_CAND = 64, RB_TOTAL = 72;
+	PinBuf<unsigned long long> p_rb; static constexpr int RB_CAND = 64, RB_BQ = 65, RB_TOTAL = 72;
 	// record offsets of the resident tile are expanded on demand (ensure_recoff): a job whose consumers all ride the chain walk never reads them
 	bool lazy_recoff = false; int recoff_tile = -1;
 	struct RecoffArgs { const uint8_t* base = nullptr; int64_t total = 0; const BlockDesc* desc = nullptr; int64_t ne = 0, prefix = 0, n_rec = 0, nm = 0; int ksh = 0; int tile = -1; } rw;
@@ -248,6 +248,7 @@ struct ngsqc_handle
 	{
 		virtual void fused_launch(ngsqc_handle* h, const uint8_t* infl, int64_t total, int sgn, const BlockDesc* d_desc, int64_t ne, int64_t prefix, int ksh, int64_t nm, int64_t scan_limit) = 0;
 		virtual void fused_readback(ngsqc_handle* h) = 0;     // enqueues the copy of its accumulators (and of what rides with it) into h->p_rb
+		virtual unsigned long long fused_bq_cap() = 0;        // entries the list of min_baseq records holds (p_rb[RB_BQ] must not exceed it)
 		virtual ~FusedScan() = default;
 	};
 	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
@@ -1103,7 +1104,8 @@ void index_tile(ngsqc_handle* h, int t)
 	const bool aligned = !anchor_by_guess && n_viol == 0 && !getenv("NGSQC_K2_GENERAL");
 	if (try_fuse)
 	{
-		if (aligned && n_corrupt == 0 && sm[2] <= (unsigned long long)h->d_long.n) h->fused_tile = t;
+		const bool lists_fit = sm[2] <= (unsigned long long)h->d_long.n && h->p_rb.p[ngsqc_handle::RB_BQ] <= h->fuse->fused_bq_cap();
+		if (aligned && n_corrupt == 0 && lists_fit) h->fused_tile = t;
 		else if (!aligned || n_corrupt == 0)
 		{
 			// the chain did not check out (or more deferred records than the list holds): what the riding scan added is taken back, the scan runs behind K2 as usual.
@@ -1391,6 +1393,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 struct ScanState : ngsqc_handle::FusedScan
 {
 	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<uint32_t> d_fix;   // d_fix: scratch of the parallel order-dependent fix-up
+	DevBuf<int64_t> d_bq; DevBuf<unsigned long long> d_bq_count; bool bq_ride = false; size_t bq_min = 0;   // MODE_DEPTH with min_baseq riding the walk: records that overlap a region, masked by baseq_list_kernel behind the walk
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
 	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
 	// running state of the in-pass fix
@@ -1406,6 +1409,9 @@ struct ScanState : ngsqc_handle::FusedScan
 		HIPCHK(hipMemcpyAsync(d_counters.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		sp.counters = d_counters.p; sp.n_ref = (int32_t)h->ref_names.size();
+		bq_ride = sp.mode == MODE_DEPTH && sp.min_baseq > 0 && !getenv("NGSQC_BASEQ_INLINE"); if (bq_ride) d_bq_count.ensure(1);
+		bq_min = 0;
+		sp.bq_list = nullptr; sp.bq_count = nullptr; sp.bq_cap = 0;
 		run_max = 0; paired_seen = false; sum_runmax = 0; fix_len = 0; prev_total = 0; prev_usable = 0; best_key = 0; first_paired = ~0ull;
 		kernel_ms = 0; stage_ms = 0; launches = 0;
 	}
@@ -1414,6 +1420,12 @@ struct ScanState : ngsqc_handle::FusedScan
 	{
 		sp.scan_limit = scan_limit; sp.infl = infl; sp.total = total; sp.recoff = nullptr; sp.n_rec = 0; sp.ord_base = 0;
 		sp.long_list = h->d_long.p; sp.long_cap = (int64_t)h->d_long.n; sp.entry_base = nullptr; sp.sgn = sgn; sp.tile_slots = 1;
+		if (bq_ride)
+		{
+			if (sgn > 0) { d_bq.ensure_slack(std::max((size_t)std::max<int64_t>(total / 2048, 1 << 16), bq_min)); HIPCHK(hipMemsetAsync(d_bq_count.p, 0, sizeof(unsigned long long), h->stream)); }   // (one record in fifty overlaps an exome: 340 bytes x 50 = a list entry per 17 KB; sized for one per 2 KB, checked by index_tile)
+			sp.bq_list = d_bq.p; sp.bq_count = d_bq_count.p; sp.bq_cap = (int64_t)d_bq.n;
+			if (const char* e = getenv("NGSQC_BQ_LIST_CAP")) sp.bq_cap = std::min<int64_t>(sp.bq_cap, std::max<int64_t>(1, atoll(e)));   // (tests: a list that overflows)
+		}
 		if (sgn > 0)
 		{
 			unsigned long long* s = h->p_small.p + 40; s[0] = 0; s[1] = ~0ull;
@@ -1427,10 +1439,12 @@ struct ScanState : ngsqc_handle::FusedScan
 		sp.sgn = 1; sp.scan_limit = INT64_MAX;
 	}
 	// round 5: everything the host needs of a tile scanned by the walk arrives with K2's own wait (index_tile) - one copy of the accumulators' head
+	unsigned long long fused_bq_cap() override { return bq_ride ? (unsigned long long)sp.bq_cap : ~0ull; }
 	void fused_readback(ngsqc_handle* h) override
 	{
 		HIPCHK(hipMemcpyAsync(h->p_rb.p, d_counters.p, (size_t)A_HIST0 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-		h->p_rb.p[ngsqc_handle::RB_CAND] = 0;
+		h->p_rb.p[ngsqc_handle::RB_CAND] = 0; h->p_rb.p[ngsqc_handle::RB_BQ] = 0;
+		if (bq_ride) HIPCHK(hipMemcpyAsync(h->p_rb.p + ngsqc_handle::RB_BQ, d_bq_count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		if (sp.pile.list) HIPCHK(hipMemcpyAsync(h->p_rb.p + ngsqc_handle::RB_CAND, sp.pile.count, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 	}
 
@@ -1441,6 +1455,8 @@ struct ScanState : ngsqc_handle::FusedScan
 		sp.infl = c.infl; sp.total = c.total; sp.recoff = c.recoff /* null: not expanded yet (ensure_recoff) */; sp.n_rec = c.n_rec; sp.ord_base = c.ord_base;
 		sp.long_list = h->d_long.p; sp.long_cap = fused ? (int64_t)h->d_long.n : c.n_rec; sp.sgn = 1;
 		sp.entry_base = fused ? h->d_base.p : nullptr; sp.tile_slots = fused ? 1 : 0;
+		if (!fused) { sp.bq_list = nullptr; sp.bq_count = nullptr; sp.bq_cap = 0; }   // (the scan kernel masks low-quality bases record by record)
+		if (!fused && bq_ride && h->fuse == this && h->p_rb.p[ngsqc_handle::RB_BQ] > (unsigned long long)d_bq.n) bq_min = (size_t)(h->p_rb.p[ngsqc_handle::RB_BQ] + h->p_rb.p[ngsqc_handle::RB_BQ] / 4);   // (the list was too short for this tile: longer for the next)
 		EvLog& ev = *h->evlog;
 		const size_t ivs = ev.begin(h->stream, &stage_ms);
 		unsigned long long s[16] = {0};
@@ -1477,6 +1493,12 @@ struct ScanState : ngsqc_handle::FusedScan
 			launch_scan_long(sp, (int64_t)s[0], h->stream);
 			ev.end(ivk, h->stream); launches++;
 			readback();
+		}
+		if (fused && bq_ride && h->p_rb.p[ngsqc_handle::RB_BQ])
+		{
+			const size_t ivk = ev.begin(h->stream, &kernel_ms);
+			launch_baseq_list(sp, (int64_t)h->p_rb.p[ngsqc_handle::RB_BQ], h->stream);
+			ev.end(ivk, h->stream); launches++;
 		}
 		if (fused)
 		{
@@ -2089,7 +2111,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_sites && do_map) pile.attach(map.scan.sp, &map.scan);   // (the pileup's candidates come from the scan that rides K2's chain walk)
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
 	const double w1 = wall_ms();
-	FuseGuard fg(h, do_map ? &map.scan : (do_depth && j->depth->min_baseq <= 0 ? &dscan : nullptr));
+	FuseGuard fg(h, do_map ? &map.scan : (do_depth ? &dscan : nullptr));
 	// the record offsets of a tile are only expanded when a consumer reads them: the mapping scan rides the chain walk (deferred long-CIGAR records and the
 	// order-dependent fix-ups ask for them), the site pileup works on the walk's candidate list; the extra depth scan and the raw-read QC read every record
 	struct LazyGuard { ngsqc_handle* h; ~LazyGuard() { h->lazy_recoff = false; } } lg{h};
@@ -2566,9 +2588,9 @@ void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 	ScanState sc; sc.in_pass_fix = false;
 	depth_setup(h, p, h->ds[0], sc);
 	sc.begin(h);
-	// (base-quality decrements make a record's scan long: a thread per RECORD - K2, then the scan kernel - beats the thread per member of the fused walk,
-	// 147 vs 224 ms per 96 M reads with -min_baseq 20)
-	{ FuseGuard fg(h, p->min_baseq > 0 ? nullptr : &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
+	// (round 5: with -min_baseq the records that overlap a region leave the walk for a list and a wave-per-record kernel masks their low-quality bases; rounds 3-4
+	// took the thread-per-record path - K2, then the scan kernel - because the decrements inside the walk stalled its lanes: 147 vs 224 ms per 96 M reads)
+	{ FuseGuard fg(h, &sc); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
 	sc.end(h);
 	h->cur_ds = 0;
 	h->tm.scan_ms = sc.stage_ms; h->tm.scan_kernel_ms = sc.kernel_ms; h->tm.scan_launches = sc.launches; h->tm.scan_algorithmic_bytes = (int64_t)sc.dev[A_ALG_BYTES];

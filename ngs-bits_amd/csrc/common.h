@@ -144,6 +144,8 @@ struct ScanParams
 	// the site pileup of the job riding the same walk: records whose span holds a known site leave their offset in list (list == nullptr: no pileup rides)
 	struct Pile { const int32_t* site_pos = nullptr; const int32_t* tid_first = nullptr; const int32_t* tid_last = nullptr; const int32_t* bucket = nullptr; const int64_t* tid_bucket0 = nullptr;
 	              int64_t* list = nullptr; unsigned long long* count = nullptr; int64_t cap = 0; int32_t min_mapq = 0, include_npp = 0; } pile;
+	// MODE_DEPTH with min_baseq riding the walk (round 5): a record that overlaps a region leaves its offset here, a wave per record masks its low-quality bases afterwards
+	int64_t* bq_list = nullptr; unsigned long long* bq_count = nullptr; int64_t bq_cap = 0;
 	const int64_t* entry_base = nullptr; int32_t sgn = 1; int32_t tile_slots = 0; int64_t scan_limit = INT64_MAX;   // scan_limit: (a shard) records that start at or behind this tile-local offset are walked, not scanned
 };
 
@@ -152,6 +154,7 @@ void launch_scan(const ScanParams& p, hipStream_t s);
 void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
 void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
+void launch_baseq_list(const ScanParams& p, int64_t n_max, hipStream_t s);   // the min_baseq mask of the records in p.bq_list (count on the device)
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s,
                        uint32_t* d_scratch = nullptr /* prefix_fix_scratch_words(max(upto_max, upto_paired)) words: the parallel form; null: one workgroup */);
 size_t prefix_fix_scratch_words(int64_t upto);

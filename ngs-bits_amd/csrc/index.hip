@@ -11,6 +11,7 @@
 #include "common.h"
 #include "k2_guess.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ngsqc {
 
@@ -330,7 +331,8 @@ void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	if (ksh < 0) { hipLaunchKernelGGL(index_guess_wide_kernel, dim3((int)std::min<int64_t>(n, 256 * 8)), dim3(1024), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK(); return; }   // (groups of members: long reads)
+	static const bool wide = !getenv("NGSQC_WIDE_GUESS") || atoi(getenv("NGSQC_WIDE_GUESS")) != 0;   // (0: a wave per group, as in the first long-read build)
+	if (ksh < 0 && wide) { hipLaunchKernelGGL(index_guess_wide_kernel, dim3((int)std::min<int64_t>(n, 256 * 8)), dim3(1024), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK(); return; }   // (groups of members: long reads)
 	const int64_t wg = (n + 3) / 4;
 	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK();
 }

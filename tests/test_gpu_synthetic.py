@@ -98,6 +98,29 @@ def test_roi_mode_exome_like(tmp_path):
     h.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"NGSQC_BASEQ_INLINE": "1"}, {"NGSQC_BQ_LIST_CAP": "7"}, {"NGSQC_TILE_MEMBERS": "11"}, {"NGSQC_TILE_MEMBERS": "11", "NGSQC_BQ_LIST_CAP": "50"}, {"NGSQC_NO_FUSED_SCAN": "1"}])
+def test_min_baseq_rides_the_walk(tmp_path, monkeypatch, env):
+    """BedLowCoverage -min_baseq (BamAlignment::qualities): round 5 lets the depth scan ride K2's chain walk with min_baseq too - the records that overlap a region go to
+    a list, a wave per record masks their low-quality bases. The same depth as the oracle, as the inline form (NGSQC_BASEQ_INLINE), with a list that overflows
+    (the tile is taken back and scanned record by record) and across tiles."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    bed = tmp_path / "x.bed"
+    rng = np.random.default_rng(9)
+    starts = np.sort(rng.integers(16_000_000, 16_900_000, 400))
+    bed.write_text("".join(f"chr1\t{s_}\t{s_ + int(rng.integers(40, 700))}\n" for s_ in starts))
+    p = str(tmp_path / "bq.bam"); G.write(p, n_reads=150_000, seed=21, start_pos=15_900_000)
+    ob = O.Bam(p); h = ngsqc.Handle(path=p)
+    regs, _ = H.bed_regions(str(bed), h.refs, 2)
+    for baseq in (20, 30, 0):
+        h.scan_depth(regs, min_mapq=1, min_baseq=baseq)
+        exp = O.low_high_coverage(ob, str(bed), 20, 1, baseq, is_high=False, random_access=True, tool_merge=1)
+        assert np.array_equal(h.depth(exp["roi_bases"]), exp["depth"]), baseq
+        if baseq and "NGSQC_NO_FUSED_SCAN" not in env and "NGSQC_BQ_LIST_CAP" not in env:
+            assert h.timings()["tiles_scan_fused"] == h.timings()["n_tiles"]
+    h.close()
+
+
 @pytest.mark.parametrize("tile_members", [1, 3, 7, 33])
 def test_tiled_processing_matches_single_tile(tmp_path, monkeypatch, tile_members):
     """Files larger than HBM are processed in member ranges ("tiles"); records straddling tile borders are carried.
