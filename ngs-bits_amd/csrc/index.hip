@@ -41,17 +41,12 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 		for (int64_t base = lo; base < hi && found < 0;)
 		{
 			const int nwin = base == lo ? 1 : 4;
-			uint32_t w[4][4];
+			uint32_t w[4][8];
 			#pragma unroll
 			for (int q = 0; q < 4; ++q)
 			{
-				w[q][0] = w[q][1] = w[q][2] = w[q][3] = 0u;
 				const int64_t o0 = base + 256 * q + 4 * lane;
-				if (q < nwin && o0 < hi + 16)
-				{
-					if (o0 + 16 <= total) __builtin_memcpy(w[q], infl + o0, 16);
-					else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[q][k] = ld32u(infl + o0 + 4 * k);
-				}
+				if (q < nwin && o0 < hi) load_window(infl, total, o0, w[q]); else for (int k = 0; k < 8; ++k) w[q][k] = 0u;
 			}
 			#pragma unroll
 			for (int q = 0; q < 4; ++q)
@@ -59,14 +54,7 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 				if (q < nwin && found < 0)
 				{
 					const int64_t o0 = base + 256 * q + 4 * lane;
-					uint32_t cand = 0;   // bit t: offset o0 + t passes the cheap test
-					#pragma unroll
-					for (int t = 0; t < 4; ++t)
-					{
-						const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[q][1], w[q][0], 8u * t) : w[q][0];
-						const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[q][2], w[q][1], 8u * t) : w[q][1]);
-						if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
-					}
+					const uint32_t cand = cheap_candidates(w[q], o0, hi, total, n_ref);   // bit t: offset o0 + t passes the cheap test
 					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
 					{
 						int32_t mine = -1;
@@ -99,13 +87,12 @@ __global__ __launch_bounds__(1024) void index_guess_wide_kernel(const uint8_t* _
 		int32_t found = -1;
 		for (int64_t base = wlo; base < whi && found < 0; base += 1024)
 		{
-			uint32_t w[4][4];
+			uint32_t w[4][8];
 			#pragma unroll
 			for (int q = 0; q < 4; ++q)
 			{
-				w[q][0] = w[q][1] = w[q][2] = w[q][3] = 0u;
 				const int64_t o0 = base + 256 * q + 4 * lane;
-				if (o0 < whi + 16) { if (o0 + 16 <= total) __builtin_memcpy(w[q], infl + o0, 16); else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[q][k] = ld32u(infl + o0 + 4 * k); }
+				if (o0 < whi) load_window(infl, total, o0, w[q]); else for (int k = 0; k < 8; ++k) w[q][k] = 0u;
 			}
 			#pragma unroll
 			for (int q = 0; q < 4; ++q)
@@ -113,14 +100,7 @@ __global__ __launch_bounds__(1024) void index_guess_wide_kernel(const uint8_t* _
 				if (found < 0)
 				{
 					const int64_t o0 = base + 256 * q + 4 * lane;
-					uint32_t cand = 0;
-					#pragma unroll
-					for (int t = 0; t < 4; ++t)
-					{
-						const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[q][1], w[q][0], 8u * t) : w[q][0];
-						const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[q][2], w[q][1], 8u * t) : w[q][1]);
-						if (o0 + t < whi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref) cand |= 1u << t;
-					}
+					const uint32_t cand = cheap_candidates(w[q], o0, whi, total, n_ref);
 					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
 					{
 						int32_t mine = -1;

@@ -81,6 +81,32 @@ __device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64
 }
 
 
+// The cheap test of the four offsets o0 .. o0 + 3 on the 28 bytes behind o0 (w[0..6]; the fields of offset o0 + t are funnel shifts of neighbouring words): the
+// length word, refID and position in range, a read name, and the fixed part + name + CIGAR + bases + qualities no longer than the record says. Round 5: the
+// last test was added when the scan of a long read's CG:B,I array turned out to call the full test (a dozen dependent loads) on every word - small integers pass
+// as length word and refID; as l_seq and block_size of one record they almost never fit. Bit t of the result: offset o0 + t is worth the full test.
+__device__ __forceinline__ uint32_t cheap_candidates(const uint32_t (&w)[8], int64_t o0, int64_t hi, int64_t total, int32_t n_ref)
+{
+	uint32_t cand = 0;
+	#pragma unroll
+	for (int t = 0; t < 4; ++t)
+	{
+		uint32_t f[6];
+		#pragma unroll
+		for (int i = 0; i < 6; ++i) f[i] = t ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 8u * t) : w[i];
+		const uint32_t bs = f[0], l_name = f[3] & 0xffu, n_cig = f[4] & 0xffffu; const int32_t tid = (int32_t)f[1], pos = (int32_t)f[2], l_seq = (int32_t)f[5];
+		const bool ok = o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref && pos >= -1 && l_name != 0 && l_seq >= 0
+		                && 32ull + l_name + 4ull * n_cig + ((uint64_t)(uint32_t)l_seq + 1) / 2 + (uint64_t)(uint32_t)l_seq <= (uint64_t)bs;
+		cand |= ok ? 1u << t : 0u;
+	}
+	return cand;
+}
+__device__ __forceinline__ void load_window(const uint8_t* infl, int64_t total, int64_t o0, uint32_t (&w)[8])
+{
+	if (o0 + 32 <= total) __builtin_memcpy(w, infl + o0, 32);
+	else for (int k = 0; k < 8; ++k) w[k] = o0 + 4 * k + 4 <= total ? ld32u(infl + o0 + 4 * k) : 0u;
+}
+
 // One lane looks for the first record of its piece [lo, hi) by itself (round 5: a walker of the second half of a short-read member finds its first record ~170
 // bytes in - twenty 16-byte loads of three lines that it reads anyway - where the separate guess kernel cost a wave and a dozen dependent round trips per piece,
 // 0.35 ms per tile and walker). Four offsets per load, the same tests as the guess kernel. -1: no record starts in the piece.
@@ -88,16 +114,9 @@ __device__ static int32_t lane_guess(const uint8_t* infl, int64_t total, int64_t
 {
 	for (int64_t o0 = lo; o0 < hi; o0 += 4)
 	{
-		uint32_t w[4] = {0u, 0u, 0u, 0u};
-		if (o0 + 16 <= total) __builtin_memcpy(w, infl + o0, 16);
-		else for (int k = 0; k < 4; ++k) if (o0 + 4 * k + 4 <= total) w[k] = ld32u(infl + o0 + 4 * k);
-		#pragma unroll
-		for (int t = 0; t < 4; ++t)
-		{
-			const uint32_t bs = t ? __builtin_amdgcn_alignbit(w[1], w[0], 8u * t) : w[0];
-			const int32_t tid = (int32_t)(t ? __builtin_amdgcn_alignbit(w[2], w[1], 8u * t) : w[1]);
-			if (o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref && plausible_chain(infl, total, o0 + t, n_ref)) return (int32_t)(o0 + t - lo);
-		}
+		uint32_t w[8]; load_window(infl, total, o0, w);
+		const uint32_t cand = cheap_candidates(w, o0, hi, total, n_ref);
+		for (int t = 0; t < 4; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) return (int32_t)(o0 + t - lo);
 	}
 	return -1;
 }

@@ -207,12 +207,12 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		for (; i1 < last && p.reg_start[i1] <= end1; ++i1) diff_add(p, i1, max(start1, p.reg_start[i1]), min(end1, p.reg_end[i1]));
 		if (p.min_baseq > 0 && i1 > i0)
 		{
-			if (!p.bq_list) baseq_decrements(p, r, start1, i0, i1);
+			if (!p.bq_list || i0 >= (1 << 28)) baseq_decrements(p, r, start1, i0, i1);   // (a list entry holds the region index in 28 bits)
 			else if (p.sgn > 0)
 			{
 				// (the walk's lanes do not stop for 150 quality bytes of one record in fifty: baseq_list_kernel masks them, a wave per record)
 				const unsigned long long k = atomicAdd(p.bq_count, 1ull);
-				if ((long long)k < p.bq_cap) p.bq_list[k] = (int64_t)(r.core - 4 - p.infl);
+				if ((long long)k < p.bq_cap) p.bq_list[k] = (int64_t)((unsigned long long)(r.core - 4 - p.infl) | ((unsigned long long)(uint32_t)i0 << 36));   // (offset in the tile: < 2^36; first overlapped region)
 			}
 		}
 		return;
@@ -569,44 +569,26 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 	flush(p, a, lds_hist);
 }
 
-// ---- MODE_DEPTH with min_baseq behind the riding walk (round 5): the records that overlap a region (passed the coverage filters, at most LONG_CIGAR operations), a wave
-// each. BamAlignment::qualities (BamReader.cpp:210-255): only M operations look at qualities; M, I, S advance the read index, M, D, N the genome index, '=' / 'X' /
-// 'H' / 'P' neither. The lanes take the operations (prefix sums give each its read / genome index), then the bases of every M operation, 64 at a time. ----
-static int scan_grid_cap(long long n) { const long long wgs = (n + 3) / 4; return (int)(wgs < 1 ? 1 : (wgs < 2048 ? wgs : 2048)); }
+// ---- MODE_DEPTH with min_baseq behind the riding walk (round 5): the records that overlap a region (passed the coverage filters, at most LONG_CIGAR operations) were
+// compacted into a list by the walk; here a LANE per record masks its low-quality bases (BamAlignment::qualities, BamReader.cpp:210-255: baseq_decrements above).
+// Inside the walk the same loop stalled 63 lanes for the one whose record overlapped a region (224 vs 147 ms per 96 M reads, round 3); on the compacted list every
+// lane has a record. (A wave per record was tried first: 20 dependent loads per record with nothing to overlap them - 5.6 ms per 48 M reads.) ----
+static int scan_grid_cap(long long n) { const long long wgs = (n + 255) / 256; return (int)(wgs < 1 ? 1 : (wgs < 2048 ? wgs : 2048)); }
 __global__ __launch_bounds__(256) void baseq_list_kernel(const ScanParams p)
 {
-	const int lane = threadIdx.x & 63;
-	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
 	long long n = (long long)*p.bq_count; if (n > p.bq_cap) n = p.bq_cap;
-	for (long long w = wave; w < n; w += n_waves)
+	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < n; li += (long long)gridDim.x * blockDim.x)
 	{
-		const RecView r = load_rec(p.infl, p.bq_list[w]);
-		uint32_t op = 15u; long long len = 0;
-		if ((uint32_t)lane < r.n_cigar) { const uint32_t c = ld32(r.cigar + 4ull * lane); op = c & 15u; len = c >> 4; }
-		long long a = (op == 0 || op == 1 || op == 4) ? len : 0, g = (op == 0 || op == 2 || op == 3) ? len : 0, rl = ((0x18Du >> op) & 1u) ? len : 0;
-		const long long da = a, dg = g;
-		#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const long long ta = __shfl_up(a, o), tg = __shfl_up(g, o); if (lane >= o) { a += ta; g += tg; } }
-		rl = wave_sum(rl); if (rl == 0) rl = 1;
-		const long long ai = a - da, gi = g - dg;   // indices in front of this lane's operation
-		const int start1 = r.pos + 1, end1 = (int)(r.pos + rl);
-		const int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
-		const int i0 = lower_region(p.reg_end, first, last, start1);
+		const unsigned long long e = (unsigned long long)p.bq_list[li];
+		const RecView r = load_rec(p.infl, (int64_t)(e & ((1ull << 36) - 1ull)));
+		long long ref_len = 0;
+		for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
+		if (ref_len == 0) ref_len = 1;
+		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
+		const int last = p.tid_reg_last[r.tid];
+		const int i0 = (int)(e >> 36);   // (the walk's region search: not repeated)
 		int i1 = i0; while (i1 < last && p.reg_start[i1] <= end1) ++i1;
-		const uint8_t* q = rec_qual(r);
-		for (uint32_t k = 0; k < r.n_cigar; ++k)
-		{
-			if (__shfl((int)op, (int)k) != 0) continue;
-			const long long len_k = __shfl(len, (int)k), ai_k = __shfl(ai, (int)k), gi_k = __shfl(gi, (int)k);
-			for (long long j = lane; j < len_k && ai_k + j < (long long)r.l_seq; j += 64)
-			{
-				if (q[ai_k + j] < p.min_baseq)
-				{
-					const int pos1 = start1 + (int)gi_k + (int)j;
-					for (int i = i0; i < i1; ++i) if (pos1 >= p.reg_start[i] && pos1 <= p.reg_end[i]) { int32_t* d = p.diff + p.reg_doff[i] - p.reg_start[i]; atomicAdd(d + pos1, -1); atomicAdd(d + pos1 + 1, 1); }
-				}
-			}
-		}
+		baseq_decrements(p, r, start1, i0, i1);
 	}
 }
 void launch_baseq_list(const ScanParams& p, int64_t n_max, hipStream_t s)

@@ -1,3 +1,6 @@
+#include <exception>
+#include <mutex>
+#include <atomic>
 #include "Statistics.hpp"
 #include <ctime>
 #include <thread>
@@ -1137,7 +1140,7 @@ GenderEstimate Statistics::genderSRY(const std::string& build, const std::string
 // line) are served by one index-driven handle per CLUSTER of lines instead of one handle over the range from the first line to the last: the per-line ranges of the
 // BAI (ngsqc_bai_ranges) are sorted and merged while they overlap or lie closer than 8 MB of compressed bytes. Returns false when that does not pay (no index, one
 // cluster, too many lines or clusters): the caller takes the single-handle path.
-static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file, int min_mapq, int decimals, const std::string& ref_file, bool skip_mismapped)
+static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file, int min_mapq, int decimals, const std::string& ref_file, bool skip_mismapped, int threads)
 {
 	const char* es = getenv("NGSQC_INDEX_SELECT");
 	if ((es && atoi(es) == 0) || bed_file.count() < 2 || bed_file.count() > 4096 || getenv("NGSQC_SHARDS")) return false;
@@ -1162,8 +1165,10 @@ static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file,
 	}
 	if (clusters.size() < 2 || clusters.size() > 64) return false;
 	std::vector<int64_t> sums(n, 0);
-	for (const std::vector<size_t>& cl : clusters)
-	{
+	// -threads (Statistics.cpp:2778-2797: the reference runs its random-access chunks in a QThreadPool(threads), one BamReader each): the clusters are independent
+	// index-driven handles with streams of their own, up to `threads` of them at work at once; every cluster writes its own lines' sums - the result does not
+	// depend on the number of threads, as the reference's tests ask
+	auto one = [&](const std::vector<size_t>& cl) {
 		BedFile sub; for (size_t i : cl) sub.append(bed_file[(long long)i]);
 		BamReader reader(bam_file, ref_file, true, sub);
 		reader.requireIndex();
@@ -1174,17 +1179,35 @@ static bool avgCoverageClustered(BedFile& bed_file, const std::string& bam_file,
 		std::vector<int64_t> ss(sl.size(), 0);
 		reader.check(ngsqc_region_sums(reader.handle(), sl.data(), (int64_t)sl.size(), ss.data()));
 		for (size_t k = 0; k < cl.size(); ++k) sums[cl[k]] = ss[k];
+	};
+	const int workers = (int)std::min<size_t>((size_t)std::max(1, threads), clusters.size());
+	if (workers <= 1) for (const std::vector<size_t>& cl : clusters) one(cl);
+	else
+	{
+		std::atomic<size_t> next(0); std::mutex mu; std::exception_ptr first;
+		std::vector<std::thread> pool;
+		for (int t = 0; t < workers; ++t) pool.emplace_back([&] {
+			for (;;)
+			{
+				const size_t i = next.fetch_add(1);
+				if (i >= clusters.size()) return;
+				{ std::lock_guard<std::mutex> g(mu); if (first) return; }
+				try { one(clusters[i]); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); return; }
+			}
+		});
+		for (auto& t : pool) t.join();
+		if (first) std::rethrow_exception(first);
 	}
 	if (getenv("NGSQC_TIMING")) fprintf(stderr, "[ngsqc] index-driven open: %zu clusters of lines\n", clusters.size());
 	for (long long i = 0; i < bed_file.count(); ++i) bed_file[i].annotations().push_back(number((double)sums[(size_t)i] / bed_file[i].length(), decimals));
 	return true;
 }
 
-void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int /*threads*/, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
+void Statistics::avgCoverage(BedFile& bed_file, const std::string& bam_file, int min_mapq, int threads, int decimals, const std::string& ref_file, bool random_access, bool skip_mismapped, bool /*debug*/)
 {
 	if (!random_access && !bed_file.isSorted()) NB_THROW(ArgumentException, "Input BED file has to be sorted for sweep algorithm!");
 	if (bed_file.count() == 0) return;
-	if (avgCoverageClustered(bed_file, bam_file, min_mapq, decimals, ref_file, skip_mismapped)) return;
+	if (avgCoverageClustered(bed_file, bam_file, min_mapq, decimals, ref_file, skip_mismapped, threads)) return;
 	BamReader reader(bam_file, ref_file, true, bed_file);   // (only the BGZF blocks the index names for the lines)
 	reader.requireIndex();
 	std::vector<ngsqc_region> regions = unionRegions(bed_file, reader, true);

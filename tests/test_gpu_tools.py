@@ -272,6 +272,10 @@ def test_bedcoverage_random_access_over_scattered_lines_stays_partial(index, tmp
     c = run(*base, env={"NGSQC_INDEX_SELECT": "0"})
     assert a.stdout == b.stdout == c.stdout and len(a.stdout.splitlines()) >= 4
     assert "3 clusters of lines" in a.stderr, a.stderr
+    # -threads (the reference runs its random-access chunks in a thread pool of that size, Statistics.cpp:2778-2797): the clusters are opened and scanned side by
+    # side, the output does not change
+    for th in ("2", "8"):
+        assert run(*base, "-threads", th, env={"NGSQC_INDEX_CLUSTER_GAP_KB": "512"}).stdout == a.stdout, th
     got = sum(int(x) for x in re.findall(r"index-driven open: (\d+) BGZF members", a.stderr))
     one = sum(int(x) for x in re.findall(r"index-driven open: (\d+) BGZF members", b.stderr))
     assert got * 4 < one and one <= n_members, (got, one, n_members)
