@@ -242,6 +242,13 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
  * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1 codecs: NGSQC_E_UNSUPPORTED (bzip2 / lzma blocks need libbz2 / liblzma on the machine, loaded on first use). ngsqc_cram_to_bam writes the decoded records as a BAM file
  * (host only; the checker of the decoder: tests compare it record by record with oracle/cram_decode.py). */
 int ngsqc_set_reference(const char* fasta_path);
+/* What later ngsqc_open* calls on a CRAM need not decode (process-wide, like ngsqc_set_reference). Replaces BamReader::skipTags() and the read-name half of
+ * htslib's CRAM_OPT_REQUIRED_FIELDS, src/cppNGS/BamReader.cpp:525-572: the reference's coverage workers drop bases, tags and qualities before they iterate
+ * (WorkerLowOrHighCoverage.cpp:28-31). Names: every record carries "*"; tags: no optional fields except RG. Only external blocks that no other series reads are
+ * left un-inflated (a series kept in the core block is decoded and dropped). No QC result reads a name; MappingQC's target-region mode reads the DP tag. */
+#define NGSQC_CRAM_SKIP_NAMES 1
+#define NGSQC_CRAM_SKIP_TAGS  2
+int ngsqc_set_cram_skip(int32_t flags);
 int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions);   /* regions NULL / 0: every record */
 
 /* ---- writing the index. The reference never builds one: every indexed path above fails with "Could not load index of BAM/CRAM file"

@@ -170,7 +170,7 @@ EXPORTS = [
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
     "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan", "ngsqc_write_csi", "ngsqc_csi_assemble", "ngsqc_bai_ranges",
-    "ngsqc_set_reference", "ngsqc_cram_to_bam",
+    "ngsqc_set_reference", "ngsqc_set_cram_skip", "ngsqc_cram_to_bam",
 ]
 
 
@@ -203,6 +203,16 @@ def set_reference(fasta_path):
     """The reference genome (FASTA with .fai) CRAM files are decoded against (process-wide, like the reference's RefGenomeService); None: none."""
     L = lib(); L.ngsqc_set_reference.restype = C.c_int; L.ngsqc_set_reference.argtypes = [C.c_char_p]
     L.ngsqc_set_reference(os.fsencode(fasta_path) if fasta_path else None)
+
+
+CRAM_SKIP_NAMES, CRAM_SKIP_TAGS = 1, 2
+
+
+def set_cram_skip(flags):
+    """What later opens of a CRAM need not decode (ngsqc_set_cram_skip: read names and / or optional fields; BamReader::skipTags in the reference)."""
+    L = lib(); L.ngsqc_set_cram_skip.restype = C.c_int; L.ngsqc_set_cram_skip.argtypes = [C.c_int32]
+    if L.ngsqc_set_cram_skip(int(flags)) != 0:
+        raise ValueError("invalid CRAM skip flags")
 
 
 def cram_to_bam(cram_path, bam_path, regions=None):

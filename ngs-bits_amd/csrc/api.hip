@@ -1393,7 +1393,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 struct ScanState : ngsqc_handle::FusedScan
 {
 	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<uint32_t> d_fix;   // d_fix: scratch of the parallel order-dependent fix-up
-	DevBuf<int64_t> d_bq; DevBuf<unsigned long long> d_bq_count; bool bq_ride = false; size_t bq_min = 0;   // MODE_DEPTH with min_baseq riding the walk: records that overlap a region, masked by baseq_list_kernel behind the walk
+	DevBuf<int64_t> d_bq, d_bq_sorted; DevBuf<uint8_t> d_bq_tmp; DevBuf<unsigned long long> d_bq_count; bool bq_ride = false; size_t bq_min = 0;   // MODE_DEPTH with min_baseq riding the walk: records that overlap a region, masked by baseq_list_kernel behind the walk
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
 	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
 	// running state of the in-pass fix
@@ -1497,7 +1497,9 @@ struct ScanState : ngsqc_handle::FusedScan
 		if (fused && bq_ride && h->p_rb.p[ngsqc_handle::RB_BQ])
 		{
 			const size_t ivk = ev.begin(h->stream, &kernel_ms);
-			launch_baseq_list(sp, (int64_t)h->p_rb.p[ngsqc_handle::RB_BQ], h->stream);
+			const int64_t nb = (int64_t)h->p_rb.p[ngsqc_handle::RB_BQ];
+			d_bq_sorted.ensure_slack((size_t)nb); const size_t tb = baseq_sort_bytes(nb); d_bq_tmp.ensure_slack(tb + 256);
+			launch_baseq_list(sp, nb, h->stream, d_bq_sorted.p, d_bq_tmp.p, tb);
 			ev.end(ivk, h->stream); launches++;
 		}
 		if (fused)
@@ -2240,6 +2242,7 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int ngsqc_set_reference(const char* fasta_path) { ngsqc::cram_set_reference(fasta_path); return NGSQC_OK; }
+int ngsqc_set_cram_skip(int32_t flags) { if (flags & ~(NGSQC_CRAM_SKIP_NAMES | NGSQC_CRAM_SKIP_TAGS)) return NGSQC_E_ARG; ngsqc::cram_set_skip(flags); return NGSQC_OK; }
 int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions)
 {
 	if (!cram_path || !bam_path || n_regions < 0 || (!regions && n_regions > 0)) return NGSQC_E_ARG;

@@ -59,6 +59,8 @@ inline std::string chr_norm(std::string c)
 bool is_cram(const uint8_t* d, size_t n);
 void cram_set_reference(const char* fasta);
 std::string cram_reference();
+void cram_set_skip(int flags);   // bit 0: read names, bit 1: optional fields are not needed (not decoded where their blocks are theirs alone)
+int cram_skip();
 struct CramSelect { struct Region { std::string chr; int32_t start, end; }; std::vector<Region> regions; int64_t max_slices = 0; };   // regions: only slices that can hold their records; max_slices: the first slices only
 // The quality arrays of a CRAM (QS series: one rANS 4x8 block per slice, about half of a BAM record's bytes) can stay compressed on the host: the plan names every such
 // block (where its four rANS states start in the CRAM image, its frequency tables in a compact form) and, per record, where its qualities go in the BAM stream; the
@@ -154,7 +156,8 @@ void launch_scan(const ScanParams& p, hipStream_t s);
 void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s);
 void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int64_t from, int32_t* d_start, int32_t n_ref, hipStream_t s);
 void launch_scan_long(const ScanParams& p, int64_t n_long, hipStream_t s);
-void launch_baseq_list(const ScanParams& p, int64_t n_max, hipStream_t s);   // the min_baseq mask of the records in p.bq_list (count on the device)
+void launch_baseq_list(const ScanParams& p, int64_t n, hipStream_t s, int64_t* d_sorted, void* d_tmp, size_t tmp_bytes);   // the min_baseq mask of the n records in p.bq_list (sorted by offset into d_sorted first)
+size_t baseq_sort_bytes(int64_t n);
 void launch_prefix_fix(const ScanParams& p, int64_t upto_max, int64_t upto_paired, const uint32_t* d_head /* captured records, or null: read the resident tile */, hipStream_t s,
                        uint32_t* d_scratch = nullptr /* prefix_fix_scratch_words(max(upto_max, upto_paired)) words: the parallel form; null: one workgroup */);
 size_t prefix_fix_scratch_words(int64_t upto);

@@ -212,10 +212,19 @@ void lzma_block(const uint8_t* raw, size_t csize, size_t rsize, std::vector<uint
 	out.resize(rsize);
 }
 
+// What a caller does not need of the records (the reference's readers say so too: BamReader::skipBases / skipTags / skipQualities set htslib's
+// CRAM_OPT_REQUIRED_FIELDS, BamReader.cpp:525-572): read names and / or optional fields. Their blocks - gzip, mostly: a third of a CRAM's bytes - are then
+// not inflated and the records carry "*" / no tags. Only external blocks that nothing else reads can be left out; a series in the core block is decoded and dropped.
+std::atomic<int> g_cram_skip{0};
+} // namespace
+void cram_set_skip(int flags) { g_cram_skip = flags & 3; }
+int cram_skip() { return g_cram_skip.load(); }
+namespace {
+
 // ---------------------------------------------------------------------------------------------------------------- blocks, containers
 struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; const uint8_t* raw = nullptr; size_t raw_n = 0; bool lazy = false; };
 uint32_t crc_of(const uint8_t* p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
-void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1)   // lazy_cid: an external rANS block with this content id stays compressed (b.lazy; b.n = its decoded size)
+void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1, const std::set<int32_t>* skip_ids = nullptr)   // lazy_cid: an external rANS block with this content id stays compressed (b.lazy; b.n = its decoded size); skip_ids: external blocks nobody will read
 {
 	const size_t start = c.p;
 	b.method = c.byte(); b.ctype = c.byte(); b.cid = c.itf8(); const int32_t csize = c.itf8(), rsize = c.itf8();
@@ -225,6 +234,7 @@ void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1)   // lazy_cid: an externa
 	if (crc_of(c.d + start, crc_at - start) != crc) throw CramError("CRAM block CRC mismatch");
 	b.raw = raw; b.raw_n = (size_t)csize;
 	if (lazy_cid >= 0 && b.ctype == 4 && b.cid == lazy_cid && b.method == 4) { b.lazy = true; b.p = nullptr; b.n = (size_t)rsize; return; }
+	if (skip_ids && b.ctype == 4 && skip_ids->count(b.cid)) { b.p = nullptr; b.n = 0; return; }   // (CRC checked, not inflated)
 	if (b.method == 0) { b.p = raw; b.n = (size_t)csize; }
 	else if (b.method == 1)
 	{
@@ -306,6 +316,7 @@ struct CompHdr
 	std::map<uint16_t, Enc> ds; std::map<int32_t, Enc> tags;
 	char subst[5][4];   // [reference base ACGTN][code] -> read base
 	int32_t qs_only_id = -1;   // content id of the external block that ONLY the QS series reads (-1: none): the block the device may decode
+	bool skip_rn = false; std::set<int32_t> skip_tags, skip_ids;   // cram_skip(): read names / tag keys that are not decoded, and the external blocks that are then not inflated
 	const Enc& series(const char* k) const
 	{
 		auto it = ds.find(ds_key(k));
@@ -358,6 +369,42 @@ void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
 			for (const auto& kv : h.tags) walk(kv.second);
 			if (users == 1) h.qs_only_id = id;
 		}
+	}
+	// what cram_skip() lets go: a series is left out only if all it reads are external blocks that no series which stays reads
+	if (const int skip = cram_skip())
+	{
+		std::function<bool(const Enc&, std::set<int32_t>&)> ids_of = [&](const Enc& e, std::set<int32_t>& out) -> bool {   // false: it reads the core block (bits between other series' bits)
+			bool ext = true;
+			if (e.kind == E_EXTERNAL) out.insert(e.a);
+			else if (e.kind == E_BYTE_ARRAY_STOP) out.insert(e.b);
+			else if (e.kind == E_BYTE_ARRAY_LEN) { if (e.e1) ext = ids_of(*e.e1, out) && ext; if (e.e2) ext = ids_of(*e.e2, out) && ext; }
+			else if (e.kind == E_HUFFMAN && e.syms.size() <= 1) { /* a constant: no bits at all */ }
+			else ext = false;
+			return ext;
+		};
+		std::set<int32_t> needed, rn_ids; std::map<int32_t, std::set<int32_t>> tag_ids;
+		bool rn_ok = false;
+		for (const auto& kv : h.ds)
+		{
+			if ((skip & 1) && kv.first == ds_key("RN")) { rn_ok = ids_of(kv.second, rn_ids); if (!rn_ok) rn_ids.clear(); continue; }
+			std::set<int32_t> tmp; ids_of(kv.second, tmp); needed.insert(tmp.begin(), tmp.end());
+		}
+		for (const auto& kv : h.tags)
+		{
+			std::set<int32_t> tmp; const bool ok = ids_of(kv.second, tmp);
+			if ((skip & 2) && ok) tag_ids[kv.first] = tmp; else needed.insert(tmp.begin(), tmp.end());
+		}
+		auto free_of_needed = [&](const std::set<int32_t>& ids) { for (int32_t id : ids) if (needed.count(id)) return false; return true; };
+		// (a tag that shares a block with a tag that stays must stay too: until nothing changes)
+		for (bool changed = true; changed;)
+		{
+			changed = false;
+			for (auto it = tag_ids.begin(); it != tag_ids.end();)
+				if (!free_of_needed(it->second)) { needed.insert(it->second.begin(), it->second.end()); it = tag_ids.erase(it); changed = true; } else ++it;
+		}
+		if (rn_ok && free_of_needed(rn_ids)) { h.skip_rn = true; h.skip_ids.insert(rn_ids.begin(), rn_ids.end()); }
+		for (const auto& kv : tag_ids) { h.skip_tags.insert(kv.first); h.skip_ids.insert(kv.second.begin(), kv.second.end()); }
+		if (h.qs_only_id >= 0 && h.skip_ids.count(h.qs_only_id)) h.qs_only_id = -1;
 	}
 	// substitution matrix: for every reference base the four other bases in the order of their 2-bit codes
 	const char B[6] = "ACGTN";
@@ -692,11 +739,11 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		if (ch.AP) { prev_pos += ap; r.pos = (int32_t)prev_pos; } else r.pos = ap;
 		const int32_t rg = D.integer(eRG);
 		name.clear(); bool have_name = false;
-		if (ch.RN) { D.array(sRN.get(), name); have_name = true; }
+		if (ch.RN && !ch.skip_rn) { D.array(sRN.get(), name); have_name = true; }
 		if (r.cf & CF_DETACHED)
 		{
 			r.mf = D.integer(sMF.get());
-			if (!ch.RN) { D.array(sRN.get(), name); have_name = true; }
+			if (!ch.RN && !ch.skip_rn) { D.array(sRN.get(), name); have_name = true; }
 			r.ns = D.integer(sNS.get()); r.np = D.integer(sNP.get()); r.ts = D.integer(sTS.get());
 		}
 		else if (r.cf & CF_MATE_DOWNSTREAM)
@@ -712,6 +759,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		{
 			const auto& tg = ch.TD[(size_t)tl][ti]; const Enc* te = td_enc[(size_t)tl][ti];
 			if (!te) throw CramError("CRAM tag without an encoding");
+			if (!ch.skip_tags.empty() && ch.skip_tags.count(((int32_t)(tg.first >> 8) << 16) | ((int32_t)(tg.first & 0xff) << 8) | tg.second)) continue;   // (cram_skip: its block was not inflated)
 			D.array(*te, tmp);
 			tagbytes.push_back((uint8_t)(tg.first >> 8)); tagbytes.push_back((uint8_t)(tg.first & 0xff)); tagbytes.push_back(tg.second);
 			tagbytes.insert(tagbytes.end(), tmp.begin(), tmp.end());
@@ -1053,7 +1101,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 					SliceJob& j = jobs[i]; Cur bc(d, n, j.blocks_at);
 					std::vector<Blk> bl((size_t)j.sh.n_blocks);
 					const long long tb0 = now_us();
-					for (Blk& b : bl) read_block(bc, b, defer ? j.ch->qs_only_id : -1);
+					for (Blk& b : bl) read_block(bc, b, defer ? j.ch->qs_only_id : -1, j.ch->skip_ids.empty() ? nullptr : &j.ch->skip_ids);
 					auto on_host = [&](Blk& b) { rans_decode(b.raw, b.raw_n, b.own, b.n); if (b.own.size() != b.n) throw CramError("CRAM block inflates to another size than its header says"); b.p = b.own.data(); b.lazy = false; };
 					for (Blk& b : bl) if (b.lazy) { if (rans_plan(b.raw, b.raw_n, (uint64_t)(b.raw - d), b.n, j.qjob, j.qtabs, j.qsyms)) j.has_q = true; else on_host(b); }
 					const long long tb1 = now_us(); us_blocks += tb1 - tb0;

@@ -70,54 +70,6 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 	}
 }
 
-// The same search for entries that may lie inside ONE long record (long reads, round 5): sixteen waves per entry, each looking through its own sixteenth of the
-// entry for the first plausible record and stopping there; the entry's start is the find of the lowest wave that has one. A group of 16 members inside a 500 kb
-// read is then sixteen parallel scans of 64 KiB instead of one of 500 KiB (1.6 ms per tile of the ONT-like bench shard: the longest record set the kernel's time).
-__global__ __launch_bounds__(1024) void index_guess_wide_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
-                                                                int32_t* start, int32_t n_ref)
-{
-	__shared__ int32_t hit[16];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (int64_t b = from + blockIdx.x; b < n_blocks; b += gridDim.x)
-	{
-		if (start[b] != -2) continue;   // (uniform for the block)
-		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
-		const int64_t part = (((hi - lo) + 15) / 16 + 255) & ~255ll;
-		const int64_t wlo = lo + wave * part, whi = min(hi, wlo + part);
-		int32_t found = -1;
-		for (int64_t base = wlo; base < whi && found < 0; base += 1024)
-		{
-			uint32_t w[4][8];
-			#pragma unroll
-			for (int q = 0; q < 4; ++q)
-			{
-				const int64_t o0 = base + 256 * q + 4 * lane;
-				if (o0 < whi) load_window(infl, total, o0, w[q]); else for (int k = 0; k < 8; ++k) w[q][k] = 0u;
-			}
-			#pragma unroll
-			for (int q = 0; q < 4; ++q)
-			{
-				if (found < 0)
-				{
-					const int64_t o0 = base + 256 * q + 4 * lane;
-					const uint32_t cand = cheap_candidates(w[q], o0, whi, total, n_ref);
-					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
-					{
-						int32_t mine = -1;
-						if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
-						const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
-						if (m) { const int l = __builtin_ctzll(m); found = (int32_t)(base + 256 * q + 4 * l + __builtin_amdgcn_readlane(mine, l) - lo); }
-					}
-				}
-			}
-		}
-		if (lane == 0) hit[wave] = found;
-		__syncthreads();
-		if (threadIdx.x == 0) { int32_t f = -1; for (int k = 0; k < 16 && f < 0; ++k) f = hit[k]; start[b] = f; }
-		__syncthreads();
-	}
-}
-
 // start[b]: >=0 first-record offset inside entry b; -1 none (a longer record covers the whole entry); -2 guess.
 __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
@@ -311,8 +263,8 @@ void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	static const bool wide = !getenv("NGSQC_WIDE_GUESS") || atoi(getenv("NGSQC_WIDE_GUESS")) != 0;   // (0: a wave per group, as in the first long-read build)
-	if (ksh < 0 && wide) { hipLaunchKernelGGL(index_guess_wide_kernel, dim3((int)std::min<int64_t>(n, 256 * 8)), dim3(1024), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK(); return; }   // (groups of members: long reads)
+	// (Round 5 also tried sixteen waves per group of members, each looking through a sixteenth: 6.6 ms against this kernel's 1.6 ms per tile of the ONT-like shard,
+	// profiles/r05_scan_probe.txt - removed.)
 	const int64_t wg = (n + 3) / 4;
 	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK();
 }

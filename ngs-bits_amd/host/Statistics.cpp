@@ -18,6 +18,9 @@ static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
 static const double g_t0 = now_s();
 static void stamp(const char* what) { if (getenv("NGSQC_TIMING")) fprintf(stderr, "[ngsqc] +%.3f s %s\n", now_s() - g_t0, what); }
 
+void BamReader::requireTags(bool needed) { ngsqc_set_cram_skip(NGSQC_CRAM_SKIP_NAMES | (needed ? 0 : NGSQC_CRAM_SKIP_TAGS)); }
+static const bool g_cram_skip_default = (BamReader::requireTags(false), true);   // (tools: names never, tags only where a function says so)
+
 void BamReader::init(const std::string& ref, bool allow_shards, const BedFile* regions, int64_t head_members)
 {
 	head_members_ = head_members;
@@ -610,6 +613,7 @@ QCCollection Statistics::mapping(const BedFile& bed_file, const std::string& bam
 	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
 	long long roi_bases = bed_file.baseCount();
 	GcPrep gc(bed_file, fa.get());
+	struct TagsGuard { TagsGuard() { BamReader::requireTags(true); } ~TagsGuard() { BamReader::requireTags(false); } } tags_needed;   // (the DP tag of cfDNA reads, Statistics.cpp:447-470)
 	BamReader reader(bam_file, ref_file, true);
 	// ROI lines on chromosomes the BAM does not know never match a read in the reference (ChromosomalIndex lookup by name)
 	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);

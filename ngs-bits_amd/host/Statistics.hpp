@@ -24,6 +24,9 @@ public:
 	struct Head { int64_t n_members; };
 	BamReader(const std::string& bam_file, const std::string& ref_genome, Head head);
 	BamInfo info();   // BamReader.cpp:593-730
+	// BamReader::skipTags() of the reference (BamReader.cpp:525-572: htslib's CRAM_OPT_REQUIRED_FIELDS): what the readers opened from now on need of a CRAM's
+	// records. No function of this path reads a read name; only Statistics::mapping(bed ...) reads a tag (DP, cfDNA). BAM input is not affected.
+	static void requireTags(bool needed);
 	~BamReader();
 	BamReader(const BamReader&) = delete; BamReader& operator=(const BamReader&) = delete;
 	const std::vector<Chromosome>& chromosomes() const { return chrs_; }

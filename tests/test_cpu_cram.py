@@ -143,6 +143,38 @@ def test_read_with_more_than_65535_cigar_operations(tmp_path, monkeypatch):
     assert [CD.to_bam_record(r, rgs) for r in f.records] == twin["records"]
 
 
+@pytest.mark.parametrize("name", ["cramTest.cram", "SampleIdentity_in_wes.cram", "twin"])
+def test_names_and_tags_are_not_decoded_when_nobody_needs_them(name, twins, tmp_path, monkeypatch):
+    """ngsqc_set_cram_skip (BamReader::skipTags / CRAM_OPT_REQUIRED_FIELDS in the reference, BamReader.cpp:525-572): the external blocks of the read names and of
+    the optional fields are not inflated; every record is the oracle's record with the name "*" and no tags but RG - every other byte (positions, CIGAR, bases,
+    qualities, mate fields) as before."""
+    out = str(tmp_path / "s.bam"); full = str(tmp_path / "f.bam")
+    if name == "twin":
+        twin = twins["MappingQC_in2.bam"]; src = str(tmp_path / "t.cram"); CE.encode(twin["bam"], src, twin["genome"])
+        fetch = cram_twin.ref_fetch_of(twin); ngsqc.set_reference(twin["fasta"]); monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False)
+    else:
+        src = os.path.join(GI, name); fetch = None; ngsqc.set_reference(None); monkeypatch.setenv("NGSQC_CRAM_NO_REFERENCE", "1")
+    try:
+        ngsqc.cram_to_bam(src, full)
+        for flags in (ngsqc.CRAM_SKIP_NAMES | ngsqc.CRAM_SKIP_TAGS, ngsqc.CRAM_SKIP_NAMES, ngsqc.CRAM_SKIP_TAGS):
+            ngsqc.set_cram_skip(flags)
+            try:
+                ngsqc.cram_to_bam(src, out)
+            finally:
+                ngsqc.set_cram_skip(0)
+            f = CD.read_cram(src, fetch); rgs = CD.read_groups(f.header)
+            _, _, recs = split_bam(bam_stream(out)[0])
+            assert len(recs) == len(f.records) > 1000
+            for i, (got, r) in enumerate(zip(recs, f.records)):
+                if flags & ngsqc.CRAM_SKIP_NAMES: r.name = None
+                if flags & ngsqc.CRAM_SKIP_TAGS: r.tags = []
+                want = CD.to_bam_record(r, rgs)
+                assert got == want, (flags, i, got[:60].hex(), want[:60].hex())
+            assert bam_stream(out)[0] != bam_stream(full)[0]
+    finally:
+        ngsqc.set_reference(None)
+
+
 def test_genome_errors(twins, tmp_path, monkeypatch):
     twin = twins["MappingQC_in2.bam"]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "o.bam")
     CE.encode(twin["bam"], cram, twin["genome"])
