@@ -45,6 +45,15 @@ struct Cur
 	int32_t i32() { return (int32_t)u32(); }
 	int32_t itf8()
 	{
+		if (n - p >= 5 && p <= n)   // (the common case: no end test per byte)
+		{
+			const uint8_t* q = d + p; const uint32_t b0 = q[0];
+			if (b0 < 0x80) { p += 1; return (int32_t)b0; }
+			if (b0 < 0xc0) { p += 2; return (int32_t)(((b0 & 0x3f) << 8) | q[1]); }
+			if (b0 < 0xe0) { p += 3; return (int32_t)(((b0 & 0x1f) << 16) | ((uint32_t)q[1] << 8) | q[2]); }
+			if (b0 < 0xf0) { p += 4; return (int32_t)(((b0 & 0x0f) << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]); }
+			p += 5; return (int32_t)(((b0 & 0x0f) << 28) | ((uint32_t)q[1] << 20) | ((uint32_t)q[2] << 12) | ((uint32_t)q[3] << 4) | (q[4] & 0x0fu));
+		}
 		const uint32_t b0 = byte(); uint32_t v;
 		if (b0 < 0x80) v = b0;
 		else if (b0 < 0xc0) v = ((b0 & 0x3f) << 8) | byte();
@@ -271,6 +280,7 @@ struct Enc
 	int kind = E_NULL; int32_t a = 0, b = 0;
 	std::vector<int32_t> syms, lens; std::unique_ptr<Enc> e1, e2;
 	struct Code { int len; uint32_t code; int32_t sym; }; std::vector<Code> codes; int max_len = 0;   // canonical Huffman codes, ascending by (len, code)
+	uint32_t first_code[33] = {}, first_at[33] = {}, n_of_len[33] = {};   // per code length: its first code, where its codes start in `codes`, how many there are (they are consecutive)
 	bool present = false;
 };
 void read_encoding(Cur& c, Enc& e)
@@ -295,6 +305,7 @@ void read_encoding(Cur& c, Enc& e)
 		{
 			if (e.lens[i] < 0 || e.lens[i] > 31) throw CramError("bad Huffman code length");
 			code <<= (e.lens[i] - last); last = e.lens[i];
+			if (e.n_of_len[e.lens[i]]++ == 0) { e.first_code[e.lens[i]] = code; e.first_at[e.lens[i]] = (uint32_t)e.codes.size(); }
 			e.codes.push_back(Enc::Code{e.lens[i], code, e.syms[i]}); ++code;
 			e.max_len = std::max(e.max_len, e.lens[i]);
 		}
@@ -545,18 +556,18 @@ private:
 struct NeedHostQuals {};
 struct BitReader
 {
-	const uint8_t* d = nullptr; size_t n = 0, p = 0; int bit = 7;
-	uint32_t bits(int k)
+	const uint8_t* d = nullptr; size_t n = 0, at = 0;   // at: the next bit, counted from the block's first (most significant first within a byte)
+	uint32_t bits(int k)   // k <= 32
 	{
-		uint32_t v = 0;
-		for (int i = 0; i < k; ++i)
-		{
-			if (p >= n) throw CramError("CRAM core block is too short");
-			v = (v << 1) | ((d[p] >> bit) & 1u);
-			if (--bit < 0) { bit = 7; ++p; }
-		}
-		return v;
+		if (k <= 0) return 0;
+		if (at + (size_t)k > n * 8) throw CramError("CRAM core block is too short");
+		const size_t b = at >> 3; const int off = (int)(at & 7), nb = (off + k + 7) >> 3;   // at most five bytes hold the k bits
+		uint64_t w = 0;
+		for (int i = 0; i < nb; ++i) w = (w << 8) | d[b + (size_t)i];
+		at += (size_t)k;
+		return (uint32_t)((w >> (nb * 8 - off - k)) & ((1ull << k) - 1));
 	}
+	uint32_t bit1() { if (at >= n * 8) throw CramError("CRAM core block is too short"); const uint32_t v = (d[at >> 3] >> (7 - (at & 7))) & 1u; ++at; return v; }
 };
 struct Dec
 {
@@ -581,20 +592,19 @@ struct Dec
 		case E_HUFFMAN:
 		{
 			if (e.max_len == 0) return e.codes[0].sym;
-			uint32_t code = 0; size_t at = 0;
+			uint32_t code = 0;
 			for (int len = 1; len <= e.max_len; ++len)
 			{
-				code = (code << 1) | core.bits(1);
-				while (at < e.codes.size() && e.codes[at].len < len) ++at;
-				for (size_t x = at; x < e.codes.size() && e.codes[x].len == len; ++x) if (e.codes[x].code == code) return e.codes[x].sym;
+				code = (code << 1) | core.bit1();
+				if (e.n_of_len[len] && code >= e.first_code[len] && code - e.first_code[len] < e.n_of_len[len]) return e.codes[e.first_at[len] + (code - e.first_code[len])].sym;
 			}
 			throw CramError("bad Huffman code in the CRAM core block");
 		}
 		case E_BETA: return (int32_t)core.bits(e.b) - e.a;
-		case E_GAMMA: { int k = 0; while (core.bits(1) == 0) { if (++k > 31) throw CramError("bad GAMMA code"); } return (int32_t)((1u << k) | core.bits(k)) - e.a; }
+		case E_GAMMA: { int k = 0; while (core.bit1() == 0) { if (++k > 31) throw CramError("bad GAMMA code"); } return (int32_t)((1u << k) | core.bits(k)) - e.a; }
 		case E_SUBEXP:
 		{
-			int i = 0; while (core.bits(1) == 1) { if (++i > 31) throw CramError("bad SUBEXP code"); }
+			int i = 0; while (core.bit1() == 1) { if (++i > 31) throw CramError("bad SUBEXP code"); }
 			const int nb = i == 0 ? e.b : i + e.b - 1;
 			if (nb < 0 || nb > 31) throw CramError("bad SUBEXP code");
 			const uint32_t v = i == 0 ? core.bits(nb) : ((1u << nb) | core.bits(nb));
@@ -604,6 +614,16 @@ struct Dec
 		}
 	}
 	uint8_t byte(const Enc& e) { return e.kind == E_EXTERNAL ? block(e.a).byte() : (uint8_t)(integer(e) & 0xff); }
+	// a series with its cursor looked up once per slice (EXTERNAL: the common case); what cannot be resolved here goes the general way, with its errors, when it is read
+	struct Ser { const Enc* e = nullptr; Cur* c = nullptr; operator const Enc&() const { return *e; } };
+	Ser ser(const Enc& e)
+	{
+		Ser s; s.e = &e;
+		if (e.kind == E_EXTERNAL && !(e.a == defer_id && defer_id >= 0) && e.a >= 0 && (size_t)e.a < flat.size()) s.c = flat[(size_t)e.a];
+		return s;
+	}
+	int32_t integer(const Ser& s) { return s.c ? s.c->itf8() : integer(*s.e); }
+	uint8_t byte(const Ser& s) { return s.c ? s.c->byte() : byte(*s.e); }
 	void bytes_n(const Enc& e, size_t k, std::vector<uint8_t>& out)
 	{
 		if (e.kind == E_EXTERNAL && e.a == defer_id && defer_id >= 0)
@@ -700,21 +720,23 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		if (env.no_reference) { memset(dst, 'N', (size_t)n); return; }
 		const std::string* c = contig_of(ref_id);
 		if (!c) throw IoError("Error while setting reference genome for cram file " + env.path + ": a read needs bases of a sequence the genome does not hold");
+		if (p0 >= 0 && (uint64_t)(p0 + n) <= c->size()) { memcpy(dst, c->data() + p0, (size_t)n); return; }
 		for (int64_t i = 0; i < n; ++i) { const int64_t x = p0 + i; dst[i] = x >= 0 && (size_t)x < c->size() ? (uint8_t)(*c)[(size_t)x] : (uint8_t)'N'; }
 	};
 
 	const size_t nrec = (size_t)sh.n_records;
+	{ size_t raw = 0; for (const Blk& b : blocks) raw += b.n; out.reserve(out.size() + 2 * raw + 64 * nrec); }   // (a guess that saves the first doublings; the vector still grows when it is short)
 	std::vector<RecInfo> recs(nrec);
 	std::vector<uint8_t> name, seq, qual, tmp, tagbytes, fbytes; std::vector<Feature> feats; std::vector<uint32_t> cigar;
-	const Enc &eBF = ch.series("BF"), &eCF = ch.series("CF"), &eRL = ch.series("RL"), &eAP = ch.series("AP"), &eRG = ch.series("RG"), &eTL = ch.series("TL");
+	const Dec::Ser eBF = D.ser(ch.series("BF")), eCF = D.ser(ch.series("CF")), eRL = D.ser(ch.series("RL")), eAP = D.ser(ch.series("AP")), eRG = D.ser(ch.series("RG")), eTL = D.ser(ch.series("TL"));
 	struct Lazy   // the other series: looked up once, an error only when a record needs one the header does not define
 	{
-		const CompHdr& ch; const char* key; const Enc* e = nullptr; bool tried = false;
-		Lazy(const CompHdr& c, const char* k) : ch(c), key(k) {}
-		const Enc& get() { if (!tried) { tried = true; auto it = ch.ds.find(ds_key(key)); if (it != ch.ds.end()) e = &it->second; } if (!e) throw CramError(std::string("CRAM data series ") + key + " is used but has no encoding"); return *e; }
+		const CompHdr& ch; Dec& D; const char* key; Dec::Ser s; bool tried = false;
+		Lazy(const CompHdr& c, Dec& d, const char* k) : ch(c), D(d), key(k) {}
+		const Dec::Ser& get() { if (!tried) { tried = true; auto it = ch.ds.find(ds_key(key)); if (it != ch.ds.end()) s = D.ser(it->second); } if (!s.e) throw CramError(std::string("CRAM data series ") + key + " is used but has no encoding"); return s; }
 	};
-	Lazy sRI(ch, "RI"), sRN(ch, "RN"), sMF(ch, "MF"), sNS(ch, "NS"), sNP(ch, "NP"), sTS(ch, "TS"), sNF(ch, "NF"), sFN(ch, "FN"), sFC(ch, "FC"), sFP(ch, "FP"), sBA(ch, "BA"), sQS(ch, "QS"),
-	     sBS(ch, "BS"), sIN(ch, "IN"), sSC(ch, "SC"), sHC(ch, "HC"), sPD(ch, "PD"), sDL(ch, "DL"), sRS(ch, "RS"), sBB(ch, "BB"), sQQ(ch, "QQ"), sMQ(ch, "MQ");
+	Lazy sRI(ch, D, "RI"), sRN(ch, D, "RN"), sMF(ch, D, "MF"), sNS(ch, D, "NS"), sNP(ch, D, "NP"), sTS(ch, D, "TS"), sNF(ch, D, "NF"), sFN(ch, D, "FN"), sFC(ch, D, "FC"), sFP(ch, D, "FP"), sBA(ch, D, "BA"),
+	     sQS(ch, D, "QS"), sBS(ch, D, "BS"), sIN(ch, D, "IN"), sSC(ch, D, "SC"), sHC(ch, D, "HC"), sPD(ch, D, "PD"), sDL(ch, D, "DL"), sRS(ch, D, "RS"), sBB(ch, D, "BB"), sQQ(ch, D, "QQ"), sMQ(ch, D, "MQ");
 	// the tag encodings of every tag line, resolved once
 	std::vector<std::vector<const Enc*>> td_enc(ch.TD.size());
 	for (size_t l = 0; l < ch.TD.size(); ++l) for (const auto& tg : ch.TD[l])
@@ -801,9 +823,20 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 			if (qarr) D.bytes_n(sQS.get(), (size_t)rl, qual);
 			// read features -> CIGAR, bases, qualities (CRAMv3 section 10.6); between features the read follows the reference
 			int64_t ref_pos = (int64_t)r.pos - 1, read_pos = 0;
+			// The reference is fetched a stretch at a time, ahead of the features: seq[read_pos .. fill_end) holds the reference bases of the current alignment as long as
+			// ref_pos - read_pos is what it was at the fetch (a match moves both; insertions, clips, deletions and skips shift one against the other). One copy per
+			// stretch instead of one per feature; the window bounds what a read with many shifts (long reads) fetches in vain.
+			int64_t fill_delta = 0, fill_end = -1;
+			auto have = [&](int64_t upto) {   // upto > read_pos: seq[read_pos .. upto) = reference
+				const bool same = fill_delta == ref_pos - read_pos;
+				if (same && fill_end >= upto) return;
+				const int64_t from = same && fill_end > read_pos ? fill_end : read_pos, to = std::min<int64_t>(rl, std::max<int64_t>(upto, from + 128));
+				ref_bases(r.ref_id, ref_pos + (from - read_pos), to - from, seq.data() + from);
+				fill_delta = ref_pos - read_pos; fill_end = to;
+			};
 			auto match_to = [&](int64_t upto) {
 				const int64_t n = upto - read_pos;
-				if (n > 0) { ref_bases(r.ref_id, ref_pos, n, seq.data() + read_pos); add_op(0, n); ref_pos += n; read_pos = upto; }
+				if (n > 0) { have(upto); add_op(0, n); ref_pos += n; read_pos = upto; }
 			};
 			auto span_ok = [&](int64_t at, size_t n) { if (at < 0 || at + (int64_t)n > rl) throw CramError("CRAM read feature outside the read"); };
 			for (const Feature& f : feats)
@@ -820,7 +853,7 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 				case 'X':
 				{
 					span_ok(at, 1);
-					uint8_t rb = 'N'; ref_bases(r.ref_id, ref_pos, 1, &rb);
+					have(at + 1); const uint8_t rb = seq[(size_t)at];
 					const int ri = rb == 'A' ? 0 : rb == 'C' ? 1 : rb == 'G' ? 2 : rb == 'T' ? 3 : 4;
 					seq[(size_t)at] = (uint8_t)ch.subst[ri][f.v & 3]; add_op(0, 1); ++ref_pos; ++read_pos; break;
 				}
@@ -849,40 +882,41 @@ void decode_slice(const CompHdr& ch, const SliceHdr& sh, std::vector<Blk>& block
 		const size_t l_seq = have_seq ? (size_t)rl : 0;
 		if (!have_name) name.assign(1, '*');
 		if (name.size() > 254) throw CramError("read name longer than 254 bytes");
-		add32(out, 0);   // block_size
-		add32(out, (uint32_t)r.ref_id); add32(out, (uint32_t)(r.pos - 1));
-		out.push_back((uint8_t)(name.size() + 1)); out.push_back((uint8_t)mapq);
 		const int64_t pos0 = (int64_t)r.pos - 1, end0 = cigar.empty() ? pos0 + 1 : (int64_t)r.end;
-		add16(out, pos0 < 0 ? 4680u : reg2bin14(pos0, end0));
 		// more than 65535 operations do not fit n_cigar_op: the BAM convention (SAM spec 4.2.2, htslib bam_write1) - a placeholder <l_seq>S<reference length>N and
 		// the operations in a CG:B,I tag behind the record's other tags, which every reader of the image (K2 / K3, like htslib's bam_tag2cigar) puts back
 		const bool cg = cigar.size() > 65535;
-		add16(out, cg ? 2u : (uint32_t)cigar.size()); add16(out, r.bf); add32(out, (uint32_t)l_seq);
-		add32(out, 0xffffffffu); add32(out, 0xffffffffu); add32(out, 0);   // next_refID, next_pos, tlen
-		out.insert(out.end(), name.begin(), name.end()); out.push_back(0);
+		const int64_t ref_len = end0 - pos0;
+		if (cg && (l_seq >= (1u << 28) || ref_len < 0 || ref_len >= (1ll << 28))) throw CramError("a read with more than 65535 CIGAR operations is too long for the BAM placeholder CIGAR");
+		const std::string* rg_id = rg >= 0 && (size_t)rg < env.rg_ids->size() ? &(*env.rg_ids)[(size_t)rg] : nullptr;
+		const size_t n_cig = cg ? 2 : cigar.size();
+		const size_t rec_bytes = 36 + name.size() + 1 + 4 * n_cig + (l_seq + 1) / 2 + l_seq + tagbytes.size() + (rg_id ? rg_id->size() + 4 : 0) + (cg ? 8 + 4 * cigar.size() : 0);
+		out.resize(r.off + rec_bytes);   // (the record's size is known: one growth of the vector, the fields written in place)
+		uint8_t* w = out.data() + r.off;
+		auto w32 = [&](uint32_t v) { w[0] = (uint8_t)v; w[1] = (uint8_t)(v >> 8); w[2] = (uint8_t)(v >> 16); w[3] = (uint8_t)(v >> 24); w += 4; };
+		auto w16 = [&](uint32_t v) { w[0] = (uint8_t)v; w[1] = (uint8_t)(v >> 8); w += 2; };
+		auto wn = [&](const void* p, size_t k) { if (k) memcpy(w, p, k); w += k; };
+		w32((uint32_t)(rec_bytes - 4));   // block_size
+		w32((uint32_t)r.ref_id); w32((uint32_t)(r.pos - 1));
+		*w++ = (uint8_t)(name.size() + 1); *w++ = (uint8_t)mapq;
+		w16(pos0 < 0 ? 4680u : reg2bin14(pos0, end0));
+		w16((uint32_t)n_cig); w16(r.bf); w32((uint32_t)l_seq);   // flag, mate fields and template length are patched when the slice's chains are resolved
+		w32(0xffffffffu); w32(0xffffffffu); w32(0);   // next_refID, next_pos, tlen
+		wn(name.data(), name.size()); *w++ = 0;
+		if (cg) { w32(((uint32_t)l_seq << 4) | 4u); w32(((uint32_t)ref_len << 4) | 3u); }
+		else for (uint32_t c : cigar) w32(c);
+		for (size_t x = 0; x + 1 < l_seq; x += 2) *w++ = (uint8_t)((nt16[seq[x]] << 4) | nt16[seq[x + 1]]);
+		if (l_seq & 1) *w++ = (uint8_t)(nt16[seq[l_seq - 1]] << 4);
+		if (D.took) { if (patches && l_seq) patches->push_back(CramQualPlan::Patch{(uint64_t)(w - out.data()), D.last_src, (uint32_t)l_seq, 0u}); D.took = false; }
+		wn(qual.data(), l_seq);
+		wn(tagbytes.data(), tagbytes.size());
+		if (rg_id) { *w++ = 'R'; *w++ = 'G'; *w++ = 'Z'; wn(rg_id->data(), rg_id->size()); *w++ = 0; }
 		if (cg)
 		{
-			const int64_t ref_len = end0 - pos0;
-			if (l_seq >= (1u << 28) || ref_len < 0 || ref_len >= (1ll << 28)) throw CramError("a read with more than 65535 CIGAR operations is too long for the BAM placeholder CIGAR");
-			add32(out, ((uint32_t)l_seq << 4) | 4u); add32(out, ((uint32_t)ref_len << 4) | 3u);
+			*w++ = 'C'; *w++ = 'G'; *w++ = 'B'; *w++ = 'I'; w32((uint32_t)cigar.size());
+			for (uint32_t c : cigar) w32(c);
 		}
-		else for (uint32_t c : cigar) add32(out, c);
-		const size_t sq = out.size(); out.resize(sq + (l_seq + 1) / 2, 0);
-		for (size_t x = 0; x < l_seq; ++x) out[sq + (x >> 1)] |= (uint8_t)(nt16[seq[x]] << ((x & 1) ? 0 : 4));
-		if (D.took) { if (patches && l_seq) patches->push_back(CramQualPlan::Patch{(uint64_t)out.size(), D.last_src, (uint32_t)l_seq, 0u}); D.took = false; }
-		out.insert(out.end(), qual.begin(), qual.begin() + (long)l_seq);
-		out.insert(out.end(), tagbytes.begin(), tagbytes.end());
-		if (rg >= 0 && (size_t)rg < env.rg_ids->size())
-		{
-			const std::string& id = (*env.rg_ids)[(size_t)rg];
-			out.push_back('R'); out.push_back('G'); out.push_back('Z'); out.insert(out.end(), id.begin(), id.end()); out.push_back(0);
-		}
-		if (cg)
-		{
-			out.push_back('C'); out.push_back('G'); out.push_back('B'); out.push_back('I'); add32(out, (uint32_t)cigar.size());
-			for (uint32_t c : cigar) add32(out, c);
-		}
-		put32(out, r.off, (uint32_t)(out.size() - r.off - 4));
+		if (w != out.data() + out.size()) throw std::logic_error("CRAM record size bookkeeping");
 	}
 	// ---- mates (htslib cram_decode_slice_xref) ----
 	for (size_t i = 0; i < nrec; ++i)
