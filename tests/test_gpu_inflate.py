@@ -151,6 +151,39 @@ def test_crc32_mismatch_is_the_reference_read_error(raw_bam, monkeypatch):
     h.close()
 
 
+CRC_SIZES = [1, 3, 15, 16, 17, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 12345, 16383, 16384, 16385, 20000, 32768, 40001, 49152, 61441, 65279, 65280, 65281, 65535, 65536]
+
+
+@pytest.mark.parametrize("chains", ["1", "2", "4"])
+def test_crc32_chains_per_lane(raw_bam, chains, monkeypatch):
+    """the CRC kernel with 1 / 2 / 4 chains per lane (csrc/crc.hip; rounds of 4 / 8 / 16 KiB): member sizes on both sides of every round and piece boundary pass
+    with their true CRC32, and a flipped bit anywhere in a member - first byte, last byte, the bytes around the boundaries - is found in exactly that member"""
+    monkeypatch.setenv("NGSQC_CRC_CHAINS", chains)
+    stored = sorted({min(n, 65500) for n in CRC_SIZES})   # (what fits a BGZF member as stored blocks: zlib ends a level-0 stream with an empty block of its own)
+    good = rebgzf(raw_bam, stored, level=0)
+    assert _roundtrip(raw_bam, good) == 30000
+    assert _roundtrip(raw_bam, rebgzf(raw_bam, CRC_SIZES, level=6)) == 30000
+    first_record = 4 + 4 + struct.unpack_from("<i", raw_bam, 4)[0]   # (damage in the header would be another error)
+    n_ref = struct.unpack_from("<i", raw_bam, first_record)[0]; first_record += 4
+    for _ in range(n_ref):
+        first_record += 4 + struct.unpack_from("<i", raw_bam, first_record)[0] + 4
+    starts, pos, k = [], 0, 0
+    while pos < len(raw_bam):
+        starts.append((pos, min(stored[k % len(stored)], len(raw_bam) - pos))); pos += starts[-1][1]; k += 1
+    rng = np.random.default_rng(int(chains))
+    picks = [m for m in range(len(starts)) if starts[m][0] > first_record + 200000][:3 * len(stored)]   # every size three times, behind the members an open inflates
+    assert len(picks) == 3 * len(stored)
+    for i, m in enumerate(picks):
+        n = starts[m][1]
+        at = [0, n - 1, int(rng.integers(0, n))][i // len(stored)]
+        bad = _flip_payload_byte(good, m, at)
+        h = ngsqc.Handle(data=np.frombuffer(bad, dtype=np.uint8))
+        with pytest.raises(ngsqc.NgsqcError) as ei:
+            h.decode()
+        assert f"CRC32 mismatch in block {m}" in str(ei.value), (m, n, at, str(ei.value))
+        h.close()
+
+
 @pytest.mark.parametrize("field", ["l_seq", "n_cigar", "l_read_name", "neg_l_seq"])
 def test_record_with_impossible_lengths_is_the_reference_read_error(raw_bam, field):
     """htslib's bam_read1 rejects a record whose variable-length fields do not fit block_size (the reference then throws "Could not read next
