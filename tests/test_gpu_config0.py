@@ -31,7 +31,9 @@ def test_mappingqc_tool_output(inputs, tmp_path):
         p = subprocess.run([os.path.join(BIN, "MappingQC"), "-in", bam, "-roi", bed, "-no_ref", "-no_cont", "-txt", "-out", out], capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0, p.stderr
         got = dict(ln.split(": ", 1) for ln in open(out).read().splitlines() if ": " in ln)
-        assert got == {k: v for k, v in exp.items() if k in got} and len(got) >= len(exp) - 2, sorted(set(got.items()) ^ set(exp.items()))   # (-no_ref: no dropout lines)
+        dropout = {"AT dropout", "GC dropout"}   # (-no_ref: "n/a (no reference genome)" instead of a value)
+        assert {k: v for k, v in got.items() if k not in dropout} == {k: v for k, v in exp.items() if k not in dropout}, sorted(set(got.items()) ^ set(exp.items()))
+        assert all(got[k].startswith("n/a") for k in dropout)
 
 
 def test_counters_and_depth_through_the_c_abi(inputs):

@@ -177,11 +177,13 @@ def test_crc32_chains_per_lane(raw_bam, chains, monkeypatch):
         n = starts[m][1]
         at = [0, n - 1, int(rng.integers(0, n))][i // len(stored)]
         bad = _flip_payload_byte(good, m, at)
-        h = ngsqc.Handle(data=np.frombuffer(bad, dtype=np.uint8))
-        with pytest.raises(ngsqc.NgsqcError) as ei:
-            h.decode()
-        assert f"CRC32 mismatch in block {m}" in str(ei.value), (m, n, at, str(ei.value))
-        h.close()
+        with pytest.raises(ngsqc.NgsqcError) as ei:   # (the small members at the front are among those an open inflates for the header: the error may come from there)
+            h = ngsqc.Handle(data=np.frombuffer(bad, dtype=np.uint8))
+            try:
+                h.decode()
+            finally:
+                h.close()
+        assert f"CRC32 mismatch in block {m}" in str(ei.value) and ei.value.code == -2, (m, n, at, str(ei.value))
 
 
 @pytest.mark.parametrize("field", ["l_seq", "n_cigar", "l_read_name", "neg_l_seq"])

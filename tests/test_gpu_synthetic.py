@@ -72,7 +72,9 @@ def test_long_reads_cg_tag(tmp_path, monkeypatch, long_mode):
             exp_sites = O.site_pileup(ob, sites, 1, 13, True)
             assert np.array_equal(out["site_counts"][:, :6], exp_sites) and int(exp_sites.sum()) > 100
             t = h.timings()
-            assert t["tiles_chain_on_device"] >= t["n_tiles"] - 1 and t["walkers_per_member"] == -4, t   # (a tile may fall back when a guess inside a long record was wrong: exact either way)
+            # a tile falls back to the host-verified path when a group of it begins inside a record longer than a member (no header to find there) - exact either way;
+            # with tiles of 5 members and groups of 4 every tile's second group is one member, which about one tile in five of this file loses that way
+            assert t["tiles_chain_on_device"] >= (0.7 * t["n_tiles"] if tm_ == "5" else t["n_tiles"] - 1) and t["walkers_per_member"] == -4, t
             h.close()
 
 
