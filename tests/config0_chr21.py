@@ -1,26 +1,25 @@
-"""BASELINE.json configs[0], literally: "MappingQC on 100k-read chr21 exome-subset BAM". The reference checkout holds no such file (its MappingQC inputs are
-panel-sized), so the instance is generated: 100 000 short reads (tools/bamgen.cpp, 2x150 bp, 30x) on chr21 from 14.0 Mb on, and an exome-like BED on the same
-window. Two users: tests/test_cpu_config0.py (the CPU reference path = the oracle, held against the plain numpy restatement below; no GPU) and
-tests/test_gpu_config0.py (the MappingQC binary and the C ABI against the oracle)."""
+"""BASELINE.json configs[0], literally: "MappingQC on 100k-read chr21 exome-subset BAM", as SURVEY.md 8(d) config 1 spells it out: 100 000 reads on chr21 (2x150 bp
+paired end), ROI = about 2 000 exon-like intervals (length ~ LogNormal(mu 5.0, sigma 0.6) clipped to [60, 2000]) on 1 - 46.7 Mb. The reference checkout holds no such
+file (its MappingQC inputs are panel-sized), so the instance is generated (tools/bamgen.cpp at 0.33x over the chromosome). Two users: tests/test_cpu_config0.py (the
+CPU reference path = the oracle, held against the plain numpy restatement below; no GPU) and tests/test_gpu_config0.py (the MappingQC binary and the C ABI against
+the oracle)."""
 import numpy as np
 
 import bamgen_lib as G
 
 N_READS = 100_000
 CHR21 = 20            # tid of chr21 in the generator's hg38 header
-START = 14_000_000    # 100 000 x 150 bp at 30x = 500 kb of chr21 from here
+DEPTH = 0.33          # 100 000 x 150 bp over 45.5 of chr21's 46.7 Mb
+N_EXONS = 2_000
 
 
 def write_inputs(d):
     bam, bed = str(d / "chr21_100k.bam"), str(d / "chr21_exome_subset.bed")
-    G.write(bam, n_reads=N_READS, seed=210, first_contig=CHR21, start_pos=START)
+    G.write(bam, n_reads=N_READS, seed=210, first_contig=CHR21, start_pos=0, depth=DEPTH)
     rng = np.random.default_rng(21)
-    lines, p = [], START + 2_000
-    while p < START + 495_000:                      # exons of 60 .. 400 bp, introns of 0.4 .. 6 kb; every tenth exon is followed by one that overlaps it
-        n = int(rng.integers(60, 400)); lines.append(("chr21", p, p + n, "ex%03d" % len(lines)))
-        if len(lines) % 10 == 0:
-            lines.append(("chr21", p + n // 2, p + n + 40, "ex%03d" % len(lines)))
-        p += n + int(rng.integers(400, 6000))
+    length = np.clip(np.exp(rng.normal(5.0, 0.6, N_EXONS)), 60, 2000).astype(np.int64)
+    start = np.sort(rng.integers(1_000_000, 46_700_000 - 2_000, N_EXONS))          # (sorted for the eye only: some overlap, some touch; MappingQC merges its ROI)
+    lines = [("chr21", int(s), int(s + n), "ex%04d" % i) for i, (s, n) in enumerate(zip(start, length))]
     lines += [("chr1", 65_000, 65_600, "far1"), ("chrX", 2_800_000, 2_800_300, "far2")]   # targets without reads
     open(bed, "w").write("".join("%s\t%d\t%d\t%s\n" % ln for ln in lines))
     return bam, bed
@@ -64,14 +63,21 @@ def restate(inflated, offsets, bed, min_mapq=1):
     start, end = pos0 + 1, pos0 + np.maximum(ref_len, 1)                 # 1-based, inclusive (BamAlignment::start / end)
     roi = merged_chr21(bed)
     on21 = mapped & (tid == CHR21)
-    near = on21 & ((start[:, None] - 250 <= roi[None, :, 1]) & (end[:, None] + 250 >= roi[None, :, 0])).any(axis=1)     # :458-461
-    ovl = (start[:, None] <= roi[None, :, 1]) & (end[:, None] >= roi[None, :, 0])
-    on = on21 & ovl.any(axis=1)                                                                                            # :464-467
-    usable = on & ((flag & 0x400) == 0) & (mapq >= min_mapq)                                                               # :478
-    diff = np.zeros(int(roi[-1, 1]) - START + 2, dtype=np.int64)         # a difference array over the window, cut to the target afterwards
-    np.add.at(diff, start[usable] - START, 1); np.add.at(diff, end[usable] + 1 - START, -1)
-    cover = np.cumsum(diff)
-    depth = np.concatenate([cover[s - START:e + 1 - START] for s, e in roi])
+
+    def touches(lo, hi):   # does [lo, hi] overlap a line of the merged, sorted ROI: the first line that ends at or behind lo is the only candidate
+        j = np.searchsorted(roi[:, 1], lo, side="left")
+        return (j < len(roi)) & (roi[np.minimum(j, len(roi) - 1), 0] <= hi)
+    near = on21 & touches(start - 250, end + 250)                          # :458-461
+    on = on21 & touches(start, end)                                        # :464-467
+    usable = on & ((flag & 0x400) == 0) & (mapq >= min_mapq)               # :478
+    off = np.concatenate([[0], np.cumsum(roi[:, 1] - roi[:, 0] + 1)])      # where a line's bases begin in the depth array
+    depth = np.zeros(int(off[-1]), dtype=np.int64)
+    for s0, e0 in zip(start[usable], end[usable]):                         # (a few thousand reads touch the target)
+        for j in range(int(np.searchsorted(roi[:, 1], s0, side="left")), len(roi)):
+            if roi[j, 0] > e0:
+                break
+            lo, hi = max(s0, roi[j, 0]), min(e0, roi[j, 1])
+            depth[off[j] + lo - roi[j, 0]: off[j] + hi - roi[j, 0] + 1] += 1
     proper = keep & ((flag & 1) != 0) & ((flag & 2) != 0)                # :520
     ins = proper & ~(mapped & spliced) & (np.abs(isize) < 1000)          # :524-534 (an unmapped read has no CIGAR that could splice)
     return {
