@@ -14,7 +14,7 @@
 namespace ngsqc {
 
 constexpr int K2_REL_STRIDE = 512;   // record offsets (u16, relative to the entry) kept per BGZF member for K2's write pass: an entry of a member cut into 2^ksh pieces owns K2_REL_STRIDE >> ksh of them
-constexpr int K2_MAX_KSH = 3, K2_MIN_KSH = -2;   // long reads: groups of four members (measured against sixteen: 1.26 vs 1.96 ms of K2 per 150 k reads - the guess inside a long record is what counts)        // a member is walked by up to 8 threads (round 5: several walkers per member, see entry_range)
+constexpr int K2_MAX_KSH = 3, K2_MIN_KSH = -4;   // long reads: groups of sixteen members, the guess of a group by a workgroup of eight waves (index.hip; per 150 k reads K2 takes 0.50 ms - groups of four: 0.84, and 1.26 with a wave per group)        // a member is walked by up to 8 threads (round 5: several walkers per member, see entry_range)
 constexpr int NAME_SHIFT = 12;       // a record of a tile scanned by the chain walk is named (entry << NAME_SHIFT | k): a 64 KiB member holds at most 65536 / 36 records
 
 // ---- K1 ----

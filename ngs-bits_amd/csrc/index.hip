@@ -70,6 +70,58 @@ __global__ __launch_bounds__(256) void index_guess_kernel(const uint8_t* __restr
 	}
 }
 
+// The same search with a WORKGROUP per entry, for groups of members of a long-read file: an entry inside one long record is searched for kilobytes (16 KiB on average for
+// 30 kb reads, the whole entry inside a 500 kb record), and with one wave that is a chain of memory round trips - the longest of them was the whole K2 stage
+// (profiles/r05_scan_probe.txt: 1.14 ms per 150 k reads). Here the waves of the workgroup take interleaved 1 KiB stripes of a round and the round ends with the
+// lowest hit of any wave: the same first plausible offset, found in a quarter (an eighth) of the round trips, for at most one round of bytes looked at in vain.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void index_guess_wide_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm,
+                                                                      int64_t from, int32_t* start, int32_t n_ref)
+{
+	__shared__ long long s_hit[2][WAVES];   // (two rows: a wave may be a round ahead of one that still reads the row before)
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int64_t b = from + blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		if (start[b] != -2) continue;   // (the same for every thread of the workgroup)
+		int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
+		long long found = -1; int row = 0;
+		for (int64_t round = lo; round < hi && found < 0; round += 1024 * WAVES, row ^= 1)
+		{
+			const int64_t base = round + 1024 * wv;
+			uint32_t w[4][8];
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				const int64_t o0 = base + 256 * q + 4 * lane;
+				if (o0 < hi) load_window(infl, total, o0, w[q]); else for (int k = 0; k < 8; ++k) w[q][k] = 0u;
+			}
+			long long mine_abs = -1;
+			#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				if (mine_abs < 0)
+				{
+					const int64_t o0 = base + 256 * q + 4 * lane;
+					const uint32_t cand = cheap_candidates(w[q], o0, hi, total, n_ref);
+					if (__builtin_amdgcn_ballot_w64(cand != 0) != 0)
+					{
+						int32_t mine = -1;
+						if (cand) for (int t = 0; t < 4 && mine < 0; ++t) if (((cand >> t) & 1u) && plausible_chain(infl, total, o0 + t, n_ref)) mine = t;
+						const uint64_t m = __builtin_amdgcn_ballot_w64(mine >= 0);
+						if (m) { const int l = __builtin_ctzll(m); mine_abs = base + 256 * q + 4 * l + __builtin_amdgcn_readlane(mine, l); }
+					}
+				}
+			}
+			if (lane == 0) s_hit[row][wv] = mine_abs;
+			__syncthreads();
+			#pragma unroll
+			for (int k = 0; k < WAVES; ++k) { const long long x = s_hit[row][k]; if (x >= 0 && (found < 0 || x < found)) found = x; }   // (stripes ascend with k: the first hit is the lowest)
+		}
+		if (threadIdx.x == 0) start[b] = found < 0 ? -1 : (int32_t)(found - lo);
+		__syncthreads();   // (the next entry's first round writes row 0 again)
+	}
+}
+
 // start[b]: >=0 first-record offset inside entry b; -1 none (a longer record covers the whole entry); -2 guess.
 __global__ void index_count_kernel(const uint8_t* __restrict__ infl, int64_t total, const BlockDesc* __restrict__ blocks, int64_t n_blocks, int64_t prefix, int ksh, int64_t nm, int64_t from,
                                    int32_t* start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
@@ -263,8 +315,16 @@ void launch_index_guess(const uint8_t* d_infl, int64_t total, const BlockDesc* d
 {
 	const int64_t n = n_entries - from;
 	if (n <= 0) return;
-	// (Round 5 also tried sixteen waves per group of members, each looking through a sixteenth: 6.6 ms against this kernel's 1.6 ms per tile of the ONT-like shard,
-	// profiles/r05_scan_probe.txt - removed.)
+	// (Round 5 first tried sixteen waves per group of members, each looking through a contiguous sixteenth to its end: 6.6 ms against the wave-per-entry kernel's 1.6 ms
+	// per tile of the ONT-like shard, profiles/r05_scan_probe.txt - removed. Interleaved stripes with a common end of the round are the form that is kept.)
+	const char* e = getenv("NGSQC_GUESS_WAVES"); const int waves = e ? atoi(e) : (ksh <= -3 ? 8 : ksh < 0 ? 4 : 1);   // groups of members (long reads): a workgroup per entry - eight waves for groups of 8 and more (0.50 vs 0.69 ms at 16), four below (0.84 vs 1.06 ms at 4); 1: a wave per entry
+	if (waves == 4 || waves == 8)
+	{
+		const dim3 grid((unsigned)(n < 65536 ? n : 65536));
+		if (waves == 4) hipLaunchKernelGGL(index_guess_wide_kernel<4>, grid, dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref);
+		else hipLaunchKernelGGL(index_guess_wide_kernel<8>, grid, dim3(512), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref);
+		KCHECK(); return;
+	}
 	const int64_t wg = (n + 3) / 4;
 	hipLaunchKernelGGL(index_guess_kernel, dim3((int)(wg < 256 * 32 ? wg : 256 * 32)), dim3(256), 0, s, d_infl, total, d_blocks, n_entries, prefix, ksh, nm, from, d_start, n_ref); KCHECK();
 }
