@@ -7,6 +7,7 @@
 // interleaved states per block and thousands of blocks per file). Checked against oracle/cram_decode.py, which is pinned on the reference's CRAM fixtures.
 // Host code only: no kernel in this file.
 #include "common.h"
+#include "host_crc.h"
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -232,7 +233,7 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------------- blocks, containers
 struct Blk { int method = 0, ctype = 0; int32_t cid = 0; const uint8_t* p = nullptr; size_t n = 0; std::vector<uint8_t> own; const uint8_t* raw = nullptr; size_t raw_n = 0; bool lazy = false; };
-uint32_t crc_of(const uint8_t* p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
+uint32_t crc_of(const uint8_t* p, size_t n) { return host_crc32(p, n); }   // (host_crc.h: carry-less multiplication where the CPU has it, else zlib)
 void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1, const std::set<int32_t>* skip_ids = nullptr)   // lazy_cid: an external rANS block with this content id stays compressed (b.lazy; b.n = its decoded size); skip_ids: external blocks nobody will read
 {
 	const size_t start = c.p;
