@@ -2,7 +2,9 @@
 // a member guess their own first record). Guessing is never trusted: the chain check (index_chain_kernel / the host's verification) accepts a tile only if every
 // walker's exit is the next walker's start.
 #pragma once
+#ifndef NGSQC_K2_GUESS_ON_CPU   // (tests/emul/k2_guess_emul.cpp compiles this text for the CPU, with the three device keywords and v_alignbit defined away)
 #include "common.h"
+#endif
 
 namespace ngsqc {
 

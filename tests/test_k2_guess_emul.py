@@ -1,0 +1,103 @@
+"""K2's guess of a record start (ngs-bits_amd/csrc/k2_guess.h - the text the GPU library compiles into its guess kernels and into the walkers of a member's pieces) on the
+CPU, over real inflated BAM streams. The guess is never trusted on the device (the chain check decides), so what matters is that it never MISSES a true record - a miss
+costs a tile the host-verified path - and that it is selective enough to find the FIRST record of a piece: both are properties of plain integer code and are held here
+without a GPU. BAM record layout: SAM spec 4.2; the reference reaches it through htslib's bam_read1 (BamReader.h:386-398)."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bamgen_lib as G
+import oracle_lib as O
+from conftest import ROOT
+
+EMUL = os.path.join(ROOT, "tests", "emul")
+CSRC = os.path.join(ROOT, "ngs-bits_amd", "csrc")
+GI = os.path.join(ROOT, "tests", "golden", "ref_in")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(EMUL, "libk2guess.so")
+    srcs = [os.path.join(EMUL, "k2_guess_emul.cpp"), os.path.join(CSRC, "k2_guess.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+    L = C.CDLL(so)
+    L.k2_guess_classify.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    L.k2_guess_first.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.k2_guess_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    return L
+
+
+def _stream(path):
+    ob = O.Bam(path)
+    infl = np.ascontiguousarray(ob.inflated()); offs = np.ascontiguousarray(ob.record_offsets())
+    pad = np.concatenate([infl, np.zeros(64, np.uint8)])   # (the device buffers are padded as well; `total` stays the stream's size)
+    return pad, int(infl.size), offs, len(ob.refs)
+
+
+def _inputs(tmp):
+    out = {}
+    for name, kw in (("short", dict(n_reads=60_000, seed=31, start_pos=15_900_000)), ("unaligned", dict(n_reads=40_000, seed=32, aligned=False, start_pos=15_900_000)),
+                     ("ont", dict(n_reads=1_200, seed=33, mode=1, depth=40.0, start_pos=15_900_000)), ("chrX", dict(n_reads=30_000, seed=34, first_contig=22, start_pos=156_000_000, depth=2.0))):
+        p = str(tmp / (name + ".bam")); G.write(p, **kw); out[name] = p
+    for f in sorted(glob.glob(os.path.join(GI, "*.bam"))):
+        out["ref:" + os.path.basename(f)] = f
+    return out
+
+
+@pytest.fixture(scope="module")
+def streams(tmp_path_factory):
+    return {k: _stream(p) for k, p in _inputs(tmp_path_factory.mktemp("k2guess")).items()}
+
+
+def test_no_true_record_is_refused(lib, streams):
+    """every record of every file passes all three stages: the cheap test on the 32-byte window (from each of the four window positions that hold it), plausible(),
+    plausible_chain() with the optional fields of long records parsed tag by tag"""
+    n_total = 0
+    for name, (infl, total, offs, n_ref) in streams.items():
+        if offs.size == 0:
+            continue
+        out = np.zeros(offs.size, np.uint8)
+        lib.k2_guess_classify(infl.ctypes.data, total, n_ref, offs.ctypes.data, offs.size, out.ctypes.data)
+        bad = np.nonzero(out != 7)[0]
+        assert bad.size == 0, (name, int(bad.size), [(int(offs[i]), int(out[i])) for i in bad[:5]])
+        n_total += offs.size
+    assert n_total > 200_000
+
+
+@pytest.mark.parametrize("name", ["short", "unaligned", "ont", "chrX"])
+def test_first_guess_of_a_piece_is_its_first_record(lib, streams, name):
+    """a walker that starts anywhere in the stream - inside a read name, bases, qualities, a CG:B,I array of small integers - finds the first TRUE record behind it.
+    A wrong guess is allowed by the design (the chain check sends that tile to the host-verified path), so the bar is a rate: below one piece in a thousand."""
+    infl, total, offs, n_ref = streams[name]
+    rng = np.random.default_rng(5)
+    n = 4000 if name != "ont" else 1500
+    lo = np.sort(rng.integers(int(offs[0]), total - 64, n)).astype(np.int64)
+    hi = np.minimum(lo + (1 << 18), total).astype(np.int64)
+    got = np.zeros(n, np.int64)
+    lib.k2_guess_first(infl.ctypes.data, total, n_ref, lo.ctypes.data, hi.ctypes.data, n, got.ctypes.data)
+    j = np.searchsorted(offs, lo, side="left")
+    want = np.where(j < offs.size, offs[np.minimum(j, offs.size - 1)], -1)
+    want = np.where((want >= 0) & (want < hi), want, -1)
+    # the last record of the stream cannot be confirmed by successors and a piece whose first record is cut by the stream's end is refused by design
+    wrong = np.nonzero(got != want)[0]
+    rate = wrong.size / n
+    assert rate < 1e-3, (name, wrong.size, [(int(lo[i]), int(got[i]), int(want[i])) for i in wrong[:5]])
+
+
+@pytest.mark.parametrize("name", ["short", "ont"])
+def test_selectivity_of_the_two_stages(lib, streams, name):
+    """the cheap window test lets through a small multiple of the true record starts (so the expensive chain test runs rarely), the chain test nothing but them"""
+    infl, total, offs, n_ref = streams[name]
+    lo, hi = int(offs[0]), int(min(total, offs[0] + (8 << 20)))
+    true = int(((offs >= lo) & (offs < hi)).sum())
+    n_cheap, n_chain = C.c_int64(0), C.c_int64(0)
+    lib.k2_guess_counts(infl.ctypes.data, total, n_ref, lo, hi, C.byref(n_cheap), C.byref(n_chain))
+    assert n_chain.value >= true - 1 and n_chain.value <= true + max(3, true // 500), (true, n_cheap.value, n_chain.value)
+    # measured: short reads 1.0x the true starts; long reads one offset in ~1 200 - single-base operations of a CG:B,I array read as small refIDs in front of small
+    # integers that fit each other as lengths - i.e. about one chain test per 1 KiB step of the guess kernel
+    assert n_cheap.value <= 3 * true + (hi - lo) // 600, (true, n_cheap.value)
