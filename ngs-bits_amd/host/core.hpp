@@ -43,7 +43,7 @@ inline std::vector<std::string> split(const std::string& s, char sep)
 	return f;
 }
 inline std::string join(const std::vector<std::string>& v, const std::string& sep) { std::string o; for (size_t i = 0; i < v.size(); ++i) { if (i) o += sep; o += v[i]; } return o; }
-inline std::string number(double v, int prec) { char b[64]; snprintf(b, sizeof(b), "%.*f", prec, v); return b; }  // QString::number(d,'f',prec)
+inline std::string number(double v, int prec) { if (v != v) return "nan"; char b[64]; snprintf(b, sizeof(b), "%.*f", prec, v); return b; }  // QString::number(d,'f',prec); Qt prints a NaN (0 reads: 0 / 0) as "nan", printf as "-nan"
 inline std::string fileName(const std::string& p) { size_t i = p.find_last_of('/'); return i == std::string::npos ? p : p.substr(i + 1); }   // QFileInfo::fileName
 inline std::string baseName(const std::string& p) { std::string f = fileName(p); size_t i = f.find('.'); return i == std::string::npos ? f : f.substr(0, i); } // QFileInfo::baseName
 std::string& defaultReferenceGenome();   // the genome of the settings (src/cppNGS/RefGenomeService.h), set by ToolBase before main()

@@ -92,7 +92,7 @@ static inline double gc_content(const std::string& s) // Sequence.cpp:86-101
 // ---------------------------------------------------------------- result containers
 struct QcLine { std::string accession, name, value; bool is_plot = false; };
 
-static inline std::string fmt(double v, int prec = 2) { char b[64]; snprintf(b, sizeof(b), "%.*f", prec, v); return b; } // QString::number(d,'f',prec)
+static inline std::string fmt(double v, int prec = 2) { if (v != v) return "nan"; char b[64]; snprintf(b, sizeof(b), "%.*f", prec, v); return b; } // QString::number(d,'f',prec): a NaN is "nan" whatever its sign (QCCollection.cpp:121-126)
 
 struct MappingResult
 {

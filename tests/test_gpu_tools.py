@@ -281,3 +281,34 @@ def test_bedcoverage_random_access_over_scattered_lines_stays_partial(index, tmp
     assert got * 4 < one and one <= n_members, (got, one, n_members)
     cov = [float(ln.split("\t")[-1]) for ln in a.stdout.splitlines() if not ln.startswith("#")]
     assert all(10.0 < v < 60.0 for v in cov), cov   # ~30x everywhere
+
+
+def test_header_only_bam(tmp_path):
+    """a BAM without a single record (header and EOF member only) through the C ABI and the tools: zero counters, a depth array of zeros, the percentages that divide by the
+    read count printed as "nan" like QString::number does (QCCollection.cpp:121-126) - against the oracle"""
+    import hand_vectors as HV
+    import hostprep as H
+    bam = str(tmp_path / "empty.bam"); HV.write_bam(bam, [])
+    bed = str(tmp_path / "roi.bed"); open(bed, "w").write("chr1\t100\t200\tx\n")
+    ob = O.Bam(bam)
+    h = ngsqc.Handle(path=bam)
+    try:
+        assert h.n_records == 0
+        regs, _ = H.bed_regions(bed, h.refs, 1); tx, ty = H.xy_tids(h.refs)
+        counters, _ = h.scan_mapping(ngsqc.MODE_ROI, regions=regs, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(h.refs))
+        exp = O.mapping(ob, O.MODE_ROI, bed, merge_bed=True)
+        assert [int(c) for c in counters[:26]] == [int(c) for c in exp.counters[:26]] == [0] * 26 and int(counters[26]) == 100
+        assert not h.depth(100).any()
+    finally:
+        h.close()
+    out = str(tmp_path / "qc.txt")
+    run("MappingQC", "-in", bam, "-roi", bed, "-no_ref", "-no_cont", "-txt", "-out", out)
+    got = dict(ln.split(": ", 1) for ln in open(out).read().splitlines() if ": " in ln)
+    want = exp.values()
+    assert got["mapped read percentage"] == "nan" and {k: v for k, v in got.items() if "dropout" not in k} == {k: v for k, v in want.items() if "dropout" not in k}
+    out = str(tmp_path / "cov.tsv")
+    run("BedCoverage", "-bam", bam, "-in", bed, "-out", out)
+    assert open(out).read().splitlines()[1:] == ["chr1\t100\t200\tx\t0.00"]
+    out = str(tmp_path / "low.bed")
+    run("BedLowCoverage", "-bam", bam, "-in", bed, "-cutoff", "5", "-out", out)
+    assert [ln for ln in open(out).read().splitlines() if not ln.startswith("#")] == ["chr1\t100\t200\tx"]

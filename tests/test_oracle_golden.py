@@ -206,3 +206,19 @@ def test_reads_qc_known_answers():  # src/tools-TEST/MappingQC_Test.cpp:78-91 ->
     # internal consistency of the derived counters the GPU side does not transfer
     assert q["c_base_q20"] == q["base_qualities"][20:].sum() and q["c_base_q30"] == q["base_qualities"][30:].sum()
     assert q["c_read_q20"] == q["qscore_dist_r1"][20:].sum() + q["qscore_dist_r2"][20:].sum()
+
+
+def test_header_only_bam_prints_nan_like_qt(tmp_path):
+    """no reads at all: the reference's percentages are 0 / 0, and QCValue::toString -> QString::number(NaN, 'f', 2) prints "nan" (QCCollection.cpp:121-126) where printf would
+    print "-nan"; everything that does not divide by the read count stays a number (an empty ROI depth array is 100 % covered at half depth 0)"""
+    import hand_vectors as HV
+    bam = str(tmp_path / "empty.bam"); HV.write_bam(bam, [])
+    bed = str(tmp_path / "roi.bed"); open(bed, "w").write("chr1\t100\t200\tx\n")
+    ob = O.Bam(bam)
+    assert ob.count == 0
+    v = O.mapping(ob, O.MODE_ROI, bed, merge_bed=True).values()
+    assert v["mapped read percentage"] == v["on-target read percentage"] == v["trimmed base percentage"] == v["clipped base percentage"] == "nan"
+    assert v["target region read depth"] == "0.00" and v["target region 20x percentage"] == "0.00" and v["target region half depth percentage"] == "100.00"
+    assert O.mapping(ob, O.MODE_NOROI).values()["mapped read percentage"] == "nan"
+    assert O.avg_coverage(ob, bed)[1] == "chr1\t100\t200\tx\t0.00\n"
+    assert O.low_high_coverage(ob, bed, 5)["bed"].splitlines() == ["chr1\t100\t200\tx"]
