@@ -288,6 +288,7 @@ def test_header_only_bam(tmp_path):
     read count printed as "nan" like QString::number does (QCCollection.cpp:121-126) - against the oracle"""
     import hand_vectors as HV
     import hostprep as H
+    ngsqc = __import__("importlib").import_module("ngs-bits_amd")
     bam = str(tmp_path / "empty.bam"); HV.write_bam(bam, [])
     bed = str(tmp_path / "roi.bed"); open(bed, "w").write("chr1\t100\t200\tx\n")
     ob = O.Bam(bam)
