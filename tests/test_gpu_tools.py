@@ -284,7 +284,7 @@ def test_bedcoverage_random_access_over_scattered_lines_stays_partial(index, tmp
 
 
 def test_header_only_bam(tmp_path):
-    """a BAM without a single record (header and EOF member only) through the C ABI and the tools: zero counters, a depth array of zeros, the percentages that divide by the
+    """a BAM without a single record (header and EOF member only) through the C ABI and MappingQC: zero counters, a depth array of zeros, the percentages that divide by the
     read count printed as "nan" like QString::number does (QCCollection.cpp:121-126) - against the oracle"""
     import hand_vectors as HV
     import hostprep as H
@@ -307,9 +307,3 @@ def test_header_only_bam(tmp_path):
     got = dict(ln.split(": ", 1) for ln in open(out).read().splitlines() if ": " in ln)
     want = exp.values()
     assert got["mapped read percentage"] == "nan" and {k: v for k, v in got.items() if "dropout" not in k} == {k: v for k, v in want.items() if "dropout" not in k}
-    out = str(tmp_path / "cov.tsv")
-    run("BedCoverage", "-bam", bam, "-in", bed, "-out", out)
-    assert open(out).read().splitlines()[1:] == ["chr1\t100\t200\tx\t0.00"]
-    out = str(tmp_path / "low.bed")
-    run("BedLowCoverage", "-bam", bam, "-in", bed, "-cutoff", "5", "-out", out)
-    assert [ln for ln in open(out).read().splitlines() if not ln.startswith("#")] == ["chr1\t100\t200\tx"]
