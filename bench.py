@@ -235,9 +235,9 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
     out["generate_s"] = round(gen_s, 1)
     h.close()
     if not args.no_cpu_baseline:
-        c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, min(150_000, reads))
+        c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, min(150_000, reads), sites=sites_arr, site_params=(1, 13, True))
         out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 5), "unit": "Mreads/s", "cores": 1, "kind": "port",
-                               "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop, {secs:.1f} s"}
+                               "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop (the same job incl. the site pileup), {secs:.1f} s"}
         # long reads span BGZF members, so the file cannot be cut into per-thread member ranges for an all-cores parity pass: parity of the generator's data is
         # checked on a small BAM of the same generator (all counters of the GPU job vs the sequential oracle, bit-exact)
         small = G.generate(20_000, **dict(gen_kw, threads=0))
@@ -633,10 +633,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and tool == "mappingqc":
             import oracle_lib as O
             sample = min(args.cpu_sample_reads if not args.ont else 150_000, n_rec)
-            c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, sample)
+            c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, sample, sites=sites_arr, site_params=(1, 13, bool(args.ont)))
             out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
                                    "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop "
-                                             f"(mapping_wgs + ROI depth + yxRatio; no contamination pass: less work than the GPU step), {secs:.1f} s"}
+                                             f"(the GPU step's job: mapping_wgs + ROI depth + yxRatio + the contamination pileup of {int(sites_arr.shape[0])} known sites, all in one pass), {secs:.1f} s"}
             if args.ont:
                 # long reads span BGZF members, so the file cannot be cut into per-thread member ranges: parity of the generator's data is checked on a
                 # small BAM of the same generator instead (all 1032 counters of the GPU job vs the sequential oracle, bit-exact)

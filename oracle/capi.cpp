@@ -181,6 +181,28 @@ double orc_baseline_wgs_stream(const uint8_t* image, int64_t n, const char* bed,
 	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }
 }
 
+// The same with the contamination pileup of n_sites known sites (tid, 1-based pos) in the same pass: out_site_counts[6 * i ..] = A, C, G, T, N, deletion of site i
+// (site_pileup()'s rules with min_mapq = site_min_mapq). The job the GPU step runs, timed as one loop.
+double orc_baseline_wgs_stream_sites(const uint8_t* image, int64_t n, const char* bed, int min_mapq, int64_t max_records, const int32_t* tid, const int32_t* pos, int64_t n_sites,
+                                     int site_min_mapq, int min_baseq, int include_not_properly_paired, int64_t* out_counters, int64_t* out_stats, int64_t* out_site_counts, char* err, int errlen)
+{
+	try
+	{
+		BedFile roi; bool have = bed && *bed; if (have) roi.load(bed);
+		StreamSites ss; ss.min_mapq = site_min_mapq; ss.min_baseq = min_baseq; ss.include_not_properly_paired = include_not_properly_paired != 0; ss.counts = out_site_counts;
+		for (int64_t i = 0; i < n_sites; ++i) ss.add(tid[i], pos[i], i);
+		ss.finish();
+		for (int64_t i = 0; i < 6 * n_sites; ++i) out_site_counts[i] = 0;
+		StreamStats st; double t0 = now();
+		Result r; r.m = mapping_wgs_stream(image, (size_t)n, have ? &roi : nullptr, min_mapq, max_records, st, 0, (size_t)-1, nullptr, &ss);
+		double secs = now() - t0;
+		if (out_counters) orc_result_counters(&r, out_counters);
+		if (out_stats) { out_stats[0] = st.n_records; out_stats[1] = st.inflated; out_stats[2] = st.compressed; }
+		return secs;
+	}
+	catch (std::exception& e) { seterr(err, errlen, e.what()); return -1.0; }
+}
+
 // GC bin of every roi.chunk(100) line (Statistics.cpp:363-387): what the host layer hands to the C ABI as gc_bin. merge_mode as in
 // orc_bed_roundtrip (1 = merge(), 3 = sort + merge). Returns the number of chunks; bins[i] = floor(100 * gc) or -1 (no A/C/G/T in the chunk).
 int64_t orc_gc_bins(const char* fasta, const char* bed, int merge_mode, int32_t* bins, int64_t cap, char* err, int errlen)

@@ -5,7 +5,10 @@
 // BamReader::getNextAlignment (src/cppNGS/BamReader.h:386-398; the reference adds one htslib inflate helper thread,
 // BamReader.cpp:472). The per-record body is the same restatement as stats.hpp (Statistics.cpp:1068-1182), with the
 // indexed ROI pass and the chrX/chrY queries evaluated on the fly for every record — i.e. the CPU does LESS work than
-// the reference (no second, index-driven re-read), which only makes the reported baseline faster.
+// the reference (no second, index-driven re-read), which only makes the reported baseline faster. With a StreamSites the loop also
+// does what MappingQC's third pass does (Statistics::contamination, Statistics.cpp:2333-2386: BamReader::getPileup at every known SNV),
+// again on the fly: every record is looked up in the sorted sites of its reference and counted with site_pileup()'s rules - the work of
+// the GPU's fused job, so that the baseline is timed on the same job.
 // tests/test_oracle_stream.py checks that its counters equal mapping_wgs() of stats.hpp.
 // ============================================================================
 #pragma once
@@ -16,12 +19,29 @@
 namespace orc {
 
 struct StreamStats { int64_t n_records = 0, inflated = 0, compressed = 0; double seconds = 0; };
+// the known sites of the contamination pileup: per reference the sorted 1-based positions and the row of each in counts (6 per site: A, C, G, T, N, deletion)
+struct StreamSites
+{
+	std::vector<std::vector<int>> pos; std::vector<std::vector<int64_t>> row; int min_mapq = 1, min_baseq = 13; bool include_not_properly_paired = false; int64_t* counts = nullptr;
+	void add(int tid, int p, int64_t r) { if (tid < 0) return; if ((size_t)tid >= pos.size()) { pos.resize((size_t)tid + 1); row.resize((size_t)tid + 1); } pos[(size_t)tid].push_back(p); row[(size_t)tid].push_back(r); }
+	void finish()   // sort every reference's sites by position (rows follow)
+	{
+		for (size_t t = 0; t < pos.size(); ++t)
+		{
+			std::vector<size_t> o(pos[t].size()); for (size_t i = 0; i < o.size(); ++i) o[i] = i;
+			std::stable_sort(o.begin(), o.end(), [&](size_t a, size_t b) { return pos[t][a] < pos[t][b]; });
+			std::vector<int> p2(o.size()); std::vector<int64_t> r2(o.size());
+			for (size_t i = 0; i < o.size(); ++i) { p2[i] = pos[t][o[i]]; r2[i] = row[t][o[i]]; }
+			pos[t].swap(p2); row[t].swap(r2);
+		}
+	}
+};
 
 // begin_off / end_off (multi-threaded baseline only): process the members in [begin_off, end_off) after reading the header
 // from the start of the file; begin_off must be the offset of a member at which a record starts (true for every member of an
 // htslib-style "aligned" BAM such as bench.py's synthetic input). shared_depth: depth array shared by the threads (atomic adds).
 inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const BedFile* roi_in, int min_mapq, int64_t max_records, StreamStats& st,
-                                        size_t begin_off = 0, size_t end_off = (size_t)-1, int32_t* shared_depth = nullptr)
+                                        size_t begin_off = 0, size_t end_off = (size_t)-1, int32_t* shared_depth = nullptr, const StreamSites* sites = nullptr)
 {
 	MappingResult r;
 	std::vector<uint8_t> fv; // bgzf_scan works on a vector; avoid the copy by scanning headers inline
@@ -59,6 +79,23 @@ inline MappingResult mapping_wgs_stream(const uint8_t* file, size_t n, const Bed
 					else { int* d = r.depth.data() + doff[i] - reg.start; for (int p = a; p <= b; ++p) d[p] += 1; }
 				}
 			});
+		}
+		// contamination pileup (site_pileup() of stats.hpp, BamReader.cpp:830-866), for the sites inside the record's span
+		if (sites && al.tid >= 0 && (size_t)al.tid < sites->pos.size() && !sites->pos[(size_t)al.tid].empty() && !al.isSecondary() && !al.isSupplementary() && !al.isDuplicate() && !al.isUnmapped()
+		    && (al.isProperPair() || sites->include_not_properly_paired) && (int)al.mapq >= sites->min_mapq)
+		{
+			const std::vector<int>& P = sites->pos[(size_t)al.tid]; const int a0 = al.start(), a1 = al.end();
+			for (size_t k = (size_t)(std::lower_bound(P.begin(), P.end(), a0) - P.begin()); k < P.size() && P[k] <= a1; ++k)
+			{
+				const auto base = extract_base_by_cigar(al, P[k]);
+				if (base.second < sites->min_baseq) continue;
+				int64_t* c = sites->counts + 6 * sites->row[(size_t)al.tid][k];
+				switch (base.first)
+				{
+					case 'A': ++c[0]; break; case 'C': ++c[1]; break; case 'G': ++c[2]; break; case 'T': ++c[3]; break; case 'N': ++c[4]; break; case '-': ++c[5]; break; case '~': break;
+					default: throw Error(std::string("Unknown base '") + base.first + "' in pileup!");
+				}
+			}
 		}
 		if (al.isSecondary() || al.isSupplementary()) return;
 		++r.al_total;

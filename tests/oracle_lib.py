@@ -224,16 +224,32 @@ def gc_bins(fasta, bed, merge_mode=1):
     return out[:n]
 
 
-def baseline_wgs_stream(image, bed=None, min_mapq=1, max_records=-1):
-    """Streaming single-thread MappingQC -wgs loop on a BAM image (numpy uint8). Returns (counters, stats dict, seconds)."""
+def baseline_wgs_stream(image, bed=None, min_mapq=1, max_records=-1, sites=None, site_params=(1, 13, False)):
+    """Streaming single-thread MappingQC -wgs loop on a BAM image (numpy uint8). Returns (counters, stats dict, seconds). sites: rows of (tid, 1-based pos, ...) - the
+    contamination pileup of MappingQC's third pass rides the same loop (site_params = (min_mapq, min_baseq, include_not_properly_paired)); stats["site_counts"] = int64[n, 6]."""
     img = np.ascontiguousarray(image, dtype=np.uint8)
     counters = np.zeros(NCOUNTERS, dtype=np.int64)
     st = np.zeros(3, dtype=np.int64)
     err = C.create_string_buffer(1024)
-    secs = lib().orc_baseline_wgs_stream(img.ctypes.data, img.size, _b(bed), min_mapq, max_records, counters.ctypes.data, st.ctypes.data, err, 1024)
+    L = lib()
+    if sites is None:
+        secs = L.orc_baseline_wgs_stream(img.ctypes.data, img.size, _b(bed), min_mapq, max_records, counters.ctypes.data, st.ctypes.data, err, 1024)
+        site_counts = None
+    else:
+        s2 = np.asarray(sites, dtype=np.int64).reshape(len(sites), -1)
+        tid = np.ascontiguousarray(s2[:, 0], dtype=np.int32); pos = np.ascontiguousarray(s2[:, 1], dtype=np.int32)
+        site_counts = np.zeros((len(tid), 6), dtype=np.int64)
+        L.orc_baseline_wgs_stream_sites.restype = C.c_double
+        L.orc_baseline_wgs_stream_sites.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_char_p, C.c_int]
+        secs = L.orc_baseline_wgs_stream_sites(img.ctypes.data, img.size, _b(bed), min_mapq, max_records, tid.ctypes.data, pos.ctypes.data, len(tid), int(site_params[0]), int(site_params[1]),
+                                               int(bool(site_params[2])), counters.ctypes.data, st.ctypes.data, site_counts.ctypes.data, err, 1024)
     if secs < 0:
         raise OracleError(err.value.decode())
-    return counters, {"n_records": int(st[0]), "inflated": int(st[1]), "compressed": int(st[2])}, secs
+    out = {"n_records": int(st[0]), "inflated": int(st[1]), "compressed": int(st[2])}
+    if site_counts is not None:
+        out["site_counts"] = site_counts
+    return counters, out, secs
 
 
 def site_pileup(bam, sites, min_mapq=1, min_baseq=13, include_not_properly_paired=False):

@@ -39,3 +39,26 @@ def test_all_cores_baseline_visits_every_record_once():
         st, secs, cs, hist = O.baseline_wgs_stream_mt(img, bed, 1, threads, want_counters=True)
         assert np.array_equal(cs[additive], c1[additive]), threads
         assert int(hist.sum()) == int(c1[26]) and int((hist * np.arange(hist.size)).sum()) > 0
+
+
+@pytest.mark.parametrize("mode,include_npp", [(0, False), (0, True), (1, True)])
+def test_stream_with_the_contamination_pileup_riding(tmp_path, mode, include_npp):
+    """bench.py's cpu_baseline runs the job the GPU step runs: the known-site pileup of MappingQC's third pass (Statistics::contamination -> BamReader::getPileup) rides the
+    streaming loop. Its counts must be the indexed oracle's (site_pileup of stats.hpp, pinned by BamReader_Test.cpp:256-292), the mapping counters must not change."""
+    import bamgen_lib as G
+    import hostprep as H
+    p = str(tmp_path / "s.bam")
+    G.write(p, **(dict(n_reads=60_000, seed=41, start_pos=15_900_000, flavor=1) if mode == 0 else dict(n_reads=600, seed=42, mode=1, depth=40.0, start_pos=15_900_000)))
+    ob = O.Bam(p)
+    known = H.known_sites(ob.refs)
+    lo, hi = 15_900_000, 15_900_000 + (60_000 * 150 // 30 if mode == 0 else 400_000)
+    near = known[(known[:, 0] == 0) & (known[:, 1] >= lo - 1000) & (known[:, 1] <= hi + 1000)]
+    extra = np.array([[0, q, 0] for q in range(lo + 500, hi, 997)], dtype=known.dtype).reshape(-1, known.shape[1])   # (the known sites are sparse: a regular grid of positions as well)
+    sites = np.concatenate([near, extra, known[known[:, 0] == 5][:50]])
+    bed = os.path.join(RESOURCES, "hg38_440_omim_genes.bed")
+    img = np.fromfile(p, dtype=np.uint8)
+    c0, _, _ = O.baseline_wgs_stream(img, bed, 1, -1)
+    c1, st, secs = O.baseline_wgs_stream(img, bed, 1, -1, sites=sites, site_params=(1, 13, include_npp))
+    assert np.array_equal(c0, c1) and secs > 0
+    want = O.site_pileup(ob, [(int(t), int(q)) for t, q in sites[:, :2]], 1, 13, include_npp)
+    assert np.array_equal(st["site_counts"], want) and int(want.sum()) > 1000
