@@ -232,7 +232,8 @@ static std::string plotPng(const std::vector<double>& x, const std::vector<std::
 	double xmin = 1e300, xmax = -1e300, ymin = 0, ymax = -1e300;
 	for (double v : x) { xmin = std::min(xmin, v); xmax = std::max(xmax, v); }
 	for (auto& l : lines) for (double v : l) if (std::isfinite(v)) ymax = std::max(ymax, v);
-	if (!(xmax > xmin)) xmax = xmin + 1; if (!(ymax > ymin)) ymax = ymin + 1;
+	if (!(xmax > xmin)) xmax = xmin + 1;
+	if (!(ymax > ymin)) ymax = ymin + 1;
 	const uint8_t cols[3][3] = {{31, 119, 180}, {255, 127, 14}, {44, 160, 44}}; int li = 0;
 	for (auto& l : lines)
 	{
