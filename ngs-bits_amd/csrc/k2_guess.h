@@ -83,8 +83,8 @@ __device__ static bool plausible_chain(const uint8_t* infl, int64_t total, int64
 }
 
 
-// The cheap test of the four offsets o0 .. o0 + 3 on the 28 bytes behind o0 (w[0..6]; the fields of offset o0 + t are funnel shifts of neighbouring words): the
-// length word, refID and position in range, a read name, and the fixed part + name + CIGAR + bases + qualities no longer than the record says. Round 5: the
+// The cheap test of the four offsets o0 .. o0 + 3 on the 32 bytes behind o0 (w[0..7]; the fields of offset o0 + t are funnel shifts of neighbouring words): the
+// length word, refID, the mate's refID and position in range, a read name, and the fixed part + name + CIGAR + bases + qualities no longer than the record says. Round 5: the
 // last test was added when the scan of a long read's CG:B,I array turned out to call the full test (a dozen dependent loads) on every word - small integers pass
 // as length word and refID; as l_seq and block_size of one record they almost never fit. Bit t of the result: offset o0 + t is worth the full test.
 __device__ __forceinline__ uint32_t cheap_candidates(const uint32_t (&w)[8], int64_t o0, int64_t hi, int64_t total, int32_t n_ref)
@@ -93,11 +93,13 @@ __device__ __forceinline__ uint32_t cheap_candidates(const uint32_t (&w)[8], int
 	#pragma unroll
 	for (int t = 0; t < 4; ++t)
 	{
-		uint32_t f[6];
+		uint32_t f[7];
 		#pragma unroll
-		for (int i = 0; i < 6; ++i) f[i] = t ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 8u * t) : w[i];
-		const uint32_t bs = f[0], l_name = f[3] & 0xffu, n_cig = f[4] & 0xffffu; const int32_t tid = (int32_t)f[1], pos = (int32_t)f[2], l_seq = (int32_t)f[5];
-		const bool ok = o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref && pos >= -1 && l_name != 0 && l_seq >= 0
+		for (int i = 0; i < 7; ++i) f[i] = t ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 8u * t) : w[i];
+		const uint32_t bs = f[0], l_name = f[3] & 0xffu, n_cig = f[4] & 0xffffu; const int32_t tid = (int32_t)f[1], pos = (int32_t)f[2], l_seq = (int32_t)f[5], mtid = (int32_t)f[6];
+		// (the mate's refID, the window's last word: of the 7 072 offsets in 8 MiB of long reads that passed the other tests - single-base operations of a CG:B,I array
+		// in front of small integers - 531 pass this one, 199 of them true records; measured on the CPU with this text, tests/test_k2_guess_emul.py)
+		const bool ok = o0 + t < hi && o0 + t + 36 <= total && bs >= 32 && bs <= (1u << 28) && tid >= -1 && tid < n_ref && mtid >= -1 && mtid < n_ref && pos >= -1 && l_name != 0 && l_seq >= 0
 		                && 32ull + l_name + 4ull * n_cig + ((uint64_t)(uint32_t)l_seq + 1) / 2 + (uint64_t)(uint32_t)l_seq <= (uint64_t)bs;
 		cand |= ok ? 1u << t : 0u;
 	}

@@ -98,6 +98,7 @@ def test_selectivity_of_the_two_stages(lib, streams, name):
     n_cheap, n_chain = C.c_int64(0), C.c_int64(0)
     lib.k2_guess_counts(infl.ctypes.data, total, n_ref, lo, hi, C.byref(n_cheap), C.byref(n_chain))
     assert n_chain.value >= true - 1 and n_chain.value <= true + max(3, true // 500), (true, n_cheap.value, n_chain.value)
-    # measured: short reads 1.0x the true starts; long reads one offset in ~1 200 - single-base operations of a CG:B,I array read as small refIDs in front of small
-    # integers that fit each other as lengths - i.e. about one chain test per 1 KiB step of the guess kernel
-    assert n_cheap.value <= 3 * true + (hi - lo) // 600, (true, n_cheap.value)
+    # measured: short reads 1.0x the true starts; long reads one offset in ~16 000 (531 in 8 MiB, 199 of them true). Before the mate's refID joined the cheap test
+    # it was one in ~1 200 - single-base operations of a CG:B,I array read as small refIDs in front of small integers that fit each other as lengths - i.e. about
+    # one chain test (a dozen dependent loads) per 1 KiB step of the guess kernel
+    assert n_cheap.value <= 3 * true + (hi - lo) // 5000, (true, n_cheap.value)
