@@ -280,6 +280,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		{
 			if (wv::ballot(state - 1u < 6u) == 0) break;
 			if (lane == 0) K1_STAT(2);
+			K1_WSTAT(1);
 			input_service();
 			if (state == S_FINISH)
 			{
@@ -528,6 +529,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 			else if (wv::ballot(state != S_DONE) == 0) break;
 		}
 		if (lane == 0) K1_STAT(0);
+		K1_WSTAT(0);
 		#pragma unroll
 		for (int i = 0; i < P1_TRIPS; ++i) trip(sl[i]);
 	}
@@ -546,29 +548,31 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 //   distance 1 the byte in front of the item, repeated; an item that overlaps its own source otherwise (rare) is copied byte by byte
 // and the item's bytes are written to LDS with two stores at the same offsets (lengths 1..3: a 16-bit and an 8-bit store). When all steps
 // are done the batch leaves LDS for HBM as whole dwords (256 consecutive bytes per store instruction).
-constexpr int P2_BMAX = 1536;                  // output bytes per batch: at least one whole group (4 x 259 bytes) always fits
+constexpr int P2_BMAX = 2032;                  // output bytes per batch (an item's place in the batch has 11 bits); at least one whole group (4 x 259 bytes) always fits
 constexpr int P2_GROUPS = 64;                  // groups per batch: one per lane
 constexpr int P2_HIST = 16;                    // output bytes in front of the batch that stay in LDS (a near item's source starts at most 15 bytes in front)
+constexpr int P2_IMAX = 192;                   // items per batch: a batch is cut so that its items fill whole steps of 64 (round 6: 129 -> 109 steps per member of the bench data)
 constexpr int P2_NW = P2_BMAX / 32 + 1;        // words of the item-start bit mask (one lane each in the count scan)
-constexpr int P2_ITEMS = P2_GROUPS * 4 + P2_BMAX / 16;   // at most one item per word and one more per 16 output bytes
-static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_NW <= 64 && P2_HIST % 4 == 0, "phase-2 batch geometry");
+constexpr int P2_LONG = P2_IMAX / 2;           // matches of more than 16 bytes in a batch (each has at least two items)
+constexpr int P2_TRASH = P2_BMAX + 15;         // a staging byte nobody reads: where the stores of lanes without a literal go (no branch around a store)
+static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_BMAX % 8 == 0 && P2_NW <= 64 && P2_HIST % 4 == 0 && P2_IMAX >= 4 * 17 && P2_IMAX % 64 == 0, "phase-2 batch geometry");
 // item word: first byte (batch-relative) | (length - 1) << 11 | (distance - 1) << 15; a raw run: bit 31 | payload offset << 15. An item of a distance-1 match
 // (a run of one byte: the usual self-overlapping match of BAM data) carries bit 30 and the distance to the byte IN FRONT OF THE MATCH instead: every item of
 // the run repeats that byte, none of them waits for its predecessor
 struct P2Lds
 {
-	uint32_t it[P2_ITEMS + 8];
+	uint32_t it[P2_IMAX + 8];                              // (the last word: where the item words of lanes without an item go)
 	uint32_t ib[2 * 64];                                   // per 32 output bytes: {item-start bit mask, items that start in front of them}
-	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes]
+	uint32_t lg[2 * P2_LONG];                              // the batch's matches of more than 16 bytes: {first byte | length << 11 | index of the first item << 20, key}
+	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes | slack]
 	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
 };
 
-K1_DEV uint32_t tok_len(uint32_t t)
-{
-	return t >= K1_TOK_MATCH ? ((t >> 15) & 255u) + 3u + (t >> 31) : (t < K1_TOK_RAW ? 1u + ((t >> 16) & 1u) : (t < 2u * K1_TOK_RAW ? ((t >> 16) & 255u) + 1u : 0u));
-}
-
-// Register budget of eight waves per SIMD: next to the decoder waves the register file and LDS decide how many phase-2 waves a CU holds.
+// Round 6: the kernel's instruction count, not its memory traffic, is what the pipelined K1 pays for (the chip's instruction issue is what phase 1, phase 2 and the CRC
+// share), and two thirds of the instructions were scalar: exec-mask bookkeeping of nested branches. So the control flow is FLAT - a store that a lane does not take
+// goes to a trash byte instead of behind a branch, the length classes of an item are predicates side by side, rare kinds (raw runs, runs of a byte, an item that
+// overlaps its source) leave through one ballot-guarded block - the items of a long match come from a compacted list (a lane per long match) instead of four
+// divergent loops, a batch is cut to whole steps of 64 items, and the batch leaves LDS eight bytes per lane.
 K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, const uint32_t* __restrict__ tok_first, const uint32_t* __restrict__ tok_count,
                                       const BlockDesc* __restrict__ blocks, int64_t n_blocks, uint8_t* __restrict__ out_base, BlockStatus* __restrict__ status, const uint8_t* __restrict__ comp)
 {
@@ -607,6 +611,7 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			const uint64_t tabm = wv::ballot(valid && t0 == K1_TOK_TABLE);
 			if (tabm & 1ull)
 			{
+				K1_WSTAT(18);
 				wv::barrier();   // (the previous batch's readers of S.lit are done)
 				((uint32_t*)S.lit)[lane] = pool[(uint64_t)wv::readlane(t1, 0) + (uint32_t)lane];
 				wv::barrier();
@@ -621,50 +626,76 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			#pragma unroll
 			for (int k = 0; k < 4; ++k)
 			{
-				ll[k] = valid ? tok_len(tt[k]) : 0u;
-				cl[k] = tt[k] >= K1_TOK_MATCH ? ll[k] - (tt[k] >> 31) : (tt[k] >= K1_TOK_RAW ? ll[k] : 0u);
+				// (selects, not branches: a match | one or two literals | a raw run | nothing)
+				const uint32_t t = tt[k];
+				const uint32_t lm = ((t >> 15) & 255u) + 3u, lr = ((t >> 16) & 255u) + 1u;
+				const bool ism = t >= K1_TOK_MATCH, isl = t < K1_TOK_RAW, isr = !isl && t < 2u * K1_TOK_RAW;
+				const uint32_t cp = ism ? lm : (isr ? lr : 0u);
+				const uint32_t lt = isl ? 1u + ((t >> 16) & 1u) : t >> 31;   // literal bytes of the word
+				cl[k] = valid ? cp : 0u;
+				ll[k] = valid ? cp + lt : 0u;
 				s += ll[k]; c += (cl[k] + 15u) >> 4;
 			}
 			const uint32_t E = wv::scan_incl(s | (c << 17));   // (64 groups: < 2^17 bytes, < 2^15 items)
 			const uint32_t Eb = E & 0x1ffffu, Ei = E >> 17;
-			// the longest prefix of groups whose output fits the staging buffer (the sums are non-decreasing: the ballot is a prefix mask)
-			const uint32_t ng = wv::popc64(wv::ballot(valid && Eb <= (uint32_t)P2_BMAX));
+			// the longest prefix of groups whose output fits the staging buffer and whose items fill at most three steps (the sums are non-decreasing: the ballot is a prefix mask)
+			const uint32_t ng = wv::popc64(wv::ballot(valid && Eb <= (uint32_t)P2_BMAX && Ei <= (uint32_t)P2_IMAX));
 			if (ng == 0) { fail = 18; break; }   // a group longer than 4 x 259 bytes: not a token stream of phase 1
 			const uint32_t B = wv::readlane(Eb, (int)ng - 1), NI = wv::readlane(Ei, (int)ng - 1);
 			if (P + B > usize) { fail = 16; break; }
 			S.ib[2 * lane] = 0u;
 			wv::barrier();
-			// per word: literal bytes to their place, the items of the copied part
-			if ((uint32_t)lane < ng)
+			// per word: literal bytes to their place, the FIRST item of the copied part; a match of more than 16 bytes (one in four) is listed for the second pass
+			auto item_key = [&](uint32_t t) -> uint32_t {   // the item word without its position and length
+				return t >= K1_TOK_MATCH ? ((t & 0x7fffu) == 0u ? 0x40000000u : (t & 0x7fffu) << 15) : 0x80000000u | ((t & 0xffffu) << 15);
+			};
+			uint32_t nlong = 0;
 			{
+				const bool inb = (uint32_t)lane < ng;
 				uint32_t st = Eb - s, ix = Ei - c;
 				#pragma unroll
 				for (int k = 0; k < 4; ++k)
-					if (ll[k])
+				{
+					const uint32_t t = tt[k], n = inb ? cl[k] : 0u, l = inb ? ll[k] : 0u;
+					K1_WSTAT(11);
+					const bool lmt = (t >> 31) != 0u, isl = t < K1_TOK_RAW;
+					const bool l1 = l != 0u && (lmt || isl), l2 = isl && l == 2u;
+					const uint32_t i1 = lmt ? (t >> 23) & 255u : t & 255u;
+					vb[l1 ? st : (uint32_t)P2_TRASH] = S.lit[i1];
+					vb[l2 ? st + 1u : (uint32_t)P2_TRASH] = S.lit[(t >> 8) & 255u];
+					const bool has = n != 0u;
+					const uint32_t d = has ? st + l - n : 0u, key = item_key(t);
+					S.it[has ? ix : (uint32_t)(P2_IMAX + 7)] = d | (((n < 16u ? n : 16u) - 1u) << 11) | key;
+					wv::lds_or32(&S.ib[2 * (d >> 5)], has ? 1u << (d & 31u) : 0u);
+					const uint64_t lgm = wv::ballot(n > 16u);
+					if (lgm != 0ull)
 					{
-						const uint32_t t = tt[k];
-						uint32_t key;   // the item word without its position and length
-						if (t >= K1_TOK_MATCH)
+						if (n > 16u)
 						{
-							if (t >> 31) vb[st] = S.lit[(t >> 23) & 255u];
-							key = (t & 0x7fffu) == 0u ? 0x40000000u : (t & 0x7fffu) << 15;
+							const uint32_t j = nlong + wv::mbcnt(lgm);
+							S.lg[2 * j] = d | (n << 11) | (ix << 20); S.lg[2 * j + 1] = key;
 						}
-						else if (t < K1_TOK_RAW)
-						{
-							vb[st] = S.lit[t & 255u];
-							if (t & K1_TOK_LIT2) vb[st + 1] = S.lit[(t >> 8) & 255u];
-							key = 0;
-						}
-						else key = 0x80000000u | ((t & 0xffffu) << 15);
-						const uint32_t n = cl[k], ms = st + ll[k] - n, il = n < 16u ? n : 16u;
-						for (uint32_t o = 0; o < n; o += 16u)
-						{
-							const uint32_t off = o + il <= n ? o : n - il, d = ms + off;   // (the last item of a long match overlaps its predecessor)
-							S.it[ix++] = d | ((il - 1u) << 11) | (key + ((key >> 30) ? off << 15 : 0u));   // (raw run: payload offset of the item; run of a byte: distance to the byte in front of the match)
-							wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
-						}
-						st += ll[k];
+						nlong += wv::popc64(lgm);
 					}
+					st += l; ix += (n + 15u) >> 4;
+				}
+			}
+			wv::barrier();
+			// the further items of the long matches: a lane per match
+			for (uint32_t j0 = 0; j0 < nlong; j0 += 64u)
+			{
+				const uint32_t j = j0 + (uint32_t)lane;
+				if (j < nlong)
+				{
+					const uint32_t w = S.lg[2 * j], key = S.lg[2 * j + 1], ms = w & 0x7ffu, n = (w >> 11) & 511u, ix = w >> 20;
+					for (uint32_t o = 16u; o < n; o += 16u)
+					{
+						K1_WSTAT(12);
+						const uint32_t off = o + 16u <= n ? o : n - 16u, d = ms + off;   // (the last item of a long match overlaps its predecessor)
+						S.it[ix + (o >> 4)] = d | (15u << 11) | (key + ((key >> 30) ? off << 15 : 0u));   // (raw run: payload offset of the item; run of a byte: distance to the byte in front of the match)
+						wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
+					}
+				}
 			}
 			wv::barrier();
 			{
@@ -684,101 +715,110 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 			}
 
 			if (lane == 0) K1_STAT(7);
+			K1_WSTAT(10);
 			// one step's worth of item state; the loads of a far (or raw) item are issued a step ahead
 			// An item's bytes travel in two overlapping pieces: lengths 9..16 as the two 8-byte words at 0 and len - 8, lengths 4..8 as the two dwords at 0 and
 			// len - 4, shorter ones as one dword (stored as a 16-bit and an 8-bit piece) - the LDS traffic follows the item's length
-			struct Item { uint32_t w, mode, w0, w1; uint64_t lo, hi; };   // mode: 0 nothing to do, 1 loaded, 2 near, 3 raw run (loaded in its step: rare)
+			// x: what is left to do - 0 nothing, 1 loaded (far item: its bytes are on their way into w0 / w1 or lo / hi), 2 / 3 / 5 near item of 9..16 / 4..8 / 3 bytes, 4 a near item of a rare
+			// kind (a run of a byte, an item that overlaps its own source), 6 raw run (loaded in its step: rare)
+			struct Item { uint32_t w, x, w0, w1; uint64_t lo, hi; };
 			auto fetch = [&](uint32_t i0) -> Item {
-				Item q; const uint32_t idx = i0 + (uint32_t)lane;
-				q.w = idx < NI ? S.it[idx] : 0u; q.mode = 0; q.w0 = q.w1 = 0; q.lo = q.hi = 0;
-				if (idx < NI)
-				{
-					if (q.w >> 31) q.mode = 3;
-					else
-					{
-						const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
-						const int src = (int)d - (int)(wv::bfe(q.w, 15, 15) + 1u);
-						const bool run = (q.w >> 30) != 0u;
-						if (src + (run ? 1 : (int)len) <= 0)
-						{
-							const uint32_t a = P + (uint32_t)src;
-							if (len >= 9u && !run) { q.lo = outld.load64(a); q.hi = outld.load64(a + len - 8u); }
-							else { q.w0 = outld.load32(a); q.w1 = outld.load32(a + (len >= 4u && !run ? len - 4u : 0u)); }
-							q.mode = 1;
-						}
-						else q.mode = 2;
-					}
-				}
+				Item q; const uint32_t idx = i0 + (uint32_t)lane; K1_WSTAT(13);
+				const bool in = idx < NI;
+				q.w = in ? S.it[idx] : 0u; q.lo = q.hi = 0; q.w0 = q.w1 = 0;
+				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
+				const int src = (int)d - (int)dist;
+				const bool raw = (q.w >> 31) != 0u, run = (q.w >> 30) == 1u;
+				const bool far = src + (run ? 1 : (int)len) <= 0;
+				const uint32_t xn = run || dist < len ? 4u : (len >= 9u ? 2u : (len >= 4u ? 3u : 5u));
+				q.x = !in ? 0u : (raw ? 6u : (far ? 1u : xn));
+				const uint32_t a = P + (uint32_t)src;
+				const bool wide = len >= 9u && !run;
+				if (q.x == 1u && wide) { q.lo = outld.load64(a); q.hi = outld.load64(a + len - 8u); }
+				if (q.x == 1u && !wide) { q.w0 = outld.load32(a); q.w1 = outld.load32(a + (len >= 4u && !run ? len - 4u : 0u)); }
 				return q;
 			};
 			auto starts_before = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
 			auto process = [&](Item& q, const uint32_t i0) {
 				if (lane == 0) K1_STAT(4);
+				K1_WSTAT(14);
 				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
-				if (wv::ballot(q.mode == 3u) != 0ull)
+				const bool run = (q.w >> 30) == 1u;
+				const int src = (int)d - (int)dist;
+				uint8_t* const pd = vb + d; uint8_t* const pd2 = pd + len - (len >= 9u ? 8u : 4u);
+				const uint8_t* const ps = vb + src; const uint8_t* const ps2 = ps + len - (len >= 9u ? 8u : 4u);
+				auto put_any = [&](uint64_t x, uint64_t y) {   // (rare kinds) any length from registers: x, y the two pieces (dwords in their low halves below nine bytes)
+					if (len >= 9u) { wv::lds_store64u(pd, x); wv::lds_store64u(pd2, y); }
+					else if (len >= 4u) { wv::lds_store32u(pd, (uint32_t)x); wv::lds_store32u(pd2, (uint32_t)y); }
+					else
+					{
+						if (len >= 2u) wv::lds_store16u(pd, (uint32_t)x);
+						vb[d + len - 1u] = (uint8_t)((uint32_t)x >> (8u * (len - 1u)));
+					}
+				};
+				// the loaded items first: nothing in the batch depends on where they come from
+				if (wv::ballot(q.x == 6u || (q.x == 1u && (run || len < 3u))) != 0ull)
 				{
-					// (rare) a stored block's bytes come from the compressed input
-					if (q.mode == 3u)
+					// (rare) a stored block's bytes come from the compressed input; a loaded item of a run repeats its byte; a raw item of one or two bytes
+					if (q.x == 6u)
 					{
 						const uint32_t a = wv::bfe(q.w, 15, 16);
 						if (len >= 9u) { q.lo = cin.load64(a); q.hi = cin.load64(a + len - 8u); }
 						else { q.w0 = cin.load32(a); q.w1 = cin.load32(a + (len >= 4u ? len - 4u : 0u)); }
-						q.mode = 1;
+						q.x = 1u;
 					}
 					wv::wait_vm0();
+					if (q.x == 1u && (run || len < 3u))
+					{
+						if (run) { const uint32_t r4 = (q.w0 & 255u) * 0x01010101u; put_any(((uint64_t)r4 << 32) | r4, ((uint64_t)r4 << 32) | r4); }
+						else put_any(q.w0, q.w1);
+						q.x = 0u;
+					}
 				}
-				const int src = (int)d - (int)dist;
-				const bool run = (q.w >> 30) == 1u;
-				const uint32_t slen = run ? 1u : len;   // source bytes
-				auto spread = [&](uint32_t byte) { q.w0 = (byte & 255u) * 0x01010101u; q.w1 = q.w0; q.lo = ((uint64_t)q.w0 << 32) | q.w0; q.hi = q.lo; };
-				if (run && q.mode == 1u) spread(q.w0);
+				{
+					const bool far = q.x == 1u;
+					if (far && len >= 9u) { wv::lds_store64u(pd, q.lo); wv::lds_store64u(pd2, q.hi); }
+					if (far && len >= 4u && len < 9u) { wv::lds_store32u(pd, q.w0); wv::lds_store32u(pd2, q.w1); }
+					if (far && len == 3u) { wv::lds_store16u(pd, q.w0); pd[2] = (uint8_t)(q.w0 >> 16); }
+					if (far) q.x = 0u;
+				}
 				// the lanes of this step that may write into a near item's source: the items that start in (src - 16, src + slen), as far as they lie in front of this
 				// item (an exact first lane - from a second bit plane of item ends - saved one round in seventy)
 				uint64_t dep = 0;
-				if (q.mode == 2u)
+				if (q.x != 0u)
 				{
+					const uint32_t slen = run ? 1u : len;   // source bytes
 					const int lo = (int)starts_before((uint32_t)(src > 15 ? src - 15 : 0)) - (int)i0;
 					int hi = (int)starts_before((uint32_t)(src + (int)slen)) - 1 - (int)i0;
 					hi = hi < lane ? hi : lane - 1;
 					const int l0 = lo > 0 ? lo : 0;
 					if (hi >= l0) dep = ((2ull << (hi - l0)) - 1ull) << l0;
 				}
-				auto put = [&]() {
-					if (len >= 9u) { wv::lds_store64u(vb + d, q.lo); wv::lds_store64u(vb + d + len - 8u, q.hi); }
-					else if (len >= 4u) { wv::lds_store32u(vb + d, q.w0); wv::lds_store32u(vb + d + len - 4u, q.w1); }
-					else
-					{
-						if (len >= 2u) wv::lds_store16u(vb + d, q.w0);
-						vb[d + len - 1u] = (uint8_t)(q.w0 >> (8u * (len - 1u)));
-					}
-				};
-				// the loaded items first: nothing in the batch depends on where they come from
-				if (q.mode == 1u) { put(); q.mode = 0u; }
 				wv::barrier();
+				// (the three length classes as predicates that live across the rounds - scalar masks; compared inside the loop, a kind number becomes a decision tree of nested branches)
+				const bool c9 = len >= 9u, c4 = len >= 4u && len < 9u, c3 = len == 3u;
+				uint32_t x = q.x >= 2u && q.x != 4u ? 2u : q.x;   // 0 done, 2 near item of two pieces, 4 near item of a rare kind
+				const bool any4 = wv::ballot(x == 4u) != 0ull;     // (wave-uniform: the rounds of a step without such an item do not look for one)
 				for (;;)
 				{
 					if (lane == 0) K1_STAT(6);
-					const uint64_t open = wv::ballot(q.mode != 0u);
+					K1_WSTAT(15);
+					const uint64_t open = wv::ballot(x != 0u);
 					if (open == 0ull) break;
-					const bool go = q.mode == 2u && (open & dep) == 0ull;
-					bool slow = false;
-					if (go)
+					const bool free = (open & dep) == 0ull;   // the lane's source is complete
+					if (any4)
 					{
-						if (run) spread((uint32_t)vb[src]);
-						else if (dist >= len)
+						if (free && x == 4u)
 						{
-							if (len >= 9u) { q.lo = wv::lds_load64u(vb + src); q.hi = wv::lds_load64u(vb + src + (int)len - 8); }
-							else { q.w0 = wv::lds_load32u(vb + src); q.w1 = wv::lds_load32u(vb + src + (len >= 4u ? (int)len - 4 : 0)); }
+							if (run) { const uint32_t r4 = (uint32_t)*ps * 0x01010101u; put_any(((uint64_t)r4 << 32) | r4, ((uint64_t)r4 << 32) | r4); }
+							else for (uint32_t k = 0; k < len; ++k) { K1_WSTAT(16); pd[k] = ps[k]; }   // an item that overlaps its own source with a distance of 2..15: byte by byte
 						}
-						else slow = true;
 					}
-					if (wv::ballot(slow) != 0ull)
-					{
-						// (rare) an item that overlaps its own source with a distance of 2..15: byte by byte
-						if (slow) for (uint32_t k = 0; k < len; ++k) vb[d + k] = vb[src + (int)k];
-					}
-					if (go && !slow) put();
-					if (go) q.mode = 0u;
+					const bool g = free && x == 2u;
+					if (g && c9) { const uint64_t u = wv::lds_load64u(ps), v = wv::lds_load64u(ps2); wv::lds_store64u(pd, u); wv::lds_store64u(pd2, v); }
+					if (g && c4) { const uint32_t u = wv::lds_load32u(ps), v = wv::lds_load32u(ps2); wv::lds_store32u(pd, u); wv::lds_store32u(pd2, v); }
+					if (g && c3) { const uint32_t u = wv::lds_load32u(ps); wv::lds_store16u(pd, u); pd[2] = (uint8_t)(u >> 16); }
+					x = free ? 0u : x;
 					wv::barrier();
 				}
 			};
@@ -796,19 +836,17 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					process(qb, i0 + 64u);
 				}
 			}
-			// ---- the batch leaves for HBM ----
+			// ---- the batch leaves for HBM: eight bytes per lane and store, the last 1..7 bytes one by one ----
 			wv::barrier();
-			#pragma nounroll
-			for (uint32_t j = 4u * (uint32_t)lane; j < B; j += 256u)
 			{
-				const uint32_t v = wv::lds_load32(vb + j);
-				if (j + 4u <= B) out.store32(P + j, v);
-				else
+				const uint32_t B8 = B & ~7u;
+				#pragma nounroll
+				for (uint32_t j0 = 0; j0 < B8; j0 += 512u)
 				{
-					out.store(P + j, v);
-					if (j + 1u < B) out.store(P + j + 1u, v >> 8);
-					if (j + 2u < B) out.store(P + j + 2u, v >> 16);
+					const uint32_t j = j0 + 8u * (uint32_t)lane; K1_WSTAT(17);
+					if (j < B8) out.store64(P + j, wv::lds_load64(vb + j));
 				}
+				if ((uint32_t)lane < (B & 7u)) out.store(P + B8 + (uint32_t)lane, vb[B8 + (uint32_t)lane]);
 			}
 			// the last P2_HIST bytes stay in LDS in front of the next batch
 			{

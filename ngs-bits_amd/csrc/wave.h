@@ -10,7 +10,8 @@
 #define K1_KERNEL_OCC(bounds, waves_per_simd) __global__ __launch_bounds__(bounds, waves_per_simd)   // + a register budget for that many waves per SIMD
 #define K1_SHARED __shared__
 #define K1_DEV __device__ __forceinline__
-#define K1_STAT(i) ((void)0)   // (instrumentation hook of the wave emulator)
+#define K1_STAT(i) ((void)0)   // (instrumentation hooks of the wave emulator)
+#define K1_WSTAT(i) ((void)0)
 
 namespace ngsqc { namespace wv {
 
@@ -53,6 +54,7 @@ K1_DEV void lds_store32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
 K1_DEV void lds_store32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 K1_DEV uint64_t lds_load64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 K1_DEV void lds_store64u(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+K1_DEV uint64_t lds_load64(const uint8_t* p) { return *(const uint64_t*)p; }   // (8-aligned)
 K1_DEV void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
 
 // A byte range in HBM behind a buffer resource: 32-bit offsets (one VALU add per address) and hardware bounds clamping
@@ -72,6 +74,7 @@ struct ByteBuf
 	// a dword at any byte offset (in range: off + 4 <= bytes; a dword that is not wholly inside the range reads 0 / is dropped)
 	K1_DEV uint32_t load32(uint32_t off) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0); }
 	K1_DEV void store32(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)off, 0, 0); }
+	K1_DEV void store64(uint32_t off, uint64_t v) const { typedef uint32_t v2 __attribute__((ext_vector_type(2))); v2 x; x.x = (uint32_t)v; x.y = (uint32_t)(v >> 32); __builtin_amdgcn_raw_buffer_store_b64(x, rs, (int)off, 0, 0); }   // (8 bytes at any byte offset, wholly inside the range)
 	K1_DEV uint64_t load64(uint32_t off) const { typedef uint32_t v2 __attribute__((ext_vector_type(2))); const v2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0); return ((uint64_t)r.y << 32) | r.x; }
 };
 

@@ -21,6 +21,7 @@
 #define K1_SHARED static
 #define K1_DEV inline
 #define K1_STAT(i) (++::ngsqc::wv::emu_stats()[i])   // instrumentation of the kernels (compiled out in the library)
+#define K1_WSTAT(i) (++::ngsqc::wv::emu().whit[i][::ngsqc::wv::emu().cur])   // wave-level count of a code region: per stretch between two rendezvous the MAXIMUM over the lanes (what a lockstep wave executes)
 #ifndef __restrict__
 #define __restrict__
 #endif
@@ -40,6 +41,8 @@ struct Emu
 	int64_t block = 0, grid = 1;
 	uint64_t opno[W], xv[2][W], stamp[2][W]; const void* site[2][W];
 	uint64_t n_sync = 0;
+	static constexpr int NW = 32;
+	uint32_t whit[NW][W] = {}; uint64_t wtot[NW] = {};
 	std::function<void()> body;
 };
 inline Emu& emu() { static Emu e; return e; }
@@ -73,6 +76,12 @@ inline void run_block(int64_t block, int64_t grid, std::function<void()> body)
 		any = false;
 		for (int l = 0; l < Emu::W; ++l)
 			if (E.live[l]) { E.cur = l; swapcontext(&E.main_ctx, &E.ctx[l]); any = any || E.live[l]; }
+		for (int r = 0; r < Emu::NW; ++r)
+		{
+			uint32_t m = 0;
+			for (int l = 0; l < Emu::W; ++l) { m = E.whit[r][l] > m ? E.whit[r][l] : m; E.whit[r][l] = 0; }
+			E.wtot[r] += m;
+		}
 	}
 }
 
@@ -125,6 +134,7 @@ inline uint32_t lds_load32(const uint8_t* p) { if ((uintptr_t)p & 3u) { fprintf(
 inline void lds_store32u(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
 inline uint64_t lds_load64u(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 inline void lds_store64u(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+inline uint64_t lds_load64(const uint8_t* p) { if ((uintptr_t)p & 7u) { fprintf(stderr, "wave_emul: misaligned lds_load64\n"); abort(); } uint64_t v; memcpy(&v, p, 8); return v; }
 inline void lds_store16u(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; memcpy(p, &h, 2); }
 inline void lds_store32(uint8_t* p, uint32_t v) { if ((uintptr_t)p & 3u) { fprintf(stderr, "wave_emul: misaligned lds_store32\n"); abort(); } memcpy(p, &v, 4); }
 
@@ -137,6 +147,7 @@ struct ByteBuf
 	// the strict reading of the hardware's range check: a dword that is not wholly inside the range reads 0 / is dropped
 	uint32_t load32(uint32_t off) const { uint32_t v = 0; if ((uint64_t)off + 4 <= bytes) memcpy(&v, p + off, 4); return v; }
 	void store32(uint32_t off, uint32_t v) const { if ((uint64_t)off + 4 <= bytes) memcpy(p + off, &v, 4); }
+	void store64(uint32_t off, uint64_t v) const { if ((uint64_t)off + 8 <= bytes) memcpy(p + off, &v, 8); }   // (the hardware checks the whole access of a raw buffer with swizzle off: out of range = dropped)
 	uint64_t load64(uint32_t off) const { return (uint64_t)load32(off) | ((uint64_t)load32(off + 4) << 32); }   // (each dword is range-checked on its own)
 };
 
