@@ -249,6 +249,10 @@ int ngsqc_set_reference(const char* fasta_path);
 #define NGSQC_CRAM_SKIP_NAMES 1
 #define NGSQC_CRAM_SKIP_TAGS  2
 int ngsqc_set_cram_skip(int32_t flags);
+/* The same choice for the files the CALLING THREAD opens from now on (flags >= 0; -1: back to the process-wide choice). Returns the thread's previous value (-1: none),
+ * so that a scope can restore what it found: a function that needs tags for its own reader (Statistics::mapping reads DP) must not change what a reader opened by
+ * another thread decodes. */
+int32_t ngsqc_set_cram_skip_thread(int32_t flags);
 int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions);   /* regions NULL / 0: every record */
 
 /* ---- writing the index. The reference never builds one: every indexed path above fails with "Could not load index of BAM/CRAM file"

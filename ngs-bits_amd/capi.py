@@ -170,7 +170,7 @@ EXPORTS = [
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",
     "ngsqc_write_bai", "ngsqc_bai_assemble", "ngsqc_bgzf_scan", "ngsqc_write_csi", "ngsqc_csi_assemble", "ngsqc_bai_ranges",
-    "ngsqc_set_reference", "ngsqc_set_cram_skip", "ngsqc_cram_to_bam",
+    "ngsqc_set_reference", "ngsqc_set_cram_skip", "ngsqc_set_cram_skip_thread", "ngsqc_cram_to_bam",
 ]
 
 
@@ -213,6 +213,12 @@ def set_cram_skip(flags):
     L = lib(); L.ngsqc_set_cram_skip.restype = C.c_int; L.ngsqc_set_cram_skip.argtypes = [C.c_int32]
     if L.ngsqc_set_cram_skip(int(flags)) != 0:
         raise ValueError("invalid CRAM skip flags")
+
+
+def set_cram_skip_thread(flags):
+    """The calling thread's own choice (ngsqc_set_cram_skip_thread; -1: back to the process-wide one). Returns the previous value (-1: none)."""
+    L = lib(); L.ngsqc_set_cram_skip_thread.restype = C.c_int32; L.ngsqc_set_cram_skip_thread.argtypes = [C.c_int32]
+    return int(L.ngsqc_set_cram_skip_thread(int(flags)))
 
 
 def cram_to_bam(cram_path, bam_path, regions=None):

@@ -72,6 +72,7 @@ int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ng
 	catch (std::exception& e) { g_open_error = e.what(); return NGSQC_E_DEVICE; }
 }
 int ngsqc_set_reference(const char* fasta_path) { ngsqc::cram_set_reference(fasta_path); return NGSQC_OK; }
+int32_t ngsqc_set_cram_skip_thread(int32_t flags) { if (flags >= 0 && (flags & ~(NGSQC_CRAM_SKIP_NAMES | NGSQC_CRAM_SKIP_TAGS))) return NGSQC_E_ARG; return ngsqc::cram_set_skip_thread(flags); }
 int ngsqc_set_cram_skip(int32_t flags) { if (flags & ~(NGSQC_CRAM_SKIP_NAMES | NGSQC_CRAM_SKIP_TAGS)) return NGSQC_E_ARG; ngsqc::cram_set_skip(flags); return NGSQC_OK; }
 int ngsqc_cram_to_bam(const char* cram_path, const char* bam_path, const ngsqc_named_region* regions, int64_t n_regions)
 {

@@ -59,6 +59,7 @@ inline std::string chr_norm(std::string c)
 bool is_cram(const uint8_t* d, size_t n);
 void cram_set_reference(const char* fasta);
 std::string cram_reference();
+int cram_set_skip_thread(int flags);   // the calling thread's own choice (-1: none); returns the previous one
 void cram_set_skip(int flags);   // bit 0: read names, bit 1: optional fields are not needed (not decoded where their blocks are theirs alone)
 int cram_skip();
 struct CramSelect { struct Region { std::string chr; int32_t start, end; }; std::vector<Region> regions; int64_t max_slices = 0; };   // regions: only slices that can hold their records; max_slices: the first slices only

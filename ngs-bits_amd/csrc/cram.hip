@@ -226,9 +226,11 @@ void lzma_block(const uint8_t* raw, size_t csize, size_t rsize, std::vector<uint
 // CRAM_OPT_REQUIRED_FIELDS, BamReader.cpp:525-572): read names and / or optional fields. Their blocks - gzip, mostly: a third of a CRAM's bytes - are then
 // not inflated and the records carry "*" / no tags. Only external blocks that nothing else reads can be left out; a series in the core block is decoded and dropped.
 std::atomic<int> g_cram_skip{0};
+thread_local int tl_cram_skip = -1;   // a thread's own choice for the files IT opens (-1: the process-wide one) - a guard around one function's opens must not change what another thread's open decodes
 } // namespace
 void cram_set_skip(int flags) { g_cram_skip = flags & 3; }
-int cram_skip() { return g_cram_skip.load(); }
+int cram_set_skip_thread(int flags) { const int old = tl_cram_skip; tl_cram_skip = flags < 0 ? -1 : (flags & 3); return old; }
+int cram_skip() { return tl_cram_skip >= 0 ? tl_cram_skip : g_cram_skip.load(); }
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------- blocks, containers
@@ -395,10 +397,10 @@ void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
 			return ext;
 		};
 		std::set<int32_t> needed, rn_ids; std::map<int32_t, std::set<int32_t>> tag_ids;
-		bool rn_ok = false;
+		bool rn_seen = false, rn_ok = false;
 		for (const auto& kv : h.ds)
 		{
-			if ((skip & 1) && kv.first == ds_key("RN")) { rn_ok = ids_of(kv.second, rn_ids); if (!rn_ok) rn_ids.clear(); continue; }
+			if ((skip & 1) && kv.first == ds_key("RN")) { rn_seen = true; rn_ok = ids_of(kv.second, rn_ids); continue; }
 			std::set<int32_t> tmp; ids_of(kv.second, tmp); needed.insert(tmp.begin(), tmp.end());
 		}
 		for (const auto& kv : h.tags)
@@ -407,14 +409,23 @@ void read_compression_header(const uint8_t* d, size_t n, CompHdr& h)
 			if ((skip & 2) && ok) tag_ids[kv.first] = tmp; else needed.insert(tmp.begin(), tmp.end());
 		}
 		auto free_of_needed = [&](const std::set<int32_t>& ids) { for (int32_t id : ids) if (needed.count(id)) return false; return true; };
-		// (a tag that shares a block with a tag that stays must stay too: until nothing changes)
-		for (bool changed = true; changed;)
+		// (a tag that shares a block with a series that stays must stay too: until nothing changes)
+		auto settle_tags = [&]() {
+			for (bool changed = true; changed;)
+			{
+				changed = false;
+				for (auto it = tag_ids.begin(); it != tag_ids.end();)
+					if (!free_of_needed(it->second)) { needed.insert(it->second.begin(), it->second.end()); it = tag_ids.erase(it); changed = true; } else ++it;
+			}
+		};
+		// RN is decided FIRST where it cannot be skipped (it reads core bits): its blocks are needed like any other series' before a tag may let go of one it shares
+		if (rn_seen && !rn_ok) needed.insert(rn_ids.begin(), rn_ids.end());
+		settle_tags();
+		if (rn_seen && rn_ok)
 		{
-			changed = false;
-			for (auto it = tag_ids.begin(); it != tag_ids.end();)
-				if (!free_of_needed(it->second)) { needed.insert(it->second.begin(), it->second.end()); it = tag_ids.erase(it); changed = true; } else ++it;
+			if (free_of_needed(rn_ids)) { h.skip_rn = true; h.skip_ids.insert(rn_ids.begin(), rn_ids.end()); }
+			else { needed.insert(rn_ids.begin(), rn_ids.end()); settle_tags(); }   // RN stays because it shares a block with a series that stays: a tag that shares one with RN stays, too
 		}
-		if (rn_ok && free_of_needed(rn_ids)) { h.skip_rn = true; h.skip_ids.insert(rn_ids.begin(), rn_ids.end()); }
 		for (const auto& kv : tag_ids) { h.skip_tags.insert(kv.first); h.skip_ids.insert(kv.second.begin(), kv.second.end()); }
 		if (h.qs_only_id >= 0 && h.skip_ids.count(h.qs_only_id)) h.qs_only_id = -1;
 	}

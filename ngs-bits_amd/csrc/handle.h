@@ -244,7 +244,8 @@ struct ngsqc_handle
 		virtual ~FusedScan() = default;
 	};
 	FusedScan* fuse = nullptr; bool fuse_ok = true; int fused_tile = -1;
-	bool long_reads = false;   // the file's first record is longer than 8 KiB (index_tile): entries are groups of members, nothing is assumed about member starts
+	bool long_reads = false;   // the file's first records are longer than 8 KiB on average (index_tile): entries are groups of members, nothing is assumed about member starts
+	int lr_failures = 0;       // tiles in a row that failed the group path of long-read mode (three: the mode is dropped)
 	bool k2_plain = false;   // a tile of the running stream did not pass the chain check on the device: the later tiles walk whole members, as the general path needs them
 	std::vector<int64_t> rq_len_hist, rq_cyc;   // results of the last raw-read QC pass
 	struct Partial;                        // state between ngsqc_scan_mapping_partial and ngsqc_scan_mapping_finish

@@ -159,7 +159,7 @@ __global__ void index_init_kernel(const BlockDesc* __restrict__ blocks, int64_t 
 	int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
 	int64_t lo, hi; entry_range(blocks, b, prefix, ksh, nm, lo, hi);
-	const bool first_piece = b > 0 && ((b - 1) & ((1ll << ksh) - 1)) == 0;
+	const bool first_piece = b > 0 && (ksh <= 0 || ((b - 1) & ((1ll << ksh) - 1)) == 0);   // (ksh < 0: an entry is a group of members - no shift by a negative count)
 	start[b] = hi <= lo ? -1 : guess_all ? -2 : (hi <= exp0 ? -1 : (lo <= exp0 ? (int32_t)(exp0 - lo) : (assume0 && first_piece ? 0 : -2)));   // (an empty entry holds no record start)
 }
 

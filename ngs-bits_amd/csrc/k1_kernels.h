@@ -580,8 +580,8 @@ static_assert(P2_BMAX >= 4 * 259 && P2_BMAX < 2048 && P2_BMAX % 8 == 0 && P2_NW 
 struct P2Lds
 {
 	uint32_t it[P2_IMAX + 8];                              // (the last word: where the item words of lanes without an item go)
-	uint32_t ib[2 * 64];                                   // per 32 output bytes: {item-start bit mask, items that start in front of them}
-	uint32_t lg[2 * P2_LONG];                              // the batch's matches of more than 16 bytes: {first byte | length << 11 | index of the first item << 20, key}
+	uint32_t ib[2 * 64];                                   // per 32 output bytes: {bit mask of the first bytes of NEAR items, near items that start in front of them}
+	uint32_t lg[2 * P2_LONG + 8];                            // the batch's matches of more than 16 bytes: {first byte | length << 11 | index of the first item << 20, key}; then (pass A / B) the near items
 	alignas(16) uint8_t val[P2_HIST + P2_BMAX + 16];       // [history | the batch's bytes | slack]
 	alignas(4) uint8_t lit[256];                           // the literal table of the current DEFLATE block
 };
@@ -684,7 +684,6 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					const bool has = n != 0u;
 					const uint32_t d = has ? st + l - n : 0u, key = item_key(t);
 					S.it[has ? ix : (uint32_t)(P2_IMAX + 7)] = d | (((n < 16u ? n : 16u) - 1u) << 11) | key;
-					wv::lds_or32(&S.ib[2 * (d >> 5)], has ? 1u << (d & 31u) : 0u);
 					const uint64_t lgm = wv::ballot(n > 16u);
 					if (lgm != 0ull)
 					{
@@ -711,16 +710,8 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 						K1_WSTAT(12);
 						const uint32_t off = o + 16u <= n ? o : n - 16u, d = ms + off;   // (the last item of a long match overlaps its predecessor)
 						S.it[ix + (o >> 4)] = d | (15u << 11) | (key + ((key >> 30) ? off << 15 : 0u));   // (raw run: payload offset of the item; run of a byte: distance to the byte in front of the match)
-						wv::lds_or32(&S.ib[2 * (d >> 5)], 1u << (d & 31u));
 					}
 				}
-			}
-			wv::barrier();
-			{
-				// items that start in front of each 32-byte piece
-				const uint32_t cn = lane < P2_NW ? wv::bcnt(S.ib[2 * lane]) : 0u;
-				const uint32_t inc = wv::scan_incl(cn);
-				if (lane < P2_NW) S.ib[2 * lane + 1] = inc - cn;
 			}
 			wv::barrier();
 			// stores of earlier batches must be complete before this batch loads from the window behind P
@@ -734,76 +725,112 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 
 			if (lane == 0) K1_STAT(7);
 			K1_WSTAT(10);
-			// one step's worth of item state; the loads of a far (or raw) item are issued a step ahead
+			// ---- the items, in two passes (round 6) ----
+			// Pass A, 64 items per step: a FAR item (its source lies in front of the batch: seven in ten on BAM data) is two overlapping loads from the member's output in HBM, issued a
+			// step ahead, and two stores into the staging bytes - no dependencies, no rounds; a NEAR item is only moved to a compact list (S.lg, in output order) and its first byte
+			// marked in the bit mask. Pass B resolves the near items, 64 per step, in dependency rounds: what they read is then in LDS except what other near items of the same step
+			// write. (Round 5 resolved every step of 64 mixed items in rounds: 109 steps and 370 rounds per member of the bench data, each round a walk over three length classes.)
 			// An item's bytes travel in two overlapping pieces: lengths 9..16 as the two 8-byte words at 0 and len - 8, lengths 4..8 as the two dwords at 0 and
-			// len - 4, shorter ones as one dword (stored as a 16-bit and an 8-bit piece) - the LDS traffic follows the item's length
-			// x: what is left to do - 0 nothing, 1 loaded (far item: its bytes are on their way into w0 / w1 or lo / hi), 2 / 3 / 5 near item of 9..16 / 4..8 / 3 bytes, 4 a near item of a rare
-			// kind (a run of a byte, an item that overlaps its own source), 6 raw run (loaded in its step: rare)
-			struct Item { uint32_t w, x, w0, w1; uint64_t lo, hi; };
-			auto fetch = [&](uint32_t i0) -> Item {
-				Item q; const uint32_t idx = i0 + (uint32_t)lane; K1_WSTAT(13);
+			// len - 4, three bytes as one dword (stored as a 16-bit and an 8-bit piece)
+			struct Far { uint32_t w, k, w0, w1; uint64_t lo, hi; };   // k: 0 nothing to store, 1 / 2 / 3 loaded item of 9..16 / 4..8 / 3 bytes, 4 a rare kind (raw run, far item of a run, one or two bytes)
+			uint32_t nn = 0;   // near items so far
+			auto fetch = [&](uint32_t i0) -> Far {
+				Far q; const uint32_t idx = i0 + (uint32_t)lane; K1_WSTAT(13);
 				const bool in = idx < NI;
 				q.w = in ? S.it[idx] : 0u; q.lo = q.hi = 0; q.w0 = q.w1 = 0;
 				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
 				const int src = (int)d - (int)dist;
 				const bool raw = (q.w >> 31) != 0u, run = (q.w >> 30) == 1u;
 				const bool far = src + (run ? 1 : (int)len) <= 0;
-				const uint32_t xn = run || dist < len ? 4u : (len >= 9u ? 2u : (len >= 4u ? 3u : 5u));
-				q.x = !in ? 0u : (raw ? 6u : (far ? 1u : xn));
+				const bool near = in && !raw && !far;
+				q.k = !in || near ? 0u : (raw || run || len < 3u ? 4u : (len >= 9u ? 1u : (len >= 4u ? 2u : 3u)));
+				// near items: to the list
+				const uint64_t nm = wv::ballot(near);
+				const uint32_t dn = near ? d : 0u;
+				S.lg[near ? nn + wv::mbcnt(nm) : (uint32_t)(2 * P2_LONG + 7)] = q.w;
+				wv::lds_or32(&S.ib[2 * (dn >> 5)], near ? 1u << (dn & 31u) : 0u);
+				nn += wv::popc64(nm);
+				// far items: the loads (a run's byte: one dword)
 				const uint32_t a = P + (uint32_t)src;
-				const bool wide = len >= 9u && !run;
-				if (q.x == 1u && wide) { q.lo = outld.load64(a); q.hi = outld.load64(a + len - 8u); }
-				if (q.x == 1u && !wide) { q.w0 = outld.load32(a); q.w1 = outld.load32(a + (len >= 4u && !run ? len - 4u : 0u)); }
+				const bool ldf = in && !near && !raw, wide = len >= 9u && !run;
+				if (ldf && wide) { q.lo = outld.load64(a); q.hi = outld.load64(a + len - 8u); }
+				if (ldf && !wide) { q.w0 = outld.load32(a); q.w1 = outld.load32(a + (len >= 4u && !run ? len - 4u : 0u)); }
 				return q;
 			};
-			auto starts_before = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // items that start in front of byte p
-			auto process = [&](Item& q, const uint32_t i0) {
-				if (lane == 0) K1_STAT(4);
+			auto store_far = [&](Far& q) {
 				K1_WSTAT(14);
-				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u, dist = wv::bfe(q.w, 15, 15) + 1u;
-				const bool run = (q.w >> 30) == 1u;
-				const int src = (int)d - (int)dist;
+				const uint32_t d = q.w & 0x7ffu, len = wv::bfe(q.w, 11, 4) + 1u;
 				uint8_t* const pd = vb + d; uint8_t* const pd2 = pd + len - (len >= 9u ? 8u : 4u);
-				const uint8_t* const ps = vb + src; const uint8_t* const ps2 = ps + len - (len >= 9u ? 8u : 4u);
-				auto put_any = [&](uint64_t x, uint64_t y) {   // (rare kinds) any length from registers: x, y the two pieces (dwords in their low halves below nine bytes)
-					if (len >= 9u) { wv::lds_store64u(pd, x); wv::lds_store64u(pd2, y); }
-					else if (len >= 4u) { wv::lds_store32u(pd, (uint32_t)x); wv::lds_store32u(pd2, (uint32_t)y); }
-					else
-					{
-						if (len >= 2u) wv::lds_store16u(pd, (uint32_t)x);
-						vb[d + len - 1u] = (uint8_t)((uint32_t)x >> (8u * (len - 1u)));
-					}
-				};
-				// the loaded items first: nothing in the batch depends on where they come from
-				if (wv::ballot(q.x == 6u || (q.x == 1u && (run || len < 3u))) != 0ull)
+				if (wv::ballot(q.k == 4u) != 0ull)
 				{
 					// (rare) a stored block's bytes come from the compressed input; a loaded item of a run repeats its byte; a raw item of one or two bytes
-					if (q.x == 6u)
+					const bool raw = (q.w >> 31) != 0u;
+					if (q.k == 4u && raw)
 					{
 						const uint32_t a = wv::bfe(q.w, 15, 16);
 						if (len >= 9u) { q.lo = cin.load64(a); q.hi = cin.load64(a + len - 8u); }
 						else { q.w0 = cin.load32(a); q.w1 = cin.load32(a + (len >= 4u ? len - 4u : 0u)); }
-						q.x = 1u;
 					}
 					wv::wait_vm0();
-					if (q.x == 1u && (run || len < 3u))
+					if (q.k == 4u)
 					{
-						if (run) { const uint32_t r4 = (q.w0 & 255u) * 0x01010101u; put_any(((uint64_t)r4 << 32) | r4, ((uint64_t)r4 << 32) | r4); }
-						else put_any(q.w0, q.w1);
-						q.x = 0u;
+						if (!raw) { const uint32_t r4 = (q.w0 & 255u) * 0x01010101u; q.w0 = q.w1 = r4; q.lo = q.hi = ((uint64_t)r4 << 32) | r4; }
+						if (len >= 9u) { wv::lds_store64u(pd, q.lo); wv::lds_store64u(pd2, q.hi); }
+						else if (len >= 4u) { wv::lds_store32u(pd, q.w0); wv::lds_store32u(pd2, q.w1); }
+						else
+						{
+							if (len >= 2u) wv::lds_store16u(pd, q.w0);
+							vb[d + len - 1u] = (uint8_t)(q.w0 >> (8u * (len - 1u)));
+						}
 					}
 				}
+				// (predicates of the length, not comparisons of q.k with 1, 2, 3: those become a decision tree of nested branches)
+				const bool ld = q.k != 0u && q.k != 4u;
+				if (ld && len >= 9u) { wv::lds_store64u(pd, q.lo); wv::lds_store64u(pd2, q.hi); }
+				if (ld && len >= 4u && len < 9u) { wv::lds_store32u(pd, q.w0); wv::lds_store32u(pd2, q.w1); }
+				if (ld && len == 3u) { wv::lds_store16u(pd, q.w0); pd[2] = (uint8_t)(q.w0 >> 16); }
+			};
+			wv::barrier();   // (the list of long matches in S.lg has been read)
+			{
+				// two steps per trip: the loads of one step's far items are in flight while the other step is stored (only loads are in flight: they return in order)
+				Far qa = fetch(0u), qb = qa;
+				#pragma nounroll
+				for (uint32_t i0 = 0; i0 < NI; i0 += 128u)
 				{
-					const bool far = q.x == 1u;
-					if (far && len >= 9u) { wv::lds_store64u(pd, q.lo); wv::lds_store64u(pd2, q.hi); }
-					if (far && len >= 4u && len < 9u) { wv::lds_store32u(pd, q.w0); wv::lds_store32u(pd2, q.w1); }
-					if (far && len == 3u) { wv::lds_store16u(pd, q.w0); pd[2] = (uint8_t)(q.w0 >> 16); }
-					if (far) q.x = 0u;
+					const bool hb = i0 + 64u < NI;
+					if (hb) { qb = fetch(i0 + 64u); wv::wait_vm4(); } else wv::wait_vm0();
+					store_far(qa);
+					if (hb)
+					{
+						if (i0 + 128u < NI) { qa = fetch(i0 + 128u); wv::wait_vm4(); } else wv::wait_vm0();
+						store_far(qb);
+					}
 				}
-				// the lanes of this step that may write into a near item's source: the items that start in (src - 16, src + slen), as far as they lie in front of this
+			}
+			wv::barrier();
+			{
+				// near items that start in front of each 32-byte piece
+				const uint32_t cn = lane < P2_NW ? wv::bcnt(S.ib[2 * lane]) : 0u;
+				const uint32_t inc = wv::scan_incl(cn);
+				if (lane < P2_NW) S.ib[2 * lane + 1] = inc - cn;
+			}
+			wv::barrier();
+			auto starts_before = [&](uint32_t p) -> uint32_t { return S.ib[2 * (p >> 5) + 1] + wv::bcnt(wv::bfe(S.ib[2 * (p >> 5)], 0, p & 31u)); };   // near items that start in front of byte p
+			#pragma nounroll
+			for (uint32_t i0 = 0; i0 < nn; i0 += 64u)
+			{
+				if (lane == 0) K1_STAT(4);
+				K1_WSTAT(19);
+				const uint32_t idx = i0 + (uint32_t)lane;
+				const uint32_t w = idx < nn ? S.lg[idx] : 0u;
+				const uint32_t d = w & 0x7ffu, len = wv::bfe(w, 11, 4) + 1u, dist = wv::bfe(w, 15, 15) + 1u;
+				const bool run = (w >> 30) == 1u;
+				const int src = (int)d - (int)dist;
+				uint8_t* const pd = vb + d; uint8_t* const pd2 = pd + len - (len >= 9u ? 8u : 4u);
+				const uint8_t* const ps = vb + src; const uint8_t* const ps2 = ps + len - (len >= 9u ? 8u : 4u);
+				// the lanes of this step that may write into the item's source: the near items that start in (src - 16, src + slen), as far as they lie in front of this
 				// item (an exact first lane - from a second bit plane of item ends - saved one round in seventy)
 				uint64_t dep = 0;
-				if (q.x != 0u)
 				{
 					const uint32_t slen = run ? 1u : len;   // source bytes
 					const int lo = (int)starts_before((uint32_t)(src > 15 ? src - 15 : 0)) - (int)i0;
@@ -812,11 +839,10 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					const int l0 = lo > 0 ? lo : 0;
 					if (hi >= l0) dep = ((2ull << (hi - l0)) - 1ull) << l0;
 				}
-				wv::barrier();
 				// (the three length classes as predicates that live across the rounds - scalar masks; compared inside the loop, a kind number becomes a decision tree of nested branches)
 				const bool c9 = len >= 9u, c4 = len >= 4u && len < 9u, c3 = len == 3u;
-				uint32_t x = q.x >= 2u && q.x != 4u ? 2u : q.x;   // 0 done, 2 near item of two pieces, 4 near item of a rare kind
-				const bool any4 = wv::ballot(x == 4u) != 0ull;     // (wave-uniform: the rounds of a step without such an item do not look for one)
+				uint32_t x = idx >= nn ? 0u : (run || dist < len ? 4u : 2u);   // 0 done, 2 near item of two pieces, 4 near item of a rare kind (a run of a byte, an item that overlaps its own source)
+				const bool any4 = wv::ballot(x == 4u) != 0ull;                 // (wave-uniform: the rounds of a step without such an item do not look for one)
 				for (;;)
 				{
 					if (lane == 0) K1_STAT(6);
@@ -828,7 +854,13 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					{
 						if (free && x == 4u)
 						{
-							if (run) { const uint32_t r4 = (uint32_t)*ps * 0x01010101u; put_any(((uint64_t)r4 << 32) | r4, ((uint64_t)r4 << 32) | r4); }
+							if (run)
+							{
+								const uint32_t r4 = (uint32_t)*ps * 0x01010101u; const uint64_t r8 = ((uint64_t)r4 << 32) | r4;
+								if (len >= 9u) { wv::lds_store64u(pd, r8); wv::lds_store64u(pd2, r8); }
+								else if (len >= 4u) { wv::lds_store32u(pd, r4); wv::lds_store32u(pd2, r4); }
+								else { wv::lds_store16u(pd, r4); pd[2] = (uint8_t)r4; }
+							}
 							else for (uint32_t k = 0; k < len; ++k) { K1_WSTAT(16); pd[k] = ps[k]; }   // an item that overlaps its own source with a distance of 2..15: byte by byte
 						}
 					}
@@ -838,20 +870,6 @@ K1_KERNEL_OCC(64, 8) void lz77_groups_kernel(const uint32_t* __restrict__ pool, 
 					if (g && c3) { const uint32_t u = wv::lds_load32u(ps); wv::lds_store16u(pd, u); pd[2] = (uint8_t)(u >> 16); }
 					x = free ? 0u : x;
 					wv::barrier();
-				}
-			};
-			// two steps per trip: the loads of one step's far items are in flight while the other step is resolved (only loads are in flight: they return in order)
-			Item qa = fetch(0u), qb = qa;
-			#pragma nounroll
-			for (uint32_t i0 = 0; i0 < NI; i0 += 128u)
-			{
-				const bool hb = i0 + 64u < NI;
-				if (hb) { qb = fetch(i0 + 64u); wv::wait_vm4(); } else wv::wait_vm0();
-				process(qa, i0);
-				if (hb)
-				{
-					if (i0 + 128u < NI) { qa = fetch(i0 + 128u); wv::wait_vm4(); } else wv::wait_vm0();
-					process(qb, i0 + 64u);
 				}
 			}
 			// ---- the batch leaves for HBM: eight bytes per lane and store, the last 1..7 bytes one by one ----

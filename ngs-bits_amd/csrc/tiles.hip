@@ -129,10 +129,18 @@ void index_tile(ngsqc_handle* h, int t)
 		if (elr) h->long_reads = atoi(elr) != 0 && !anchor_by_guess;
 		else if (!anchor_by_guess && exp0 >= 0 && exp0 + 4 <= total)
 		{
-			uint32_t bs0 = 0;
-			HIPCHK(hipMemcpyAsync(&bs0, base + exp0, 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
-			h->long_reads = bs0 > 8192;
+			// (a sample, not one record: the mean block_size of up to eight records along the chain - an ONT file may well begin with a short read)
+			int64_t off = exp0, sum = 0; int n = 0;
+			for (; n < 8 && off + 4 <= total; ++n)
+			{
+				uint32_t bs = 0;
+				HIPCHK(hipMemcpyAsync(&bs, base + off, 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream));
+				if (bs < 32 || bs > (1u << 30)) break;   // (not a record: K2 will say so)
+				sum += bs; off += 4 + (int64_t)bs;
+			}
+			h->long_reads = n > 0 && sum / n > 8192;
 		}
+		h->lr_failures = 0;
 	}
 	int ksh = 0; if (const char* e = getenv("NGSQC_WALKERS")) { const int k = atoi(e); ksh = k >= 8 ? 3 : k >= 4 ? 2 : k >= 2 ? 1 : 0; }
 	if (h->long_reads) { ksh = K2_MIN_KSH; if (const char* e = getenv("NGSQC_GROUP_SHIFT")) ksh = -std::min(8, std::max(0, atoi(e))); }
@@ -197,6 +205,7 @@ void index_tile(ngsqc_handle* h, int t)
 	if (aligned)
 	{
 		if (n_corrupt) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (corrupt record chain)");
+		h->lr_failures = 0;
 		straddle = (int64_t)sm[1]; h->tm.tiles_chain_on_device++; if (h->fused_tile == t) h->tm.tiles_scan_fused++;
 		h->tm.walkers_per_member = ksh >= 0 ? 1ll << ksh : -(1ll << -ksh);   // (negative: members per walker)
 		if (straddle >= 0 && last && !tail_may_cut_a_record) throw FormatError("Could not read next alignment in BAM/CRAM file " + h->path + " (truncated record)");
@@ -207,6 +216,9 @@ void index_tile(ngsqc_handle* h, int t)
 	// ---- general path: records cut by tile borders, false guesses, shards that guess their first record. Whole members (ksh = 0): the host verifies that every
 	// member's exit lands on the next member's start and repairs the first mismatch, round by round ----
 	if (!anchor_by_guess) h->k2_plain = true;
+	// (long-read mode bypasses k2_plain: a file that keeps failing the group path - short reads behind a long first read, entries with more records than a name holds - pays
+	// the fused walk, its take-back and this path for every tile; after three tiles in a row the mode is dropped for the rest of the file)
+	if (h->long_reads && ++h->lr_failures >= 3) h->long_reads = false;
 	if (ksh != 0 || assume0)
 	{
 		ksh = 0; ne = ne0;

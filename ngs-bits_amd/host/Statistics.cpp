@@ -614,7 +614,7 @@ QCCollection Statistics::mapping(const BedFile& bed_file, const std::string& bam
 	std::unique_ptr<FastaFileIndex> fa; if (ref_file != NO_REF) fa.reset(new FastaFileIndex(ref_file));
 	long long roi_bases = bed_file.baseCount();
 	GcPrep gc(bed_file, fa.get());
-	struct TagsGuard { TagsGuard() { BamReader::requireTags(true); } ~TagsGuard() { BamReader::requireTags(false); } } tags_needed;   // (the DP tag of cfDNA reads, Statistics.cpp:447-470)
+	struct TagsGuard { int32_t old; TagsGuard() : old(ngsqc_set_cram_skip_thread(NGSQC_CRAM_SKIP_NAMES)) {} ~TagsGuard() { ngsqc_set_cram_skip_thread(old); } } tags_needed;   // (this thread's readers only; what was set before comes back)   // (the DP tag of cfDNA reads, Statistics.cpp:447-470)
 	BamReader reader(bam_file, ref_file, true);
 	// ROI lines on chromosomes the BAM does not know never match a read in the reference (ChromosomalIndex lookup by name)
 	std::vector<ngsqc_region> regions = toRegions(bed_file, reader, false);

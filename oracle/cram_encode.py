@@ -297,6 +297,9 @@ def huffman_lengths(values):
     return syms, [depth[s] for s in syms]
 
 
+SHARED_BLOCK = False   # test switch: RN, IN and the first tag's values share one external block (the skip bookkeeping of the product must keep all of them: tests/test_cpu_cram.py)
+
+
 def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False, slices_per_container=1):
     """genome: {contig name: bytes, upper case}. rr = False writes every base into the file ('b' features: no genome needed to read it). multi_ref packs several
     references into one slice (RI series, absolute positions). embed_ref stores the slice's reference stretch in the file. variety = False: raw EXTERNAL only."""
@@ -369,6 +372,7 @@ def encode_container(gs, refs, rgs, genome, rr, multi_ref, chains, embed_ref, va
         ids.setdefault(key, len(ids) + 1); return ("EXTERNAL", ids[key])
     E = {k: ext(k) for k in ("BF", "RL", "AP", "NP", "TS", "NF", "TL", "FP", "BS", "BA", "QS", "RI", "MF", "NS", "HC", "PD", "RS", "FC")}
     E["RN"] = ("BYTE_ARRAY_STOP", 0, ext("RN")[1]); E["IN"] = ("BYTE_ARRAY_STOP", 0, ext("IN")[1]); E["SC"] = ("BYTE_ARRAY_STOP", 0, ext("SC")[1])
+    if SHARED_BLOCK: E["RN"] = ("BYTE_ARRAY_STOP", 0, ext("IN")[1])   # (a legal layout htslib does not write: read names, inserted bases and - below - one tag's values in ONE external block)
     E["BB"] = ("BYTE_ARRAY_LEN", ext("BBl"), ext("BBv")); E["QQ"] = ("BYTE_ARRAY_LEN", ext("QQl"), ext("QQv"))
     all_rg = [x for p in P for x in p["rg_of"]]; all_cf = [x for p in P for x in p["cf"]]
     if variety:
@@ -388,7 +392,7 @@ def encode_container(gs, refs, rgs, genome, rr, multi_ref, chains, embed_ref, va
             p["tl_of"].append(TD.index(line))
             for t, typ, _ in tags:
                 key = (t[0] << 16) | (t[1] << 8) | typ
-                if key not in tag_enc: tag_enc[key] = ("BYTE_ARRAY_LEN", ext("tl%d" % key), ext("tv%d" % key))
+                if key not in tag_enc: tag_enc[key] = ("BYTE_ARRAY_LEN", ext("tl%d" % key), ext("IN") if SHARED_BLOCK and not tag_enc else ext("tv%d" % key))
     sm = SUBST_DEFAULT
     subst_code = {}
     for ri, rb in enumerate(BASES):

@@ -175,6 +175,50 @@ def test_names_and_tags_are_not_decoded_when_nobody_needs_them(name, twins, tmp_
         ngsqc.set_reference(None)
 
 
+def test_read_names_that_share_a_block_with_a_series_that_stays(twins, tmp_path, monkeypatch):
+    """RN, IN (inserted bases: always needed) and one tag's values in ONE external block - RN cannot be skipped, so its block is needed, so the tag that
+    shares it stays as well; every other tag goes. Before the fix RN's blocks never reached the needed set, the tag was dropped, its block was not inflated and RN was
+    decoded from an empty block: a CramError on a valid file."""
+    twin = twins["MappingQC_in2.bam"]; src = str(tmp_path / "shared.cram"); out = str(tmp_path / "s.bam")
+    monkeypatch.setattr(CE, "SHARED_BLOCK", True)
+    CE.encode(twin["bam"], src, twin["genome"])
+    fetch = cram_twin.ref_fetch_of(twin); ngsqc.set_reference(twin["fasta"]); monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False)
+    try:
+        f = CD.read_cram(src, fetch); rgs = CD.read_groups(f.header)
+        ngsqc.set_cram_skip(ngsqc.CRAM_SKIP_NAMES | ngsqc.CRAM_SKIP_TAGS)
+        try:
+            ngsqc.cram_to_bam(src, out)
+        finally:
+            ngsqc.set_cram_skip(0)
+        _, _, recs = split_bam(bam_stream(out)[0])
+        assert len(recs) == len(f.records) > 1000
+        n_tagged = 0
+        for got, r in zip(recs, f.records):
+            full = CD.to_bam_record(r, rgs)
+            assert got[4:36 + len(r.name) + 1] == full[4:36 + len(r.name) + 1]   # the names stayed (their block is needed); [0:4] is block_size: most tags are gone
+            kept = [t for t in r.tags if bytes(t[0]) in got[36:]]; n_tagged += bool(kept)
+        assert n_tagged > 0
+    finally:
+        ngsqc.set_reference(None)
+
+
+def test_a_threads_own_skip_choice_is_its_own(tmp_path):
+    """ngsqc_set_cram_skip_thread: a scope's choice holds for the calling thread only and gives back what was set before (ADVICE r05: the guard of Statistics::mapping)."""
+    import threading
+    ngsqc.set_cram_skip(ngsqc.CRAM_SKIP_NAMES | ngsqc.CRAM_SKIP_TAGS)
+    try:
+        assert ngsqc.set_cram_skip_thread(ngsqc.CRAM_SKIP_NAMES) == -1
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ngsqc.set_cram_skip_thread(-1))); t.start(); t.join()
+        assert seen == [-1]                                                       # the other thread never had a choice of its own
+        assert ngsqc.set_cram_skip_thread(0) == ngsqc.CRAM_SKIP_NAMES             # ours is still there
+        assert ngsqc.set_cram_skip_thread(-1) == 0
+        assert ngsqc.set_cram_skip_thread(64) == -3                               # NGSQC_E_ARG: not a flag
+        assert ngsqc.set_cram_skip_thread(-1) == -1                               # ... and nothing was set
+    finally:
+        ngsqc.set_cram_skip_thread(-1); ngsqc.set_cram_skip(0)
+
+
 def test_genome_errors(twins, tmp_path, monkeypatch):
     twin = twins["MappingQC_in2.bam"]; cram = str(tmp_path / "twin.cram"); out = str(tmp_path / "o.bam")
     CE.encode(twin["bam"], cram, twin["genome"])
