@@ -361,8 +361,18 @@ typedef struct ngsqc_timings {
 	int64_t tiles_chain_on_device;    /* tiles whose chain passed the check on the device (every walker's exit = the next walker's start): no host verification */
 	int64_t tiles_scan_fused;         /* ... of which the job's mapping / depth scan rode the chain walk (one read of every record's first line) */
 	int64_t walkers_per_member;       /* walkers per BGZF member of the last tile's fast path (NGSQC_WALKERS) */
+	/* round 6: the state of the switches that can change a RESULT (all others only change a schedule). NGSQC_SW_* bits; the defaults are NGSQC_SW_VERIFY_CRC alone */
+	int64_t switches;
 } ngsqc_timings;
+#define NGSQC_SW_VERIFY_CRC        1   /* every member's CRC32 is checked against its gzip trailer (NGSQC_VERIFY_CRC=0 turns it off: a measurement switch) */
+#define NGSQC_SW_CRAM_IGNORE_MD5   2   /* NGSQC_CRAM_IGNORE_MD5=1: a slice's reference MD5 is not compared (htslib's ignore_md5 option) */
+#define NGSQC_SW_CRAM_NO_REFERENCE 4   /* NGSQC_CRAM_NO_REFERENCE=1: bases that come from the genome are N (the reference's skipBases mode; test switch) */
+/* The struct grows at its END from round to round and this call writes sizeof(ngsqc_timings) of the LIBRARY: a caller compiled against an older header must be
+ * rebuilt - or call ngsqc_get_timings_sized with ITS sizeof: at most that many bytes are written (the fields it knows). ngsqc_abi_version() is the round of the
+ * header the library was built from (6). */
 int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t);
+int ngsqc_get_timings_sized(const ngsqc_handle* h, void* t, size_t struct_size);
+int32_t ngsqc_abi_version(void);
 
 /* library / device info string (static storage) */
 const char* ngsqc_version(void);

@@ -200,9 +200,24 @@ int ngsqc_copy_record_offsets(ngsqc_handle* h, int64_t* out, int64_t cap)
 	});
 }
 
-int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t) { if (!h || !t) return NGSQC_E_ARG; *t = h->tm; return NGSQC_OK; }
+static ngsqc_timings timings_of(const ngsqc_handle* h)
+{
+	ngsqc_timings t = h->tm;
+	const char* e1 = getenv("NGSQC_CRAM_IGNORE_MD5"); const char* e2 = getenv("NGSQC_CRAM_NO_REFERENCE");
+	t.switches = (h->verify_crc ? NGSQC_SW_VERIFY_CRC : 0) | (e1 && atoi(e1) != 0 ? NGSQC_SW_CRAM_IGNORE_MD5 : 0) | (e2 && atoi(e2) != 0 ? NGSQC_SW_CRAM_NO_REFERENCE : 0);
+	return t;
+}
+int ngsqc_get_timings(const ngsqc_handle* h, ngsqc_timings* t) { if (!h || !t) return NGSQC_E_ARG; *t = timings_of(h); return NGSQC_OK; }
+int ngsqc_get_timings_sized(const ngsqc_handle* h, void* t, size_t struct_size)
+{
+	if (!h || !t) return NGSQC_E_ARG;
+	const ngsqc_timings full = timings_of(h);
+	memcpy(t, &full, struct_size < sizeof(full) ? struct_size : sizeof(full));
+	return NGSQC_OK;
+}
+int32_t ngsqc_abi_version(void) { return 6; }
 
-const char* ngsqc_version(void) { return "ngsqc-hip 0.2 (gfx950; K1 bgzf inflate + crc32, K2 bam record index, K3-K5 scan / pileup / read QC, K6 depth; tile stream)"; }
+const char* ngsqc_version(void) { return "ngsqc-hip 0.3 abi 6 (gfx950; K1 bgzf inflate + crc32, K2 bam record index, K3-K5 scan / pileup / read QC, K6 depth; tile stream)"; }
 
 } // extern "C"
 

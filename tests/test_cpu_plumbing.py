@@ -1,5 +1,6 @@
 """CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/ngsqc.h, fails loudly without a
 device, the host tools parse their CLI like the reference, and the multi-process counter reduction works on gloo."""
+import ctypes as C
 import importlib
 import os
 import re
@@ -23,6 +24,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert b"gfx950" in L.ngsqc_version()
+    L.ngsqc_abi_version.restype = C.c_int32
+    assert L.ngsqc_abi_version() == 6 and b"abi 6" in L.ngsqc_version()   # (the round of include/ngsqc.h the library was built from: ngsqc_timings grows at its end)
 
 
 def test_no_cpu_fallback():
