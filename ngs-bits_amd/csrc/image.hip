@@ -118,10 +118,13 @@ void init_device(ngsqc_handle* h, int device)
 	HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
 	HIPCHK(hipStreamCreateWithFlags(&h->s_p1[0], hipStreamNonBlocking));
 	HIPCHK(hipStreamCreateWithFlags(&h->s_p1[1], hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&h->s_p2, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&h->s_crc, hipStreamNonBlocking));
+	{
+		const bool p2_hi = getenv("NGSQC_P2_PRIO") && atoi(getenv("NGSQC_P2_PRIO")) != 0;   // (dev: the short-lived phase-2 / CRC waves ahead of the decoder's long-lived ones when a CU's LDS frees up)
+		HIPCHK(hipStreamCreateWithPriority(&h->s_p2, hipStreamNonBlocking, p2_hi ? prio_hi : 0));
+		HIPCHK(hipStreamCreateWithPriority(&h->s_crc, hipStreamNonBlocking, p2_hi ? prio_hi : 0));
+	}
 	int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cu = cu;
-	const int pw = P1_WAVES_PER_CU;
+	const int pw = getenv("NGSQC_P1_WAVES") ? std::max(1, atoi(getenv("NGSQC_P1_WAVES"))) : P1_WAVES_PER_CU;   // (dev: decoder waves per CU a launch keeps resident)
 	h->p1_wgs = h->n_cu * pw;
 	k1_read_switches();
 	if (const char* e = getenv("NGSQC_VERIFY_CRC")) h->verify_crc = atoi(e) != 0;
@@ -549,7 +552,8 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	// buffers (28 GB/s when another process has just given the memory back): half-size chunks and one chunk per tile cut the ring, the token pool and the tile
 	// buffers from 65 GB to 23 GB for the 30x file; the job stays behind the copy
 	if (h->stream_img && !getenv("NGSQC_K1_CHUNK_DIV")) div = 2;
-	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * K1_CHUNK_WAVES_PER_CU * 64 * mul / div);
+	const int64_t cw = getenv("NGSQC_K1_CHUNK_WAVES") ? std::max(1, atoi(getenv("NGSQC_K1_CHUNK_WAVES"))) : K1_CHUNK_WAVES_PER_CU;   // (dev: chunk size in decoder waves per CU)
+	const int64_t lanes = std::max<int64_t>(64, (int64_t)h->n_cu * cw * 64 * mul / div);
 	// two K1 chunks per tile (192 M reads, 12 chunks; job Mreads/s | un-pipelined scan-stage share of the HBM roofline): 1 chunk 919 | 0.36, 2 chunks 931-941 | 0.43-0.44, 4 chunks
 	// 930 | 0.46. The job barely cares; the chain walk of the fused scan has one thread per MEMBER, so a tile of 195 k members keeps twice the lines in flight of a 97 k one.
 	int64_t cpt = h->stream_img ? 1 : 2; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));

@@ -63,7 +63,7 @@ struct GcTables { DevBuf<int32_t> start, end, bin, tf, tl; };
 struct ScanState : ngsqc_handle::FusedScan
 {
 	ScanParams sp{}; DevBuf<unsigned long long> d_counters; DevBuf<uint32_t> d_fix;   // d_fix: scratch of the parallel order-dependent fix-up
-	DevBuf<int64_t> d_bq, d_bq_sorted; DevBuf<uint8_t> d_bq_tmp; DevBuf<unsigned long long> d_bq_count; bool bq_ride = false; size_t bq_min = 0;   // MODE_DEPTH with min_baseq riding the walk: records that overlap a region, masked by baseq_list_kernel behind the walk
+	DevBuf<int64_t> d_bq, d_bq_sorted; DevBuf<uint8_t> d_bq_tmp; DevBuf<unsigned long long> d_bq_count; bool bq_ride = false; size_t bq_min = 0;   // MODE_DEPTH with min_baseq riding the walk: records that overlap a region, masked by baseq_tile_kernel behind the walk
 	std::vector<unsigned long long> dev;   // device accumulators after the last tile
 	bool in_pass_fix = true;               // false: shard protocol (ngsqc_scan_mapping_partial / _finish)
 	// running state of the in-pass fix
@@ -82,7 +82,7 @@ struct ScanState : ngsqc_handle::FusedScan
 		// (opt-in, NGSQC_BASEQ_RIDE=1: on the bench's data - four quality levels, half of all bases below 20 - the mask is 75 atomic pairs per record, and the compacted
 		// list concentrates them on neighbouring addresses: 10.1 ms of kernels per 48 M reads against 6.2 for K2 + the thread-per-record scan, profiles/r05_scan_probe.txt;
 		// with instrument qualities - a few per cent below 20 - the walk's index time, 0.3 against 2.6 ms, is what is left)
-		{ const char* e = getenv("NGSQC_BASEQ_RIDE"); bq_ride = sp.mode == MODE_DEPTH && sp.min_baseq > 0 && e && atoi(e) != 0; } if (bq_ride) d_bq_count.ensure(1);
+		{ const char* e = getenv("NGSQC_BASEQ_RIDE"); bq_ride = sp.mode == MODE_DEPTH && sp.min_baseq > 0 && !(e && atoi(e) == 0); } if (bq_ride) d_bq_count.ensure(1);   // (round 6: on by default - the list's decrements are aggregated in LDS tiles, baseq_tile_kernel; NGSQC_BASEQ_RIDE=0: K2 + the thread-per-record scan)
 		bq_min = 0;
 		sp.bq_list = nullptr; sp.bq_count = nullptr; sp.bq_cap = 0;
 		run_max = 0; paired_seen = false; sum_runmax = 0; fix_len = 0; prev_total = 0; prev_usable = 0; best_key = 0; first_paired = ~0ull;
@@ -593,7 +593,7 @@ void run_job(ngsqc_handle* h, const ngsqc_job_desc* j, ngsqc_job_result* r, ngsq
 	if (do_sites && do_map) pile.attach(map.scan.sp, &map.scan);   // (the pileup's candidates come from the scan that rides K2's chain walk)
 	if (do_reads) reads.begin(h, j->read_qc_single_end);
 	const double w1 = wall_ms();
-	const bool depth_rides = do_depth && (j->depth->min_baseq <= 0 || (getenv("NGSQC_BASEQ_RIDE") && atoi(getenv("NGSQC_BASEQ_RIDE")) != 0));
+	const bool depth_rides = do_depth && (j->depth->min_baseq <= 0 || !(getenv("NGSQC_BASEQ_RIDE") && atoi(getenv("NGSQC_BASEQ_RIDE")) == 0));
 	FuseGuard fg(h, do_map ? &map.scan : (depth_rides ? &dscan : nullptr));
 	// the record offsets of a tile are only expanded when a consumer reads them: the mapping scan rides the chain walk (deferred long-CIGAR records and the
 	// order-dependent fix-ups ask for them), the site pileup works on the walk's candidate list; the extra depth scan and the raw-read QC read every record
@@ -883,7 +883,7 @@ void depth_scan(ngsqc_handle* h, const ngsqc_depth_params* p, bool finalize)
 	sc.begin(h);
 	// (round 5: with -min_baseq the records that overlap a region leave the walk for a list and a wave-per-record kernel masks their low-quality bases; rounds 3-4
 	// took the thread-per-record path - K2, then the scan kernel - because the decrements inside the walk stalled its lanes: 147 vs 224 ms per 96 M reads)
-	{ const char* e = getenv("NGSQC_BASEQ_RIDE"); const bool ride = p->min_baseq <= 0 || (e && atoi(e) != 0); FuseGuard fg(h, ride ? &sc : nullptr); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
+	{ const char* e = getenv("NGSQC_BASEQ_RIDE"); const bool ride = p->min_baseq <= 0 || !(e && atoi(e) == 0); FuseGuard fg(h, ride ? &sc : nullptr); stream_tiles(h, [&](const TileCtx& c) { sc.tile(h, c); return true; }); }
 	sc.end(h);
 	h->cur_ds = 0;
 	h->tm.scan_ms = sc.stage_ms; h->tm.scan_kernel_ms = sc.kernel_ms; h->tm.scan_launches = sc.launches; h->tm.scan_algorithmic_bytes = (int64_t)sc.dev[A_ALG_BYTES];

@@ -212,7 +212,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 			if (!p.bq_list || i0 >= (1 << 28)) baseq_decrements(p, r, start1, i0, i1);   // (a list entry holds the region index in 28 bits)
 			else if (p.sgn > 0)
 			{
-				// (the walk's lanes do not stop for 150 quality bytes of one record in fifty: baseq_list_kernel masks them, a wave per record)
+				// (the walk's lanes do not stop for 150 quality bytes of one record in fifty: baseq_tile_kernel masks them behind the walk)
 				const unsigned long long k = atomicAdd(p.bq_count, 1ull);
 				if ((long long)k < p.bq_cap) p.bq_list[k] = (int64_t)((unsigned long long)(r.core - 4 - p.infl) | ((unsigned long long)(uint32_t)i0 << 36));   // (offset in the tile: < 2^36; first overlapped region)
 			}
@@ -576,20 +576,78 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 // Inside the walk the same loop stalled 63 lanes for the one whose record overlapped a region (224 vs 147 ms per 96 M reads, round 3); on the compacted list every
 // lane has a record. (A wave per record was tried first: 20 dependent loads per record with nothing to overlap them - 5.6 ms per 48 M reads.) ----
 static int scan_grid_cap(long long n) { const long long wgs = (n + 255) / 256; return (int)(wgs < 1 ? 1 : (wgs < 2048 ? wgs : 2048)); }
-__global__ __launch_bounds__(256) void baseq_list_kernel(const ScanParams p, long long n)
+// Round 6: the decrements of 256 neighbouring records of the sorted list are first counted in an LDS TILE of the difference array (BQ_TILE slots behind the lowest
+// slot any of them touches: the records are coordinate-sorted and the array holds the regions back to back, so a chunk's decrements lie within a few thousand slots)
+// and leave as ONE atomic per slot: diff[o] += dec[o - 1] - dec[o]. At 30x every position of a region is masked by about fifteen reads - the round-5 kernel sent
+// two global atomics per masked base to neighbouring addresses (1.8 * 10^9 per step of the bench, 26 G/s: what -min_baseq cost), this one two per position.
+// A decrement outside the tile (a chunk that spans more than the tile) goes to the array directly.
+constexpr int BQ_TILE = 4096;
+__global__ __launch_bounds__(256) void baseq_tile_kernel(const ScanParams p, long long n)
 {
-	for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li < n; li += (long long)gridDim.x * blockDim.x)
+	__shared__ int32_t dec[BQ_TILE + 1];
+	__shared__ unsigned long long s_base;
+	for (long long c0 = (long long)blockIdx.x * 256; c0 < n; c0 += (long long)gridDim.x * 256)
 	{
-		const unsigned long long e = (unsigned long long)p.bq_list[li];
-		const RecView r = load_rec(p.infl, (int64_t)(e & ((1ull << 36) - 1ull)));
-		long long ref_len = 0;
-		for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
-		if (ref_len == 0) ref_len = 1;
-		const int start1 = r.pos + 1, end1 = (int)(r.pos + ref_len);
-		const int last = p.tid_reg_last[r.tid];
-		const int i0 = (int)(e >> 36);   // (the walk's region search: not repeated)
-		int i1 = i0; while (i1 < last && p.reg_start[i1] <= end1) ++i1;
-		baseq_decrements(p, r, start1, i0, i1);
+		for (int k = threadIdx.x; k <= BQ_TILE; k += 256) dec[k] = 0;
+		if (threadIdx.x == 0) s_base = ~0ull;
+		__syncthreads();
+		const long long li = c0 + threadIdx.x;
+		const bool have = li < n;
+		RecView r{}; int start1 = 0, i0 = 0, i1 = 0;
+		if (have)
+		{
+			const unsigned long long e = (unsigned long long)p.bq_list[li];
+			r = load_rec(p.infl, (int64_t)(e & ((1ull << 36) - 1ull)));
+			long long ref_len = 0;
+			for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
+			if (ref_len == 0) ref_len = 1;
+			start1 = r.pos + 1; const int end1 = (int)(r.pos + ref_len);
+			const int last = p.tid_reg_last[r.tid];
+			i0 = (int)(e >> 36);   // (the walk's region search: not repeated)
+			i1 = i0; while (i1 < last && p.reg_start[i1] <= end1) ++i1;
+			if (i1 > i0) atomicMin(&s_base, (unsigned long long)(p.reg_doff[i0] + (long long)(max(start1, p.reg_start[i0]) - p.reg_start[i0])));
+		}
+		__syncthreads();
+		const long long base = (long long)s_base;
+		if (have && i1 > i0)
+		{
+			// BamAlignment::qualities (BamReader.cpp:210-255), as baseq_decrements: M bases below min_baseq; '=' / 'X' / 'H' / 'P' advance neither index
+			const uint8_t* q = rec_qual(r);
+			uint32_t ai = 0; int gi = 0;
+			for (uint32_t k = 0; k < r.n_cigar; ++k)
+			{
+				const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u, len = c >> 4;
+				if (op == 0)
+				{
+					int ri = i0;   // (the positions of an M stretch ascend: so does the region that holds them)
+					for (uint32_t j = 0; j < len && ai + j < (uint32_t)r.l_seq; ++j)
+					{
+						if (q[ai + j] >= p.min_baseq) continue;
+						const int pos1 = start1 + gi + (int)j;
+						while (ri < i1 && p.reg_end[ri] < pos1) ++ri;
+						// (regions of an unmerged BED may overlap: every region that holds the position, as the reference's per-line depth does)
+						for (int i = ri; i < i1 && p.reg_start[i] <= pos1; ++i)
+							if (pos1 <= p.reg_end[i])
+							{
+								const long long o = p.reg_doff[i] + (long long)(pos1 - p.reg_start[i]), rel = o - base;
+								if (rel >= 0 && rel < BQ_TILE) atomicAdd(&dec[rel], 1);
+								else { atomicAdd(p.diff + o, -p.sgn); atomicAdd(p.diff + o + 1, p.sgn); }
+							}
+					}
+					ai += len; gi += (int)len;
+				}
+				else if (op == 2 || op == 3) gi += (int)len;
+				else if (op == 1 || op == 4) ai += len;
+			}
+		}
+		__syncthreads();
+		if (base >= 0 && s_base != ~0ull)
+			for (int k = threadIdx.x; k <= BQ_TILE; k += 256)
+			{
+				const int v = (k ? dec[k - 1] : 0) - (k < BQ_TILE ? dec[k] : 0);
+				if (v) atomicAdd(p.diff + base + k, v * p.sgn);
+			}
+		__syncthreads();
 	}
 }
 // The walk's lanes append to the list in whatever order their atomics arrive: neighbouring entries lie anywhere in a 12 GB tile, and a lane-per-record pass over
@@ -610,7 +668,7 @@ void launch_baseq_list(const ScanParams& p, int64_t n, hipStream_t s, int64_t* d
 		if (rocprim::radix_sort_keys(d_tmp, tmp_bytes, (unsigned long long*)p.bq_list, (unsigned long long*)d_sorted, (size_t)n, 0, 36, s) != hipSuccess) throw std::runtime_error("rocprim::radix_sort_keys failed");
 		q.bq_list = d_sorted;
 	}
-	hipLaunchKernelGGL(baseq_list_kernel, dim3(scan_grid_cap(n)), dim3(256), 0, s, q, (long long)n); KCHECK();
+	hipLaunchKernelGGL(baseq_tile_kernel, dim3(scan_grid_cap(n)), dim3(256), 0, s, q, (long long)n); KCHECK();
 }
 
 // ---- the scan fused into K2's chain walk ----

@@ -31,7 +31,8 @@ void enqueue_k1_tile(ngsqc_handle* h, int t)
 	auto launch_p1 = [&](int64_t c) {
 		const int64_t c0 = c * h->chunk, cn = std::min(h->chunk, nb - c0);
 		hipEvent_t* e4 = &h->ev_chunk[(size_t)(4 * c)];
-		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[c & 1];
+		static const int p1_streams = getenv("NGSQC_P1_STREAMS") ? atoi(getenv("NGSQC_P1_STREAMS")) : 2;   // (dev: 1 = one decoder launch at a time)
+		hipStream_t s1 = k1_serial ? h->s_p2 : h->s_p1[p1_streams >= 2 ? (c & 1) : 0];
 		if (c >= h->k1_slots) HIPCHK(hipStreamWaitEvent(s1, h->ev_chunk[(size_t)(4 * (c - h->k1_slots) + 3)], 0));   // the ring slot is free again
 		if (h->stream_img) stream_wait_chunk(h, c, s1);
 		else if (h->up) { const BlockDesc& lb = h->blocks[(size_t)(c0 + cn - 1)]; upload_wait(h, (size_t)(lb.cpos + lb.clen + 64), s1, k1_serial ? 3 : 1 + (int)(c & 1)); }

@@ -100,12 +100,13 @@ def test_roi_mode_exome_like(tmp_path):
     h.close()
 
 
-@pytest.mark.parametrize("env", [{"NGSQC_BASEQ_RIDE": "1"}, {}, {"NGSQC_BASEQ_RIDE": "1", "NGSQC_BQ_LIST_CAP": "7"}, {"NGSQC_BASEQ_RIDE": "1", "NGSQC_TILE_MEMBERS": "11"},
-                                 {"NGSQC_BASEQ_RIDE": "1", "NGSQC_TILE_MEMBERS": "11", "NGSQC_BQ_LIST_CAP": "50"}, {"NGSQC_NO_FUSED_SCAN": "1"}])
+@pytest.mark.parametrize("env", [{}, {"NGSQC_BASEQ_RIDE": "0"}, {"NGSQC_BQ_LIST_CAP": "7"}, {"NGSQC_TILE_MEMBERS": "11"},
+                                 {"NGSQC_TILE_MEMBERS": "11", "NGSQC_BQ_LIST_CAP": "50"}, {"NGSQC_NO_FUSED_SCAN": "1"}])
 def test_min_baseq_rides_the_walk(tmp_path, monkeypatch, env):
-    """BedLowCoverage -min_baseq (BamAlignment::qualities): the depth scan can ride K2's chain walk with min_baseq too (NGSQC_BASEQ_RIDE=1: the records that overlap a
-    region go to a list, sorted by offset, and a lane per record masks their low-quality bases; the default is K2 + the thread-per-record scan, which the bench's
-    quality model favours). The same depth as the oracle either way, with a list that overflows (the tile is taken back and scanned record by record) and across tiles."""
+    """BedLowCoverage -min_baseq (BamAlignment::qualities): the depth scan rides K2's chain walk with min_baseq too (round 6: the default - the records that overlap a
+    region go to a list, sorted by offset, and a lane per record counts their low-quality bases in an LDS tile of the difference array that leaves as one atomic per
+    slot; NGSQC_BASEQ_RIDE=0: K2 + the thread-per-record scan). The same depth as the oracle either way, with a list that overflows (the tile is taken back and
+    scanned record by record) and across tiles."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     bed = tmp_path / "x.bed"
@@ -119,7 +120,7 @@ def test_min_baseq_rides_the_walk(tmp_path, monkeypatch, env):
         h.scan_depth(regs, min_mapq=1, min_baseq=baseq)
         exp = O.low_high_coverage(ob, str(bed), 20, 1, baseq, is_high=False, random_access=True, tool_merge=1)
         assert np.array_equal(h.depth(exp["roi_bases"]), exp["depth"]), baseq
-        if baseq and "NGSQC_BASEQ_RIDE" in env and "NGSQC_BQ_LIST_CAP" not in env:
+        if baseq and "NGSQC_BASEQ_RIDE" not in env and "NGSQC_NO_FUSED_SCAN" not in env and "NGSQC_BQ_LIST_CAP" not in env:
             assert h.timings()["tiles_scan_fused"] == h.timings()["n_tiles"]
     h.close()
 
