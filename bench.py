@@ -137,7 +137,9 @@ def scan_roofline(tm):
     gbs = b / max(t_scan, 1e-9) / 1e6
     return {"stage": "K2-K6 on resident inflated data, un-pipelined step", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes": b, "t_scan_ms": round(t_scan, 4),
-            "scan_kernel_only": {"frac": round(b / max(tm["scan_kernel_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 5), "ms": round(tm["scan_kernel_ms"], 4)}}
+            "scan_kernel_only": {"frac": round(b / max(tm["scan_kernel_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 5), "ms": round(tm["scan_kernel_ms"], 4)},
+            "itemised_ms": {"k2_index_incl_start_guess": round(tm["index_ms"], 4), "scan_kernels": round(tm["scan_kernel_ms"], 4),
+                            "scan_stage_other": round(tm["scan_ms"] - tm["scan_kernel_ms"], 4), "depth_finalize": round(tm["finalize_ms"], 4)}}
 
 
 def timed_steps(step, h, steps):
@@ -157,7 +159,7 @@ def timed_steps(step, h, steps):
     n_rec = int(tm["n_records"])
     return res, {"value": round(n_rec * steps / el / 1e6, 3), "unit": "Mreads/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "reads_per_step": n_rec,
                  "members_inflated_per_step": int(tm["members_inflated"]), "tiles": int(tm["n_tiles"]), "tiles_scan_fused": int(tm["tiles_scan_fused"]),
-                 "walkers_per_member": int(tm["walkers_per_member"]), "roofline_scan": scan_roofline(serial)}
+                 "walkers_per_member": int(tm["walkers_per_member"]), "roofline_scan": scan_roofline(serial), "inflate_stage_unpipelined_ms": round(serial["inflate_ms"], 3)}
 
 
 def coverage_tool_leg(ngsqc, H, O, h, image, refs, tool, min_baseq, steps, args, device):
@@ -213,9 +215,13 @@ def coverage_tool_leg(ngsqc, H, O, h, image, refs, tool, min_baseq, steps, args,
 
 
 def ont_leg(ngsqc, G, H, O, args, device, steps):
-    """configs[4]: MappingQC -wgs (fused job incl. contamination pileup) on a shard of the 40x ONT file: 400 k of ~8e6 reads (N50 ~20 kb, ~1 CIGAR op per 12 bp, CG-tag
-    records) - the long-read generator is the limit of the shard's size, not the GPU. Reference: Statistics.cpp:1068-1182 over BamReader::cigarData (long CIGAR / CG tag)."""
-    reads = int(os.environ.get("NGSQC_BENCH_ONT_READS", "400000"))
+    """configs[4]: MappingQC -wgs (fused job incl. contamination pileup) on the largest piece of the 40x ONT file that fits the bench's time and the host's memory:
+    2 000 000 of ~8e6 reads by default (N50 ~20 kb, ~1 CIGAR op per 12 bp, CG-tag records: ~22 GB compressed, ~84 GB inflated, ~2.5 min of generator; NGSQC_BENCH_ONT_READS
+    overrides, the whole file is 8 000 000) - scaled down when the host cannot hold it. Reference: Statistics.cpp:1068-1182 over BamReader::cigarData (long CIGAR / CG tag)."""
+    reads = int(os.environ.get("NGSQC_BENCH_ONT_READS", "2000000"))
+    avail = host_memory_available()
+    if avail:   # ~11 KB of compressed image per read, twice that while the generator's pieces are joined
+        reads = max(100_000, min(reads, int(0.4 * avail / 11_000) // 100_000 * 100_000))
     gen_kw = dict(seed=args.seed, mode=1, depth=40.0, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=0)
     t0 = time.time(); image = G.generate(reads, threads=2 * G.effective_cpus(), **gen_kw); gen_s = time.time() - t0
     h = ngsqc.Handle(data=image, device=device)
@@ -229,8 +235,9 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
         return h.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, True))["counters"]
     _, out = timed_steps(step, h, steps)
     tm = h.timings()
-    out["workload"] = (f"MappingQC -wgs as one fused job on a SHARD of configs[4]: {out['reads_per_step']} of ~8e6 reads of the 40x ONT-like BAM (N50 ~20 kb, ~1 CIGAR op per 12 bp, "
-                       f"CG-tag records), {int(tm['compressed_bytes'])} compressed / {int(tm['inflated_bytes'])} inflated bytes; compressed image resident, every step from the compressed bytes")
+    out["workload"] = (f"MappingQC -wgs as one fused job on {out['reads_per_step']} of the ~8e6 reads of configs[4] (the 40x ONT-like BAM: N50 ~20 kb, ~1 CIGAR op per 12 bp, "
+                       f"CG-tag records), {int(tm['compressed_bytes'])} compressed / {int(tm['inflated_bytes'])} inflated bytes in {int(tm['n_tiles'])} tiles; compressed image resident, "
+                       f"every step from the compressed bytes")
     out["gbases_per_s"] = round(out["value"] * 1e6 * (int(tm["inflated_bytes"]) / max(out["reads_per_step"], 1)) / 1.72 / 1e9, 2)   # (~1.72 inflated bytes per base: 4-bit SEQ + QUAL + CIGAR share)
     out["generate_s"] = round(gen_s, 1)
     h.close()
@@ -238,14 +245,54 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
         c_cpu, st, secs = O.baseline_wgs_stream(image, omim, 1, min(150_000, reads), sites=sites_arr, site_params=(1, 13, True))
         out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 5), "unit": "Mreads/s", "cores": 1, "kind": "port",
                                "sample": f"first {st['n_records']} records of the same BAM ({st['compressed']} compressed bytes), oracle/stream.hpp single-thread sequential loop (the same job incl. the site pileup), {secs:.1f} s"}
+        del image
         # long reads span BGZF members, so the file cannot be cut into per-thread member ranges for an all-cores parity pass: parity of the generator's data is
-        # checked on a small BAM of the same generator (all counters of the GPU job vs the sequential oracle, bit-exact)
-        small = G.generate(20_000, **dict(gen_kw, threads=0))
+        # checked on a 200 000-read BAM of the same generator (all counters of the GPU job vs the sequential oracle, bit-exact)
+        n_par = int(os.environ.get("NGSQC_BENCH_ONT_PARITY_READS", "200000"))
+        small = G.generate(n_par, **dict(gen_kw, threads=2 * G.effective_cpus()))
         hs = ngsqc.Handle(data=small, device=device)
-        got = hs.run_job(mapping=mp)["counters"]; hs.close()
-        c_small, _, _ = O.baseline_wgs_stream(small, omim, 1, -1)
+        got = hs.run_job(mapping=mp)["counters"]; n_tiles_small = int(hs.timings()["n_tiles"]); hs.close()
+        t1 = time.time(); c_small, _, _ = O.baseline_wgs_stream(small, omim, 1, -1); t_par = time.time() - t1
         out["counters_match_gpu"] = bool(all(int(got[i]) == int(c_small[i]) for i in range(len(got)) if i not in (27, 28)))
-        out["counters_match_note"] = "a 20 000-read BAM of the same generator and seed: all counters of the GPU job vs the sequential oracle, bit-exact"
+        out["counters_match_note"] = f"a {n_par}-read BAM of the same generator and seed ({n_tiles_small} tiles on the device): all counters of the GPU job vs the sequential oracle ({t_par:.0f} s), bit-exact"
+    return out
+
+
+def flavor_leg(ngsqc, G, H, O, args, device, steps, flavor=5, reads=96_000_000):
+    """K1's cost is the token mix: the headline is measured on SURVEY.md 8(d)'s shape (random SEQ, 4-level QUAL: ratio 3.45, matches of 11 bytes on average), the easiest
+    one for phase 2. This leg runs the same fused MappingQC -wgs job on a 96 M-read shard of generator flavor 5 (SEQ from a synthetic reference genome - overlapping reads
+    share sequence, as real data does - and 40-level qualities: ratio 2.5, literal-heavy). No reference line; SURVEY 8(d) config 2 is the spec of the shape."""
+    gen_kw = dict(seed=args.seed, mode=0, depth=30.0, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=flavor)
+    t0 = time.time(); image = G.generate(reads, threads=2 * G.effective_cpus(), **gen_kw); gen_s = time.time() - t0
+    h = ngsqc.Handle(data=image, device=device)
+    refs = h.refs
+    omim = os.path.join(ROOT, "ngs-bits_amd", "resources", "hg38_440_omim_genes.bed")
+    tx, ty = H.xy_tids(refs); regs, _ = H.bed_regions(omim, refs, 3); sites_arr = H.known_sites(refs)
+    mp = dict(mode=ngsqc.MODE_WGS, regions=regs, min_mapq=1, tid_x=tx, tid_y=ty, nonspecial=H.nonspecial(refs))
+    last = {}
+
+    def step():
+        h.drop_decoded()
+        last["c"] = h.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, False))["counters"]
+        return last["c"]
+    _, out = timed_steps(step, h, steps)
+    tm = h.timings()
+    out["workload"] = (f"MappingQC -wgs as one fused job on a {out['reads_per_step']}-read shard of generator flavor {flavor} (SEQ from a synthetic reference genome, 40-level QUAL; "
+                       f"{int(tm['compressed_bytes'])} compressed / {int(tm['inflated_bytes'])} inflated bytes, ratio {int(tm['inflated_bytes']) / max(int(tm['compressed_bytes']), 1):.2f})")
+    out["generate_s"] = round(gen_s, 1)
+    got = np.asarray(last["c"]).copy()
+    h.close()
+    if not args.no_cpu_baseline:
+        # parity on a prefix of the same image: the sequential oracle against the GPU job over the same records
+        samp = prefix_image(image, min(int(image.size), 6_000_000 * BYTES_PER_READ_COMPRESSED))
+        hs = ngsqc.Handle(data=samp, device=device)
+        g2 = hs.run_job(mapping=mp, sites=sites_arr, site_params=(1, 13, False))["counters"]; hs.close()
+        t1 = time.time(); c_cpu, st, secs = O.baseline_wgs_stream(samp, omim, 1, -1, sites=sites_arr, site_params=(1, 13, False))
+        out["cpu_baseline"] = {"value": round(st["n_records"] / secs / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {st['n_records']} records of the same BAM, oracle/stream.hpp single-thread sequential loop, {secs:.1f} s"}
+        out["counters_match_gpu"] = bool(all(int(g2[i]) == int(c_cpu[i]) for i in range(len(g2)) if i not in (27, 28)))
+        out["counters_match_note"] = "all counters of the GPU job over the sample vs the sequential oracle over the same records, bit-exact"
+    del got
     return out
 
 
@@ -559,11 +606,13 @@ def main():
                                    f"{' (' + size_note + ')' if size_note else ''}; compressed image resident in HBM, streamed through {int(tms[-1]['n_tiles'])} tiles",
                        "reads_per_gpu_per_step": n_rec, "compressed_bytes_per_gpu": c_bytes, "inflated_bytes_per_gpu": u_bytes,
                        "tiles": int(tms[-1]["n_tiles"]), "k1_chunks": k1_launches, "members_inflated_per_step": int(tms[-1]["members_inflated"]), "bgzf_members": int(h.n_blocks),
+                       "result_switches": (lambda sw: {"verify_crc": bool(sw & 1), "cram_ignore_md5": bool(sw & 2), "cram_no_reference": bool(sw & 4),
+                                                       "at_defaults": sw == 1, "note": "ngsqc_timings.switches of the timed handle: the switches that can change a result"})(int(tms[-1].get("switches", 1))),
                        "roi": "hg38_440_omim_genes.bed (430 merged regions, 41.6 Mb)" if tool == "mappingqc" else f"synthetic exome BED ({aux.get('bed_lines')} lines, {aux.get('bed_bases')} merged bases)",
                        "parallelism": (f"one BAM sharded over {world} GPU(s) by BGZF member range, 1 process/GPU; all-gather of shard summaries, "
                                        "SUM all-reduce of counters and of the int32 difference array (RCCL)") if args.single_bam
                                       else f"{world} BAM(s), one per GPU, 1 process/GPU, RCCL all-reduce of the counter vectors"},
-            "roofline": {"kernel": dom[0], "bound": "hbm", "limited_by": "instruction issue (VALU / LDS), not HBM: see profiles/r05_sq_counters.txt", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": dom[0], "bound": "hbm", "limited_by": "instruction issue (VALU / LDS), not HBM: see profiles/r06_sq_counters.txt", "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_gbs / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(dom[1]),
                          "avg_launch_ms": round(dom[2], 4), "launches_per_step": k1_launches, "sum_launches_ms": round(dom[2] * k1_launches, 3),
                          "isolated": iso is not None,
@@ -603,7 +652,7 @@ def main():
             per = {}
             settings_ok = False
             want = "k1_format=r04-word-per-trip tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
-            for ln in open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_pmc.txt")):
+            for ln in open(os.path.join(ROOT, "profiles", "r06_hbm_traffic_pmc.txt")):
                 if ln.startswith("# settings: "):
                     settings_ok = want in ln   # (the per-member figures only describe launches of the same kernels under the same schedule)
                 if not settings_ok:
@@ -617,7 +666,7 @@ def main():
                 fb, wb = per[(kname, "FETCH_SIZE")] * members_per_launch, per[(kname, "WRITE_SIZE")] * members_per_launch
                 out["roofline"]["traffic"] = int(fb + wb)
                 out["roofline"]["traffic_pmc"] = {"fetch_bytes_raw": int(fb), "write_bytes_raw": int(wb), "members_per_launch": int(members_per_launch),
-                                                  "source": "profiles/r05_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
+                                                  "source": "profiles/r06_hbm_traffic_pmc.txt (raw counter bytes per BGZF member x the members of this run's launch)",
                                                   "ratio_to_algorithmic": round((fb + wb) / max(dom[1], 1), 2),
                                                   "note": "raw FETCH_SIZE / WRITE_SIZE x 1024 B (no x2: the K1 accesses are 16-byte pieces of 64 different member streams per "
                                                           "instruction, between the guide's narrow and wide regimes)"}
@@ -626,7 +675,7 @@ def main():
                 if keys:
                     tot = sum(per[k] for k in keys) * n_rec
                     out["roofline_scan"]["traffic"] = int(tot)
-                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r05_hbm_traffic_pmc.txt) x the records of the step; the "
+                    out["roofline_scan"]["traffic_note"] = ("raw FETCH_SIZE + WRITE_SIZE of the K2 / scan kernels per record (profiles/r06_hbm_traffic_pmc.txt) x the records of the step; the "
                                                             "kernels gather one or two 128-byte lines per record, so the guide's x2 for wide streams does not apply")
         except OSError:
             pass
@@ -707,6 +756,11 @@ def main():
             out["ont"] = ont_leg(ngsqc, G, H, O, args, local_rank, 3)
         except Exception as e:
             out["ont"] = {"error": str(e)[:300]}
+    if want_extra and os.environ.get("NGSQC_BENCH_NO_FLAVORS") is None and not args.flavor:
+        try:
+            out["flavors"] = {"flavor5_refseq_40level_qual": flavor_leg(ngsqc, G, H, O, args, local_rank, 3)}
+        except Exception as e:
+            out["flavors"] = {"error": str(e)[:300]}
     if args.single_bam and rank == 0 and tool == "mappingqc" and image is not None:
         # parity of the sharded path: the unsharded job on this rank's GPU over the whole BAM (all 1032 counters and the depth histogram)
         try:

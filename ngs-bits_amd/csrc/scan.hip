@@ -203,9 +203,20 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		if (dup || secondary || supp || unmapped || (int)r.mapq < p.min_mapq) return;
 		if (p.skip_mismapped && !proper && r.mapq < 20) return;
 		if (!tid_ok) return;
-		int first = p.tid_reg_first[r.tid], last = p.tid_reg_last[r.tid];
-		if (first >= last) return;
-		int i0 = lower_region(p.reg_end, first, last, start1), i1 = i0;
+		// (round 6: the per-lane cache of the last search's answer, as in MODE_WGS - a walker's records lie a few bases apart, the binary search over an exome's 200 000
+		// regions was 17 dependent loads per record: what made this mode 3 ms per step slower than MODE_WGS on the same walk)
+		if (a.rc_tid != r.tid || start1 <= a.rc_lo || start1 > a.rc_hi)
+		{
+			const int first = p.tid_reg_first[r.tid], lastr = p.tid_reg_last[r.tid];
+			const int j0 = first < lastr ? lower_region(p.reg_end, first, lastr, start1) : lastr;
+			a.rc_tid = r.tid; a.rc_idx = j0; a.rc_last = lastr;
+			a.rc_lo = j0 > first ? p.reg_end[j0 - 1] : INT32_MIN;
+			a.rc_hi = j0 < lastr ? p.reg_end[j0] : INT32_MAX;
+			a.rc_start = j0 < lastr ? p.reg_start[j0] : INT32_MAX;
+		}
+		const int last = a.rc_last;
+		if (a.rc_start > end1) return;   // (the first region that ends at or behind the read's start begins behind its end: no overlap)
+		int i0 = a.rc_idx, i1 = i0;
 		for (; i1 < last && p.reg_start[i1] <= end1; ++i1) diff_add(p, i1, max(start1, p.reg_start[i1]), min(end1, p.reg_end[i1]));
 		if (p.min_baseq > 0 && i1 > i0)
 		{
@@ -620,9 +631,8 @@ __global__ __launch_bounds__(256) void baseq_tile_kernel(const ScanParams p, lon
 				if (op == 0)
 				{
 					int ri = i0;   // (the positions of an M stretch ascend: so does the region that holds them)
-					for (uint32_t j = 0; j < len && ai + j < (uint32_t)r.l_seq; ++j)
-					{
-						if (q[ai + j] >= p.min_baseq) continue;
+					const uint32_t n_m = ai < (uint32_t)r.l_seq ? min(len, (uint32_t)r.l_seq - ai) : 0u;   // (a CIGAR longer than SEQ: htslib would read past the qualities)
+					auto masked = [&](uint32_t j) {
 						const int pos1 = start1 + gi + (int)j;
 						while (ri < i1 && p.reg_end[ri] < pos1) ++ri;
 						// (regions of an unmerged BED may overlap: every region that holds the position, as the reference's per-line depth does)
@@ -633,7 +643,26 @@ __global__ __launch_bounds__(256) void baseq_tile_kernel(const ScanParams p, lon
 								if (rel >= 0 && rel < BQ_TILE) atomicAdd(&dec[rel], 1);
 								else { atomicAdd(p.diff + o, -p.sgn); atomicAdd(p.diff + o + 1, p.sgn); }
 							}
+					};
+					if (p.min_baseq <= 127)
+					{
+						// sixteen qualities per load; the bytes below the threshold as the high bits of (x | y) with y = (x | 0x80) - min_baseq per byte: bit 7 of y is
+						// set iff the byte's low seven bits reach the threshold, bit 7 of x iff the byte is 128 or more (0xff: no quality) - clear in both: below
+						const uint32_t thr = 0x01010101u * (uint32_t)p.min_baseq;
+						for (uint32_t j0 = 0; j0 < n_m; j0 += 16u)
+						{
+							uint32_t w[4]; __builtin_memcpy(w, q + ai + j0, 16);   // (behind the qualities lie the record's tags / the next record / the buffer's slack: masked below)
+							#pragma unroll
+							for (int k = 0; k < 4; ++k)
+							{
+								uint32_t lt = ~(((w[k] | 0x80808080u) - thr) | w[k]) & 0x80808080u;
+								const uint32_t left = n_m - j0 - 4u * (uint32_t)k;   // bases of the stretch from this dword on
+								if (j0 + 4u * (uint32_t)k >= n_m) lt = 0u; else if (left < 4u) lt &= (1u << (8u * left)) - 1u;
+								while (lt) { const uint32_t bit = (uint32_t)__builtin_ctz(lt); lt &= lt - 1u; masked(j0 + 4u * (uint32_t)k + (bit >> 3)); }
+							}
+						}
 					}
+					else for (uint32_t j = 0; j < n_m; ++j) if (q[ai + j] < p.min_baseq) masked(j);
 					ai += len; gi += (int)len;
 				}
 				else if (op == 2 || op == 3) gi += (int)len;

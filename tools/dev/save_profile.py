@@ -11,16 +11,16 @@ import sqlite3
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-PFX = "r1" if tag.startswith("r01") else ("r2" if tag.startswith("r02") else ("r3" if tag.startswith("r03") else ("r4" if tag.startswith("r04") else "r5")))
+PFX = "r1" if tag.startswith("r01") else ("r2" if tag.startswith("r02") else ("r3" if tag.startswith("r03") else ("r4" if tag.startswith("r04") else ("r5" if tag.startswith("r05") else "r6"))))
 # what the per-member / per-record figures depend on: bench.py only scales them to its own launches when it runs with the same settings
-SETTINGS = "settings: k1_format=r04-word-per-trip tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
+SETTINGS = "settings: k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
 try:
     import subprocess
     SETTINGS += " commit=" + subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     pass
 CMD = ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)" if PFX == "r1" else
-       "NGSQC_BENCH_NO_STRONG=1 NGSQC_BENCH_NO_E2E=1 python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles, 3 K1 chunks per job; 6 jobs per run: 1 warm-up + 3 timed + the un-pipelined and the isolated-K1 extra steps; 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)" if PFX in ("r3", "r4", "r5") else
+       "NGSQC_BENCH_NO_STRONG=1 NGSQC_BENCH_NO_E2E=1 python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles, 3 K1 chunks per job; 6 jobs per run: 1 warm-up + 3 timed + the un-pipelined and the isolated-K1 extra steps; 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)" if PFX in ("r3", "r4", "r5", "r6") else
        "python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles per step, 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)")
 out = open(f"profiles/{tag}_kernel_stats.txt", "w")
 c = sqlite3.connect(f"gpurun_out/{PFX}_trace/t_results.db")
@@ -34,7 +34,7 @@ pm.write(f"# separate passes: rocprofv3 --pmc FETCH_SIZE -- <cmd> ; rocprofv3 --
 pm.write("# per-kernel SUM over dispatches / number of dispatches = per-launch value; rocprofv3 reports these in KiB.\n")
 pm.write("# gfx950 note (MI355X_MICROARCH.md HBM section): FETCH_SIZE counts 64 B per 128 B request for wide coalesced streams (x2 correction);\n")
 pm.write("# other access widths (the scan kernel's sparse 4-byte gathers, the inflate kernels' byte traffic) are uncalibrated.\n")
-if PFX in ("r4", "r5"):
+if PFX in ("r4", "r5", "r6"):
     pm.write(f"# {SETTINGS}\n")
 pm.write("# kernel\tcounter\tdispatches\tsum_KiB\tper_launch\n")
 for db, ctr in ((f"gpurun_out/{PFX}_fetch/f_results.db", "FETCH_SIZE"), (f"gpurun_out/{PFX}_write/w_results.db", "WRITE_SIZE")):
@@ -43,7 +43,7 @@ for db, ctr in ((f"gpurun_out/{PFX}_fetch/f_results.db", "FETCH_SIZE"), (f"gpuru
     c = sqlite3.connect(db)
     for r in c.execute("select kernel_name, count(*), sum(value), max(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
         pm.write(f"{r[0][:70]}\t{ctr}\t{r[1]}\t{r[2]:.1f}\tavg_launch={r[2]/r[1]:.1f}\n")
-if PFX in ("r3", "r4", "r5"):
+if PFX in ("r3", "r4", "r5", "r6"):
     # bytes per BGZF member (K1 kernels: 3 chunk launches of 83 008 members per job + one 8-member launch of the header read) and per record (K2 / scan
     # kernels: 48 000 000 records per job), raw counter x 1024 - what bench.py scales to its own launches (roofline.traffic, roofline_scan.traffic)
     pm.write("# kernel\tcounter\tbytes_per_member | bytes_per_record\tvalue\t(jobs in the run)\n")
@@ -58,7 +58,7 @@ if PFX in ("r3", "r4", "r5"):
                 jobs = (n - 1) / 3.0
         for k, (n, tot) in rows.items():
             short = k.split("(")[0].split("::")[-1].split("<")[0]
-            if jobs and short in ("huff_tokens_kernel", "lz77_groups_kernel", "crc32_kernel"):
+            if jobs and short in ("huff_tokens_kernel", "lz77_groups_kernel", "crc32_kernel", "crc32_chains_kernel"):
                 pm.write(f"{short}\t{ctr}\tbytes_per_member\t{tot * 1024.0 / (jobs * 249024 + 8):.2f}\t{jobs:.1f}\n")
             elif jobs and short in ("walk_scan_kernel", "scan_kernel", "index_count_kernel", "index_write_kernel", "index_guess_kernel", "pileup_kernel"):
                 pm.write(f"{short}\t{ctr}\tbytes_per_record\t{tot * 1024.0 / (jobs * 48000000):.3f}\t{jobs:.1f}\n")
