@@ -175,6 +175,42 @@ __device__ static void baseq_decrements(const ScanParams& p, const RecView& r, i
 	}
 }
 
+// The list of the records whose qualities baseq_tile_kernel masks behind the walk (MODE_DEPTH with min_baseq). Round 6: a WAVE takes the list's slots in blocks of
+// BQ_BLOCK from the global counter and its lanes fill the block by rank (ballot of the lanes that append in this trip of the walk) - round 5 had every lane wait for
+// its own atomic on ONE address, a round trip in nearly every trip of the wave's loop (some lane of the 64 met a region): the walk of -min_baseq took twice the time
+// of the same walk without. A block's unused tail is filled with BQ_HOLE (the radix sort moves the holes behind the records; the mask kernel skips them).
+// state: two LDS words of the one-wave workgroup {next free slot, end of the block}.
+constexpr uint32_t BQ_BLOCK = 64;
+constexpr unsigned long long BQ_OFF_MASK = (1ull << 36) - 1ull, BQ_HOLE = ~0ull;
+__device__ __forceinline__ void bq_append(const ScanParams& p, uint32_t* state_, unsigned long long entry)
+{
+	volatile uint32_t* state = state_;   // (written by whichever lane has rank 0: never kept in a register)
+	const unsigned long long m = __builtin_amdgcn_ballot_w64(true);   // the lanes that append now
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), n = (uint32_t)__popcll(m);
+	uint32_t cur = 0;
+	if (rank == 0)
+	{
+		cur = state[0]; uint32_t end = state[1];
+		if (cur + n > end)
+		{
+			for (uint32_t k = cur; k < end; ++k) if ((long long)k < p.bq_cap) p.bq_list[k] = (int64_t)BQ_HOLE;
+			cur = (uint32_t)atomicAdd(p.bq_count, (unsigned long long)BQ_BLOCK); end = cur + BQ_BLOCK;
+			state[1] = end;
+		}
+		state[0] = cur + n;
+	}
+	cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);   // (the first active lane is the one of rank 0)
+	const long long k = (long long)cur + rank;
+	if (k < p.bq_cap) p.bq_list[k] = (int64_t)entry;
+}
+// the end of the wave's walk: the rest of its last block
+__device__ __forceinline__ void bq_close(const ScanParams& p, const uint32_t* state_)
+{
+	const volatile uint32_t* state = state_;
+	const long long k = (long long)state[0] + (threadIdx.x & 63u);
+	if (k < (long long)state[1] && k < p.bq_cap) p.bq_list[k] = (int64_t)BQ_HOLE;
+}
+
 // Everything after the CIGAR sums are known. ord = ordinal of the record in the file.
 template <int MODE>
 __device__ static void classify(const ScanParams& p, const RecView& r, long long ord, long long ref_len, long long clip, bool spliced, Acc& a, uint32_t* lds_hist)
@@ -221,12 +257,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 		if (p.min_baseq > 0 && i1 > i0)
 		{
 			if (!p.bq_list || i0 >= (1 << 28)) baseq_decrements(p, r, start1, i0, i1);   // (a list entry holds the region index in 28 bits)
-			else if (p.sgn > 0)
-			{
-				// (the walk's lanes do not stop for 150 quality bytes of one record in fifty: baseq_tile_kernel masks them behind the walk)
-				const unsigned long long k = atomicAdd(p.bq_count, 1ull);
-				if ((long long)k < p.bq_cap) p.bq_list[k] = (int64_t)((unsigned long long)(r.core - 4 - p.infl) | ((unsigned long long)(uint32_t)i0 << 36));   // (offset in the tile: < 2^36; first overlapped region)
-			}
+			else if (p.sgn > 0) bq_append(p, lds_hist + 1000, (unsigned long long)(r.core - 4 - p.infl) | ((unsigned long long)(uint32_t)i0 << 36));   // (offset in the tile: < 2^36; first overlapped region)
 		}
 		return;
 	}
@@ -593,80 +624,112 @@ static int scan_grid_cap(long long n) { const long long wgs = (n + 255) / 256; r
 // two global atomics per masked base to neighbouring addresses (1.8 * 10^9 per step of the bench, 26 G/s: what -min_baseq cost), this one two per position.
 // A decrement outside the tile (a chunk that spans more than the tile) goes to the array directly.
 constexpr int BQ_TILE = 4096;
+constexpr uint32_t BQ_BITS = 256;   // read positions whose "below min_baseq" flags a lane keeps as bits (four words of 64; longer reads: the rest byte by byte)
+// Round 6 (second half): what a masked base cost was not the atomics but FOUR DEPENDENT LOADS of the region table per base (reg_end, reg_start, reg_end, reg_doff:
+// ~75 masked bases per record of the bench data) behind a serial 16-byte quality loop. Now a lane (1) asks for its record's header and - at the same time - for the
+// bounds of the region the walk found, (2) asks for all qualities at once, 64 bytes per request group, and turns them into bits "below the threshold" (the bytes of a
+// dword tested together, the four flags gathered with one multiplication), (3) walks the CIGAR once per overlapped region: an M stretch is cut to the region's bounds
+// in registers, and only the set bits of that range are visited - each one LDS atomic. No load depends on a base.
 __global__ __launch_bounds__(256) void baseq_tile_kernel(const ScanParams p, long long n)
 {
 	__shared__ int32_t dec[BQ_TILE + 1];
 	__shared__ unsigned long long s_base;
+	const uint32_t thr = 0x01010101u * (uint32_t)(p.min_baseq & 127);
 	for (long long c0 = (long long)blockIdx.x * 256; c0 < n; c0 += (long long)gridDim.x * 256)
 	{
 		for (int k = threadIdx.x; k <= BQ_TILE; k += 256) dec[k] = 0;
 		if (threadIdx.x == 0) s_base = ~0ull;
 		__syncthreads();
 		const long long li = c0 + threadIdx.x;
-		const bool have = li < n;
-		RecView r{}; int start1 = 0, i0 = 0, i1 = 0;
+		const unsigned long long e = li < n ? (unsigned long long)p.bq_list[li] : BQ_HOLE;
+		const bool have = (e & BQ_OFF_MASK) != BQ_OFF_MASK;   // (a hole: the unused tail of a wave's block)
+		RecView r{}; int start1 = 0, end1 = 0, i0 = 0, i1 = 0; int rs = 0, re = 0; long long doff = 0;
+		uint32_t c4[4] = {0, 0, 0, 0};
+		unsigned long long low[BQ_BITS / 64] = {0, 0, 0, 0};
 		if (have)
 		{
-			const unsigned long long e = (unsigned long long)p.bq_list[li];
-			r = load_rec(p.infl, (int64_t)(e & ((1ull << 36) - 1ull)));
-			long long ref_len = 0;
-			for (uint32_t k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
-			if (ref_len == 0) ref_len = 1;
-			start1 = r.pos + 1; const int end1 = (int)(r.pos + ref_len);
-			const int last = p.tid_reg_last[r.tid];
 			i0 = (int)(e >> 36);   // (the walk's region search: not repeated)
-			i1 = i0; while (i1 < last && p.reg_start[i1] <= end1) ++i1;
-			if (i1 > i0) atomicMin(&s_base, (unsigned long long)(p.reg_doff[i0] + (long long)(max(start1, p.reg_start[i0]) - p.reg_start[i0])));
+			const Hdr hd = load_hdr(p.infl + (int64_t)(e & BQ_OFF_MASK));
+			rs = p.reg_start[i0]; re = p.reg_end[i0]; doff = p.reg_doff[i0];
+			r = make_rec(p.infl, (int64_t)(e & BQ_OFF_MASK), hd);
+			load_cigar4(r, c4);
+			const uint8_t* q = rec_qual(r);
+			const uint32_t nq = min((uint32_t)r.l_seq, BQ_BITS);
+			// (behind the qualities lie the record's tags / the next record / the tile buffer's 64 spare bytes: bits at or behind l_seq are cleared below)
+			#pragma unroll
+			for (uint32_t c = 0; c < BQ_BITS / 64; ++c)
+				if (64u * c < nq)
+				{
+					uint32_t w[16]; __builtin_memcpy(w, q + 64u * c, 64);
+					unsigned long long mm = 0;
+					#pragma unroll
+					for (int k = 0; k < 16; ++k)
+					{
+						// bit 7 of a byte of y = (x | 0x80) - min_baseq is set iff the byte's low seven bits reach the threshold, bit 7 of x iff the byte is 128 or more
+						// (0xff: no quality): clear in both = below. The four flags (bits 7, 15, 23, 31) move to bits 21..24 of the product: no two terms meet in a bit
+						const uint32_t lt = (~(((w[k] | 0x80808080u) - thr) | w[k]) & 0x80808080u) >> 7;
+						mm |= (unsigned long long)(((lt * 0x00204081u) >> 21) & 15u) << (4 * k);
+					}
+					const uint32_t left = nq - 64u * c;
+					low[c] = left >= 64u ? mm : mm & ((1ull << left) - 1ull);
+				}
+			if (p.min_baseq > 127) { low[0] = low[1] = low[2] = low[3] = 0; }   // (a threshold the byte trick does not hold for: every base goes the byte way below)
+			long long ref_len = 0;
+			#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) if (k < r.n_cigar && ((0x18Du >> (c4[k] & 15u)) & 1u)) ref_len += c4[k] >> 4;
+			for (uint32_t k = 4; k < r.n_cigar; ++k) { const uint32_t c = ld32(r.cigar + 4ull * k); if ((0x18Du >> (c & 15u)) & 1u) ref_len += c >> 4; }
+			if (ref_len == 0) ref_len = 1;
+			start1 = r.pos + 1; end1 = (int)(r.pos + ref_len);
+			const int last = p.tid_reg_last[r.tid];
+			i1 = i0; if (i1 < last && rs <= end1) ++i1;
+			while (i1 > i0 && i1 < last && p.reg_start[i1] <= end1) ++i1;
+			if (i1 > i0) atomicMin(&s_base, (unsigned long long)(doff + (long long)(max(start1, rs) - rs)));
 		}
 		__syncthreads();
 		const long long base = (long long)s_base;
 		if (have && i1 > i0)
 		{
-			// BamAlignment::qualities (BamReader.cpp:210-255), as baseq_decrements: M bases below min_baseq; '=' / 'X' / 'H' / 'P' advance neither index
+			// BamAlignment::qualities (BamReader.cpp:210-255), as baseq_decrements: M bases below min_baseq; '=' / 'X' / 'H' / 'P' advance neither index.
+			// (regions of an unmerged BED may overlap: every region that holds the position, as the reference's per-line depth does - a pass per region)
 			const uint8_t* q = rec_qual(r);
-			uint32_t ai = 0; int gi = 0;
-			for (uint32_t k = 0; k < r.n_cigar; ++k)
+			const bool by_byte = p.min_baseq > 127;
+			for (int i = i0; i < i1; ++i)
 			{
-				const uint32_t c = ld32(r.cigar + 4ull * k), op = c & 15u, len = c >> 4;
-				if (op == 0)
+				if (i > i0) { rs = p.reg_start[i]; re = p.reg_end[i]; doff = p.reg_doff[i]; }
+				uint32_t ai = 0; int gi = 0;
+				for (uint32_t k = 0; k < r.n_cigar; ++k)
 				{
-					int ri = i0;   // (the positions of an M stretch ascend: so does the region that holds them)
-					const uint32_t n_m = ai < (uint32_t)r.l_seq ? min(len, (uint32_t)r.l_seq - ai) : 0u;   // (a CIGAR longer than SEQ: htslib would read past the qualities)
-					auto masked = [&](uint32_t j) {
-						const int pos1 = start1 + gi + (int)j;
-						while (ri < i1 && p.reg_end[ri] < pos1) ++ri;
-						// (regions of an unmerged BED may overlap: every region that holds the position, as the reference's per-line depth does)
-						for (int i = ri; i < i1 && p.reg_start[i] <= pos1; ++i)
-							if (pos1 <= p.reg_end[i])
-							{
-								const long long o = p.reg_doff[i] + (long long)(pos1 - p.reg_start[i]), rel = o - base;
+					const uint32_t c = k < 4 ? (k == 0 ? c4[0] : k == 1 ? c4[1] : k == 2 ? c4[2] : c4[3]) : ld32(r.cigar + 4ull * k), op = c & 15u, len = c >> 4;
+					if (op == 0)
+					{
+						const uint32_t n_m = ai < (uint32_t)r.l_seq ? min(len, (uint32_t)r.l_seq - ai) : 0u;   // (a CIGAR longer than SEQ: htslib would read past the qualities)
+						// base j of the stretch lies at reference position p0 + j; inside the region: j in [j_lo, j_hi)
+						const long long p0 = (long long)start1 + gi;
+						const long long j_lo = max(0ll, (long long)rs - p0), j_hi = min((long long)n_m, (long long)re - p0 + 1);
+						if (j_lo < j_hi)
+						{
+							const uint32_t a_lo = ai + (uint32_t)j_lo, a_hi = ai + (uint32_t)j_hi;        // read positions [a_lo, a_hi)
+							const long long slot0 = doff + (p0 - (long long)ai - rs);                       // slot of read position x: slot0 + x
+							auto masked = [&](uint32_t x) {
+								const long long o = slot0 + (long long)x, rel = o - base;
 								if (rel >= 0 && rel < BQ_TILE) atomicAdd(&dec[rel], 1);
 								else { atomicAdd(p.diff + o, -p.sgn); atomicAdd(p.diff + o + 1, p.sgn); }
-							}
-					};
-					if (p.min_baseq <= 127)
-					{
-						// sixteen qualities per load; the bytes below the threshold as the high bits of (x | y) with y = (x | 0x80) - min_baseq per byte: bit 7 of y is
-						// set iff the byte's low seven bits reach the threshold, bit 7 of x iff the byte is 128 or more (0xff: no quality) - clear in both: below
-						const uint32_t thr = 0x01010101u * (uint32_t)p.min_baseq;
-						for (uint32_t j0 = 0; j0 < n_m; j0 += 16u)
-						{
-							uint32_t w[4]; __builtin_memcpy(w, q + ai + j0, 16);   // (behind the qualities lie the record's tags / the next record / the buffer's slack: masked below)
-							#pragma unroll
-							for (int k = 0; k < 4; ++k)
+							};
+							const uint32_t b_hi = by_byte ? a_lo : min(a_hi, BQ_BITS);
+							for (uint32_t cw = a_lo >> 6; cw * 64u < b_hi; ++cw)
 							{
-								uint32_t lt = ~(((w[k] | 0x80808080u) - thr) | w[k]) & 0x80808080u;
-								const uint32_t left = n_m - j0 - 4u * (uint32_t)k;   // bases of the stretch from this dword on
-								if (j0 + 4u * (uint32_t)k >= n_m) lt = 0u; else if (left < 4u) lt &= (1u << (8u * left)) - 1u;
-								while (lt) { const uint32_t bit = (uint32_t)__builtin_ctz(lt); lt &= lt - 1u; masked(j0 + 4u * (uint32_t)k + (bit >> 3)); }
+								unsigned long long m = cw == 0 ? low[0] : cw == 1 ? low[1] : cw == 2 ? low[2] : low[3];
+								if (a_lo > 64u * cw) m &= ~0ull << (a_lo - 64u * cw);
+								if (b_hi < 64u * cw + 64u) m &= (1ull << (b_hi - 64u * cw)) - 1ull;
+								while (m) { const uint32_t bit = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; masked(64u * cw + bit); }
 							}
+							for (uint32_t x = max(a_lo, b_hi); x < a_hi; ++x) if (q[x] < p.min_baseq) masked(x);   // (reads longer than BQ_BITS)
 						}
+						ai += len; gi += (int)len;
 					}
-					else for (uint32_t j = 0; j < n_m; ++j) if (q[ai + j] < p.min_baseq) masked(j);
-					ai += len; gi += (int)len;
+					else if (op == 2 || op == 3) gi += (int)len;
+					else if (op == 1 || op == 4) ai += len;
 				}
-				else if (op == 2 || op == 3) gi += (int)len;
-				else if (op == 1 || op == 4) ai += len;
 			}
 		}
 		__syncthreads();
@@ -716,7 +779,8 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
                                                         const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
-	__shared__ uint32_t lds_hist[1000];
+	__shared__ uint32_t lds_hist[1002];   // (1000, 1001: the wave's block of the min_baseq list, bq_append)
+	if (threadIdx.x < 2) lds_hist[1000 + threadIdx.x] = 0;
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
 	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
@@ -781,6 +845,7 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 			if (stop && res == -2) atomicAdd(bad, 1u);
 		}
 	}
+	if (MODE == 3 && p.bq_list && p.sgn > 0) bq_close(p, lds_hist + 1000);
 	flush(p, a, lds_hist);
 }
 

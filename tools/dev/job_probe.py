@@ -37,6 +37,7 @@ VARIANTS = {
     "prio3_nopad": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PAD": "0"}, "prio0_nocrc": {"NGSQC_P1_PRIO": "0", "NGSQC_VERIFY_CRC": "0"}, "prio3_nocrc": {"NGSQC_P1_PRIO": "3", "NGSQC_VERIFY_CRC": "0"},
     "mul2": {"NGSQC_K1_CHUNK_MUL": "2", "NGSQC_TILE_CHUNKS": "1"}, "mul3": {"NGSQC_K1_CHUNK_MUL": "3", "NGSQC_TILE_CHUNKS": "1"}, "mul2_t2": {"NGSQC_K1_CHUNK_MUL": "2"},
     "serial": {"NGSQC_K1_SERIAL": "1", "NGSQC_PIPELINE": "0"},
+    "dmasafe": {"NGSQC_P1_DMA_SAFE": "1"}, "serial_dmasafe": {"NGSQC_K1_SERIAL": "1", "NGSQC_PIPELINE": "0", "NGSQC_P1_DMA_SAFE": "1"},
     "bufs2": {"NGSQC_TILE_BUFFERS": "2", "NGSQC_TOKEN_SLOTS": "3"}, "slots3": {"NGSQC_TOKEN_SLOTS": "3"}, "bufs4": {"NGSQC_TILE_BUFFERS": "4", "NGSQC_TOKEN_SLOTS": "5"},
     "tile1_b4": {"NGSQC_TILE_CHUNKS": "1", "NGSQC_TILE_BUFFERS": "4", "NGSQC_TOKEN_SLOTS": "4"}, "tile1_b3": {"NGSQC_TILE_CHUNKS": "1"}, "tile3": {"NGSQC_TILE_CHUNKS": "3", "NGSQC_TOKEN_SLOTS": "5"},
     "prio3_park32": {"NGSQC_P1_PRIO": "3", "NGSQC_P1_PARK": "32"}, "prio2": {"NGSQC_P1_PRIO": "2"},
