@@ -38,10 +38,10 @@ namespace ngsqc { namespace k1 {
 // LDS words of a lane (element-major)
 constexpr int P1_W_RING = 0;      // compressed input window: word k of the member's piece stream sits in slot k & 7; slots 8, 9 mirror 0, 1, so
                                   // that the three words under a bit cursor are always slots s, s + 1, s + 2
-constexpr int P1_W_LINFO = 10;    // per code length l (1..15) of the literal/length code: literals n | first literal index << 9 | (first non-literal index - n + 256) << 18;
+constexpr int P1_W_LINFO = 10;    // per code length l (1..15) of the literal/length code, fields on byte boundaries (the ISA reads them as sub-dword operands): literals n (bits 0..15) | first literal index << 16 | ((first non-literal index - n) & 255) << 24;
                                   // word 0: the same for the all-ones code (see LimTab); during the header passes: counts, then placement cursors
-constexpr int P1_W_NONLIT = 26;   // the symbols 256.. of the block in code order, one byte each: (symbol - 256) * 4
-constexpr int P1_W_DSYM = 34;     // the distance symbols in code order, one byte each: symbol * 4
+constexpr int P1_W_NONLIT = 26;   // the symbols 256.. of the block in code order, one byte each: (symbol - 256) * 4 - LANE-major, 32 bytes per lane (round 6: the address is one v_and_or; the element-major form cost four VALU per lookup, and the decoder is what the chip's VALU issue pays for)
+constexpr int P1_W_DSYM = 34;     // the distance symbols in code order, one byte each: symbol * 4 (same layout)
 constexpr int P1_LANE_W = 42;
 constexpr int P1_RING_SLOTS = 8;
 constexpr int P1_TRIPS = 4;             // trips between two service blocks = the four words of a token group (one word per trip)
@@ -59,27 +59,27 @@ struct P1Lds
 	K1_DEV uint8_t* bytes() const { return (uint8_t*)base; }
 	K1_DEV uint32_t lane4() const { return (uint32_t)lane * 4u; }
 	K1_DEV uint32_t& at(int k) const { return base[k * 64 + lane]; }
-	K1_DEV const uint32_t* ring(uint32_t abit) const { return (const uint32_t*)(bytes() + (((abit << 3) & 0x700u) | lane4())); }   // slot (abit >> 5) & 7
+	K1_DEV const uint32_t* ring(uint32_t abit) const { return (const uint32_t*)(bytes() + wv::and_or(abit << 3, 0x700u, lane4())); }   // slot (abit >> 5) & 7
 	K1_DEV void stage(uint32_t wr, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const   // a piece = four words, wr a multiple of 4
 	{
 		uint32_t* p = &at((int)(wr & 4u)); p[0] = a; p[64] = b; p[128] = c; p[192] = d;
 		if ((wr & 4u) == 0) { at(8) = a; at(9) = b; }
 	}
 	K1_DEV uint32_t& linfo(uint32_t l) const { return at(P1_W_LINFO + (int)(l & 15u)); }
-	K1_DEV uint32_t linfo_of(uint32_t w) const { return *(const uint32_t*)(bytes() + P1_W_LINFO * 256 + ((w & 0xf00u) | lane4())); }   // word index = bits 8..11 of a limit word
-	K1_DEV uint8_t& sym_byte(int w0, uint32_t i) const { return bytes()[w0 * 256 + (((i << 6) & 0x700u) | (i & 3u) | lane4())]; }   // byte i & 31 of an 8-word table
+	K1_DEV uint32_t linfo_of(uint32_t w) const { return *(const uint32_t*)(bytes() + P1_W_LINFO * 256 + wv::and_or(w, 0xf00u, lane4())); }   // word index = bits 8..11 of a limit word
+	K1_DEV uint8_t& sym_byte(int w0, uint32_t i) const { return bytes()[w0 * 256 + wv::and_or(i, 31u, (uint32_t)lane << 5)]; }   // byte i & 31 of the lane's 32-byte table
 };
 
 // Canonical decode out of registers. With v = the next 15 stream bits MSB-first and, for k = 1..15,
 //   limit_k = (first_code_k + count_k) << (15 - k)   (the left-aligned upper bound of the codes of length <= k; non-decreasing in k)
 // the code length is n + 1 with n = #{k : v >= limit_k}, and the code is the ((v - limit_n) >> (15 - (n + 1)))-th of its length
 // (limit_0 = 0). Word W_k (k = 1..15, w[k - 1]) describes what follows when v >= limit_k is the last true comparison:
-//   bits 17..31 limit_k | 12..15 code length n + 1 | 8..11 (L) index of the LINFO word | 6..10 (D) index of the length's first symbol | 5 invalid | 0..4 32 - length
+//   bits 17..31 limit_k | 12..15 code length n + 1 | 8..11 (L) index of the LINFO word | 6..10 (D) index of the length's first symbol | 0..4 32 - length
 // The comparison is a plain 32-bit one of vx = v << 17 | 0x1ffff against W_k; t = (vx - W_n) >> (W_n & 31).
 // limit_k = 0x8000 (every code is at most k long) does not fit 15 bits: it is stored as 0x7fff, which is wrong for v = 0x7fff only - the
 // all-ones code, the last code of the longest length lmax - so the words k >= lmax describe exactly that code (LINFO word 0 / last symbol).
-// An incomplete code (zlib accepts a single code of length 1, and an empty distance code) marks the words k >= lmax invalid instead.
-constexpr uint32_t W_INV = 0x20u;
+// An incomplete code (zlib accepts a single code of length 1, and an empty distance code): the words k >= lmax decode - as a code of length 1 - to entries 30 / 31
+// of the symbol bytes, which the header pass points at invalid entries of the base / extra-bits table.
 constexpr uint32_t W0_L = (1u << 12) | (1u << 8) | 31u, W0_D = (1u << 12) | 31u;   // W_0: limit 0, length 1, first symbol 0
 struct LimTab
 {
@@ -109,7 +109,9 @@ struct LimTab
 		uint32_t lim = ((code + c) << (15 - k)) & 0xffffu; if (lim > 0x7fffu) lim = 0x7fffu;
 		if ((uint32_t)k < lmax) return (lim << 17) | ((uint32_t)(k + 1) << 12) | (dist ? off << 6 : (uint32_t)(k + 1) << 8) | (uint32_t)(32 - (k + 1));
 		if (!incomplete) return (0x7fffu << 17) | (lmax << 12) | (dist ? (total - 1) << 6 : 0u) | (32u - lmax);
-		return (lim << 17) | W_INV | 31u;
+		// an incomplete code (one code of length 1, or no code): what lies behind it decodes - as a code of length 1, index 0 or 1 - to entries 30 / 31 of the symbol
+		// bytes, which the header pass points at the invalid entries of the base / extra-bits table (the symbol loop has no test of its own for this)
+		return (lim << 17) | (1u << 12) | (dist ? 30u << 6 : 0u) | 31u;
 	}
 };
 // what zlib's inftrees.c checks of a set of code lengths: over-subscribed = error; incomplete = error unless it is a single code of length 1 (or no code at all)
@@ -138,7 +140,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		const uint32_t i = (uint32_t)lane;
 		if (i < 32)
 		{
-			uint32_t v = TAB_BAD;
+			uint32_t v = TAB_BAD | TAB_EOB;   // (286 / 287 and the entries an incomplete code decodes to: they leave the symbol loop the way the end of a block does)
 			if (i == 0) v = TAB_EOB;
 			else if (i < 30)
 			{
@@ -179,7 +181,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	for (int i = 0; i < P1_TRIPS; ++i) sl[i] = K1_TOK_NOOP;
 	LimTab limL, limD;
 	#pragma unroll
-	for (int i = 0; i < 15; ++i) { limL.w[i] = W_INV | 31u; limD.w[i] = W_INV | 31u; }
+	for (int i = 0; i < 15; ++i) { limL.w[i] = 31u; limD.w[i] = 31u; }
 
 	auto exhausted = [&]() -> bool { return next_q >= n_q && !pf_valid; };   // every piece of the member is in the window (what lies behind it is never consumed by a valid stream)
 	auto ready = [&](uint32_t bits) -> bool { return (int)(wr * 32u - abit) >= (int)bits || exhausted(); };
@@ -229,8 +231,11 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	auto input_service = [&]() { input_commit(); input_request(); };
 
 	// One trip of the symbol loop: up to two literal/length symbols and one distance. At most 15 + (15 + 5) + (15 + 13) = 63 bits.
-	auto trip = [&](uint32_t& slot) {
-		const bool act = (state == S_SYM) & (((int)(wr - (abit >> 5)) >= 3) | ((next_q >= n_q) & !pf_valid));   // (the three window words are staged, or the member has no more input)
+	// alim: the lane decodes while its cursor is in front of this bit (set by the service block: the window words in front of it are staged, or the member has no
+	// more input; 0: the lane does not decode). Round 6, an instruction diet (the decoder's VALU count is what the pipelined K1 pays for): no test for invalid codes
+	// (an incomplete code decodes to table entries that end the loop / fail the distance check), LINFO fields and symbol bytes on byte boundaries.
+	auto trip = [&](uint32_t& slot, uint32_t& alim) {
+		const bool act = abit < alim;
 		const uint32_t* p = L.ring(abit);
 		const uint32_t p0 = p[0], p1 = p[64], p2 = p[128];
 		const uint32_t w0 = wv::alignbit(p1, p0, abit), w1 = wv::alignbit(p2, p1, abit);   // 64 stream bits from the cursor on
@@ -241,10 +246,10 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		limL.decode(W0_L, wv::alignbit(w1, w0, len1), sb, tb);   // the second symbol as if the first were a literal
 		const uint32_t len2 = wv::bfe(sb, 12, 4);
 		const uint32_t li2 = L.linfo_of(sb);
-		const bool lit1 = ta < (li1 & 511u), lit2 = tb < (li2 & 511u);
-		const uint32_t tok1 = ta + wv::bfe(li1, 9, 9), tok2 = tb + wv::bfe(li2, 9, 9);   // literal: index in the block's literal table
+		const bool lit1 = ta < (li1 & 0xffffu), lit2 = tb < (li2 & 0xffffu);
+		const uint32_t tok1 = ta + ((li1 >> 16) & 255u), tok2 = tb + ((li2 >> 16) & 255u);   // literal: index in the block's literal table
 		// the symbol >= 256 of the trip (if any): the first symbol, else the second
-		const uint32_t e = lit1 ? tb + (li2 >> 18) : ta + (li1 >> 18);   // 256 + index in code order
+		const uint32_t e = lit1 ? tb + (li2 >> 24) : ta + (li1 >> 24);   // index in code order (mod 32: sym_byte masks it)
 		const uint32_t ub = lit1 ? len1 + len2 : len1;                   // bits up to and including its code (<= 30); both literals: the bits of the trip
 		const bool nonlit = !(lit1 && lit2);
 		const uint32_t lt = *(const uint32_t*)((const uint8_t*)tab + L.sym_byte(P1_W_NONLIT, e));
@@ -257,15 +262,14 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		const uint32_t dl = wv::bfe(sd, 12, 4);
 		const uint32_t dt = *(const uint32_t*)((const uint8_t*)tab + 128 + L.sym_byte(P1_W_DSYM, td + wv::bfe(sd, 6, 5)));
 		const uint32_t deb = wv::bfe(dt, 16, 4);
-		const uint32_t mdist = (dt & 0x7fffu) + wv::bfe(wd, dl, deb);
-		const bool eob = nonlit && (int32_t)lt < 0, match = nonlit && (int32_t)lt >= 0;
+		const uint32_t mdist = (dt & (TAB_BAD | 0x7fffu)) + wv::bfe(wd, dl, deb);   // (an invalid distance symbol: farther back than any output)
+		const bool stop = nonlit && (int32_t)lt < 0, match = nonlit && (int32_t)lt >= 0;   // stop: the end of the block, or an invalid length symbol
 		const uint32_t used = match ? u2 + dl + deb : ub;
 		const uint32_t nlit = lit1 ? (lit2 ? 2u : 1u) : 0u;             // literals in front of the match / the end of the block
 		const uint32_t add = match ? nlit + mlen : nlit;
 		const uint32_t tokm = (mlen << 15) + mdist - ((3u << 15) + 1u);                 // = (mlen - 3) << 15 | (mdist - 1)
-		const uint32_t inv = (sa | (lit1 ? sb : 0u) | (match ? sd | (lt >> 25) | (dt >> 25) : 0u)) & W_INV;   // (TAB_BAD >> 25 == W_INV)
-		const bool bad = inv != 0 || (match && mdist > out_n + nlit) || out_n + add > usize;
-		if ((state == S_SYM) & !act) K1_STAT(3);
+		const bool bad = (match && mdist > out_n + nlit) || out_n + add > usize;
+		if ((alim != 0) & !act) K1_STAT(3);
 		const bool ok = act && !bad;
 		// the trip's word: two literals | a literal, then a match | a literal (in front of the end of the block) | a match | nothing
 		const uint32_t w_lit = lit2 ? (K1_TOK_LIT2 | tok1 | (tok2 << 8)) : (match ? (K1_TOK_LITMATCH | (tok1 << 23) | tokm) : tok1);
@@ -273,11 +277,12 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		slot = ok ? (lit1 ? w_lit : w_non) : K1_TOK_NOOP;
 		if (ok) K1_STAT(1);
 		abit += ok ? used : 0u; out_n += ok ? add : 0u;
-		state = ok && eob ? (bfinal ? (uint32_t)S_FINISH : (uint32_t)S_HDR) : state;
-		if (act && bad)
+		if (act && (bad || stop))
 		{
-			err = (sa & W_INV) || (lit1 && (sb & W_INV)) ? 9u : !match ? 3u : (lt & TAB_BAD) ? 10u : (sd & W_INV) ? 11u : (dt & TAB_BAD) ? 12u : mdist > out_n + nlit ? 13u : 3u;
-			state = S_FINISH;
+			alim = 0;
+			if (bad) { err = !match ? 3u : (dt & TAB_BAD) ? 12u : mdist > out_n + nlit ? 13u : 3u; state = S_FINISH; }
+			else if (lt & TAB_BAD) { err = 10u; state = S_FINISH; }   // 286 / 287, or a code that does not exist in an incomplete set
+			else state = bfinal ? (uint32_t)S_FINISH : (uint32_t)S_HDR;
 		}
 	};
 
@@ -494,16 +499,21 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 								else
 								{
 									// cursors (now the END of every length) -> what the symbol loop reads: literals of the length, first literal index, first index of the symbols 256..
-									uint32_t pa = 0, pb = 0; bool last_non = false;
+									uint32_t pa = 0, pb = 0, pc = 0; bool last_non = false; int leftL = 1, leftD = 1;
 									#pragma nounroll
 									for (uint32_t l = 1; l <= 15; ++l)
 									{
-										const uint32_t v = L.linfo(l), ea = v & 511u, eb2 = (v >> 9) & 511u, nl = ea - pa, nn = eb2 - pb;
-										L.linfo(l) = nl | (pa << 9) | ((pb + 256u - nl) << 18);
+										const uint32_t v = L.linfo(l), ea = v & 511u, eb2 = (v >> 9) & 511u, ec = v >> 18, nl = ea - pa, nn = eb2 - pb;
+										L.linfo(l) = nl | ((pa & 255u) << 16) | (((pb - nl) & 255u) << 24);
 										if (nl + nn) last_non = nn != 0;
-										pa = ea; pb = eb2;
+										leftL = (leftL << 1) - (int)(nl + nn); leftD = (leftD << 1) - (int)(ec - pc);
+										pa = ea; pb = eb2; pc = ec;
 									}
-									L.linfo(0) = last_non ? ((pb - 1u + 256u) << 18) : (1u | ((pa - 1u) << 9));   // the all-ones code: the last symbol of the longest length
+									L.linfo(0) = last_non ? (((pb - 1u) & 255u) << 24) : (1u | (((pa - 1u) & 255u) << 16));   // the all-ones code: the last symbol of the longest length
+									// an incomplete set (the check above let it pass: a single code of length 1 / no distance code): the decode words of the bits behind its codes
+									// lead to entries 30 and 31 of the symbol bytes (free: at most one symbol is in use) - the invalid entries of the base / extra-bits tables
+									if (leftL > 0) { L.linfo(0) = 30u << 24; L.sym_byte(P1_W_NONLIT, 30u) = 30u * 4u; L.sym_byte(P1_W_NONLIT, 31u) = 31u * 4u; }
+									if (leftD > 0) { L.sym_byte(P1_W_DSYM, 30u) = 30u * 4u; L.sym_byte(P1_W_DSYM, 31u) = 31u * 4u; }
 									state = S_SYM;
 								}
 							}
@@ -548,8 +558,9 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		}
 		if (lane == 0) K1_STAT(0);
 		K1_WSTAT(0);
+		uint32_t alim = state == S_SYM ? (exhausted() ? 0xffffffffu : (wr - 2u) * 32u) : 0u;   // (wr >= 8 once a member is open)
 		#pragma unroll
-		for (int i = 0; i < P1_TRIPS; ++i) trip(sl[i]);
+		for (int i = 0; i < P1_TRIPS; ++i) trip(sl[i], alim);
 	}
 }
 

@@ -94,6 +94,9 @@ K1_DEV uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }     // 
 K1_DEV uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }     // x != 0
 K1_DEV uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }   // x != 0
 K1_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }   // v_perm_b32: result byte k = byte sel.byte[k] of {hi, lo} (0..3: lo, 4..7: hi)
+// (x & m) | y in ONE instruction, m a constant kept in a scalar register (v_and_or_b32: a VOP3 takes no literal, and the compiler turns an OR of disjoint bits into
+// an ADD it cannot fuse with the AND - the decoder's LDS addresses are made of exactly that)
+K1_DEV uint32_t and_or(uint32_t x, uint32_t m, uint32_t y) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(y)); return r; }
 K1_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }               // v_bfi_b32
 
 } } // namespace ngsqc::wv

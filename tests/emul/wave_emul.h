@@ -173,6 +173,7 @@ inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 	for (int k = 0; k < 4; ++k) { const uint32_t s = (sel >> (8 * k)) & 255u; r |= (s < 8 ? (uint32_t)(v >> (8 * s)) & 255u : (s >= 13 ? 255u : 0u)) << (8 * k); }
 	return r;
 }
+inline uint32_t and_or(uint32_t x, uint32_t m, uint32_t y) { return (x & m) | y; }
 inline uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
 
 } } // namespace ngsqc::wv
