@@ -220,7 +220,7 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
     overrides, the whole file is 8 000 000) - scaled down when the host cannot hold it. Reference: Statistics.cpp:1068-1182 over BamReader::cigarData (long CIGAR / CG tag)."""
     reads = int(os.environ.get("NGSQC_BENCH_ONT_READS", "2000000"))
     avail = host_memory_available()
-    if avail:   # ~11 KB of compressed image per read, twice that while the generator's pieces are joined
+    if avail and reads > 100_000:   # ~11 KB of compressed image per read, twice that while the generator's pieces are joined
         reads = max(100_000, min(reads, int(0.4 * avail / 11_000) // 100_000 * 100_000))
     gen_kw = dict(seed=args.seed, mode=1, depth=40.0, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=0)
     t0 = time.time(); image = G.generate(reads, threads=2 * G.effective_cpus(), **gen_kw); gen_s = time.time() - t0
@@ -248,7 +248,7 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
         del image
         # long reads span BGZF members, so the file cannot be cut into per-thread member ranges for an all-cores parity pass: parity of the generator's data is
         # checked on a 200 000-read BAM of the same generator (all counters of the GPU job vs the sequential oracle, bit-exact)
-        n_par = int(os.environ.get("NGSQC_BENCH_ONT_PARITY_READS", "200000"))
+        n_par = min(reads, int(os.environ.get("NGSQC_BENCH_ONT_PARITY_READS", "200000")))
         small = G.generate(n_par, **dict(gen_kw, threads=2 * G.effective_cpus()))
         hs = ngsqc.Handle(data=small, device=device)
         got = hs.run_job(mapping=mp)["counters"]; n_tiles_small = int(hs.timings()["n_tiles"]); hs.close()
@@ -258,10 +258,12 @@ def ont_leg(ngsqc, G, H, O, args, device, steps):
     return out
 
 
-def flavor_leg(ngsqc, G, H, O, args, device, steps, flavor=5, reads=96_000_000):
+def flavor_leg(ngsqc, G, H, O, args, device, steps, flavor=5, reads=None):
     """K1's cost is the token mix: the headline is measured on SURVEY.md 8(d)'s shape (random SEQ, 4-level QUAL: ratio 3.45, matches of 11 bytes on average), the easiest
     one for phase 2. This leg runs the same fused MappingQC -wgs job on a 96 M-read shard of generator flavor 5 (SEQ from a synthetic reference genome - overlapping reads
     share sequence, as real data does - and 40-level qualities: ratio 2.5, literal-heavy). No reference line; SURVEY 8(d) config 2 is the spec of the shape."""
+    if reads is None:
+        reads = int(os.environ.get("NGSQC_BENCH_FLAVOR_READS", "96000000"))
     gen_kw = dict(seed=args.seed, mode=0, depth=30.0, first_contig=0, start_pos=0, level=args.level, aligned=True, flavor=flavor)
     t0 = time.time(); image = G.generate(reads, threads=2 * G.effective_cpus(), **gen_kw); gen_s = time.time() - t0
     h = ngsqc.Handle(data=image, device=device)

@@ -265,22 +265,23 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		const uint32_t mdist = (dt & (TAB_BAD | 0x7fffu)) + wv::bfe(wd, dl, deb);   // (an invalid distance symbol: farther back than any output)
 		const bool stop = nonlit && (int32_t)lt < 0, match = nonlit && (int32_t)lt >= 0;   // stop: the end of the block, or an invalid length symbol
 		const uint32_t used = match ? u2 + dl + deb : ub;
-		const uint32_t nlit = lit1 ? (lit2 ? 2u : 1u) : 0u;             // literals in front of the match / the end of the block
-		const uint32_t add = match ? nlit + mlen : nlit;
 		const uint32_t tokm = (mlen << 15) + mdist - ((3u << 15) + 1u);                 // = (mlen - 3) << 15 | (mdist - 1)
-		const bool bad = (match && mdist > out_n + nlit) || out_n + add > usize;
+		// the output position behind the trip's literals, then behind its match (a lane that does not decode adds nothing). A trip that turns out bad
+		// still writes its word and moves the cursors: the member ends with an error and phase 2 never looks at its tokens
+		const uint32_t o1 = out_n + ((act && lit1) ? 1u : 0u) + ((act && lit1 && lit2) ? 1u : 0u);
+		const uint32_t o2 = o1 + ((act && match) ? mlen : 0u);
+		const bool bad = (match && mdist > o1) || o2 > usize;
 		if ((alim != 0) & !act) K1_STAT(3);
-		const bool ok = act && !bad;
 		// the trip's word: two literals | a literal, then a match | a literal (in front of the end of the block) | a match | nothing
 		const uint32_t w_lit = lit2 ? (K1_TOK_LIT2 | tok1 | (tok2 << 8)) : (match ? (K1_TOK_LITMATCH | (tok1 << 23) | tokm) : tok1);
 		const uint32_t w_non = match ? (K1_TOK_MATCH | tokm) : K1_TOK_NOOP;
-		slot = ok ? (lit1 ? w_lit : w_non) : K1_TOK_NOOP;
-		if (ok) K1_STAT(1);
-		abit += ok ? used : 0u; out_n += ok ? add : 0u;
+		slot = act ? (lit1 ? w_lit : w_non) : K1_TOK_NOOP;
+		if (act) K1_STAT(1);
+		abit += act ? used : 0u; out_n = o2;
 		if (act && (bad || stop))
 		{
 			alim = 0;
-			if (bad) { err = !match ? 3u : (dt & TAB_BAD) ? 12u : mdist > out_n + nlit ? 13u : 3u; state = S_FINISH; }
+			if (bad) { err = !match ? 3u : (dt & TAB_BAD) ? 12u : mdist > o1 ? 13u : 3u; state = S_FINISH; }
 			else if (lt & TAB_BAD) { err = 10u; state = S_FINISH; }   // 286 / 287, or a code that does not exist in an incomplete set
 			else state = bfinal ? (uint32_t)S_FINISH : (uint32_t)S_HDR;
 		}

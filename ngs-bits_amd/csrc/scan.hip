@@ -175,6 +175,36 @@ __device__ static void baseq_decrements(const ScanParams& p, const RecView& r, i
 	}
 }
 
+// A list that the walk's lanes append to (the site pileup's candidates, the records deferred to the wave-per-record kernel): the entries of a WAVE are collected in
+// LDS and leave in batches - one global atomic per batch for the exact count (no holes), and no lane waits for an atomic of its own (round 5: every appending lane
+// waited for its atomic on one address; a long-read file appends every record). buf: 64 entries + the fill count, of the one-wave workgroup.
+struct WaveList { unsigned long long e[64]; uint32_t n; uint32_t pad; };
+typedef volatile __attribute__((address_space(3))) WaveList* WaveListP;   // (an LDS pointer as such: no generic pointer, no aperture test)
+#define WAVE_LIST_P(x) ((WaveListP)(&(x)))
+__device__ __forceinline__ void wave_list_flush(WaveListP b, int64_t* list, unsigned long long* count, int64_t cap, uint32_t rank, uint32_t n_act)
+{
+	// (called by the n_act active lanes, ranks 0 .. n_act - 1)
+	const uint32_t cur = b->n;
+	unsigned long long base = 0;
+	if (rank == 0) base = atomicAdd(count, (unsigned long long)cur);
+	base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+	for (uint32_t i = rank; i < cur; i += n_act) if ((long long)(base + i) < cap) list[base + i] = (int64_t)b->e[i];
+}
+__device__ __forceinline__ void wave_list_append(WaveListP b, int64_t* list, unsigned long long* count, int64_t cap, unsigned long long value)
+{
+	const unsigned long long m = __builtin_amdgcn_ballot_w64(true);   // the lanes that append now
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), n = (uint32_t)__popcll(m);
+	uint32_t cur = b->n;
+	if (cur + n > 64u) { wave_list_flush(b, list, count, cap, rank, n); cur = 0; }
+	b->e[cur + rank] = value;
+	if (rank == 0) b->n = cur + n;
+}
+// the end of the wave's walk (all lanes)
+__device__ __forceinline__ void wave_list_close(WaveListP b, int64_t* list, unsigned long long* count, int64_t cap)
+{
+	if (b->n) wave_list_flush(b, list, count, cap, threadIdx.x & 63u, 64u);
+}
+
 // The list of the records whose qualities baseq_tile_kernel masks behind the walk (MODE_DEPTH with min_baseq). Round 6: a WAVE takes the list's slots in blocks of
 // BQ_BLOCK from the global counter and its lanes fill the block by rank (ballot of the lanes that append in this trip of the walk) - round 5 had every lane wait for
 // its own atomic on ONE address, a round trip in nearly every trip of the wave's loop (some lane of the 64 met a region): the walk of -min_baseq took twice the time
@@ -184,7 +214,7 @@ constexpr uint32_t BQ_BLOCK = 64;
 constexpr unsigned long long BQ_OFF_MASK = (1ull << 36) - 1ull, BQ_HOLE = ~0ull;
 __device__ __forceinline__ void bq_append(const ScanParams& p, uint32_t* state_, unsigned long long entry)
 {
-	volatile uint32_t* state = state_;   // (written by whichever lane has rank 0: never kept in a register)
+	volatile __attribute__((address_space(3))) uint32_t* state = (volatile __attribute__((address_space(3))) uint32_t*)state_;   // (an LDS pointer; written by whichever lane has rank 0: never kept in a register)
 	const unsigned long long m = __builtin_amdgcn_ballot_w64(true);   // the lanes that append now
 	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), n = (uint32_t)__popcll(m);
 	uint32_t cur = 0;
@@ -206,7 +236,7 @@ __device__ __forceinline__ void bq_append(const ScanParams& p, uint32_t* state_,
 // the end of the wave's walk: the rest of its last block
 __device__ __forceinline__ void bq_close(const ScanParams& p, const uint32_t* state_)
 {
-	const volatile uint32_t* state = state_;
+	const volatile __attribute__((address_space(3))) uint32_t* state = (const volatile __attribute__((address_space(3))) uint32_t*)state_;
 	const long long k = (long long)state[0] + (threadIdx.x & 63u);
 	if (k < (long long)state[1] && k < p.bq_cap) p.bq_list[k] = (int64_t)BQ_HOLE;
 }
@@ -459,7 +489,7 @@ __device__ __forceinline__ bool scan_record(const ScanParams& p, RecView& r, lon
 // The site pileup of a job riding the same walk (round 4): a record that passes the pileup's read filters (BamReader.cpp:830-836) and whose reference span holds
 // at least one known site (or whose span is not known here: a deferred long-CIGAR record) leaves its tile-local offset in a list - 0.15 % of the records of a 30x
 // WGS for the 29 k contamination sites - and pileup_kernel runs over that list instead of reading every record of the tile a second time.
-__device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecView& r, int64_t o, bool span_known, long long ref_len, Acc& a)
+__device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecView& r, int64_t o, bool span_known, long long ref_len, Acc& a, WaveListP wl)
 {
 	const uint32_t flag = r.flag;
 	if (flag & (0x100u | 0x800u | 0x400u | 0x4u)) return;
@@ -483,8 +513,7 @@ __device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecVie
 		}
 	}
 	if (a.pc_next == INT32_MAX || a.pc_next > end1) return;
-	const unsigned long long k = atomicAdd(p.pile.count, 1ull);
-	if ((long long)k < p.pile.cap) p.pile.list[k] = o;
+	wave_list_append(wl, p.pile.list, p.pile.count, p.pile.cap, (unsigned long long)o);
 }
 
 template <int MODE>
@@ -519,46 +548,85 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 	const int lane = threadIdx.x & 63;
 	const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-	for (long long w = wave; w < n_long; w += n_waves)
+	// Round 6: a record of this kernel used to cost its wave a dozen DEPENDENT round trips (list entry -> entry base -> record offset -> header -> first
+	// operation -> seven steps of the CIGAR, each waited for on its own), 64 us per record with nothing in between. Now a wave takes a CONTIGUOUS stretch of the
+	// list, its lanes resolve the offsets of up to 64 records at once (one chain of round trips per 64 records), the next record's header is requested while
+	// this one is processed, and the CIGAR's 16-byte loads are issued four steps (1 024 operations) at a time.
+	const long long per_wave = (n_long + n_waves - 1) / n_waves, w_end = min(n_long, (wave + 1) * per_wave);
+	for (long long wb = wave * per_wave; wb < w_end; wb += 64)
 	{
-		long long li = p.long_list[w]; long long ord;
-		if (p.entry_base) { ord = li; li = p.entry_base[li >> NAME_SHIFT] + (li & ((1ll << NAME_SHIFT) - 1)); }   // a tile scanned by the chain walk: records are compared by their (entry, k) names
-		else ord = p.ord_base + li;
-		RecView r = load_rec(p.infl, p.recoff[li]);
-		// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries
-		if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
+		const int nb = (int)min(64ll, w_end - wb);
+		long long my_off = 0, my_ord = 0;
+		if (lane < nb)
 		{
-			uint32_t c0 = ld32(r.cigar);
-			if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq)
-			{
-				unsigned long long cg = 0; uint32_t n = 0;
-				if (lane == 0)
-				{
-					const uint8_t* t = aux_find(rec_aux(r), rec_end(r), 'C', 'G');
-					if (t && t[0] == 'B' && t[1] == 'I') { n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) cg = (unsigned long long)(uintptr_t)(t + 6); }
-				}
-				cg = __shfl(cg, 0); n = __shfl(n, 0);
-				if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; }
-			}
+			long long li = p.long_list[wb + lane];
+			if (p.entry_base) { my_ord = li; li = p.entry_base[li >> NAME_SHIFT] + (li & ((1ll << NAME_SHIFT) - 1)); }   // a tile scanned by the chain walk: records are compared by their (entry, k) names
+			else my_ord = p.ord_base + li;
+			my_off = p.recoff[li];
 		}
-		// the CIGAR, four operations per lane and step (16-byte loads: a read of 20 kb has ~1 700 operations = seven steps of the wave; round 4 took one per lane)
-		long long ref_len = 0, clip = 0; int spl = 0;
-		for (uint32_t k0 = 4u * lane; k0 < r.n_cigar; k0 += 256u)
+		auto lane_ll = [&](long long v, int j) -> long long {
+			return (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j));
+		};
+		Hdr h_nx = load_hdr(p.infl + lane_ll(my_off, 0));
+	for (int jr = 0; jr < nb; ++jr)
+	{
+		const long long off = lane_ll(my_off, jr), ord = lane_ll(my_ord, jr);
+		const Hdr h_cur = h_nx;
+		if (jr + 1 < nb) h_nx = load_hdr(p.infl + lane_ll(my_off, jr + 1));
+		RecView r = make_rec(p.infl, off, h_cur);
+		// the CIGAR, four operations per lane and step, four steps per request group (a read of 20 kb has ~1 700 operations: two groups). What lies behind the last
+		// operation (the record's bases; the next record or the tile's spare bytes behind a CG:B,I array) is loaded and not looked at.
+		long long ref_len = 0, clip = 0; int spl = 0; uint32_t c_first = 0; bool cg_checked = false;
+		for (int pass = 0; pass < 2; ++pass)
 		{
-			uint32_t c4[4] = {0u, 0u, 0u, 0u};
-			if (k0 + 4u <= r.n_cigar) __builtin_memcpy(c4, r.cigar + 4ull * k0, 16);
-			else for (uint32_t j = 0; k0 + j < r.n_cigar; ++j) c4[j] = ld32(r.cigar + 4ull * (k0 + j));
-			#pragma unroll
-			for (uint32_t j = 0; j < 4u; ++j)
+			ref_len = 0; clip = 0; spl = 0;
+			for (uint32_t g0 = 0; g0 < r.n_cigar; g0 += 1024u)
 			{
-				if (k0 + j < r.n_cigar)
+				const uint32_t k0 = g0 + 4u * (uint32_t)lane;
+				uint32_t c4[4][4];
+				#pragma unroll
+				for (uint32_t u = 0; u < 4u; ++u)
 				{
-					const uint32_t c = c4[j], op = c & 15u, len = c >> 4;
-					if ((0x18Du >> op) & 1u) ref_len += len;
-					else if (op == 4 || op == 5) clip += len;
-					if (op == 3) spl = 1;
+					const uint32_t kk = k0 + 256u * u;
+					if (kk < r.n_cigar) __builtin_memcpy(c4[u], r.cigar + 4ull * kk, 16); else { c4[u][0] = c4[u][1] = c4[u][2] = c4[u][3] = 0u; }
+				}
+				if (k0 == 0) c_first = c4[0][0];
+				#pragma unroll
+				for (uint32_t u = 0; u < 4u; ++u)
+				{
+					#pragma unroll
+					for (uint32_t j = 0; j < 4u; ++j)
+					{
+						if (k0 + 256u * u + j < r.n_cigar)
+						{
+							const uint32_t c = c4[u][j], op = c & 15u, len = c >> 4;
+							if ((0x18Du >> op) & 1u) ref_len += len;
+							else if (op == 4 || op == 5) clip += len;
+							if (op == 3) spl = 1;
+						}
+					}
 				}
 			}
+			if (cg_checked) break;
+			cg_checked = true;
+			// CG:B,I substitution (htslib bam_tag2cigar): first op kS with k == l_seq, tag present with >= n_cigar entries - then the sums are taken again over the tag's array
+			bool redo = false;
+			if (r.n_cigar_raw > 0 && r.tid >= 0 && r.pos >= 0)
+			{
+				const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c_first, 0);
+				if ((c0 & 15u) == 4 && (int32_t)(c0 >> 4) == r.l_seq)
+				{
+					unsigned long long cg = 0; uint32_t n = 0;
+					if (lane == 0)
+					{
+						const uint8_t* t = aux_find(rec_aux(r), rec_end(r), 'C', 'G');
+						if (t && t[0] == 'B' && t[1] == 'I') { n = ld32(t + 2); if (n >= r.n_cigar_raw && n < (1u << 29)) cg = (unsigned long long)(uintptr_t)(t + 6); }
+					}
+					cg = __shfl(cg, 0); n = __shfl(n, 0);
+					if (cg) { r.cigar = (const uint8_t*)(uintptr_t)cg; r.n_cigar = n; redo = true; }
+				}
+			}
+			if (!redo) break;
 		}
 		ref_len = wave_sum(ref_len); clip = wave_sum(clip); spl = __any(spl);
 		if (MODE == 3 && p.min_baseq > 0)
@@ -609,6 +677,7 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const ScanParams p, long
 		{
 			classify<MODE>(p, r, ord, ref_len, clip, spl != 0 && !(r.flag & 0x4u), a, lds_hist);
 		}
+	}
 	}
 	flush(p, a, lds_hist);
 }
@@ -780,7 +849,9 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
 	__shared__ uint32_t lds_hist[1002];   // (1000, 1001: the wave's block of the min_baseq list, bq_append)
+	__shared__ WaveList wl_long, wl_pile;
 	if (threadIdx.x < 2) lds_hist[1000 + threadIdx.x] = 0;
+	if (threadIdx.x == 0) { wl_long.n = 0; wl_pile.n = 0; }
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
 	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
@@ -826,12 +897,8 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 					const long long name = (long long)((b << NAME_SHIFT) | (int64_t)n);
 					long long ref_len = 0;
 					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len, c4);
-					if (!scanned && p.sgn > 0)
-					{
-						unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull);
-						if ((long long)k < p.long_cap) p.long_list[k] = name;
-					}
-					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a);
+					if (!scanned && p.sgn > 0) wave_list_append(WAVE_LIST_P(wl_long), p.long_list, &p.counters[A_LONG_COUNT], p.long_cap, (unsigned long long)name);
+					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a, WAVE_LIST_P(wl_pile));
 				}
 				++n; o = o_next;
 			}
@@ -846,6 +913,7 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 		}
 	}
 	if (MODE == 3 && p.bq_list && p.sgn > 0) bq_close(p, lds_hist + 1000);
+	if (p.sgn > 0) { wave_list_close(WAVE_LIST_P(wl_long), p.long_list, &p.counters[A_LONG_COUNT], p.long_cap); if (p.pile.list) wave_list_close(WAVE_LIST_P(wl_pile), p.pile.list, p.pile.count, p.pile.cap); }
 	flush(p, a, lds_hist);
 }
 

@@ -23,7 +23,7 @@ def _bench(*args, timeout=600, env=None):
 
 @pytest.mark.timeout(900)
 def test_bench_line_on_a_small_shard():
-    d = _bench("--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "1000000", env={"NGSQC_BENCH_ONT_READS": "6000"})
+    d = _bench("--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "1000000", env={"NGSQC_BENCH_ONT_READS": "6000", "NGSQC_BENCH_FLAVOR_READS": "1500000"})
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
@@ -39,7 +39,10 @@ def test_bench_line_on_a_small_shard():
         assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["steps"] >= 3 and leg["roofline_scan"]["frac"] > 0
         assert leg["cpu_baseline"]["kind"] == "port" and leg["counters_match_gpu"] is True
     assert all(leg["reads_per_step"] == d["config"]["reads_per_gpu_per_step"] for leg in d["tools"].values())
-    assert d["ont"]["reads_per_step"] == 6000 and "SHARD" in d["ont"]["workload"]
+    assert d["ont"]["reads_per_step"] == 6000 and "configs[4]" in d["ont"]["workload"]
+    # the realistic token mix (reference-derived SEQ, 40-level QUAL) rides in the same line
+    fl = d["flavors"]["flavor5_refseq_40level_qual"]
+    assert "error" not in fl and fl["value"] > 0 and fl["reads_per_step"] == 1500000 and fl["counters_match_gpu"] is True and fl["inflate_stage_unpipelined_ms"] > 0
 
 
 @pytest.mark.timeout(900)
