@@ -172,6 +172,21 @@ void ToolBase::parse()
 	for (size_t j = 0; j < params_.size(); ++j) if (!params_[j].optional && !given[j]) NB_THROW(CommandLineParsingException, "Mandatory parameter '" + params_[j].name + "' not given.");
 }
 
+// NGSQC_TIMING: the age of the process (from the kernel's start time of the process: exec, the dynamic loader and the static initialisers lie in front of main)
+static void process_age_stamp(const char* what)
+{
+	if (!getenv("NGSQC_TIMING")) return;
+	double up = 0; unsigned long long start_ticks = 0;
+	if (FILE* f = fopen("/proc/uptime", "r")) { if (fscanf(f, "%lf", &up) != 1) up = 0; fclose(f); }
+	if (FILE* f = fopen("/proc/self/stat", "r"))
+	{
+		char buf[2048]; const size_t n = fread(buf, 1, sizeof(buf) - 1, f); buf[n] = 0; fclose(f);
+		if (const char* p = strrchr(buf, ')')) { int field = 2; for (const char* q = p + 1; *q; ++q) if (*q == ' ' && ++field == 22) { start_ticks = strtoull(q + 1, nullptr, 10); break; } }
+	}
+	const long hz = sysconf(_SC_CLK_TCK);
+	if (up > 0 && start_ticks && hz > 0) fprintf(stderr, "[ngsqc] process age %.2f s at %s\n", up - (double)start_ticks / (double)hz, what);
+}
+
 int ToolBase::execute()
 {
 	try
@@ -193,10 +208,12 @@ int ToolBase::execute()
 				settings_override_ = args_[i + 1]; args_.erase(args_.begin() + (long)i, args_.begin() + (long)i + 2); --i;
 			}
 		parse();
+		process_age_stamp("main (the loader has mapped the HIP runtime and this tool)");
 		defaultReferenceGenome() = settingsString("reference_genome");   // (RefGenomeService::getReferenceGenome: what a BamReader without an explicit genome opens a CRAM with)
 		main();
 		// The outputs are written and closed. Leaving through exit() would run the static destructors and the HIP runtime's teardown, which gives tens of GB of
 		// device memory back page by page (0.9 s for the buffers of a 60 GB BAM, profiles/r03_tool_probe.txt); the driver reclaims them at once when the process is gone.
+		process_age_stamp("exit (outputs written and closed)");
 		fflush(stdout); fflush(stderr);
 		if (!getenv("NGSQC_SLOW_EXIT")) _exit(0);
 		return 0;
