@@ -144,6 +144,169 @@ void rans_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out, size_t e
 	while (idx[3] < n_out) step(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- rANS Nx16 (CRAM 3.1, block method 5)
+// hts-specs CRAMcodecs "rANS Nx16" (what htslib links as htscodecs' rANS_static4x16pr.c; neither is in /root/reference): one byte of flags - 0x01 order 1, 0x04 32
+// interleaved states instead of 4, 0x08 striped, 0x10 no size, 0x20 stored, 0x40 run lengths, 0x80 bit packing - 7-bit big-endian varints, frequencies that add
+// up to a power of two (scaled up to 4096 / 1 << shift by the reader), 16-bit renormalisation. oracle/cram_decode.py rans_nx16_decode is the same text in Python;
+// the reference holds no CRAM 3.1 file, so both are held against oracle/cram_encode.py's writer of the same specification only.
+struct Nx16
+{
+	static uint32_t u7(Cur& c) { uint32_t v = 0; for (int k = 0; k < 5; ++k) { const uint8_t b = c.byte(); v = (v << 7) | (b & 0x7fu); if (!(b & 0x80u)) return v; } throw CramError("bad varint in a rANS Nx16 block"); }
+	static void alphabet(Cur& c, bool (&A)[256])
+	{
+		memset(A, 0, sizeof A);
+		int sym = c.byte(), last = sym, rle = 0;
+		for (;;)
+		{
+			A[sym] = true;
+			if (rle) { --rle; ++sym; if (sym > 255) throw CramError("bad rANS Nx16 alphabet"); }
+			else { sym = c.byte(); if (sym == last + 1) rle = c.byte(); }
+			last = sym;
+			if (sym == 0) break;
+		}
+	}
+	struct Tab { uint32_t F[256]; uint32_t C[256]; std::vector<uint8_t> L; bool set = false; };
+	static void finish(Tab& t, int bits)
+	{
+		uint64_t tot = 0; for (int s = 0; s < 256; ++s) tot += t.F[s];
+		if (tot != 0 && tot != (1ull << bits))
+		{
+			if (tot > (1ull << bits)) throw CramError("rANS Nx16 frequencies exceed their total");
+			int sh = 0; while (tot < (1ull << bits)) { tot *= 2; ++sh; }
+			for (int s = 0; s < 256; ++s) t.F[s] <<= sh;
+		}
+		t.L.assign((size_t)1 << bits, 0); uint64_t acc = 0;
+		for (int s = 0; s < 256; ++s)
+		{
+			t.C[s] = (uint32_t)acc;
+			if (acc + t.F[s] > (1ull << bits)) throw CramError("rANS Nx16 frequencies exceed their total");
+			memset(t.L.data() + acc, s, t.F[s]); acc += t.F[s];
+		}
+		t.set = true;
+	}
+	static uint32_t renorm(Cur& c, uint32_t x) { if (x < (1u << 15)) { const uint8_t* q = c.take(2); x = (x << 16) | (uint32_t)q[0] | ((uint32_t)q[1] << 8); } return x; }
+	static void order0(Cur& c, size_t n, int N, std::vector<uint8_t>& out)
+	{
+		bool A[256]; alphabet(c, A);
+		std::unique_ptr<Tab> t(new Tab()); memset(t->F, 0, sizeof t->F);
+		for (int s = 0; s < 256; ++s) if (A[s]) t->F[s] = u7(c);
+		finish(*t, 12);
+		uint32_t R[32]; for (int j = 0; j < N; ++j) R[j] = c.u32();
+		out.assign(n, 0);
+		for (size_t i = 0; i < n; ++i)
+		{
+			const int j = (int)(i % (size_t)N); const uint32_t f = R[j] & 0xfffu; const uint8_t s = t->L[f]; out[i] = s;
+			R[j] = renorm(c, t->F[s] * (R[j] >> 12) + f - t->C[s]);
+		}
+	}
+	static void order1(Cur& c, size_t n, int N, std::vector<uint8_t>& out)
+	{
+		const uint8_t comp = c.byte(); const int shift = comp >> 4;
+		if (shift < 1 || shift > 12) throw CramError("bad frequency precision in a rANS Nx16 block");
+		std::vector<uint8_t> tbuf; Cur tc;
+		if (comp & 1)
+		{
+			const uint32_t ulen = u7(c), clen = u7(c);
+			if (ulen > (1u << 20)) throw CramError("bad table size in a rANS Nx16 block");
+			Cur sub(c.take(clen), clen); order0(sub, ulen, 4, tbuf); tc = Cur(tbuf.data(), tbuf.size());
+		}
+		Cur& t = (comp & 1) ? tc : c;
+		bool A[256]; alphabet(t, A);
+		std::vector<Tab> T(256);
+		for (int i = 0; i < 256; ++i)
+		{
+			if (!A[i]) continue;
+			memset(T[(size_t)i].F, 0, sizeof T[(size_t)i].F); int run = 0;
+			for (int j = 0; j < 256; ++j)
+			{
+				if (!A[j]) continue;
+				if (run) { --run; continue; }
+				const uint32_t f = u7(t); T[(size_t)i].F[j] = f;
+				if (f == 0) run = t.byte();
+			}
+			finish(T[(size_t)i], shift);
+		}
+		uint32_t R[32]; for (int j = 0; j < N; ++j) R[j] = c.u32();
+		const size_t q = n / (size_t)N; size_t idx[32]; uint8_t last[32];
+		for (int j = 0; j < N; ++j) { idx[j] = (size_t)j * q; last[j] = 0; }
+		out.assign(n, 0); const uint32_t mask = (1u << shift) - 1u;
+		auto step = [&](int j) {
+			const Tab& tb = T[last[j]];
+			if (!tb.set) throw CramError("rANS Nx16 order-1 context without a table");
+			const uint32_t f = R[j] & mask; const uint8_t s = tb.L[f]; out[idx[j]++] = s;
+			R[j] = renorm(c, tb.F[s] * (R[j] >> shift) + f - tb.C[s]); last[j] = s;
+		};
+		for (size_t i = 0; i < q; ++i) for (int j = 0; j < N; ++j) step(j);
+		while (idx[N - 1] < n) step(N - 1);
+	}
+	// expect: the decoded size the caller knows (a block's raw size; a stripe's share); have_n: the stream may leave its size out
+	static void decode(Cur& c, std::vector<uint8_t>& out, size_t expect, int depth = 0)
+	{
+		if (depth > 2) throw CramError("rANS Nx16 stripes nested too deeply");
+		const uint8_t flags = c.byte();
+		size_t n = expect;
+		if (!(flags & 0x10)) { n = u7(c); if (n != expect) throw CramError("rANS Nx16 block of another size than its header says"); }
+		const int N = (flags & 0x04) ? 32 : 4;
+		if (flags & 0x08)
+		{
+			const int k = c.byte(); if (k == 0) throw CramError("rANS Nx16 stripe count of zero");
+			std::vector<uint32_t> clen((size_t)k); for (auto& x : clen) x = u7(c);
+			out.assign(n, 0); std::vector<uint8_t> part;
+			for (int j = 0; j < k; ++j)
+			{
+				const size_t un = n / (size_t)k + ((n % (size_t)k) > (size_t)j ? 1 : 0);
+				Cur sub(c.take(clen[(size_t)j]), clen[(size_t)j]); decode(sub, part, un, depth + 1);
+				for (size_t i = 0; i < un; ++i) out[i * (size_t)k + (size_t)j] = part[i];
+			}
+			return;
+		}
+		size_t pack_len = 0, rle_len = 0; int nsym = 0; uint8_t P[256];
+		if (flags & 0x80) { pack_len = n; nsym = c.byte(); for (int i = 0; i < nsym; ++i) P[i] = c.byte(); n = u7(c); }
+		std::vector<uint8_t> mbuf; Cur meta; bool Lr[256]; memset(Lr, 0, sizeof Lr);
+		if (flags & 0x40)
+		{
+			rle_len = n; const uint32_t mlen = u7(c); n = u7(c);
+			if (mlen & 1) { const uint8_t* q = c.take(mlen / 2); meta = Cur(q, mlen / 2); }
+			else { const uint32_t cm = u7(c); Cur sub(c.take(cm), cm); order0(sub, mlen / 2, 4, mbuf); meta = Cur(mbuf.data(), mbuf.size()); }
+			int k = meta.byte(); if (k == 0) k = 256;
+			for (int i = 0; i < k; ++i) Lr[meta.byte()] = true;
+		}
+		// (sizes come from the file: nothing larger than what the caller expects may be asked for - packing and run lengths only ever shrink the coded stream)
+		if (n > (expect > 64 ? expect : 64) * 2 + 1024) throw CramError("rANS Nx16 block with an implausible inner size");
+		std::vector<uint8_t> data;
+		if (flags & 0x20) { const uint8_t* q = c.take(n); data.assign(q, q + n); }
+		else if (flags & 0x01) order1(c, n, N, data);
+		else order0(c, n, N, data);
+		if (flags & 0x40)
+		{
+			std::vector<uint8_t> o; o.reserve(rle_len);
+			for (uint8_t s : data)
+			{
+				size_t k = 1; if (Lr[s]) k = (size_t)u7(meta) + 1;
+				if (o.size() + k > rle_len) throw CramError("rANS Nx16 run lengths do not add up");
+				o.insert(o.end(), k, s);
+			}
+			if (o.size() != rle_len) throw CramError("rANS Nx16 run lengths do not add up");
+			data.swap(o);
+		}
+		if (flags & 0x80)
+		{
+			std::vector<uint8_t> o(pack_len);
+			if (nsym <= 1) { if (pack_len && nsym == 0) throw CramError("rANS Nx16 packing without symbols"); if (pack_len) memset(o.data(), P[0], pack_len); data.swap(o); }
+			else if (nsym <= 16)
+			{
+				const int per = nsym <= 2 ? 8 : (nsym <= 4 ? 4 : 2), bits = nsym <= 2 ? 1 : (nsym <= 4 ? 2 : 4);
+				if (data.size() < (pack_len + (size_t)per - 1) / (size_t)per) throw CramError("rANS Nx16 packed data too short");
+				for (size_t i = 0; i < pack_len; ++i) { const uint32_t v = (data[i / (size_t)per] >> (bits * (int)(i % (size_t)per))) & ((1u << bits) - 1u); if ((int)v >= nsym) throw CramError("rANS Nx16 packed symbol out of range"); o[i] = P[v]; }
+				data.swap(o);
+			}
+		}
+		if (data.size() != expect) throw CramError("rANS Nx16 block of another size than its header says");
+		out.swap(data);
+	}
+};
+void rans_nx16_decode(const uint8_t* d, size_t n, std::vector<uint8_t>& out, size_t expect) { Cur c(d, n); Nx16::decode(c, out, expect); }
+
 // the plan of one rANS block for the device decoder (cram_dev.hip): false = not eligible (the host decodes it): more than 64 different symbols, a short block,
 // tables that do not parse
 bool rans_plan(const uint8_t* d, size_t n, uint64_t file_off, size_t rsize, CramQualPlan::Job& job, std::vector<uint16_t>& tabs, std::vector<uint8_t>& syms)
@@ -262,7 +425,8 @@ void read_block(Cur& c, Blk& b, int32_t lazy_cid = -1, const std::set<int32_t>* 
 	else if (b.method == 4) { rans_decode(raw, (size_t)csize, b.own, (size_t)rsize); b.p = b.own.data(); b.n = b.own.size(); }
 	else if (b.method == 2) { bz2_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
 	else if (b.method == 3) { lzma_block(raw, (size_t)csize, (size_t)rsize, b.own); b.p = b.own.data(); b.n = b.own.size(); }
-	else throw std::domain_error("CRAM 3.1 block codec " + std::to_string(b.method) + " is not supported by the HIP path");
+	else if (b.method == 5) { rans_nx16_decode(raw, (size_t)csize, b.own, (size_t)rsize); b.p = b.own.data(); b.n = b.own.size(); }
+	else throw std::domain_error("CRAM 3.1 block codec " + std::to_string(b.method) + " (6: adaptive arithmetic coder, 7: fqzcomp, 8: name tokeniser) is not supported by the HIP path");
 	if (b.n != (size_t)rsize) throw CramError("CRAM block inflates to another size than its header says");
 }
 struct ContainerHdr { int32_t length = 0, ref_id = 0, start = 0, span = 0, n_records = 0, n_blocks = 0; int64_t counter = 0, bases = 0; std::vector<int32_t> landmarks; };
@@ -1028,7 +1192,7 @@ void cram_to_bam_stream_impl(const uint8_t* d, size_t n, const std::string& path
 		const auto t0 = std::chrono::steady_clock::now();
 		auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
 		if (n < 26 || memcmp(d, "CRAM", 4) != 0) throw CramError("not a CRAM file");
-		if (d[4] != 3 || d[5] != 0) throw std::domain_error("CRAM " + std::to_string(d[4]) + "." + std::to_string(d[5]) + " input is not supported by the HIP path (CRAM 3.0 only)");
+		if (d[4] != 3 || d[5] > 1) throw std::domain_error("CRAM " + std::to_string(d[4]) + "." + std::to_string(d[5]) + " input is not supported by the HIP path (CRAM 3.0 and 3.1 only)");
 		Cur c(d, n, 26);
 		// ---- the SAM header ----
 		ContainerHdr k; read_container_header(c, k);

@@ -3,7 +3,7 @@ reconstruction of BAM records (hts-specs CRAMv3; the reference reads CRAM throug
 525-572, with the reference genome the user names). htslib is a third-party dependency that is absent from /root/reference, so the published format is
 restated here:
   * file definition, containers, blocks (CRC-32 of every container header and block is CHECKED), ITF8 / LTF8
-  * block methods raw (0), gzip (1), bzip2 (2), lzma (3), rANS 4x8 order 0 / order 1 (4)
+  * block methods raw (0), gzip (1), bzip2 (2), lzma (3), rANS 4x8 order 0 / order 1 (4); of CRAM 3.1: rANS Nx16 (5) with all its transforms - UNPINNED, see there
   * compression header: preservation map (RN, AP, RR, SM, TD), data-series encodings, tag encodings
   * encodings NULL, EXTERNAL, HUFFMAN, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP, BETA, SUBEXP, GAMMA
   * slice header, records, read features -> CIGAR / bases / qualities, mate chains inside a slice (NF) and detached mates, template length rules
@@ -60,6 +60,132 @@ class Cursor:
 
     def array_itf8(self):
         return [self.itf8() for _ in range(self.itf8())]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ rANS Nx16 (CRAM 3.1, block method 5)
+# hts-specs CRAMcodecs "rANS Nx16" (htscodecs rANS_static4x16pr.c is the implementation htslib links; neither is in /root/reference and the reference holds
+# no CRAM 3.1 file: this restatement is UNPINNED - it is held against oracle/cram_encode.py's writer of the same specification only).
+# flags: 0x01 order-1, 0x04 32 interleaved states instead of 4, 0x08 striped, 0x10 no size, 0x20 stored, 0x40 run lengths, 0x80 bit packing
+def _u7(c):
+    v = 0
+    while True:
+        b = c.byte(); v = (v << 7) | (b & 0x7f)
+        if not b & 0x80: return v
+
+
+def _nx16_alphabet(c):
+    A = [False] * 256; sym = c.byte(); last = sym; rle = 0
+    while True:
+        A[sym] = True
+        if rle: rle -= 1; sym += 1
+        else:
+            sym = c.byte()
+            if sym == last + 1: rle = c.byte()
+        last = sym
+        if sym == 0: break
+    return A
+
+
+def _nx16_scale(F, bits):
+    tot = sum(F)
+    if tot == 0 or tot == 1 << bits: return
+    sh = 0
+    while tot < 1 << bits: tot *= 2; sh += 1
+    for i in range(256): F[i] <<= sh
+
+
+def _nx16_lookup(F, bits):
+    C = [0] * 257
+    for i in range(256): C[i + 1] = C[i] + F[i]
+    if C[256] > 1 << bits: raise ValueError("rANS Nx16 frequencies exceed the total")
+    L = bytearray(1 << bits)
+    for s in range(256):
+        if F[s]: L[C[s]:C[s] + F[s]] = bytes([s]) * F[s]
+    return C, L
+
+
+def _nx16_order0(c, n, N):
+    A = _nx16_alphabet(c); F = [0] * 256
+    for s in range(256):
+        if A[s]: F[s] = _u7(c)
+    _nx16_scale(F, 12); C, L = _nx16_lookup(F, 12)
+    R = [c.u32() for _ in range(N)]; out = bytearray(n)
+    for i in range(n):
+        j = i % N; f = R[j] & 0xfff; s = L[f]; out[i] = s
+        x = F[s] * (R[j] >> 12) + f - C[s]
+        if x < 1 << 15: x = (x << 16) | c.byte() | (c.byte() << 8)
+        R[j] = x
+    return bytes(out)
+
+
+def _nx16_order1(c, n, N):
+    comp = c.byte(); shift = comp >> 4
+    tc = c
+    if comp & 1:
+        ulen = _u7(c); clen = _u7(c); tc = Cursor(_nx16_order0(Cursor(c.take(clen)), ulen, 4))
+    A = _nx16_alphabet(tc); syms = [s for s in range(256) if A[s]]; T = {}
+    for i in syms:
+        F = [0] * 256; run = 0
+        for j in syms:
+            if run: run -= 1
+            else:
+                F[j] = _u7(tc)
+                if F[j] == 0: run = tc.byte()
+        _nx16_scale(F, shift); T[i] = (F,) + _nx16_lookup(F, shift)
+    R = [c.u32() for _ in range(N)]; q = n // N; idx = [j * q for j in range(N)]; last = [0] * N; out = bytearray(n); mask = (1 << shift) - 1
+
+    def step(j):
+        F, C, L = T[last[j]]
+        f = R[j] & mask; s = L[f]; out[idx[j]] = s; idx[j] += 1
+        x = F[s] * (R[j] >> shift) + f - C[s]
+        if x < 1 << 15: x = (x << 16) | c.byte() | (c.byte() << 8)
+        R[j] = x; last[j] = s
+    for _ in range(q):
+        for j in range(N): step(j)
+    while idx[N - 1] < n: step(N - 1)
+    return bytes(out)
+
+
+def rans_nx16_decode(c, n=None):
+    """c: Cursor at the stream's flags byte; n: the decoded size when the caller knows it (a stream with the no-size flag)"""
+    flags = c.byte()
+    if not flags & 0x10: n = _u7(c)
+    N = 32 if flags & 0x04 else 4
+    if flags & 0x08:
+        k = c.byte(); clen = [_u7(c) for _ in range(k)]; parts = []
+        for j in range(k):
+            sub = Cursor(c.take(clen[j])); parts.append(rans_nx16_decode(sub, n // k + (1 if n % k > j else 0)))
+        out = bytearray(n)
+        for j in range(k): out[j::k] = parts[j]
+        return bytes(out)
+    pack_len = rle_len = None
+    if flags & 0x80:
+        pack_len = n; nsym = c.byte(); P = [c.byte() for _ in range(nsym)]; n = _u7(c)
+    if flags & 0x40:
+        rle_len = n; mlen = _u7(c); n = _u7(c)
+        if mlen & 1: meta = Cursor(c.take(mlen // 2))
+        else:
+            cm = _u7(c); meta = Cursor(_nx16_order0(Cursor(c.take(cm)), mlen // 2, 4))
+        k = meta.byte() or 256; Lr = [False] * 256
+        for _ in range(k): Lr[meta.byte()] = True
+    if flags & 0x20: data = bytes(c.take(n))
+    elif flags & 0x01: data = _nx16_order1(c, n, N)
+    else: data = _nx16_order0(c, n, N)
+    if flags & 0x40:
+        out = bytearray()
+        for s in data:
+            if Lr[s]: out += bytes([s]) * (_u7(meta) + 1)
+            else: out.append(s)
+        if len(out) != rle_len: raise ValueError("rANS Nx16 run lengths do not add up")
+        data = bytes(out)
+    if flags & 0x80:
+        if nsym <= 1: data = bytes([P[0]]) * pack_len if nsym else b""
+        elif nsym <= 16:
+            per, bits = (8, 1) if nsym <= 2 else ((4, 2) if nsym <= 4 else (2, 4))
+            out = bytearray(pack_len)
+            for i in range(pack_len): out[i] = P[(data[i // per] >> (bits * (i % per))) & ((1 << bits) - 1)]
+            data = bytes(out)
+    return data
 
 
 # ------------------------------------------------------------------------------------------------------------------------------ rANS 4x8
@@ -138,7 +264,8 @@ def read_block(c):
     elif b.method == 2: b.data = bz2.decompress(raw)
     elif b.method == 3: b.data = lzma.decompress(raw)
     elif b.method == 4: b.data = rans_decode(raw)
-    else: raise ValueError("CRAM block method %d (CRAM 3.1 codec) is not supported" % b.method)
+    elif b.method == 5: b.data = rans_nx16_decode(Cursor(bytes(raw)))
+    else: raise ValueError("CRAM block method %d (CRAM 3.1 codec: 6 arithmetic coder, 7 fqzcomp, 8 name tokeniser) is not supported" % b.method)
     if len(b.data) != b.rsize: raise ValueError("CRAM block inflates to another size than its header says")
     return b
 
@@ -467,7 +594,7 @@ def read_cram(path, ref_fetch=None):
     d = open(path, "rb").read()
     if d[:4] != b"CRAM": raise ValueError("not a CRAM file")
     f = CramFile(); f.version = (d[4], d[5])
-    if d[4] != 3 or d[5] != 0: raise ValueError("CRAM %d.%d is not supported (3.0 only)" % f.version)
+    if d[4] != 3 or d[5] not in (0, 1): raise ValueError("CRAM %d.%d is not supported (3.0 and 3.1 only)" % f.version)
     c = Cursor(d, 26)
     k = read_container_header(c); end = c.p + k.length
     b = read_block(c)

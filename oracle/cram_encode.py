@@ -17,6 +17,7 @@ import zlib
 import cram_decode as CD
 
 BASES = "ACGTN"
+NAME_METHOD = None   # (encode(name_method=...): the block method of the read names' external block)
 
 
 def itf8(v):
@@ -125,6 +126,146 @@ def rans_encode(data, order):
     return head(table + bytes(reversed(buf)))
 
 
+# ------------------------------------------------------------------------------------------------------------------------------ rANS Nx16 (CRAM 3.1)
+# The writer's side of hts-specs CRAMcodecs "rANS Nx16" (see oracle/cram_decode.py rans_nx16_decode: unpinned - no CRAM 3.1 file in the reference).
+def u7(v):
+    out = [v & 0x7f]; v >>= 7
+    while v: out.append((v & 0x7f) | 0x80); v >>= 7
+    return bytes(reversed(out))
+
+
+def _nx16_alphabet(present):
+    tab = bytearray(); rle = 0
+    for c in range(256):
+        if not present[c]: continue
+        if rle: rle -= 1
+        else:
+            tab.append(c)
+            if c and present[c - 1]:
+                r = c + 1
+                while r < 256 and present[r]: r += 1
+                rle = r - (c + 1); tab.append(rle)
+    tab.append(0)
+    return bytes(tab)
+
+
+def _scale_to(counts, total):
+    """frequencies that add up to total exactly, every counted symbol at least 1"""
+    n = sum(counts); F = [0] * 256
+    if n == 0: return F
+    for s in range(256):
+        if counts[s]: F[s] = max(1, counts[s] * total // n)
+    d = total - sum(F); order = sorted(range(256), key=lambda s: -F[s])
+    k = 0
+    while d != 0:
+        s = order[k % 256]
+        if d > 0: F[s] += 1; d -= 1
+        elif F[s] > 1: F[s] -= 1; d += 1
+        k += 1
+    return F
+
+
+def _nx16_states(events, F, C, shift, N):
+    """events in decoding order: (state, context, symbol) -> N final states + the 16-bit renormalisation words in reading order"""
+    R = [1 << 15] * N; words = []
+    for j, c, s in reversed(events):
+        f = F[c][s]; x = R[j]
+        if x >= ((1 << 15) >> shift << 16) * f: words.append(x & 0xffff); x >>= 16
+        R[j] = ((x // f) << shift) + (x % f) + C[c][s]
+    return b"".join(struct.pack("<I", x) for x in R) + b"".join(struct.pack("<H", w) for w in reversed(words))
+
+
+def _nx16_order0(data, N, half_total=False):
+    counts = [0] * 256
+    for b in data: counts[b] += 1
+    F = _scale_to(counts, 4096)
+    stored = F
+    if half_total and all(f % 2 == 0 for f in F): stored = [f // 2 for f in F]   # (a table that adds up to a smaller power of two: the reader scales it up)
+    acc = 0; C = [0] * 256
+    for s in range(256): C[s] = acc; acc += F[s]
+    table = _nx16_alphabet([f > 0 for f in F]) + b"".join(u7(stored[s]) for s in range(256) if F[s])
+    return table + _nx16_states([(i % N, 0, data[i]) for i in range(len(data))], {0: F}, {0: C}, 12, N)
+
+
+def _nx16_order1(data, N, shift=12, comp_table=False):
+    n = len(data); q = n // N; events = []; idx = [j * q for j in range(N)]; last = [0] * N
+    for _ in range(q):
+        for j in range(N):
+            s = data[idx[j]]; events.append((j, last[j], s)); last[j] = s; idx[j] += 1
+    while idx[N - 1] < n:
+        s = data[idx[N - 1]]; events.append((N - 1, last[N - 1], s)); last[N - 1] = s; idx[N - 1] += 1
+    counts = {}
+    for _, c, s in events: counts.setdefault(c, [0] * 256)[s] += 1
+    present = [False] * 256
+    for c in counts: present[c] = True
+    for b in data: present[b] = True
+    syms = [s for s in range(256) if present[s]]
+    F = {c: _scale_to(counts.get(c, [0] * 256), 1 << shift) for c in syms}; C = {}
+    for c in syms:
+        acc = 0; cc = [0] * 256
+        for s in range(256): cc[s] = acc; acc += F[c][s]
+        C[c] = cc
+    tab = bytearray(_nx16_alphabet(present))
+    for i in syms:
+        k = 0
+        while k < len(syms):
+            f = F[i][syms[k]]; tab += u7(f); k += 1
+            if f == 0:
+                run = 0
+                while k < len(syms) and F[i][syms[k]] == 0 and run < 255: run += 1; k += 1
+                tab.append(run)
+    body = _nx16_states(events, F, C, shift, N)
+    if comp_table:
+        ct = _nx16_order0(bytes(tab), 4)
+        return bytes([(shift << 4) | 1]) + u7(len(tab)) + u7(len(ct)) + ct + body
+    return bytes([shift << 4]) + bytes(tab) + body
+
+
+def rans_nx16_encode(data, order=0, x32=False, pack=False, rle=False, stripe=0, cat=False, nosz=False, comp_table=False, shift=12, comp_meta=False, half_total=False):
+    data = bytes(data); n = len(data); N = 32 if x32 else 4
+    flags = (1 if order else 0) | (4 if x32 else 0) | (0x10 if nosz else 0)
+    head = b"" if nosz else u7(n)
+    if n == 0: return bytes([flags | 0x20]) + head
+    if stripe:
+        parts = [rans_nx16_encode(data[j::stripe], order=order, x32=x32, nosz=True) for j in range(stripe)]
+        return bytes([flags | 0x08]) + head + bytes([stripe]) + b"".join(u7(len(p)) for p in parts) + b"".join(parts)
+    meta = b""
+    if pack:
+        syms = sorted(set(data)); nsym = len(syms)
+        if nsym <= 16:
+            flags |= 0x80
+            if nsym <= 1: packed = b""
+            else:
+                per, bits = (8, 1) if nsym <= 2 else ((4, 2) if nsym <= 4 else (2, 4))
+                code = {s: k for k, s in enumerate(syms)}; packed = bytearray((n + per - 1) // per)
+                for i, b in enumerate(data): packed[i // per] |= code[b] << (bits * (i % per))
+            meta += bytes([nsym]) + bytes(syms) + u7(len(packed)); data = bytes(packed); n = len(data)
+    if rle and n:
+        # symbols whose runs are worth their length bytes: those that repeat at all
+        runs = []; i = 0
+        while i < n:
+            j = i
+            while j + 1 < n and data[j + 1] == data[i]: j += 1
+            runs.append((data[i], j - i)); i = j + 1
+        rl = sorted({s for s, k in runs if k > 0})
+        if rl:
+            flags |= 0x40
+            lit = bytearray(); lens = bytearray()
+            for s, k in runs:
+                if s in rl: lit.append(s); lens += u7(k)
+                else: lit += bytes([s]) * (k + 1)
+            rmeta = bytes([len(rl) & 255]) + bytes(rl) + bytes(lens)
+            if comp_meta:
+                cm = _nx16_order0(rmeta, 4)
+                meta += u7(len(rmeta) * 2) + u7(len(lit)) + u7(len(cm)) + cm
+            else: meta += u7(len(rmeta) * 2 + 1) + u7(len(lit)) + rmeta
+            data = bytes(lit); n = len(data)
+    if cat or n == 0 or (flags & 0x80 and n == 0): return bytes([flags | 0x20]) + head + meta + data
+    if order and n >= N: body = _nx16_order1(data, N, shift, comp_table)
+    else: flags &= ~1; body = _nx16_order0(data, N, half_total)
+    return bytes([flags]) + head + meta + body
+
+
 # ------------------------------------------------------------------------------------------------------------------------------ blocks
 def block(method, ctype, cid, data):
     if method == 0: comp = data
@@ -136,6 +277,13 @@ def block(method, ctype, cid, data):
         import lzma; comp = lzma.compress(data)
     elif method == 4: comp = rans_encode(data, 0)
     elif method == 41: comp = rans_encode(data, 1); method = 4
+    elif 50 <= method <= 59:
+        # CRAM 3.1 rANS Nx16, one shape per code: 50 order 0 | 51 order 1 | 52 order 0, 32 states | 53 order 1, 32 states, compressed table, 10-bit frequencies |
+        # 54 bit packing + order 0 | 55 run lengths + order 1 | 56 four stripes | 57 stored | 58 run lengths (compressed) + packing | 59 order 0, table adds up to 2048
+        kw = {50: {}, 51: dict(order=1), 52: dict(x32=True), 53: dict(order=1, x32=True, comp_table=True, shift=10), 54: dict(pack=True), 55: dict(order=1, rle=True),
+              56: dict(stripe=4), 57: dict(cat=True), 58: dict(rle=True, pack=True, comp_meta=True), 59: dict(half_total=True)}[method]
+        comp = rans_nx16_encode(data, **kw); method = 5
+    elif method == 80: comp = zlib.compress(data); method = 8   # (a block of the name tokeniser's method number: this writer has no such codec - for readers that must refuse it, or never look)
     else: raise ValueError("block method")
     b = bytes([method, ctype]) + itf8(cid) + itf8(len(comp)) + itf8(len(data)) + comp
     return b + struct.pack("<I", zlib.crc32(b))
@@ -300,12 +448,14 @@ def huffman_lengths(values):
 SHARED_BLOCK = False   # test switch: RN, IN and the first tag's values share one external block (the skip bookkeeping of the product must keep all of them: tests/test_cpu_cram.py)
 
 
-def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False, slices_per_container=1):
+def encode(bam_path, out_path, genome=None, slice_records=2500, rr=True, multi_ref=False, chains=True, embed_ref=False, variety=True, methods=None, qual_features=False, slices_per_container=1, version=(3, 0), name_method=None):
     """genome: {contig name: bytes, upper case}. rr = False writes every base into the file ('b' features: no genome needed to read it). multi_ref packs several
     references into one slice (RI series, absolute positions). embed_ref stores the slice's reference stretch in the file. variety = False: raw EXTERNAL only."""
+    global NAME_METHOD
+    NAME_METHOD = name_method
     text, refs, recs = read_bam(bam_path)
     rgs = CD.read_groups(text)
-    out = bytearray(b"CRAM" + bytes([3, 0]) + b"oracle/cram_encode\0\0"[:20].ljust(20, b"\0"))
+    out = bytearray(b"CRAM" + bytes(version) + b"oracle/cram_encode\0\0"[:20].ljust(20, b"\0"))
     hdr = struct.pack("<i", len(text)) + text.encode()
     out += container(0, 0, 0, 0, 0, 0, [block(0, 0, 0, hdr)], [0])
     # ---- slices: runs of one reference (or anything, for multi-reference slices) ----
@@ -486,6 +636,7 @@ def encode_container(gs, refs, rgs, genome, rr, multi_ref, chains, embed_ref, va
             m = methods[k % len(methods)]
             if cid == ids.get("QS") and variety and not block_methods: m = 41
             if m in (4, 41) and len(data) > 400000: m = 1
+            if NAME_METHOD is not None and cid == ids.get("RN"): m = NAME_METHOD
             ext_blocks.append(block(m, 4, cid, bytes(data))); content_ids.append(cid)
         emb_id = -1
         if embedded is not None:

@@ -74,11 +74,11 @@ def test_damaged_and_unsupported_files(tmp_path, monkeypatch):
     p = str(tmp_path / "cut.cram"); open(p, "wb").write(d[:len(d) // 3])
     with pytest.raises(ngsqc.NgsqcError):
         ngsqc.cram_to_bam(p, out)
-    v31 = bytearray(d); v31[5] = 1
-    p = str(tmp_path / "v31.cram"); open(p, "wb").write(v31)
+    v32 = bytearray(d); v32[5] = 2
+    p = str(tmp_path / "v32.cram"); open(p, "wb").write(v32)
     with pytest.raises(ngsqc.NgsqcError) as e:
         ngsqc.cram_to_bam(p, out)
-    assert e.value.code == -5 and "CRAM 3.1" in str(e.value)          # NGSQC_E_UNSUPPORTED
+    assert e.value.code == -5 and "CRAM 3.2" in str(e.value)          # NGSQC_E_UNSUPPORTED
     with pytest.raises(ngsqc.NgsqcError):
         ngsqc.cram_to_bam(os.path.join(GI, "sry.bam"), out)
 
@@ -171,6 +171,32 @@ def test_names_and_tags_are_not_decoded_when_nobody_needs_them(name, twins, tmp_
                 want = CD.to_bam_record(r, rgs)
                 assert got == want, (flags, i, got[:60].hex(), want[:60].hex())
             assert bam_stream(out)[0] != bam_stream(full)[0]
+    finally:
+        ngsqc.set_reference(None)
+
+
+def test_cram31_name_tokeniser_block_is_refused_only_when_names_are_wanted(twins, tmp_path, monkeypatch):
+    """CRAM 3.1 as samtools writes it keeps the read names in a block of the name tokeniser (method 8), which this build does not decode (nor the adaptive arithmetic
+    coder, 6, nor fqzcomp, 7): NGSQC_E_UNSUPPORTED - but only for a caller that asks for names. The tools never do (BamReader::skipTags / required fields,
+    BamReader.cpp:525-572): for them the block's CRC is checked and its bytes are not looked at, every other series comes out of rANS Nx16 blocks."""
+    twin = twins["MappingQC_in2.bam"]; src = str(tmp_path / "t31.cram"); out = str(tmp_path / "o.bam")
+    CE.encode(twin["bam"], src, twin["genome"], version=(3, 1), methods=[50, 51, 54, 55, 58], name_method=80)
+    ngsqc.set_reference(twin["fasta"]); monkeypatch.delenv("NGSQC_CRAM_NO_REFERENCE", raising=False)
+    try:
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            ngsqc.cram_to_bam(src, out)
+        assert e.value.code == -5 and "name tokeniser" in str(e.value)
+        ngsqc.set_cram_skip(ngsqc.CRAM_SKIP_NAMES)
+        try:
+            ngsqc.cram_to_bam(src, out)
+        finally:
+            ngsqc.set_cram_skip(0)
+        _, _, recs = split_bam(bam_stream(out)[0])
+        assert len(recs) == len(twin["records"]) > 1000
+        for got, want in zip(recs, twin["records"]):
+            l_name = want[12]; w = bytearray(want[:36]) + b"*\0" + want[36 + l_name:]   # the BAM's record with the name "*"
+            w[12] = 2; struct.pack_into("<i", w, 0, len(w) - 4)
+            assert got == bytes(w)
     finally:
         ngsqc.set_reference(None)
 

@@ -30,6 +30,10 @@ def twin(tmp_path_factory):
     t["cram"] = os.path.join(d, "twin.cram"); CE.encode(t["bam"], t["cram"], t["genome"])
     t["cram_multi"] = os.path.join(d, "multi.cram"); CE.encode(t["bam"], t["cram_multi"], t["genome"], multi_ref=True, slice_records=900)
     t["cram_norr"] = os.path.join(d, "norr.cram"); CE.encode(t["bam"], t["cram_norr"], t["genome"], rr=False)
+    # CRAM 3.1: every series in rANS Nx16 blocks of all shapes; and the file as samtools lays it out - the read names in a block of the name tokeniser,
+    # which the tools never open (BamReader::skipTags / required fields)
+    t["cram31"] = os.path.join(d, "v31.cram"); CE.encode(t["bam"], t["cram31"], t["genome"], version=(3, 1), methods=[50, 51, 52, 53, 54, 55, 56, 57, 58, 59])
+    t["cram31_tok3"] = os.path.join(d, "v31_tok3.cram"); CE.encode(t["bam"], t["cram31_tok3"], t["genome"], version=(3, 1), methods=[51, 50, 58, 54], name_method=80)
     h = ngsqc.Handle(path=t["bam"]); h.write_bai(); h.close()      # (the tools ask for an index next to their input, as the reference does; the CRAM's .crai is written by the encoder)
     return t
 
@@ -53,7 +57,7 @@ def _same_results(a, b):
 
 
 @pytest.mark.parametrize("quals", ["device", "host"])
-@pytest.mark.parametrize("which", ["cram", "cram_multi", "cram_norr"])
+@pytest.mark.parametrize("which", ["cram", "cram_multi", "cram_norr", "cram31"])
 def test_handle_on_a_cram_equals_the_handle_on_its_bam(twin, which, quals, monkeypatch):
     """quals: the quality arrays (rANS blocks) decoded by the kernels of csrc/cram_dev.hip into the uploaded image (the default), or on the host like the rest"""
     if quals == "host": monkeypatch.setenv("NGSQC_CRAM_DEVICE_QUALS", "0")
@@ -117,6 +121,17 @@ def test_tools_on_a_cram_write_what_they_write_for_the_bam(twin, tmp_path):
             assert m and int(m.group(1)) >= 3 and int(m.group(3)) > 1000, p.stderr[-2000:]
             print("device quality decode:", m.group(0))
     assert outs["bam"] == outs["cram"] and len(outs["bam"]) > 30
+    # a CRAM 3.1 file whose read names sit in a name-tokeniser block: the tool does not ask for names and writes the same qcML; a caller that wants every field is refused
+    o = str(tmp_path / "v31.qcML")
+    _run("MappingQC", "-in", twin["cram31_tok3"], "-wgs", "-build", "hg19", "-no_ref", "-out", o, env={"NGSQC_REFERENCE": twin["fasta"]})
+    assert [ln for ln in open(o).read().splitlines() if not re.search(r"creation |<binary>|source file|(twin|v31_tok3)\.(bam|cram)", ln)] == outs["bam"]
+    ngsqc.set_reference(twin["fasta"])
+    try:
+        with pytest.raises(ngsqc.NgsqcError) as e:
+            ngsqc.Handle(path=twin["cram31_tok3"])
+        assert e.value.code == -5 and "name tokeniser" in str(e.value)
+    finally:
+        ngsqc.set_reference(None)
     name, ln = max(twin["refs"], key=lambda x: x[1])
     bed = str(tmp_path / "r.bed"); open(bed, "w").write("%s\t100\t%d\n%s\t%d\t%d\n" % (name, ln // 2, name, ln // 2 + 50, ln - 10))
     cov = {k: _run("BedCoverage", "-bam", twin[k], "-in", bed, "-ref", twin["fasta"]).stdout for k in ("bam", "cram")}

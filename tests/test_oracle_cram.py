@@ -173,12 +173,36 @@ import cram_twin  # noqa: E402
 
 VARIANTS = {"default": {}, "no_genome_needed": dict(rr=False), "multi_reference_slices": dict(multi_ref=True, slice_records=700), "embedded_reference": dict(embed_ref=True),
             "plain_external": dict(variety=False, chains=False), "small_slices": dict(slice_records=150), "bzip2_and_lzma_blocks": dict(methods=[2, 3, 1]),
-            "containers_of_three_slices": dict(slices_per_container=3, slice_records=300), "containers_of_mixed_slices": dict(slices_per_container=4, slice_records=250, multi_ref=True)}
+            "containers_of_three_slices": dict(slices_per_container=3, slice_records=300), "containers_of_mixed_slices": dict(slices_per_container=4, slice_records=250, multi_ref=True),
+            # CRAM 3.1: every shape of the rANS Nx16 codec over the external blocks, and a mix with the 3.0 methods
+            "cram31_rans_nx16": dict(version=(3, 1), methods=[50, 51, 52, 53, 54, 55, 56, 57, 58, 59]), "cram31_mixed_methods": dict(version=(3, 1), methods=[51, 1, 58, 41, 56, 53], slice_records=400)}
 
 
 def test_eof_container_equals_the_fixtures():
     tail = open(os.path.join(GI, "cramTest.cram"), "rb").read()[-38:]
     assert CE.eof_container() == tail == open(os.path.join(GI, "SampleIdentity_in_rna.cram"), "rb").read()[-38:]
+
+
+def test_rans_nx16_round_trips():
+    """the CRAM 3.1 codec of the oracle against its own writer (no htslib-written 3.1 file exists in the reference: unpinned, see oracle/cram_decode.py): every transform
+    alone and stacked, sizes around the interleave widths, and the coded size of random ACGT (2 bits per base: the entropy coder is one)"""
+    import random
+    rng = random.Random(4)
+    shapes = [{}, dict(order=1), dict(x32=True), dict(order=1, x32=True), dict(order=1, comp_table=True, shift=10), dict(pack=True), dict(rle=True), dict(order=1, rle=True, comp_meta=True),
+              dict(rle=True, pack=True), dict(stripe=4), dict(stripe=3, order=1), dict(cat=True), dict(half_total=True), dict(order=1, x32=True, comp_table=True, rle=True, pack=True)]
+    q = bytearray(); v = 30
+    for _ in range(9000):
+        if rng.random() < 0.05: v = rng.choice([2, 12, 23, 37, 40])
+        q.append(v)
+    datas = [b"", b"A", b"A" * 44, bytes(q), bytes([7]) * 3 + bytes([9]) * 30000, b"".join(int(rng.gauss(1000, 300)).to_bytes(4, "little", signed=True) for _ in range(500))]
+    for n in (3, 4, 5, 31, 32, 33, 127, 128, 129, 2000):
+        datas += [bytes(rng.randrange(256) for _ in range(n)), bytes(rng.choice(b"ACGT") for _ in range(n)), bytes(rng.choice(b"AC") for _ in range(n))]
+    for d in datas:
+        for kw in shapes:
+            c = CE.rans_nx16_encode(d, **kw); cur = CD.Cursor(c)
+            assert CD.rans_nx16_decode(cur) == d and cur.p == len(c), (len(d), kw)
+    acgt = bytes(rng.choice(b"ACGT") for _ in range(40000))
+    assert 10000 <= len(CE.rans_nx16_encode(acgt)) <= 10000 + 200 and len(CE.rans_nx16_encode(bytes([30]) * 5000 + bytes([2]) * 3000, rle=True, pack=True)) < 64
 
 
 def test_rans_encoder_round_trips():
