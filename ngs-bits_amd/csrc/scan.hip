@@ -513,7 +513,12 @@ __device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecVie
 		}
 	}
 	if (a.pc_next == INT32_MAX || a.pc_next > end1) return;
+#ifdef NGSQC_NO_WAVE_LISTS
+	const unsigned long long k = atomicAdd(p.pile.count, 1ull);
+	if ((long long)k < p.pile.cap) p.pile.list[k] = o;
+#else
 	wave_list_append(wl, p.pile.list, p.pile.count, p.pile.cap, (unsigned long long)o);
+#endif
 }
 
 template <int MODE>
@@ -849,9 +854,11 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
                                                         uint32_t* __restrict__ bad, uint16_t* __restrict__ rel)
 {
 	__shared__ uint32_t lds_hist[1002];   // (1000, 1001: the wave's block of the min_baseq list, bq_append)
+#ifndef NGSQC_NO_WAVE_LISTS
 	__shared__ WaveList wl_long, wl_pile;
-	if (threadIdx.x < 2) lds_hist[1000 + threadIdx.x] = 0;
 	if (threadIdx.x == 0) { wl_long.n = 0; wl_pile.n = 0; }
+#endif
+	if (threadIdx.x < 2) lds_hist[1000 + threadIdx.x] = 0;
 	for (int i = threadIdx.x; i < 1000; i += blockDim.x) lds_hist[i] = 0;
 	__syncthreads();
 	Acc a; for (int i = 0; i < A_COUNT; ++i) { a.v[i] = 0; a.n[i] = 0; } a.max_len = 0; a.best_key = 0; a.first_paired = ~0ull;
@@ -897,8 +904,13 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 					const long long name = (long long)((b << NAME_SHIFT) | (int64_t)n);
 					long long ref_len = 0;
 					const bool scanned = scan_record<MODE>(p, r, name, a, lds_hist, &ref_len, c4);
+#ifdef NGSQC_NO_WAVE_LISTS
+					if (!scanned && p.sgn > 0) { unsigned long long k = atomicAdd(&p.counters[A_LONG_COUNT], 1ull); if ((long long)k < p.long_cap) p.long_list[k] = name; }
+					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a, nullptr);
+#else
 					if (!scanned && p.sgn > 0) wave_list_append(WAVE_LIST_P(wl_long), p.long_list, &p.counters[A_LONG_COUNT], p.long_cap, (unsigned long long)name);
 					if (p.pile.list && p.sgn > 0) pile_candidate(p, r, o, scanned, ref_len, a, WAVE_LIST_P(wl_pile));
+#endif
 				}
 				++n; o = o_next;
 			}
@@ -913,7 +925,9 @@ __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p
 		}
 	}
 	if (MODE == 3 && p.bq_list && p.sgn > 0) bq_close(p, lds_hist + 1000);
+#ifndef NGSQC_NO_WAVE_LISTS
 	if (p.sgn > 0) { wave_list_close(WAVE_LIST_P(wl_long), p.long_list, &p.counters[A_LONG_COUNT], p.long_cap); if (p.pile.list) wave_list_close(WAVE_LIST_P(wl_pile), p.pile.list, p.pile.count, p.pile.cap); }
+#endif
 	flush(p, a, lds_hist);
 }
 

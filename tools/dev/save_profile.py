@@ -13,14 +13,16 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PFX = "r1" if tag.startswith("r01") else ("r2" if tag.startswith("r02") else ("r3" if tag.startswith("r03") else ("r4" if tag.startswith("r04") else ("r5" if tag.startswith("r05") else "r6"))))
 # what the per-member / per-record figures depend on: bench.py only scales them to its own launches when it runs with the same settings
-SETTINGS = "settings: k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "2"), os.environ.get("NGSQC_TOKEN_SLOTS", "3"))
+SETTINGS = "settings: k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "3"), os.environ.get("NGSQC_TOKEN_SLOTS", "4"))
+import math
+CHUNKS_PER_JOB = math.ceil(249024 / (int(os.environ.get("NGSQC_K1_CHUNK_WAVES", "5")) * 256 * 64)) if PFX == "r6" else 3   # K1 launches per job of the 48 M-read shard (249 024 members)
 try:
     import subprocess
     SETTINGS += " commit=" + subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     pass
 CMD = ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard per step, 1x MI355X)" if PFX == "r1" else
-       "NGSQC_BENCH_NO_STRONG=1 NGSQC_BENCH_NO_E2E=1 python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles, 3 K1 chunks per job; 6 jobs per run: 1 warm-up + 3 timed + the un-pipelined and the isolated-K1 extra steps; 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)" if PFX in ("r3", "r4", "r5", "r6") else
+       "NGSQC_BENCH_NO_STRONG=1 NGSQC_BENCH_NO_E2E=1 python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard; K1 chunks per job: 3 until round 5, 4 since round 6 (chunks of 5 waves per CU); 6 jobs per run: 1 warm-up + 3 timed + the un-pipelined and the isolated-K1 extra steps; 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)" if PFX in ("r3", "r4", "r5", "r6") else
        "python bench.py --reads 48000000 --steps 3 --warmup 1 --no-cpu-baseline   (48M-read shard = 2 tiles per step, 1x MI355X; counter passes with NGSQC_K1_SERIAL=1 NGSQC_PIPELINE=0: every kernel alone on the chip)")
 out = open(f"profiles/{tag}_kernel_stats.txt", "w")
 c = sqlite3.connect(f"gpurun_out/{PFX}_trace/t_results.db")
@@ -55,7 +57,7 @@ if PFX in ("r3", "r4", "r5", "r6"):
         jobs = None
         for k, (n, tot) in rows.items():
             if "huff_tokens_kernel" in k:
-                jobs = (n - 1) / 3.0
+                jobs = (n - 1) / float(CHUNKS_PER_JOB)
         for k, (n, tot) in rows.items():
             short = k.split("(")[0].split("::")[-1].split("<")[0]
             if jobs and short in ("huff_tokens_kernel", "lz77_groups_kernel", "crc32_kernel", "crc32_chains_kernel"):
