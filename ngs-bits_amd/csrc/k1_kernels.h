@@ -47,8 +47,16 @@ constexpr int P1_RING_SLOTS = 8;
 constexpr int P1_TRIPS = 4;             // trips between two service blocks = the four words of a token group (one word per trip)
 constexpr int P1_WAVES_PER_SIMD = 4;   // register budget of the decoder: 128 VGPRs and 156 bytes of scratch (round 5 measured the budget of 3 - 166 VGPRs, no scratch - in the job: 45.9 against 46.1 ms per 48 M reads, no difference)
 constexpr int P1_TAB_W = 128;     // per workgroup: base | extra bits << 16 of the symbols 256..287 (words 0..31) and the distance symbols (words 32..63); the rest is padding (an index byte of a damaged stream may point behind the tables)
-constexpr int P1_STAGE_W = 16 * 64;   // per lane the four token groups of one 64-byte line of its page: they leave for the pool together (round 6; a 16-byte store per lane reached HBM as a partial line: 3.1 x write amplification)
-constexpr int P1_LDS_W = P1_LANE_W * 64 + P1_TAB_W + P1_STAGE_W;   // 15 360 B per one-wave workgroup
+#ifndef NGSQC_P1_LINE_GROUPS
+#define NGSQC_P1_LINE_GROUPS 4
+#endif
+constexpr int P1_LINE_GROUPS = NGSQC_P1_LINE_GROUPS;   // token groups a lane collects in LDS before they leave for the pool as consecutive 16-byte stores: 4 = whole 64-byte lines (a single 16-byte store per
+                                                       // lane reached HBM as a partial line: 3.1 x write amplification), 2 = 32-byte sectors and 2 KB less LDS per wave - which is what decides how
+                                                       // many resolve / scan waves fit beside the CU's ten decoder waves. Measured at full size (profiles/r06_schedule_probe.txt): 2 -> 437.5 / 440.6 ms per step, un-pipelined inflate 454 ms;
+                                                       // 4 -> 441.7 ms, 446 ms: within the spread - whole lines stay (less write traffic)
+static_assert(P1_LINE_GROUPS == 2 || P1_LINE_GROUPS == 4, "line staging");
+constexpr int P1_STAGE_W = 4 * P1_LINE_GROUPS * 64;
+constexpr int P1_LDS_W = P1_LANE_W * 64 + P1_TAB_W + P1_STAGE_W;   // 15 360 B (13 312 with half lines) per one-wave workgroup
 
 enum { S_SYM = 0, S_NEXT = 1, S_HDR = 2, S_P1 = 3, S_P2 = 4, S_RAW = 5, S_FINISH = 6, S_DONE = 7 };   // 1..6: the slow states
 constexpr uint32_t TAB_EOB = 0x80000000u, TAB_BAD = 0x40000000u;
@@ -134,7 +142,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 	wv::set_priority(park_hi >> 8); park_hi &= 255;   // (upper bits: wave priority of the decoder waves, NGSQC_P1_PRIO)
 	const wv::u32x4* const comp_q = (const wv::u32x4*)comp;
 	uint32_t* const tab = lds + P1_LANE_W * 64;
-	uint32_t* const stage = lds + P1_LANE_W * 64 + P1_TAB_W + lane * 16;   // lane-major; a lane's four groups rotated by lane / 4, so that sixteen lanes' 16-byte accesses meet sixteen different bank quads
+	uint32_t* const stage = lds + P1_LANE_W * 64 + P1_TAB_W + lane * (4 * P1_LINE_GROUPS);   // lane-major; a lane's four groups rotated by lane / 4, so that sixteen lanes' 16-byte accesses meet sixteen different bank quads
 	{
 		// RFC 1951 §3.2.5: symbol 256 ends the block, 257..285 are the 29 length symbols, 286/287 (only in the fixed code) are invalid; 30 distance symbols
 		const uint32_t i = (uint32_t)lane;
@@ -200,14 +208,15 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 		err = K1_ERR_TOKEN_OVERFLOW; state = S_FINISH; return false;
 	};
 	// A group first goes to the lane's stage; the four groups of a 64-byte line leave for the pool as four stores to consecutive addresses (gi: the group's index in its page)
-	auto staged = [&](uint32_t slot) -> wv::u32x4* { return (wv::u32x4*)(stage + (((slot + ((uint32_t)lane >> 2)) & 3u) << 2)); };
+	constexpr uint32_t LG = (uint32_t)P1_LINE_GROUPS;
+	auto staged = [&](uint32_t slot) -> wv::u32x4* { return (wv::u32x4*)(stage + (((slot + ((uint32_t)lane >> 2)) & (LG - 1u)) << 2)); };
 	auto flush_line = [&](uint32_t* line, uint32_t n) {
 		#pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) if (k < n) *(wv::u32x4*)(line + 4 * k) = *staged(k);
+		for (uint32_t k = 0; k < LG; ++k) if (k < n) *(wv::u32x4*)(line + 4 * k) = *staged(k);
 	};
 	auto put_group = [&](uint32_t gi, uint32_t a, uint32_t bb, uint32_t c, uint32_t d) {
-		*staged(gi & 3u) = wv::make4(a, bb, c, d);
-		if ((gi & 3u) == 3u) flush_line(tptr - 12, 4u);
+		*staged(gi & (LG - 1u)) = wv::make4(a, bb, c, d);
+		if ((gi & (LG - 1u)) == LG - 1u) flush_line(tptr - 4 * (LG - 1u), LG);
 		tptr += 4;
 	};
 	auto emit = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t d) {
@@ -307,7 +316,7 @@ K1_KERNEL_OCC(64, P1_WAVES_PER_SIMD) void huff_tokens_kernel(const uint8_t* __re
 				if (!err && abit > abit_end) err = 15;   // consumed bits behind the payload: a truncated stream
 				{
 					// the groups of the member's last, unfinished line
-					const uint32_t n_st = (K1_PAGE_GROUPS - 1 - tleft) & 3u;
+					const uint32_t n_st = (K1_PAGE_GROUPS - 1 - tleft) & (LG - 1u);
 					if (ngr && n_st) flush_line(tptr - 4 * n_st, n_st);
 				}
 				tok_count[b] = ngr; status[b].produced = out_n; status[b].error = err;

@@ -7,9 +7,11 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --image-cache /tmp/ngsqc_ab_full.bam"
 $CMD > $O/a1.json 2> $O/a1.err
 cp $R/ngs-bits_amd/libngsqc_hip.so /tmp/lib_a.so; RUNS="a1"
+NGSQC_K1_CHUNK_WAVES=6 $CMD > $O/a1_cw6.json 2> $O/a1_cw6.err; RUNS="$RUNS a1_cw6"
 for B in $TAGS; do cp $R/ngs-bits_amd/libngsqc_hip_$B.so $R/ngs-bits_amd/libngsqc_hip.so; $CMD > $O/$B.json 2> $O/$B.err; RUNS="$RUNS $B"; done
 cp /tmp/lib_a.so $R/ngs-bits_amd/libngsqc_hip.so
 $CMD > $O/a2.json 2> $O/a2.err; RUNS="$RUNS a2"
+NGSQC_P1_STREAMS=3 $CMD > $O/a2_s3.json 2> $O/a2_s3.err; RUNS="$RUNS a2_s3"
 python - <<PY
 import json
 for k in "$RUNS".split():
