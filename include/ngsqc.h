@@ -37,7 +37,7 @@ typedef struct ngsqc_handle ngsqc_handle;
 #define NGSQC_E_FORMAT     -2   /* not BGZF / not BAM / corrupt record           BamReader.h:389-392  */
 #define NGSQC_E_ARG        -3   /* invalid argument (ArgumentException cases)    */
 #define NGSQC_E_DEVICE     -4   /* HIP runtime error / no device / out of memory */
-#define NGSQC_E_UNSUPPORTED -5  /* CRAM 3.1 codecs                               */
+#define NGSQC_E_UNSUPPORTED -5  /* CRAM 3.1 codecs other than rANS Nx16            */
 
 /* ---- lifecycle (replaces BamReader ctor/dtor, BamReader.cpp:462-523) ---- */
 int  ngsqc_open(const char* bam_path, int device, ngsqc_handle** out);
@@ -231,15 +231,16 @@ int64_t ngsqc_header_text(const ngsqc_handle* h, char* out, int64_t cap);
 typedef struct ngsqc_bgzf_member { uint64_t file_offset, payload_offset, inflated_offset; uint32_t payload_bytes, inflated_bytes, crc32, walked_in_pieces /* 1: the table came from the multi-thread walk */; } ngsqc_bgzf_member;
 int ngsqc_bgzf_scan(const void* bam_bytes, size_t n_bytes, int32_t n_threads, ngsqc_bgzf_member* out, int64_t cap, int64_t* n_members, int64_t* inflated_bytes);
 
-/* ---- CRAM 3.0 input. The reference opens CRAM through the same BamReader (htslib; BamReader.cpp:482-492) with the reference genome the caller names
- * (hts_set_fai_filename). Here every ngsqc_open* entry point takes a CRAM 3.0 file: its container layer (containers, slices, blocks with CRC-32, gzip and rANS
+/* ---- CRAM 3.0 / 3.1 input. The reference opens CRAM through the same BamReader (htslib; BamReader.cpp:482-492) with the reference genome the caller names
+ * (hts_set_fai_filename). Here every ngsqc_open* entry point takes a CRAM 3.0 or 3.1 file: its container layer (containers, slices, blocks with CRC-32, gzip and rANS
  * 4x8 blocks, the encodings, read features, mate chains, the slices' reference MD5) is decoded on the HOST into BAM records, which reach the device as a BAM image
  * whose BGZF members hold stored blocks - the device path (K1's stored-block copy, record index, walk, depth, counters) is the BAM path. The quality arrays
  * (rANS blocks) of a whole-file handle are decoded on the device into that image (cram_dev.hip; NGSQC_CRAM_DEVICE_QUALS=0: on the host). Index-driven
  * requests on a CRAM (ngsqc_open_regions) decode only the slices whose headers overlap a region - what the .crai names, read from the slice headers themselves;
  * ngsqc_open_head the first two slices; ngsqc_open_range the whole file. ngsqc_set_reference names the genome (FASTA with .fai; NULL / "": none; NGSQC_REFERENCE is the
  * fallback) for files that need one (preservation key RR); without it: NGSQC_E_IO "Error while setting reference genome ...", a genome that does not match a
- * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1 codecs: NGSQC_E_UNSUPPORTED (bzip2 / lzma blocks need libbz2 / liblzma on the machine, loaded on first use). ngsqc_cram_to_bam writes the decoded records as a BAM file
+ * slice's MD5: NGSQC_E_FORMAT. CRAM 3.1: rANS Nx16 blocks are decoded; the adaptive arithmetic coder, fqzcomp and the name tokeniser are NGSQC_E_UNSUPPORTED - a name-tokeniser block only
+ * when names are asked for (ngsqc_set_cram_skip: the tools never do) (bzip2 / lzma blocks need libbz2 / liblzma on the machine, loaded on first use). ngsqc_cram_to_bam writes the decoded records as a BAM file
  * (host only; the checker of the decoder: tests compare it record by record with oracle/cram_decode.py). */
 int ngsqc_set_reference(const char* fasta_path);
 /* What later ngsqc_open* calls on a CRAM need not decode (process-wide, like ngsqc_set_reference). Replaces BamReader::skipTags() and the read-name half of
