@@ -378,6 +378,10 @@ int32_t ngsqc_abi_version(void);
 /* library / device info string (static storage) */
 const char* ngsqc_version(void);
 
+/* Number of HIP devices this process sees (0 when there is none or the runtime cannot start; never an error): what a caller that opens one handle per device -
+ * the reference's per-sample loop of src/MappingQC/main.cpp:60-67 spread over a node, SURVEY.md 8(e) - sizes its rank list with. */
+int32_t ngsqc_device_count(void);
+
 #ifdef __cplusplus
 }
 #endif

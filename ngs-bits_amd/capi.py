@@ -134,7 +134,7 @@ def lib():
         L.ngsqc_lowhigh_runs.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, i64, C.POINTER(i64)]
         L.ngsqc_get_timings.restype = i32; L.ngsqc_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.ngsqc_get_timings_sized.restype = i32; L.ngsqc_get_timings_sized.argtypes = [vp, vp, C.c_size_t]; L.ngsqc_abi_version.restype = i32
-        L.ngsqc_version.restype = cp
+        L.ngsqc_version.restype = cp; L.ngsqc_device_count.restype = i32; L.ngsqc_device_count.argtypes = []
         L.ngsqc_site_pileup.restype = i32; L.ngsqc_site_pileup.argtypes = [vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp]
         L.ngsqc_scan_reads.restype = i32; L.ngsqc_scan_reads.argtypes = [vp, C.c_int32, C.POINTER(ReadStats)]
         L.ngsqc_read_length_hist.restype = i32; L.ngsqc_read_length_hist.argtypes = [vp, vp, i64]
@@ -165,11 +165,17 @@ def lib():
     return _lib
 
 
+def device_count():
+    """HIP devices the library's own runtime sees (include/ngsqc.h ngsqc_device_count) - not torch's: a second HIP / HSA runtime in the process is what a test that
+    only wants a number must not load."""
+    return int(lib().ngsqc_device_count())
+
+
 EXPORTS = [
     "ngsqc_open", "ngsqc_open_memory", "ngsqc_close", "ngsqc_last_error", "ngsqc_n_ref", "ngsqc_ref_name", "ngsqc_ref_len",
     "ngsqc_n_records", "ngsqc_inflated_size", "ngsqc_n_bgzf_blocks", "ngsqc_compressed_size", "ngsqc_decode",
     "ngsqc_drop_decoded", "ngsqc_copy_inflated", "ngsqc_copy_record_offsets", "ngsqc_scan_mapping", "ngsqc_scan_depth",
-    "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_get_timings_sized", "ngsqc_abi_version", "ngsqc_version",
+    "ngsqc_depth_stats", "ngsqc_depth_copy", "ngsqc_region_sums", "ngsqc_lowhigh_runs", "ngsqc_get_timings", "ngsqc_get_timings_sized", "ngsqc_abi_version", "ngsqc_version", "ngsqc_device_count",
     "ngsqc_site_pileup", "ngsqc_scan_reads", "ngsqc_read_length_hist", "ngsqc_read_cycle_stats", "ngsqc_open_shard", "ngsqc_open_memory_shard", "ngsqc_scan_mapping_partial", "ngsqc_scan_depth_partial", "ngsqc_plan_shard_fix", "ngsqc_scan_mapping_finish",
     "ngsqc_depth_device", "ngsqc_depth_diff_copy", "ngsqc_depth_diff_set", "ngsqc_depth_finalize",
     "ngsqc_run_job", "ngsqc_depth_select", "ngsqc_depth_reduce", "ngsqc_region_read_counts", "ngsqc_upload_wait", "ngsqc_run_job_partial", "ngsqc_bai_range", "ngsqc_open_range", "ngsqc_header_text", "ngsqc_open_regions", "ngsqc_open_head",

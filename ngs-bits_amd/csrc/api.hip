@@ -217,6 +217,13 @@ int ngsqc_get_timings_sized(const ngsqc_handle* h, void* t, size_t struct_size)
 }
 int32_t ngsqc_abi_version(void) { return 6; }
 
+int32_t ngsqc_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n < 0) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
 const char* ngsqc_version(void) { return "ngsqc-hip 0.3 abi 6 (gfx950; K1 bgzf inflate + crc32, K2 bam record index, K3-K5 scan / pileup / read QC, K6 depth; tile stream)"; }
 
 } // extern "C"

@@ -268,15 +268,9 @@ def test_library_communicator_world_of_one(tmp_path):
     device; N > 1 ranks run in the driver's scaling bench, the collective there is checked against a second channel: bench.py "collective".)"""
     path = str(tmp_path / "comm.bam")
     G.write(path, n_reads=60_000, seed=17, start_pos=15_900_000)
-    import gc
-    gc.collect()   # (handles of earlier tests that nobody closed give their device memory back: RCCL's own start-up allocations failed once at the end of a full-suite run)
     uid = ngsqc.Comm.unique_id()
     assert len(uid) == 128
-    try:
-        comm = ngsqc.Comm(0, 1, uid, device=0)
-    except ngsqc.NgsqcError:
-        import time
-        time.sleep(2.0); uid = ngsqc.Comm.unique_id(); comm = ngsqc.Comm(0, 1, uid, device=0)   # (one more try with a fresh id)
+    comm = ngsqc.Comm(0, 1, uid, device=0)   # (no test of this process may import torch before this: its bundled HSA runtime beside /opt/rocm's is what RCCL then trips over)
     try:
         v = np.arange(ngsqc.NCOUNTERS, dtype=np.int64) * 3 + 1
         assert np.array_equal(comm.allreduce_counters(v), v)
