@@ -221,10 +221,6 @@ struct ngsqc_handle
 		// used it is done (p2_enq: chunks whose phase 2 is enqueued - their ev_chunk events are valid to wait for) ----
 		struct SPiece { size_t src, dst, bytes; int64_t chunk; };
 		std::vector<SPiece> sp; std::vector<size_t> chunk_first;   // pieces of the pass; first piece of every chunk (size nch + 1)
-		// (round 6) the mapping is given back BEHIND the copy: a thread follows the pieces in file order and unmaps the stretch whose pieces are on the device, slice by slice
-		// (map_cut: bytes of the mapping's front that are gone; a later pass maps the file again) - the page-table entries of a 60 GB file are no longer torn down in one
-		// piece when the process ends (stream_pass_begin)
-		std::thread unmapper; size_t map_cut = 0;
 		std::atomic<int64_t> p2_enq{0}; bool pass_running = false, pass_fresh = false; const uint8_t* src_base = nullptr;   // pass_fresh: started ahead of its job (by the layout thread), nothing consumed yet
 	};
 	Upload* up = nullptr;

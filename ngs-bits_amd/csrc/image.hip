@@ -165,8 +165,7 @@ void inflate_sync(ngsqc_handle* h, const std::vector<int64_t>& idx, const std::v
 			for (BlockDesc& d : dd)
 			{
 				const size_t a = (size_t)(d.cpos & 15u), src = (size_t)d.cpos - a, len = std::min<size_t>(a + d.clen + 64, h->up->map_n - src);
-				// (from the file, not from the mapping: a pass gives the mapping back behind its copy)
-				for (size_t got = 0; got < len;) { const ssize_t r = pread(h->up->fd, hc.data() + o + got, len - got, (off_t)(src + got)); if (r <= 0) throw IoError("Could not read BAM/CRAM file " + h->path); got += (size_t)r; }
+				memcpy(hc.data() + o, h->up->src_base + src, len);
 				d.cpos = o + a; o += (a + d.clen + 64 + 15) & ~(size_t)15;
 			}
 			h->d_sync_comp.ensure_slack(hc.size());
@@ -295,8 +294,7 @@ void upload_join(ngsqc_handle* h)
 	u->th.clear();
 	for (hipEvent_t e : u->ev) if (e) (void)hipEventDestroy(e);
 	u->ev.clear();
-	if (u->unmapper.joinable()) u->unmapper.join();
-	if (u->map) { void* m = (uint8_t*)u->map + u->map_cut; const size_t n = u->map_n - u->map_cut; const int fd = u->fd; reaper().task([m, n, fd] { if (n) munmap(m, n); if (fd >= 0) ::close(fd); }); u->map = nullptr; u->src_base = nullptr; u->map_cut = 0; u->fd = -1; }
+	if (u->map) { void* m = u->map; const size_t n = u->map_n; const int fd = u->fd; reaper().task([m, n, fd] { munmap(m, n); if (fd >= 0) ::close(fd); }); u->map = nullptr; u->fd = -1; }
 	if (u->fd >= 0) { ::close(u->fd); u->fd = -1; }
 }
 void upload_start(ngsqc_handle* h, const uint8_t* bytes, size_t beg, size_t end)
@@ -367,7 +365,6 @@ void stream_pass_end(ngsqc_handle* h)
 	if (!u || !u->pass_running) return;
 	u->cancel = true; u->cv.notify_all();
 	for (auto& t : u->th) if (t.joinable()) t.join();
-	if (u->unmapper.joinable()) u->unmapper.join();
 	u->th.clear(); u->pass_running = false; u->cancel = false;
 }
 void stream_pass_begin(ngsqc_handle* h)
@@ -382,16 +379,6 @@ void stream_pass_begin(ngsqc_handle* h)
 	T = (int)std::min<size_t>((size_t)T, u->sp.size());
 	int delay_us = 0; if (const char* e = getenv("NGSQC_H2D_DELAY_US")) delay_us = std::max(0, atoi(e));
 	uint8_t* const dst = h->d_comp.p; const int device = h->device; const int slots = h->comp_slots; hipEvent_t* const ev_chunk = h->ev_chunk.data();
-	// (round 6) an earlier pass gave the mapping (or its front) back: the file is mapped again
-	static const bool unmap_behind = !getenv("NGSQC_UNMAP_BEHIND") || atoi(getenv("NGSQC_UNMAP_BEHIND")) != 0;
-	if (u->fd >= 0 && (!u->map || u->map_cut))
-	{
-		if (u->map) munmap((uint8_t*)u->map + u->map_cut, u->map_n - u->map_cut);
-		u->map = nullptr; u->src_base = nullptr; u->map_cut = 0;
-		void* m = mmap(nullptr, u->map_n, PROT_READ, MAP_PRIVATE, u->fd, 0);
-		if (m == MAP_FAILED) throw IoError("Could not map BAM/CRAM file " + h->path);
-		u->map = m; u->src_base = (const uint8_t*)m;
-	}
 	// The source of a piece is the mapping of the file (hipMemcpyAsync stages a pageable source through the runtime's pinned buffers). Reading through the mapping
 	// faults in one page-table entry per 4 KB - 15 M of them for a 60 GB file - and tearing them down again costs 0.3 - 0.75 s at close for a 19 GB file. Measured
 	// alternatives on a 19 GB BAM (profiles/r04_tool_probe.txt; code removed in round 5): pieces read with pread into pinned buffers of the copier threads, 12.5 GB/s with four threads,
@@ -436,27 +423,6 @@ void stream_pass_begin(ngsqc_handle* h)
 			if (st) (void)hipStreamDestroy(st);
 			{ std::lock_guard<std::mutex> g(u->mu); if (++u->done == u->th.size()) u->t_done = wall_ms(); }
 			u->cv.notify_all();
-		});
-	// The mapping goes back BEHIND the copy (round 6; the handle's own mapping of a path only). Every 4 KB a copy went through has a page-table entry - 15 M for the
-	// 30x file - and tearing them down in one piece took about a second: at ngsqc_close, or (a tool that exits behind its job) while the process ended,
-	// profiles/r06_tool_probe.txt. Here a thread follows the pieces in file order, waits for each one's event and unmaps 256 MB slices whose pieces are all on the
-	// device, so the work is spread under the copy and the address-space lock is never held for long. The next pass maps the file again (above).
-	if (unmap_behind && u->map && u->fd >= 0)
-		u->unmapper = std::thread([u, device] {
-			constexpr size_t SLICE = (size_t)256 << 20;
-			(void)hipSetDevice(device);
-			uint8_t* const base = (uint8_t*)u->map; size_t cut = u->map_cut; bool all = true;
-			for (size_t i = 0; i < u->sp.size(); ++i)
-			{
-				{ std::unique_lock<std::mutex> lk(u->mu); u->cv.wait(lk, [&] { return u->recorded[i] || u->cancel.load() || !u->err.empty() || u->done == u->th.size(); }); if (!u->recorded[i]) { all = false; break; } }
-				if (hipEventSynchronize(u->ev[i]) != hipSuccess) { all = false; break; }
-				const size_t safe = i + 1 < u->sp.size() ? u->sp[i + 1].src : u->map_n;   // (a chunk's first piece may begin a few bytes in front of its predecessor's end)
-				while (cut + SLICE <= safe) { munmap(base + cut, SLICE); cut += SLICE; }
-			}
-			if (all && cut < u->map_n) { munmap(base + cut, u->map_n - cut); cut = u->map_n; }
-			std::lock_guard<std::mutex> g(u->mu);
-			u->map_cut = cut;
-			if (cut >= u->map_n) { u->map = nullptr; u->src_base = nullptr; u->map_cut = 0; }
 		});
 }
 // stream st may read chunk c's compressed bytes behind this call (the host waits until the copies are issued, the stream for their events)
