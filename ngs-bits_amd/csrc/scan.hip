@@ -949,8 +949,12 @@ static void launch_walk_scan_w(const ScanParams& p, const BlockDesc* d_blocks, i
 void launch_walk_scan(const ScanParams& p, const BlockDesc* d_blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm, int32_t* d_start, uint32_t* d_cnt, int64_t* d_next_abs, uint32_t* d_bad, uint16_t* d_rel, hipStream_t s)
 {
 	if (n_entries <= 0) return;
-	int waves = 3; if (const char* e = getenv("NGSQC_WALK_WAVES")) waves = atoi(e);
-	if (waves >= 4) launch_walk_scan_w<4>(p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
+	// MODE_DEPTH (the coverage tools) is compiled for FIVE waves per SIMD (95 VGPRs, no scratch): 5 x 4 SIMDs x 256 CUs x 64 lanes = 327 680 walkers are resident at once,
+	// which is exactly a tile of four K1 chunks - with the 99 VGPRs of the budget of three (four resident waves, 262 144 walkers) a tile of the 30x file took a second,
+	// 23 % full round of workgroups: scan kernels 30.7 ms per step with 17 tiles, 34.9 ms with the 10 tiles the K1 schedule wants (profiles/r06_bench_full_30x.json)
+	int waves = p.mode == 3 ? 5 : 3; if (const char* e = getenv("NGSQC_WALK_WAVES")) waves = atoi(e);
+	if (waves >= 5 && p.mode == 3) { const int grid = (int)((n_entries + 63) / 64); hipLaunchKernelGGL((walk_scan_kernel<3, 5>), dim3(grid), dim3(64), 0, s, p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel); KCHECK(); }
+	else if (waves >= 4) launch_walk_scan_w<4>(p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
 	else launch_walk_scan_w<3>(p, d_blocks, n_entries, prefix, ksh, nm, d_start, d_cnt, d_next_abs, d_bad, d_rel, s);
 }
 
