@@ -21,6 +21,10 @@ namespace ngsqc {
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+// The refresh of a per-lane cache (region search, next known site) is a rare branch that leaves loaded values in registers; it waits for them ITSELF (round 6): a
+// load still pending at the join makes the compiler wait with vmcnt(0) at the values' first use behind the join - in the walk that is a wait for the next record's
+// prefetched header in EVERY trip, taken or not (walk_scan_kernel 2.75 -> 2.55 ms per 48 M records, profiles/r06_walk_probe.txt).
+__device__ __forceinline__ void settle_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // per-lane partial sums (A_* in common.h), reduced per wave at the end of the kernel: one atomic per wave and counter
 struct Acc
@@ -279,6 +283,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 			a.rc_lo = j0 > first ? p.reg_end[j0 - 1] : INT32_MIN;
 			a.rc_hi = j0 < lastr ? p.reg_end[j0] : INT32_MAX;
 			a.rc_start = j0 < lastr ? p.reg_start[j0] : INT32_MAX;
+			settle_loads();
 		}
 		const int last = a.rc_last;
 		if (a.rc_start > end1) return;   // (the first region that ends at or behind the read's start begins behind its end: no overlap)
@@ -310,6 +315,7 @@ __device__ static void classify(const ScanParams& p, const RecView& r, long long
 			a.rc_lo = i0 > first ? p.reg_end[i0 - 1] : INT32_MIN;   // (start1 > reg_end[i0 - 1]: the search would still pass i0 - 1)
 			a.rc_hi = i0 < last ? p.reg_end[i0] : INT32_MAX;        // (start1 <= reg_end[i0]: it would still stop at i0)
 			a.rc_start = i0 < last ? p.reg_start[i0] : INT32_MAX;
+			settle_loads();
 		}
 		const int last = a.rc_last;
 		if (a.rc_start <= end1)   // (the first region that ends at or behind the read's start begins inside the read's span: an overlap)
@@ -511,6 +517,7 @@ __device__ __forceinline__ void pile_candidate(const ScanParams& p, const RecVie
 			if (i < last) a.pc_next = p.pile.site_pos[i];
 			if (i > first) a.pc_lo = p.pile.site_pos[i - 1];
 		}
+		settle_loads();
 	}
 	if (a.pc_next == INT32_MAX || a.pc_next > end1) return;
 #ifdef NGSQC_NO_WAVE_LISTS
@@ -848,6 +855,9 @@ void launch_baseq_list(const ScanParams& p, int64_t n, hipStream_t s, int64_t* d
 // times the lines in flight; (b) the fixed 36 bytes of the NEXT record are requested before this record is processed (round 3/4 asked for its block_size only
 // and then waited for the fields): one round trip per record is the CIGAR's, the header's is hidden behind the scan of the record in front; (c) the offsets go
 // out as 16-byte stores of eight (round 4: a 2-byte store per record and lane - 64 partial sectors per instruction, 32.6 bytes of HBM writes per record).
+// (Round 6, probed and not kept - profiles/r06_walk_probe.txt: the first 96 bytes of the next record by LDS-DMA, six global_load_lds_dwordx4 per lane, header and CIGAR
+// read out of LDS: one request per record instead of two dependent ones, and 20 % SLOWER - the walk is bound by what the address unit and the L1 process per lane,
+// not by the CIGAR's round trip: 96 bytes per lane and record instead of 52.)
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void walk_scan_kernel(const ScanParams p, const BlockDesc* __restrict__ blocks, int64_t n_entries, int64_t prefix, int ksh, int64_t nm,
                                                         const int32_t* __restrict__ start, uint32_t* __restrict__ cnt, int64_t* __restrict__ next_abs,
