@@ -45,7 +45,12 @@ constexpr int P1_W_DSYM = 34;     // the distance symbols in code order, one byt
 constexpr int P1_LANE_W = 42;
 constexpr int P1_RING_SLOTS = 8;
 constexpr int P1_TRIPS = 4;             // trips between two service blocks = the four words of a token group (one word per trip)
-constexpr int P1_WAVES_PER_SIMD = 4;   // register budget of the decoder: 128 VGPRs and 156 bytes of scratch (round 5 measured the budget of 3 - 166 VGPRs, no scratch - in the job: 45.9 against 46.1 ms per 48 M reads, no difference)
+#ifndef NGSQC_P1_WAVES_PER_SIMD
+#define NGSQC_P1_WAVES_PER_SIMD 3
+#endif
+constexpr int P1_WAVES_PER_SIMD = NGSQC_P1_WAVES_PER_SIMD;   // register budget of the decoder. Round 6: THREE waves per SIMD = 168 VGPRs and 8 bytes of scratch. The budget of four (128 VGPRs) is out of reach, the compiler then
+                                                             // kept 193 VGPRs = TWO waves per SIMD, eight decoder waves per CU whatever the LDS allowed; with three a CU holds the ten its LDS has room for: the full-size step 444 -> 435 ms,
+                                                             // K1 wall 430 -> 415 ms, although the kernel alone got slower (9.0 -> 9.6 ms per launch: the two spilled dwords), profiles/r06_schedule_probe.txt
 constexpr int P1_TAB_W = 128;     // per workgroup: base | extra bits << 16 of the symbols 256..287 (words 0..31) and the distance symbols (words 32..63); the rest is padding (an index byte of a damaged stream may point behind the tables)
 #ifndef NGSQC_P1_LINE_GROUPS
 #define NGSQC_P1_LINE_GROUPS 4
