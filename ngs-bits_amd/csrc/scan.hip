@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __built
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 // The refresh of a per-lane cache (region search, next known site) is a rare branch that leaves loaded values in registers; it waits for them ITSELF (round 6): a
 // load still pending at the join makes the compiler wait with vmcnt(0) at the values' first use behind the join - in the walk that is a wait for the next record's
-// prefetched header in EVERY trip, taken or not (walk_scan_kernel 2.75 -> 2.55 ms per 48 M records, profiles/r06_walk_probe.txt).
+// prefetched header in EVERY trip, taken or not (worth about 1 % on the 30x walk: 2.72 against 2.75 ms per 48 M records, profiles/r06_kernel_stats_serial.txt).
 __device__ __forceinline__ void settle_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // per-lane partial sums (A_* in common.h), reduced per wave at the end of the kernel: one atomic per wave and counter
