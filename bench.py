@@ -653,7 +653,7 @@ def main():
         try:
             per = {}
             settings_ok = False
-            want = "k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "5"), os.environ.get("NGSQC_TOKEN_SLOTS", "6"))
+            want = "k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "8"), os.environ.get("NGSQC_TOKEN_SLOTS", "8"))
             for ln in open(os.path.join(ROOT, "profiles", "r06_hbm_traffic_pmc.txt")):
                 if ln.startswith("# settings: "):
                     settings_ok = want in ln   # (the per-member figures only describe launches of the same kernels under the same schedule)

@@ -139,7 +139,7 @@ inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1]
 constexpr int K1_CHUNK_WAVES_PER_CU = 5;   // a K1 chunk = this many decoder waves per CU (x 64 members). Round 6: HALF of what a CU holds - two decoder launches run side by side (the two phase-1 streams), and a
                                           // chunk of 6 with room for 10 left the second launch with four waves per CU until the first was done: the full-size step 506 -> 446 ms with 5 (profiles/r06_schedule_probe.txt)
 constexpr int P1_WAVES_PER_CU = 10;       // decoder waves a CU holds (15.4 KB LDS each since the token lines are staged there, round 6; 193 VGPRs = two per SIMD)
-constexpr int K1_SLOTS_DEFAULT = 6;  // token ring: chunk c uses slot c % slots (phase 1 of the next chunks runs while phase 2 of c reads; round 6: a fourth slot is worth 1.5 % of the full-size step with chunks of 5 waves per CU - 458 -> 451 ms, a fifth 0.4 %; six with five chunks per tile); NGSQC_TOKEN_SLOTS
+constexpr int K1_SLOTS_DEFAULT = 8;  // token ring: chunk c uses slot c % slots (phase 1 of the next chunks runs while phase 2 of c reads; round 6: a fourth slot is worth 1.5 % of the full-size step with chunks of 5 waves per CU - 458 -> 451 ms, a fifth 0.4 %; eight - the most the ring holds - with eight chunks per tile); NGSQC_TOKEN_SLOTS
 constexpr int N_DEPTH_SETS = 2;      // [0] the mapping scan's target region, [1] the extra depth scan of a job (-somatic_custom_bed)
 
 // target regions + per-base depth of one scan

@@ -13,7 +13,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PFX = "r1" if tag.startswith("r01") else ("r2" if tag.startswith("r02") else ("r3" if tag.startswith("r03") else ("r4" if tag.startswith("r04") else ("r5" if tag.startswith("r05") else "r6"))))
 # what the per-member / per-record figures depend on: bench.py only scales them to its own launches when it runs with the same settings
-SETTINGS = "settings: k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "5"), os.environ.get("NGSQC_TOKEN_SLOTS", "6"))
+SETTINGS = "settings: k1_format=r06-word-per-trip-64B-lines tile_chunks=%s token_slots=%s" % (os.environ.get("NGSQC_TILE_CHUNKS", "8"), os.environ.get("NGSQC_TOKEN_SLOTS", "8"))
 import math
 CHUNKS_PER_JOB = math.ceil(249024 / (int(os.environ.get("NGSQC_K1_CHUNK_WAVES", "5")) * 256 * 64)) if PFX == "r6" else 3   # K1 launches per job of the 48 M-read shard (249 024 members)
 try:
