@@ -1,0 +1,50 @@
+"""dev: rewrite DESIGN.md section 5a (round 6) from a bench line. usage: design_5a.py profiles/r06_bench_full_30x.json"""
+import json, sys, re
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+p = 'DESIGN.md'; s = open(p).read()
+a = s.index("### 5a. Round 6"); b = s.index("### 5b. Round 5")
+u=d['stage_ms_unpipelined']; st=d['stage_ms']; r=d['roofline']; rs=d['roofline_scan']; t=d['tools']; o=d['ont']; f=d['flavors']['flavor5_refseq_40level_qual']; e=d['end_to_end']; cb=d['cpu_baseline']; ca=d['cpu_baseline_all_cores']
+it = lambda x: x['roofline_scan']['itemised_ms']
+age = [x for x in e['tool_stamps'] if 'process age' in x and 'exit' in x]
+age_exit = re.search(r"process age ([0-9.]+) s at exit", age[0]).group(1) if age else "?"
+stamp = lambda key: next((re.match(r"\+([0-9.]+) s", x).group(1) for x in e['tool_stamps'] if key in x), "?")
+job_ms = re.search(r"fused job: ([0-9.]+) ms wall", " ".join(e['tool_stamps'])).group(1)
+sec = f"""### 5a. Round 6 (`profiles/r06_bench_full_30x.json` = `python bench.py --gpus 1 --steps {d['steps']} --warmup {d['warmup']}`, the driver's command, at the round's last code: the full 30× file, {d['budget']['total_s']:.0f} s of wall time, 310 of them the generator; `_a` / `_b` / `_c` / `_d` = earlier lines of the round)
+
+What a **step** is (unchanged): `bin/MappingQC -wgs` as ONE fused job on the resident compressed image - K1 of all {d['config']['members_inflated_per_step']:,} BGZF members, the `mapping_wgs` scan + OMIM ROI depth + yxRatio
+riding K2's chain walk, the contamination pileup of 29 280 known sites, K6 - 620 000 000 reads, 60.5 GB compressed, 208.7 GB inflated in {d['config']['tiles']} tiles / {d['config']['k1_chunks']} K1 chunks, every step from the compressed bytes.
+Algorithmic bytes (SURVEY.md §8(d)): scan stage Σ(4 + block_size) = 208.71 GB per step (336.6 B per record); the dominant kernel, per launch of {r['traffic_pmc']['members_per_launch']:,} members:
+{r['algorithmic_bytes_per_launch']/1e9:.3f} GB of compressed input (18.8 KB per member).
+
+| | round 6 | round 5 (driver's line) |
+|---|---|---|
+| **`value`** | **{d['value']:.1f} Mreads/s** ({d['ms_per_step']:.1f} ms per step; `single_bam` leg {d['single_bam']['value']:.1f}) | 1 169.0 (530.4) |
+| un-pipelined stages (ms per step) | inflate **{u['inflate_stage']:.1f}** (decoder launches {u['inflate_huff']:.0f}, resolve {u['inflate_lz77']:.0f}), index {u['index']:.2f}, scan {u['scan_stage']:.1f}, finalize {u['depth_finalize']:.2f}, pileup {u['contamination_pileup']:.2f}, step wall {u['step_wall']:.1f} | inflate 537.8, index 1.04, scan 36.8, step 542.5 |
+| pipelined (timed steps) | K1 wall **{st['inflate_stage_wall']:.1f} ms** = {d['roofline_k1_stage']['achieved']:.0f} GB/s of compressed-in + inflated-out; sums of intervals: decoder {st['inflate_huff']:.0f}, resolve {st['inflate_lz77']:.0f}, index {st['index']:.1f}, scan {st['scan_stage']:.1f}, pileup {st['contamination_pileup']:.1f} | K1 wall 516-526 |
+| dominant kernel, `roofline` | `huff_tokens_kernel` alone on the chip: {r['algorithmic_bytes_per_launch']/1e9:.3f} GB ÷ {r['avg_launch_ms']:.2f} ms = {r['achieved']:.0f} GB/s = **{r['frac']:.4f}** of the HBM roofline (instruction issue, not HBM; the launch alone got SLOWER with the register budget of three waves per SIMD - 9.0 → 9.7 ms - while the pipelined job got faster: the number describes a kernel that never runs alone); `traffic` {r['traffic']/1e9:.2f} GB per launch = **{r['traffic_pmc']['ratio_to_algorithmic']}×** the algorithmic bytes (round 5: 6.6×) | 0.020; 11.3 ms per launch of 83 k members |
+| **scan stage, `roofline_scan`** | t_scan **{rs['t_scan_ms']:.2f} ms** → {rs['achieved']:.0f} GB/s = **{rs['frac']:.3f}**; kernels only {rs['scan_kernel_only']['ms']:.2f} ms = {rs['scan_kernel_only']['frac']:.3f}; `traffic` {rs['traffic']/1e9:.1f} GB per step ({rs['traffic']/rs['algorithmic_bytes']:.2f} of the algorithmic bytes: the sparse walk) | 38.25 ms = 0.682 |
+| `tools` (configs[2], the same resident image, 5 steps each) | BedCoverage **{t['bedcoverage']['value']:.0f} Mreads/s**, scan stage **{t['bedcoverage']['roofline_scan']['frac']:.3f}** (t_scan {t['bedcoverage']['roofline_scan']['t_scan_ms']:.1f} ms: index {it(t['bedcoverage'])['k2_index_incl_start_guess']:.2f} + kernels {it(t['bedcoverage'])['scan_kernels']:.1f} + finalize {it(t['bedcoverage'])['depth_finalize']:.2f}); BedLowCoverage -cutoff 20 **{t['bedlowcoverage']['value']:.0f}**, **{t['bedlowcoverage']['roofline_scan']['frac']:.3f}**; with `-min_baseq 20` **{t['bedlowcoverage_baseq20']['value']:.0f}**, **{t['bedlowcoverage_baseq20']['roofline_scan']['frac']:.3f}** (t_scan {t['bedlowcoverage_baseq20']['roofline_scan']['t_scan_ms']:.1f} ms, all tiles riding); cpu_baseline {t['bedcoverage']['cpu_baseline']['value']:.2f} / {t['bedlowcoverage']['cpu_baseline']['value']:.2f} / {t['bedlowcoverage_baseq20']['cpu_baseline']['value']:.2f} Mreads/s (oracle, 1 thread); `counters_match_gpu` {str(all(t[k]['counters_match_gpu'] for k in t)).lower()} for all three | 1 143 / 1 133 / 1 014; 0.632 / 0.633 / 0.241 |
+| `ont` (configs[4]: 2 000 000 reads, 21.8 GB compressed, 83.8 GB inflated, {o['tiles']} tiles, groups of 16 members) | **{o['value']:.2f} Mreads/s = {o['gbases_per_s']:.0f} Gbases/s** ({o['ms_per_step']:.1f} ms per step), scan stage **{o['roofline_scan']['frac']:.3f}** (K2 with the start guess {it(o)['k2_index_incl_start_guess']:.2f} ms, kernels {it(o)['scan_kernels']:.2f}, other {it(o)['scan_stage_other']:.2f}, finalize {it(o)['depth_finalize']:.2f}); cpu_baseline {o['cpu_baseline']['value']:.4f} Mreads/s; parity on a 200 000-read file {str(o['counters_match_gpu']).lower()} | 400 000 reads: 6.5, 0.406 |
+| `flavors` (generator flavor 5: reference-derived SEQ, 40-level QUAL, ratio 2.53; 96 M reads) | **{f['value']:.0f} Mreads/s** ({f['ms_per_step']:.1f} ms), scan stage {f['roofline_scan']['frac']:.3f}, `counters_match_gpu` {str(f['counters_match_gpu']).lower()} | - |
+| end to end | `ngsqc_open(path)` + first job {e['open_plus_first_job_s']:.2f} s = `value_incl_h2d` **{e['value_incl_h2d']:.0f}** (H2D {e['h2d_GBps']:.1f} GB/s beside K1); `bin/MappingQC` process start → exit **{e['tool_wall_s']:.2f} s** (open {stamp('open: done')}, fused job {float(job_ms)/1000:.2f}; the process is {age_exit} s old when its outputs are closed: the rest is the kernel taking the process down - the page-table entries of the 60 GB mapping, the device memory) | 267; 3.78 s |
+| parity of the bench input | `cpu_baseline.counters_match_gpu` {str(cb['counters_match_gpu']).lower()} (all-cores oracle over the whole BAM: 1 024 additive counters + the 600-bin depth histogram); `single_bam.counters_match_one_gpu_job` {str(d['single_bam']['counters_match_one_gpu_job']).lower()}; `end_to_end.counters_match` {str(e['counters_match']).lower()} | true |
+| `cpu_baseline` | {cb['value']:.3f} Mreads/s (oracle, 1 thread, first 12 M records); all 16 usable CPUs: {ca['value']:.2f} | 1.31; 20.3 |
+
+* **What moved the headline** (530 → {d['ms_per_step']:.0f} ms per step; `profiles/r06_schedule_probe.txt`, `r06_k1_diet_counters.txt`, `r06_sq_counters.txt`): phase 2 rewritten in two passes (40.5 k + 25.7 k → 25.1 k VALU + 15.2 k SALU per
+  member), phase 1 on a diet (24.6 k → 21.1 k VALU), token groups as whole 64-byte lines (write traffic 110.7 → 49.7 KB per member) - together 534 → 466 ms and then, because a CU now held ten
+  decoder waves by LDS while a chunk was still six per CU, 507 ms; chunks of five (two launches fill a CU) 446 ms; four chunks per tile and five slots 441 ms; the decoder compiled for three
+  waves per SIMD (it had silently kept 193 VGPRs = two) 435 ms; eight chunks per tile - as many as the HBM holds beside the image - and eight slots {d['ms_per_step']:.0f} ms (a tile boundary costs the chunk stream
+  about 4 ms: the riding walk of a tile runs at the highest stream priority, but its workgroups only get the LDS that retiring decoder waves give back). Per member the chip issues 21.1 k (decoder)
+  + 25.1 k (resolve) + 3 k (CRC) VALU instructions: 1.6·10¹¹ per step against 6.1·10¹¹/s of issue = 260 ms at a perfect packing; the job runs at {260.0/d['ms_per_step']:.2f} of that bound.
+* **Scan stage**: MappingQC 0.682 → **{rs['frac']:.3f}**, BedCoverage 0.632 → **{t['bedcoverage']['roofline_scan']['frac']:.3f}**, `-min_baseq 20` 0.241 → **{t['bedlowcoverage_baseq20']['roofline_scan']['frac']:.3f}**, ONT 0.406 → **{o['roofline_scan']['frac']:.3f}** (north_star asks for ≥ 0.70 on MappingQC + BedCoverage). The coverage tools' walk
+  runs at five waves per SIMD (a tile of eight chunks = exactly two rounds of its walkers) and leaves the record offsets unexpanded. The walk's own counters: `profiles/r06_walk_counters.txt`, the LDS-DMA
+  variant that was 20 % slower: `r06_walk_probe.txt`.
+* **End to end is where round 5 left it** (H2D 34-37 GB/s, tool 3.4-3.8 s): giving the mapping back behind the copy made the job three times slower (`profiles/r06_tool_probe.txt`: the driver's
+  invalidation callbacks hold the device's queues), pread rings were slower at every thread count; `tool_stamps` now carry the process age at main and at exit.
+* Profiles of the round (rocprofv3, 48 M-read shard, regenerated with the last code and schedule): `r06_kernel_stats.txt` / `_serial.txt` (the shard's launches hold 62 k members on the 81 920 lanes of a
+  chunk, a lane per member: the duration of a launch is that of its longest members), `r06_hbm_traffic_pmc.txt`, `r06_sq_counters.txt`, `r06_sq_stall_counters.txt`, `r06_kernel_stats_ont.txt`; probes:
+  `r06_baseq_probe.txt`, `r06_k1_lds_dma_input_probe.txt`, `r06_schedule_probe.txt`, `r06_tool_probe.txt`, `r06_walk_probe.txt`, `r06_walk_counters.txt`.
+
+"""
+open(p, 'w').write(s[:a] + sec + s[b:])
+print("5a rewritten:", d['value'], d['ms_per_step'])
