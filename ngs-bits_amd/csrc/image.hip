@@ -559,7 +559,7 @@ void plan_layout_now(ngsqc_handle* h, bool early_pass = false)
 	// (round 6: four chunks of 5 waves per CU; 17 -> 10 tiles of the 30x file, the full-size step 451 -> 446 (three chunks) -> 443 ms: fewer tile boundaries, where the chunk stream runs thin)
 	// (round 6, with the decoder at three waves per SIMD: EIGHT chunks per tile - as many as fit the HBM beside the image of the 30x file, the memory bound below - and eight token slots;
 	// 5 tiles of the 30x file. Chunks per tile | full-size step: 4 | 433 ms, 5 | 427-429, 6 | 424, 7 | 422, 8 | 414.6 (K1 wall 405 -> 370 ms: the chunk stream runs thin at every tile
-	// boundary, where the host waits for K2's verdict), profiles/r06_schedule_probe.txt. A tile of eight chunks is 655 360 walkers = exactly two rounds of the coverage tools' walk)
+	// boundary), profiles/r06_schedule_probe.txt. A tile of eight chunks is 655 360 walkers = exactly two rounds of the coverage tools' walk)
 	int64_t cpt = h->stream_img ? 1 : 8; if (const char* e = getenv("NGSQC_TILE_CHUNKS")) cpt = std::max<int64_t>(1, atoll(e));
 	// Three tile buffers: K1 of tile t+2 is queued before the host waits for tile t, so the decoder waves never run out of queued work while the
 	// host reads back K2 / consumer results of tile t (with two buffers the queue ran dry for ~6 ms per tile).

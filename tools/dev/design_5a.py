@@ -34,7 +34,7 @@ Algorithmic bytes (SURVEY.md §8(d)): scan stage Σ(4 + block_size) = 208.71 GB 
   member), phase 1 on a diet (24.6 k → 21.1 k VALU), token groups as whole 64-byte lines (write traffic 110.7 → 49.7 KB per member) - together 534 → 466 ms and then, because a CU now held ten
   decoder waves by LDS while a chunk was still six per CU, 507 ms; chunks of five (two launches fill a CU) 446 ms; four chunks per tile and five slots 441 ms; the decoder compiled for three
   waves per SIMD (it had silently kept 193 VGPRs = two) 435 ms; eight chunks per tile - as many as the HBM holds beside the image - and eight slots {d['ms_per_step']:.0f} ms (a tile boundary costs the chunk stream
-  about 4 ms: the riding walk of a tile runs at the highest stream priority, but its workgroups only get the LDS that retiring decoder waves give back). Per member the chip issues 21.1 k (decoder)
+  about 4 ms - not traced; most likely the riding walk of a tile, which runs at the highest stream priority but whose workgroups only get the LDS that retiring decoder waves give back). Per member the chip issues 21.1 k (decoder)
   + 25.1 k (resolve) + 3 k (CRC) VALU instructions: 1.6·10¹¹ per step against 6.1·10¹¹/s of issue = 260 ms at a perfect packing; the job runs at {260.0/d['ms_per_step']:.2f} of that bound.
 * **Scan stage**: MappingQC 0.682 → **{rs['frac']:.3f}**, BedCoverage 0.632 → **{t['bedcoverage']['roofline_scan']['frac']:.3f}**, `-min_baseq 20` 0.241 → **{t['bedlowcoverage_baseq20']['roofline_scan']['frac']:.3f}**, ONT 0.406 → **{o['roofline_scan']['frac']:.3f}** (north_star asks for ≥ 0.70 on MappingQC + BedCoverage). The coverage tools' walk
   runs at five waves per SIMD (a tile of eight chunks = exactly two rounds of its walkers) and leaves the record offsets unexpanded. The walk's own counters: `profiles/r06_walk_counters.txt`, the LDS-DMA
