@@ -26,6 +26,9 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.ngsqc_version()
     L.ngsqc_abi_version.restype = C.c_int32
     assert L.ngsqc_abi_version() == 6 and b"abi 6" in L.ngsqc_version()   # (the round of include/ngsqc.h the library was built from: ngsqc_timings grows at its end)
+    # ngsqc_device_count never fails: 0 on a box without a device (this container), the library's own count elsewhere - what tests/test_gpu_rccl2.py arms itself by
+    n_dev = ngsqc.device_count()
+    assert n_dev >= 0 and (n_dev == 0 or os.path.exists("/dev/kfd"))
 
 
 def test_no_cpu_fallback():
