@@ -43,7 +43,7 @@ Algorithmic bytes (SURVEY.md §8(d)): scan stage Σ(4 + block_size) = 208.71 GB 
   invalidation callbacks hold the device's queues), pread rings were slower at every thread count; `tool_stamps` now carry the process age at main and at exit.
 * Profiles of the round (rocprofv3, 48 M-read shard, regenerated with the last code and schedule): `r06_kernel_stats.txt` / `_serial.txt` (the shard's launches hold 62 k members on the 81 920 lanes of a
   chunk, a lane per member: the duration of a launch is that of its longest members), `r06_hbm_traffic_pmc.txt`, `r06_sq_counters.txt`, `r06_sq_stall_counters.txt`, `r06_kernel_stats_ont.txt`; probes:
-  `r06_baseq_probe.txt`, `r06_k1_lds_dma_input_probe.txt`, `r06_schedule_probe.txt`, `r06_tool_probe.txt`, `r06_walk_probe.txt`, `r06_walk_counters.txt`.
+  `r06_kernel_stats_bedcoverage.txt`, `r06_baseq_probe.txt`, `r06_k1_lds_dma_input_probe.txt`, `r06_schedule_probe.txt`, `r06_tool_probe.txt`, `r06_walk_probe.txt`, `r06_walk_counters.txt` (`profiles/README.md` says what each one is).
 
 """
 open(p, 'w').write(s[:a] + sec + s[b:])
