@@ -118,7 +118,7 @@ void index_tile(ngsqc_handle* h, int t)
 	const uint8_t* base = h->buf[t % h->nbuf].p + h->pfx - prefix;
 	const BlockDesc* d_desc = h->d_kdesc.p + first;
 	// entries: entry 0 = the carried prefix, then the members - on the fast path each cut into 2^ksh pieces with a walker of its own (common.h entry_range;
-	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 1: a tile of the 30x file is 190 k members = three waves per SIMD already, and more waves than the chip holds buy nothing - profiles/r05_scan_probe.txt); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
+	// NGSQC_WALKERS = 1 / 2 / 4 / 8, default 1: a tile of the 30x file was 190 k members = three waves per SIMD in round 5 and is 655 k since round 6 - more waves than the chip holds buy nothing, profiles/r05_scan_probe.txt); the general path below (and a shard's first tile, whose chain is anchored by a guess) works on whole members
 	const bool anchor_by_guess = t == 0 && h->first_rec < 0;
 	int64_t exp0 = prefix ? 0 : (h->expected_abs - u_lo);   // local offset of the first record start of this tile
 	// long reads (round 5): the file's first record says what kind of file this is - a record of more than 8 KiB means members that mostly lie inside one record.
