@@ -28,6 +28,19 @@ def _device_count():
     return ngsqc.device_count()
 
 
+def test_device_count_sees_the_box():
+    """include/ngsqc.h ngsqc_device_count: at least the device the GPU suite runs on, and a handle opens on the last one it names"""
+    n = _device_count()
+    assert n >= 1
+    h = ngsqc.Handle(path=os.path.join(ROOT, "tests", "golden", "ref_in", "Statistics_mapqc_wgs.bam"), device=n - 1)
+    try:
+        assert h.n_records > 0
+    finally:
+        h.close()
+    with pytest.raises(ngsqc.NgsqcError):
+        ngsqc.Handle(path=os.path.join(ROOT, "tests", "golden", "ref_in", "Statistics_mapqc_wgs.bam"), device=n)
+
+
 def test_two_ranks_over_rccl(tmp_path):
     world = 2
     if _device_count() < world:
